@@ -1,0 +1,335 @@
+"""Generate tests/golden/*.npz by RUNNING THE PYTHON REFERENCE on CPU (build container only).
+
+TEST INFRASTRUCTURE ONLY.  Requires /root/reference (read-only).  The reference itself never
+travels: only inputs and expected outputs (data) are written, as small .npz fixtures, together
+with this script.  Re-run:  python oracle/make_goldens.py [--only G4,G7] [--with-train-curve]
+
+Golden groups follow SURVEY.md §8c:
+  G1 level_resolutions     models.py:305-317
+  G2 corners               models.py:486-502
+  G3 spatial_hash          models.py:504-528
+  G4 encoding fwd/bwd      models.py:173-229   (hash + GNGF, three blend variants)
+  G5 bilinear              models.py:621-655
+  G6 hpd                   models.py:45-123, 5-42
+  G7 end_to_end            models.py:394-484 + utils.py:91-174 + functions.py:96-127,243-281
+  G8 train_curve           functions.py:139-355 (optional, slow)
+  G9 decoder mlp           models.py:382-392,469-470
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness as rh  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+SEED = 65535
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def np32(t):
+    return t.detach().cpu().numpy().copy()  # copy: parameters are later updated in place
+
+
+def make_net(M, mods, *, hash_mode, T, L, n_min, n_max, F=2, K=4, keep_topk=False, bw=False):
+    rh.set_flag(mods, "should_use_hash_function", hash_mode)
+    torch.manual_seed(SEED)
+    return M.GeneralNeuralGaugeFields(
+        input_dim=2, hash_table_size=T, num_levels=L, n_min=n_min, n_max=n_max,
+        MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
+        HPD_out_features=T, feature_dim=F, topk_k=K, should_keep_topk_only=keep_topk, should_bw=bw)
+
+
+def load_strawberry():
+    """PIL decode (cv2 absent).  X[:,0]=row, X[:,1]=col, row-major (utils.py:56-59); Y=RGB/255 (utils.py:61);
+    x /= max(w,h)-1 (main.py:50-51)."""
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(rh.REF_ROOT, "images", "strawberry.jpeg")).convert("RGB"))
+    h, w = img.shape[:2]
+    rows, cols = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    X = torch.tensor(np.stack([rows, cols], -1).reshape(-1, 2)).float()
+    Y = torch.tensor(img.reshape(-1, 3) / 255).float()
+    X = X / (max(w, h) - 1)
+    return img, X, Y, h, w
+
+
+def edge_coords(n_rand, gen):
+    x = torch.rand(n_rand, 2, generator=gen)
+    edges = torch.tensor([[0.0, 0.0], [1.0, 1.0], [0.0, 1.0], [1.0, 0.0], [0.5, 0.5], [0.25, 0.75],
+                          [1.0 / 8, 3.0 / 8], [1.0 / 32, 31.0 / 32], [338.0 / 507, 1.0], [506.0 / 507, 337.0 / 507],
+                          [1.0 / 16, 1.0 / 512], [0.99999994, 0.99999994], [1e-8, 1e-8]])
+    return torch.cat([x, edges], 0)
+
+
+def g1(F_, U_, M, P_):
+    mods = (F_, U_, M)
+    cases = [(8, 32, 4), (16, 512, 16), (16, 2048, 16), (16, 4096, 16), (16, 8192, 16), (16, 1024, 8), (4, 4096, 12)]
+    out = {}
+    for i, (a, b, L) in enumerate(cases):
+        net = make_net(M, mods, hash_mode=True, T=16, L=L, n_min=a, n_max=b)
+        out[f"case{i}"] = np.array([a, b, L])
+        out[f"n_ls{i}"] = np32(net._n_ls).reshape(-1)
+        print(a, b, L, out[f"n_ls{i}"])
+    out["hypercube"] = np32(net._voxels_helper_hypercube)
+    save("G1_level_resolutions", **out)
+
+
+def g2_g3(F_, U_, M, P_):
+    mods = (F_, U_, M)
+    gen = torch.Generator().manual_seed(SEED)
+    x = edge_coords(256, gen)
+    out = {"x": np32(x)}
+    for tag, (a, b, L) in {"cfg1": (8, 32, 4), "cfg2": (16, 512, 16), "cfg4": (16, 4096, 16)}.items():
+        for T in (2 ** 8, 2 ** 19, 1000):
+            net = make_net(M, mods, hash_mode=True, T=T, L=L, n_min=a, n_max=b)
+            scaled, grid = net._scale_to_grid(x)
+            out[f"{tag}_scaled"] = np32(scaled)
+            out[f"{tag}_grid"] = np32(grid)
+            out[f"{tag}_hash_T{T}"] = np32(net._fast_hash(grid.int()))
+    save("G2G3_corners_hash", **out)
+
+
+def g4(F_, U_, M, P_):
+    mods = (F_, U_, M)
+    out = {}
+    gen = torch.Generator().manual_seed(SEED)
+    for tag, (T, L, Fd, K, Pn) in {"small": (256, 4, 2, 4, 64), "mid": (4096, 16, 2, 4, 48), "f4k3": (512, 3, 4, 3, 40)}.items():
+        # hash branch (models.py:181-191)
+        rh.set_flag(mods, "should_use_hash_function", True)
+        torch.manual_seed(SEED)
+        enc = M.MultiResHashEncoding(hash_table_size=T, num_levels=L, feature_dim=Fd, topk_k=K)
+        tables = torch.stack([enc._hash_tables[l].weight.detach() for l in range(L)])
+        out[f"{tag}_tables"] = np32(tables)
+        idx = torch.randint(0, T, (Pn, L, 4), generator=gen, dtype=torch.int64)
+        idx[: Pn // 4, :, 1] = idx[: Pn // 4, :, 0]  # forced collisions inside the batch
+        g = torch.randn(Pn, Fd, L, 4, generator=gen)
+        y = enc(idx, None)
+        enc.zero_grad()
+        y.backward(g)
+        out[f"{tag}_hash_idx"] = np32(idx)
+        out[f"{tag}_hash_gout"] = np32(g)
+        out[f"{tag}_hash_out"] = np32(y)
+        out[f"{tag}_hash_dtables"] = np32(torch.stack([enc._hash_tables[l].weight.grad for l in range(L)]))
+        # GNGF branch (models.py:193-222), three blend variants
+        rh.set_flag(mods, "should_use_hash_function", False)
+        idxk = torch.randint(0, T, (Pn, L, 4, K), generator=gen, dtype=torch.int64)
+        idxk[: Pn // 4, :, :, 1] = idxk[: Pn // 4, :, :, 0]
+        probs = torch.rand(Pn, L, 4, K, generator=gen) * 0.01 + 1e-3
+        gk = torch.randn(Pn, Fd, L, 4, generator=gen)
+        out[f"{tag}_gngf_idx"] = np32(idxk)
+        out[f"{tag}_gngf_probs"] = np32(probs)
+        out[f"{tag}_gngf_gout"] = np32(gk)
+        for vname, flag in (("softmax", True), ("raw", None), ("norm", False)):
+            rh.set_flag(mods, "should_softmax_topk_features", flag)
+            p = probs.clone().requires_grad_()
+            y = enc(idxk, p)
+            enc.zero_grad()
+            y.backward(gk)
+            out[f"{tag}_gngf_{vname}_out"] = np32(y)
+            out[f"{tag}_gngf_{vname}_dtables"] = np32(torch.stack([enc._hash_tables[l].weight.grad for l in range(L)]))
+            out[f"{tag}_gngf_{vname}_dprobs"] = np32(p.grad)
+        rh.set_flag(mods, "should_softmax_topk_features", True)
+    save("G4_encoding", **out)
+
+
+def g5(F_, U_, M, P_):
+    mods = (F_, U_, M)
+    gen = torch.Generator().manual_seed(SEED + 5)
+    out = {}
+    for tag, (a, b, L, Fd) in {"cfg1": (8, 32, 4, 2), "cfg2": (16, 512, 16, 2), "f4": (16, 128, 6, 4)}.items():
+        net = make_net(M, mods, hash_mode=True, T=64, L=L, n_min=a, n_max=b, F=Fd)
+        x = edge_coords(64, gen)
+        scaled, grid = net._scale_to_grid(x)
+        feats = torch.randn(x.shape[0], Fd, L, 4, generator=gen).requires_grad_()
+        y = net._bilinear_interpolate(scaled, grid, feats)
+        g = torch.randn(y.shape, generator=gen)
+        y.backward(g)
+        out[f"{tag}_x"] = np32(x)
+        out[f"{tag}_feats"] = np32(feats)
+        out[f"{tag}_out"] = np32(y)
+        out[f"{tag}_gout"] = np32(g)
+        out[f"{tag}_dfeats"] = np32(feats.grad)
+        out[f"{tag}_cfg"] = np.array([a, b, L, Fd])
+    save("G5_bilinear", **out)
+
+
+def hpd_state(hpd):
+    return {f"hpd_{k.replace('.', '_')}": np32(v) for k, v in hpd.state_dict().items()}
+
+
+def g6(F_, U_, M, P_):
+    mods = (F_, U_, M)
+    rh.set_flag(mods, "should_use_hash_function", False)
+    _, X, _, _, _ = load_strawberry()
+    net = make_net(M, mods, hash_mode=False, T=256, L=4, n_min=8, n_max=32)
+    _, grid = net._scale_to_grid(X)
+    verts = torch.unique(grid.permute(0, 2, 3, 1).reshape(-1, 2), dim=0)  # (U,2) fp32 integer coords
+    print("unique vertices:", verts.shape)
+    out = {"verts": np32(verts)}
+    gen = torch.Generator().manual_seed(SEED + 6)
+    for T in (256, 2048):
+        dprobs = None
+        for K in (1, 4, 20):
+            torch.manual_seed(SEED + T)
+            hpd = M.HashProbDistribution([32, 64, 128], in_features=2, out_features=T, k=K)
+            # make the net less degenerate than default init so that top-K is well separated
+            with torch.no_grad():
+                for p in hpd.parameters():
+                    p.mul_(3.0)
+            vs = verts if T == 256 else verts[::4]  # keep the big-T fixture small
+            out[f"T{T}_verts"] = np32(vs)
+            v = vs.clone().requires_grad_()
+            probs, tp, ti = hpd(v)
+            dq = torch.randn(tp.shape, generator=gen)
+            if dprobs is None:  # one direct-gradient tensor per T, shared by every K
+                dprobs = torch.randn(probs.shape, generator=gen) * 1e-2
+            hpd.zero_grad()
+            (tp * dq).sum().add((probs * dprobs).sum()).backward()
+            tag = f"T{T}_K{K}"
+            if K == 1:
+                out.update({f"T{T}_{k}": v_ for k, v_ in hpd_state(hpd).items()})
+                out[f"T{T}_probs"] = np32(probs)
+                out[f"T{T}_dprobs_in"] = np32(dprobs)
+            out[f"{tag}_topk_probs"] = np32(tp)
+            out[f"{tag}_topk_idx"] = np32(ti)
+            out[f"{tag}_dq_in"] = np32(dq)
+            for k_, p_ in hpd.named_parameters():
+                out[f"{tag}_grad_{k_.replace('.', '_')}"] = np32(p_.grad)
+    save("G6_hpd", **out)
+
+
+def g9(F_, U_, M, P_):
+    mods = (F_, U_, M)
+    gen = torch.Generator().manual_seed(SEED + 9)
+    out = {}
+    for tag, (L, Fd, bw, leaky) in {"cfg1": (4, 2, False, False), "cfg2": (16, 2, False, False),
+                                     "bw_leaky": (8, 4, True, True)}.items():
+        rh.set_flag(mods, "should_leaky_relu", leaky)
+        net = make_net(M, mods, hash_mode=True, T=16, L=L, n_min=8, n_max=64, F=Fd, bw=bw)
+        with torch.no_grad():
+            for p in net.mlp.parameters():
+                p.mul_(2.0)
+        x = (torch.randn(200, L * Fd, generator=gen) * 0.5).requires_grad_()
+        y = x
+        for layer in net.mlp:
+            y = layer(y)
+        g = torch.randn(y.shape, generator=gen)
+        net.zero_grad()
+        y.backward(g)
+        out[f"{tag}_x"] = np32(x)
+        out[f"{tag}_y"] = np32(y)
+        out[f"{tag}_gy"] = np32(g)
+        out[f"{tag}_dx"] = np32(x.grad)
+        for k_, p_ in net.mlp.named_parameters():
+            out[f"{tag}_w_{k_.replace('.', '_')}"] = np32(p_)
+            out[f"{tag}_g_{k_.replace('.', '_')}"] = np32(p_.grad)
+        out[f"{tag}_cfg"] = np.array([L, Fd, int(bw), int(leaky)])
+    rh.set_flag(mods, "should_leaky_relu", False)
+    save("G9_decoder", **out)
+
+
+def g7(F_, U_, M, P_):
+    """End-to-end: one model, three optimisation steps on three 4096-pixel strawberry batches, both modes."""
+    mods = (F_, U_, M)
+    img, X, Y, h, w = load_strawberry()
+    save("strawberry_rgb", img=img)
+    torch.manual_seed(SEED)
+    perm = torch.randperm(h * w)
+    B = 4096
+    for mode in ("gngf", "hash"):
+        hash_mode = mode == "hash"
+        net = make_net(M, mods, hash_mode=hash_mode, T=256, L=4, n_min=8, n_max=32, K=4)
+        loss_fn = U_.Loss(delta=1, gamma=-2, epsilon=1)
+        opt = F_.get_optimizer(net, encoding_lr=1e-4, HPD_lr=1e-3, MLP_lr=1e-3,
+                               encoding_weight_decay=0, HPD_weight_decay=1e-6, MLP_weight_decay=1e-6)
+        out = {"perm": perm[: 3 * B].numpy().astype(np.int64), "hw": np.array([h, w])}
+        for k_, v_ in net.state_dict().items():
+            out["init_" + k_.replace(".", "_")] = np32(v_)
+        for step in range(3):
+            sl = perm[step * B:(step + 1) * B]
+            bx, by = X[sl], Y[sl]
+            opt.zero_grad()
+            rgb, probs, idx, counts = net(bx, 1 / 3, should_calc_counts=False)
+            mse, kls, coll = loss_fn(rgb, by, None if hash_mode else probs.shape[-1], probs,
+                                     None if hash_mode else torch.tensor([]), None if hash_mode else torch.tensor([]))
+            loss = 1 * mse
+            if not hash_mode:  # functions.py:243-245 with empty previous_collisions -> "+1" per level
+                loss = loss + ((1 * kls) + (1e-3 * coll if coll.nelement() != 0 else 1)).sum(0)
+            loss.backward()
+            s = f"s{step}_"
+            out[s + "rgb"] = np32(rgb)
+            out[s + "idx"] = np32(idx)
+            out[s + "mse"] = np32(mse)
+            out[s + "loss"] = np32(loss)
+            if not hash_mode:
+                out[s + "kls"] = np32(kls)
+                out[s + "pbar"] = np32(probs.sum(0).sum(1) / (probs.shape[0] * probs.shape[2]))  # (L,T)
+                tp, ti = torch.topk(probs, 4, dim=-1)
+                out[s + "topk_probs"] = np32(tp)
+            for k_, p_ in net.named_parameters():
+                if p_.grad is not None:
+                    out[s + "grad_" + k_.replace(".", "_")] = np32(p_.grad)
+            opt.step()
+            for k_, p_ in net.named_parameters():
+                out[s + "param_" + k_.replace(".", "_")] = np32(p_)
+        save(f"G7_end_to_end_{mode}", **out)
+
+
+def g8(F_, U_, M, P_):
+    """First 3 epochs of cfg1 through the reference's own train_step (slow: ~5 min)."""
+    mods = (F_, U_, M)
+    rh.set_flag(mods, "should_use_hash_function", False)
+    img, X, Y, h, w = load_strawberry()
+    torch.manual_seed(SEED)
+    shape = h * w
+    shuffled = torch.randperm(shape).int()
+    reordered = torch.zeros((shape,)).int()
+    reordered[shuffled] = torch.arange(shape).int()
+    cfg = F_.get_grid_search_configs(P_.grid_search_configs)[4061]
+    print(len(F_.get_grid_search_configs(P_.grid_search_configs)), cfg)
+    net = make_net(M, mods, hash_mode=False, T=256, L=4, n_min=8, n_max=32, K=cfg["topk_k"])
+    loss_fn = U_.Loss(delta=1, gamma=cfg["loss_gamma"], epsilon=1)
+    opt = F_.get_optimizer(net, 1e-4, cfg["HPD_lr"], cfg["MLP_lr"], 0, 1e-6, 1e-6)
+    prev_c, prev_m = torch.tensor([]), torch.tensor([])
+    rec = {"cfg_keys": np.array(list(cfg.keys())), "cfg_vals": np.array([float(v) for v in cfg.values()])}
+    mses, psnrs, losses = [], [], []
+    for e in range(3):
+        r = F_.train_step(net, loss_fn, opt, X.clone(), Y.clone(), w, h, 256, cfg["topk_k"], cfg["l_mse"],
+                          cfg["l_js_kl"], cfg["l_collisions"], batch_percentage=P_.batch_size, num_levels=4,
+                          should_shuffle=True, shuffled_indices=shuffled, reordered_indices=reordered,
+                          previous_collisions=prev_c, previous_min_possible_collisions=prev_m)
+        loss_item, show, prev_c, prev_m, _, mse, kls, colls, _ = r
+        psnr = F_.calc_psnr(show, img)
+        print(e, loss_item, mse, psnr)
+        mses.append(mse); psnrs.append(psnr); losses.append(loss_item)
+    rec.update(mse=np.array(mses), psnr=np.array(psnrs), loss=np.array(losses), shuffled=shuffled.numpy())
+    save("G8_train_curve", **rec)
+
+
+GROUPS = {"G1": g1, "G2": g2_g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--with-train-curve", action="store_true")
+    a = ap.parse_args()
+    assert rh.available(), "reference not present: goldens can only be regenerated in the build container"
+    torch.set_num_threads(8)
+    mods4 = rh.load_reference()
+    sel = [s for s in a.only.split(",") if s] or list(GROUPS)
+    for name in sel:
+        if name == "G8":
+            continue
+        GROUPS[name](*mods4)
+    if a.with_train_curve or "G8" in sel:
+        g8(*mods4)
