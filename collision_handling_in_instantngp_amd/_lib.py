@@ -1,0 +1,84 @@
+"""ctypes binding of libgngf_hip.so (C-ABI declared in include/gngf.h).
+
+The product has NO CPU fallback: if the HIP library is missing, or a tensor is not a contiguous CUDA/HIP
+tensor of the expected dtype, the call raises.  torch is used only for device memory and the current stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgngf_hip.so")
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_L = _c.c_int64
+_F = _c.c_float
+
+# name -> argtypes (all return int = hipError_t).  Must mirror include/gngf.h exactly.
+SIGNATURES = {
+    "gngf_abi_version": [],
+    "gngf_hash_indices": [_P, _P, _P, _L, _I, _L, _P],
+    "gngf_mrhe_fwd": [_P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _P],
+    "gngf_mrhe_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _P],
+    "gngf_bilinear_fwd": [_P, _P, _P, _P, _L, _I, _I, _P],
+    "gngf_bilinear_bwd": [_P, _P, _P, _P, _L, _I, _I, _P],
+    "gngf_encode_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _L, _P],
+    "gngf_encode_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _L, _P],
+}
+
+_lib = None
+
+
+class GngfLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library once.  Raises GngfLibraryError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise GngfLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C collision_handling_in_instantngp_amd/csrc`.  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise GngfLibraryError(f"{LIB_PATH} does not export {name}: stale build?") from e
+        fn.argtypes = argtypes
+        fn.restype = _I
+    ver = lib.gngf_abi_version()
+    if ver != 1:
+        raise GngfLibraryError(f"ABI version mismatch: library {ver}, binding 1")
+    _lib = lib
+    return lib
+
+
+def stream_ptr():
+    return _P(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=None, name="tensor"):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL).  Raises on CPU tensors: no CPU path."""
+    if t is None:
+        return _P(0)
+    if not t.is_cuda:
+        raise GngfLibraryError(f"{name} is on {t.device}: the gfx950 path needs CUDA/HIP tensors (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return _P(t.data_ptr())
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with hipError_t {rc}"
+                           + (" (hipErrorInvalidValue: rejected arguments)" if rc == 1 else ""))
