@@ -27,6 +27,19 @@ SIGNATURES = {
     "gngf_bilinear_bwd": [_P, _P, _P, _P, _L, _I, _I, _P],
     "gngf_encode_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _L, _P],
     "gngf_encode_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _L, _P],
+    "gngf_linear_fwd": [_P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "gngf_linear_bwd_input": [_P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "gngf_linear_bwd_weight": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "gngf_gemm_acc": [_P, _P, _P, _L, _L, _L, _I, _I, _P],
+    "gngf_softmax_topk": [_P, _P, _P, _L, _L, _I, _P],
+    "gngf_topk": [_P, _P, _P, _L, _L, _I, _P],
+    "gngf_softmax_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _L, _L, _I, _P],
+    "gngf_vertex_coords": [_P, _L, _L, _I, _P],
+    "gngf_blend_fwd": [_P, _P, _L, _I, _I, _P],
+    "gngf_blend_bwd": [_P, _P, _P, _L, _I, _I, _P],
+    "gngf_vertex_multiplicity": [_P, _P, _P, _L, _I, _I, _L, _P],
+    "gngf_multiplicity_weights": [_P, _P, _L, _I, _F, _P],
+    "gngf_expand_vertex_table": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _L, _P],
 }
 
 _lib = None

@@ -1,0 +1,356 @@
+// HashProbDistribution tail (reference models.py:85,105-123 and DifferentiableTopk models.py:5-42), evaluated
+// once per DISTINCT grid vertex instead of once per (pixel, level, corner) instance:
+//   softmax over the T slots + nan_to_num + top-K selection, and its backward WITHOUT the dense zero-filled
+//   (P,L,4,T) scatter of the reference (models.py:27-35): the K gradients are folded into the softmax
+//   backward row by row.
+// Also: vertex-coordinate generation, blend (softmax over K) forward/backward on the per-vertex table,
+// per-vertex multiplicities for the batch-mean distribution, and the expansion kernels that rebuild the
+// reference-shaped (P,L,4,K) outputs from the per-vertex table.
+#include "gngf_common.h"
+#include <limits.h>
+
+namespace gngf {
+
+constexpr int kRowBlock = 256;
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// (value desc, index asc) ordering: a beats b
+__device__ __forceinline__ bool beats(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
+
+// One 256-thread block per row.  z: logits in, probabilities out (in place).
+// torch semantics: softmax = exp(x - max) / sum; a NaN logit poisons the whole row (max = NaN), and
+// nan_to_num maps the NaNs to 0.  Top-K is taken on the final fp32 probabilities; ties -> lower index.
+__global__ void __launch_bounds__(kRowBlock)
+softmax_topk_kernel(float* __restrict__ z, float* __restrict__ topv, int32_t* __restrict__ topi, int64_t T, int K,
+                    int do_softmax) {
+  extern __shared__ float smem[];            // K*256 values, K*256 indices, then 16 floats scratch
+  float* lv = smem;
+  int* li = reinterpret_cast<int*>(smem + (size_t)K * kRowBlock);
+  float* red = smem + (size_t)2 * K * kRowBlock;
+  int* redi = reinterpret_cast<int*>(red + 8);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* p = z + (int64_t)blockIdx.x * T;
+
+  float m = -INFINITY, s = 1.f;
+  bool row_nan = false;
+  if (do_softmax) {
+    bool has_nan = false;
+    for (int64_t t = tid; t < T; t += kRowBlock) { const float v = p[t]; has_nan |= (v != v); m = fmaxf(m, v); }
+    m = wave_max(m);
+    const unsigned long long nanmask = __ballot(has_nan);
+    if (lane == 0) { red[wave] = m; redi[wave] = nanmask != 0ull; }
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    row_nan = (redi[0] | redi[1] | redi[2] | redi[3]) != 0;
+    __syncthreads();
+    s = 0.f;
+    for (int64_t t = tid; t < T; t += kRowBlock) s += expf(p[t] - m);
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+  }
+
+  for (int k = 0; k < K; ++k) { lv[k * kRowBlock + tid] = -INFINITY; li[k * kRowBlock + tid] = INT_MAX; }
+  float thr = -INFINITY;                       // value of this thread's K-th best so far
+  for (int64_t t = tid; t < T; t += kRowBlock) {
+    float q = p[t];
+    if (do_softmax) {
+      q = expf(q - m) / s;
+      if (row_nan || q != q) q = 0.f;          // nan_to_num (models.py:111)
+      else if (q > 3.4028234663852886e38f) q = 3.4028234663852886e38f;
+      p[t] = q;
+    }
+    if (q > thr) {                             // strictly: a later index never displaces an equal value
+      int k = K - 1;
+      while (k > 0 && lv[(k - 1) * kRowBlock + tid] < q) {
+        lv[k * kRowBlock + tid] = lv[(k - 1) * kRowBlock + tid];
+        li[k * kRowBlock + tid] = li[(k - 1) * kRowBlock + tid];
+        --k;
+      }
+      lv[k * kRowBlock + tid] = q;
+      li[k * kRowBlock + tid] = (int)t;
+      thr = lv[(K - 1) * kRowBlock + tid];
+    }
+  }
+  // K rounds of block-wide arg-best over the heads of the per-thread sorted lists
+  int head = 0;
+  for (int r = 0; r < K; ++r) {
+    float cv = head < K ? lv[head * kRowBlock + tid] : -INFINITY;
+    int ci = head < K ? li[head * kRowBlock + tid] : INT_MAX;
+    int owner = tid;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(cv, o, 64);
+      const int oi = __shfl_xor(ci, o, 64);
+      const int oo = __shfl_xor(owner, o, 64);
+      if (beats(ov, oi, cv, ci)) { cv = ov; ci = oi; owner = oo; }
+    }
+    if (lane == 0) { red[wave] = cv; redi[wave] = ci; redi[4 + wave] = owner; }
+    __syncthreads();
+    float bv = red[0]; int bi = redi[0], bo = redi[4];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (beats(red[w], redi[w], bv, bi)) { bv = red[w]; bi = redi[w]; bo = redi[4 + w]; }
+    if (tid == bo) ++head;
+    if (tid == 0) { topv[(int64_t)blockIdx.x * K + r] = bv; topi[(int64_t)blockIdx.x * K + r] = bi; }
+    __syncthreads();
+  }
+}
+
+// Softmax backward with the top-K gradient folded in.  One block per row.
+//   g_t = gdense[row,t] (optional) + sum_l mw[row,l] * G[l,t] (optional)  [+ dq_k at t = topi_k]
+//   dz_t = p_t * (g_t - sum_t' p_t' g_t')          (p = post-nan_to_num probabilities: NaN rows have p = 0 -> dz = 0)
+// dz may alias p (in place).
+__global__ void __launch_bounds__(kRowBlock)
+softmax_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dq, const int32_t* __restrict__ topi,
+                   const float* __restrict__ gdense, const float* __restrict__ mw, const float* __restrict__ G, int L,
+                   float* __restrict__ dZ, int64_t T, int K) {
+  __shared__ float red[4];
+  __shared__ float pk[GNGF_MAX_TOPK];
+  __shared__ float mwl[GNGF_MAX_LEVELS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row = blockIdx.x;
+  const float* p = P + row * T;
+  float* dz = dZ + row * T;
+  const float* gd = gdense ? gdense + row * T : nullptr;
+  if (tid < L && mw) mwl[tid] = mw[row * L + tid];
+  if (tid < K) pk[tid] = p[topi[row * K + tid]];
+  __syncthreads();
+  const bool lowrank = (mw != nullptr) && (G != nullptr);
+  float dot = 0.f;
+  for (int64_t t = tid; t < T; t += kRowBlock) {
+    float g = gd ? gd[t] : 0.f;
+    if (lowrank) for (int l = 0; l < L; ++l) g += mwl[l] * G[(int64_t)l * T + t];
+    dot += p[t] * g;
+  }
+  if (tid < K && dq) dot += pk[tid] * dq[row * K + tid];
+  dot = wave_sum(dot);
+  if (lane == 0) red[wave] = dot;
+  __syncthreads();
+  dot = (red[0] + red[1]) + (red[2] + red[3]);
+  for (int64_t t = tid; t < T; t += kRowBlock) {
+    float g = gd ? gd[t] : 0.f;
+    if (lowrank) for (int l = 0; l < L; ++l) g += mwl[l] * G[(int64_t)l * T + t];
+    dz[t] = p[t] * (g - dot);
+  }
+  __syncthreads();
+  if (tid < K && dq) dz[topi[row * K + tid]] += pk[tid] * dq[row * K + tid];
+}
+
+// verts[u] = (gx, gy) as fp32 with u = gy * vstride + gx   (the HPD input is the raw integer vertex, models.py:416-418)
+__global__ void vertex_coords_kernel(float2* __restrict__ verts, int64_t u0, int64_t count, int vstride) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int64_t u = u0 + i;
+  verts[i] = make_float2((float)(u % vstride), (float)(u / vstride));
+}
+
+template <int KMAX>
+__device__ __forceinline__ void blend_w(const float* q, int K, int blend, float* w) {
+  if (blend == GNGF_BLEND_RAW) { for (int k = 0; k < K; ++k) w[k] = q[k]; return; }
+  if (blend == GNGF_BLEND_SOFTMAX) {
+    float m = q[0];
+    for (int k = 1; k < K; ++k) m = fmaxf(m, q[k]);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) { w[k] = expf(q[k] - m); s += w[k]; }
+    for (int k = 0; k < K; ++k) w[k] = w[k] / s;
+    return;
+  }
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s += q[k];
+  for (int k = 0; k < K; ++k) w[k] = q[k] / s;
+}
+
+__global__ void blend_fwd_kernel(const float* __restrict__ q, float* __restrict__ w, int64_t U, int K, int blend) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= U) return;
+  float qq[GNGF_MAX_TOPK], ww[GNGF_MAX_TOPK];
+  for (int k = 0; k < K; ++k) qq[k] = q[u * K + k];
+  blend_w<GNGF_MAX_TOPK>(qq, K, blend, ww);
+  for (int k = 0; k < K; ++k) w[u * K + k] = ww[k];
+}
+
+__global__ void blend_bwd_kernel(const float* __restrict__ q, const float* __restrict__ dw, float* __restrict__ dq,
+                                 int64_t U, int K, int blend) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= U) return;
+  float qq[GNGF_MAX_TOPK], ww[GNGF_MAX_TOPK], d[GNGF_MAX_TOPK];
+  for (int k = 0; k < K; ++k) { qq[k] = q[u * K + k]; d[k] = dw[u * K + k]; }
+  blend_w<GNGF_MAX_TOPK>(qq, K, blend, ww);
+  if (blend == GNGF_BLEND_SOFTMAX) {
+    float dot = 0.f;
+    for (int k = 0; k < K; ++k) dot += ww[k] * d[k];
+    for (int k = 0; k < K; ++k) d[k] = ww[k] * (d[k] - dot);
+  } else if (blend == GNGF_BLEND_NORM) {
+    float s = 0.f, dqs = 0.f;
+    for (int k = 0; k < K; ++k) { s += qq[k]; dqs += d[k] * qq[k]; }
+    const float inv = 1.0f / s;
+    for (int k = 0; k < K; ++k) d[k] = d[k] * inv - dqs * inv * inv;
+  }
+  for (int k = 0; k < K; ++k) dq[u * K + k] = d[k];
+}
+
+// counts[l][vid] += 1 for the 4 corners of every (pixel, level): multiplicities of the per-vertex rows inside the
+// reference's (P,L,4,T) tensor (for the batch-mean distribution of utils.py:138).
+__global__ void __launch_bounds__(256)
+vertex_multiplicity_kernel(const float2* __restrict__ xy, const int32_t* __restrict__ n_ls, int32_t* __restrict__ counts,
+                           int64_t total, int L, int vstride, int64_t NV) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int64_t p = gid / L;
+  const int l = (int)(gid - p * L);
+  const float2 c = xy[p];
+  const Cell cell = make_cell(c.x, c.y, n_ls[l]);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    int64_t vid = (int64_t)(cell.gy + (v >> 1)) * vstride + (cell.gx + (v & 1));
+    vid = vid < 0 ? 0 : (vid >= NV ? NV - 1 : vid);
+    atomicAdd(counts + (int64_t)l * NV + vid, 1);
+  }
+}
+
+// counts (L,NV) int32 -> mw (NV,L) fp32 = counts / denom
+__global__ void multiplicity_weights_kernel(const int32_t* __restrict__ counts, float* __restrict__ mw, int64_t NV, int L,
+                                            float denom) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NV * L) return;
+  const int64_t u = i / L;
+  const int l = (int)(i - u * L);
+  mw[i] = (float)counts[(int64_t)l * NV + u] / denom;
+}
+
+// vid (P,L,4) int64 of every instance, and the reference-shaped expansions of per-vertex (NV,K) tables.
+__global__ void __launch_bounds__(256)
+expand_kernel(const float2* __restrict__ xy, const int32_t* __restrict__ n_ls, const int32_t* __restrict__ src_i,
+              const float* __restrict__ src_f, int64_t* __restrict__ vid_out, int64_t* __restrict__ out_i,
+              float* __restrict__ out_f, int64_t total, int L, int K, int vstride, int64_t NV) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over P*L*4
+  if (gid >= total) return;
+  const int v = (int)(gid & 3);
+  const int64_t pl = gid >> 2;
+  const int64_t p = pl / L;
+  const int l = (int)(pl - p * L);
+  const float2 c = xy[p];
+  const Cell cell = make_cell(c.x, c.y, n_ls[l]);
+  int64_t vid = (int64_t)(cell.gy + (v >> 1)) * vstride + (cell.gx + (v & 1));
+  vid = vid < 0 ? 0 : (vid >= NV ? NV - 1 : vid);
+  if (vid_out) vid_out[gid] = vid;
+  for (int k = 0; k < K; ++k) {
+    if (out_i) out_i[gid * K + k] = (int64_t)src_i[vid * K + k];
+    if (out_f) out_f[gid * K + k] = src_f[vid * K + k];
+  }
+}
+
+}  // namespace gngf
+
+using namespace gngf;
+
+extern "C" int gngf_softmax_topk(float* logits_probs, float* topk_val, int32_t* topk_idx, int64_t U, int64_t T, int K,
+                                 void* stream) {
+  GNGF_CHECK_ARG(U >= 0 && T > 0 && K > 0 && K <= GNGF_MAX_TOPK && K <= T && T < INT_MAX);
+  if (U == 0) return 0;
+  GNGF_CHECK_ARG(logits_probs && topk_val && topk_idx);
+  const size_t smem = ((size_t)2 * K * kRowBlock + 16) * sizeof(float);
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_topk_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  softmax_topk_kernel<<<dim3((unsigned)U), dim3(kRowBlock), smem, as_stream(stream)>>>(logits_probs, topk_val, topk_idx, T, K, 1);
+  GNGF_RETURN_LAUNCH();
+}
+
+// DifferentiableTopk.forward alone (models.py:11): top-K of arbitrary rows, values sorted descending, ties -> lower index.
+extern "C" int gngf_topk(const float* x, float* topk_val, int32_t* topk_idx, int64_t U, int64_t T, int K, void* stream) {
+  GNGF_CHECK_ARG(U >= 0 && T > 0 && K > 0 && K <= GNGF_MAX_TOPK && K <= T && T < INT_MAX);
+  if (U == 0) return 0;
+  GNGF_CHECK_ARG(x && topk_val && topk_idx);
+  const size_t smem = ((size_t)2 * K * kRowBlock + 16) * sizeof(float);
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_topk_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  softmax_topk_kernel<<<dim3((unsigned)U), dim3(kRowBlock), smem, as_stream(stream)>>>(const_cast<float*>(x), topk_val, topk_idx,
+                                                                                       T, K, 0);
+  GNGF_RETURN_LAUNCH();
+}
+
+extern "C" int gngf_softmax_bwd(const float* probs, const float* dq, const int32_t* topk_idx, const float* gdense,
+                                const float* mw, const float* G, int L, float* dlogits, int64_t U, int64_t T, int K,
+                                void* stream) {
+  GNGF_CHECK_ARG(U >= 0 && T > 0 && K >= 0 && K <= GNGF_MAX_TOPK && L >= 0 && L <= GNGF_MAX_LEVELS);
+  if (U == 0) return 0;
+  GNGF_CHECK_ARG(probs && dlogits && (K == 0 || topk_idx) && ((mw == nullptr) == (G == nullptr)));
+  softmax_bwd_kernel<<<dim3((unsigned)U), dim3(kRowBlock), 0, as_stream(stream)>>>(probs, dq, topk_idx, gdense, mw, G, L,
+                                                                                    dlogits, T, K);
+  GNGF_RETURN_LAUNCH();
+}
+
+extern "C" int gngf_vertex_coords(float* verts, int64_t u0, int64_t count, int vstride, void* stream) {
+  GNGF_CHECK_ARG(count >= 0 && u0 >= 0 && vstride > 0);
+  if (count == 0) return 0;
+  GNGF_CHECK_ARG(verts);
+  vertex_coords_kernel<<<dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, as_stream(stream)>>>(
+      reinterpret_cast<float2*>(verts), u0, count, vstride);
+  GNGF_RETURN_LAUNCH();
+}
+
+extern "C" int gngf_blend_fwd(const float* q, float* w, int64_t U, int K, int blend, void* stream) {
+  GNGF_CHECK_ARG(U >= 0 && K > 0 && K <= GNGF_MAX_TOPK && blend >= 0 && blend <= 2);
+  if (U == 0) return 0;
+  GNGF_CHECK_ARG(q && w);
+  blend_fwd_kernel<<<dim3((unsigned)ceil_div(U, 256)), dim3(256), 0, as_stream(stream)>>>(q, w, U, K, blend);
+  GNGF_RETURN_LAUNCH();
+}
+
+extern "C" int gngf_blend_bwd(const float* q, const float* dw, float* dq, int64_t U, int K, int blend, void* stream) {
+  GNGF_CHECK_ARG(U >= 0 && K > 0 && K <= GNGF_MAX_TOPK && blend >= 0 && blend <= 2);
+  if (U == 0) return 0;
+  GNGF_CHECK_ARG(q && dw && dq);
+  blend_bwd_kernel<<<dim3((unsigned)ceil_div(U, 256)), dim3(256), 0, as_stream(stream)>>>(q, dw, dq, U, K, blend);
+  GNGF_RETURN_LAUNCH();
+}
+
+extern "C" int gngf_vertex_multiplicity(const float* xy, const int32_t* n_ls, int32_t* counts, int64_t P, int L, int vstride,
+                                        int64_t NV, void* stream) {
+  GNGF_CHECK_ARG(P >= 0 && L > 0 && L <= GNGF_MAX_LEVELS && vstride > 0 && NV > 0);
+  if (P == 0) return 0;
+  GNGF_CHECK_ARG(xy && n_ls && counts);
+  const int64_t total = P * L;
+  vertex_multiplicity_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream)>>>(
+      reinterpret_cast<const float2*>(xy), n_ls, counts, total, L, vstride, NV);
+  GNGF_RETURN_LAUNCH();
+}
+
+extern "C" int gngf_multiplicity_weights(const int32_t* counts, float* mw, int64_t NV, int L, float denom, void* stream) {
+  GNGF_CHECK_ARG(NV >= 0 && L > 0 && L <= GNGF_MAX_LEVELS && denom > 0.f);
+  if (NV == 0) return 0;
+  GNGF_CHECK_ARG(counts && mw);
+  multiplicity_weights_kernel<<<dim3((unsigned)ceil_div(NV * L, 256)), dim3(256), 0, as_stream(stream)>>>(counts, mw, NV, L, denom);
+  GNGF_RETURN_LAUNCH();
+}
+
+extern "C" int gngf_expand_vertex_table(const float* xy, const int32_t* n_ls, const int32_t* src_idx, const float* src_val,
+                                        int64_t* vid_out, int64_t* out_idx, float* out_val, int64_t P, int L, int K,
+                                        int vstride, int64_t NV, void* stream) {
+  GNGF_CHECK_ARG(P >= 0 && L > 0 && L <= GNGF_MAX_LEVELS && K >= 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0);
+  if (P == 0) return 0;
+  GNGF_CHECK_ARG(xy && n_ls && (!out_idx || src_idx) && (!out_val || src_val));
+  const int64_t total = P * L * 4;
+  expand_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream)>>>(
+      reinterpret_cast<const float2*>(xy), n_ls, src_idx, src_val, vid_out, out_idx, out_val, total, L, K, vstride, NV);
+  GNGF_RETURN_LAUNCH();
+}

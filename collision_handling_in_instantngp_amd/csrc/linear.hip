@@ -1,0 +1,199 @@
+// Generic fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain) for the
+// dense layers that are NOT covered by the fused decoder kernel: the HashProbDistribution MLP
+// (reference models.py:80-88,105-106) forward/backward, and decoders with non-default widths
+// (models.py:382-392).  One kernel, C (+)= opA(A) * opB(B) with optional bias / activation epilogue and an
+// optional activation-backward mask fused into the A loads (dZ = dY * act'(Y)).
+//
+// Tile: 64x64 per 256-thread block, one 32x32 accumulator per wave, BK = 16 staged through LDS with a
+// +1 padded stride (bank = (17*row + k) % 32: conflict-free ds_read_b32 for the one-float A/B operands).
+#include "gngf_common.h"
+
+namespace gngf {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_SIGMOID = 3 };
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  if (act == ACT_RELU) return fmaxf(z, 0.f);
+  if (act == ACT_LEAKY) return z > 0.f ? z : z * 0.01f;
+  if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-z));
+  return z;
+}
+// derivative expressed through the OUTPUT y of the activation
+__device__ __forceinline__ float act_bwd_from_y(float y, int act) {
+  if (act == ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (act == ACT_LEAKY) return y > 0.f ? 1.f : 0.01f;
+  if (act == ACT_SIGMOID) return y * (1.f - y);
+  return 1.f;
+}
+
+constexpr int BM = 64, BN = 64, BK = 16, LDSS = BK + 1;
+
+// A(m,k) = TA ? A[k*lda + m] : A[m*lda + k]     (optionally * act'(Ymask at the same index))
+// B(k,n) = TB ? B[n*ldb + k] : B[k*ldb + n]
+// grid = (ceil(N/64), ceil(M/64), splitk); each z-slice handles kchunk of the contraction and, when
+// splitk > 1, adds its partial tile with float atomics (C must be zero-filled; bias is added by slice 0).
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256)
+gemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+            int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+            const float* __restrict__ bias, int act, const float* __restrict__ amask, int mask_act,
+            int64_t kchunk, int atomic_out) {
+  __shared__ float As[BM * LDSS];
+  __shared__ float Bs[BN * LDSS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+  f32x16 acc = {0};
+  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+    // stage A tile [64][16] and B tile [64][16]; 1024 elements each, 4 per thread
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int li = tid + e * 256;
+      // A: choose the thread->element map so that the global reads are contiguous for either storage
+      int am, ak;
+      if (TA) { am = li & 63; ak = li >> 6; } else { ak = li & 15; am = li >> 4; }
+      const int64_t gm = m0 + am, gk = k0 + ak;
+      float av = 0.f;
+      if (gm < M && gk < kend) {
+        const int64_t ai = TA ? gk * lda + gm : gm * lda + gk;
+        av = A[ai];
+        if (amask) av *= act_bwd_from_y(amask[ai], mask_act);
+      }
+      As[am * LDSS + ak] = av;
+      int bn, bk;
+      if (TB) { bk = li & 15; bn = li >> 4; } else { bn = li & 63; bk = li >> 6; }
+      const int64_t gn = n0 + bn, gk2 = k0 + bk;
+      float bv = 0.f;
+      if (gn < N && gk2 < kend) bv = TB ? B[gn * ldb + gk2] : B[gk2 * ldb + gn];
+      Bs[bn * LDSS + bk] = bv;
+    }
+    __syncthreads();
+    const float* ap = As + (wm * 32 + (lane & 31)) * LDSS + (lane >> 5);
+    const float* bp = Bs + (wn * 32 + (lane & 31)) * LDSS + (lane >> 5);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk], acc, 0, 0, 0);
+    __syncthreads();
+  }
+  const int64_t col = n0 + wn * 32 + (lane & 31);
+  if (col >= N) return;
+  const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row >= M) continue;
+    float v = acc[r] + bv;
+    if (atomic_out) {
+      atomicAdd(C + row * ldc + col, v);
+    } else {
+      C[row * ldc + col] = act_fwd(v, act);
+    }
+  }
+}
+
+// column sums of dZ = dY * act'(Y):  db[n] = sum_m dZ[m][n].  grid.x = ceil(N/64), grid.y = row slices; atomics.
+__global__ void __launch_bounds__(256)
+colsum_kernel(const float* __restrict__ dY, const float* __restrict__ Ymask, int mask_act, float* __restrict__ db,
+              int64_t M, int64_t N, int64_t rows_per_block) {
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x, c = tid & 63, rsub = tid >> 6;
+  const int64_t col = (int64_t)blockIdx.x * 64 + c;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
+  float s = 0.f;
+  if (col < N)
+    for (int64_t r = r0 + rsub; r < r1; r += 4) {
+      float v = dY[r * N + col];
+      if (Ymask) v *= act_bwd_from_y(Ymask[r * N + col], mask_act);
+      s += v;
+    }
+  red[rsub][c] = s;
+  __syncthreads();
+  if (rsub == 0 && col < N) atomicAdd(db + col, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+}
+
+template <bool TA, bool TB>
+static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                       int64_t ldc, const float* bias, int act, const float* amask, int mask_act, int splitk,
+                       hipStream_t s, bool force_atomic = false) {
+  if (M == 0 || N == 0) return 0;
+  int64_t kchunk = K;
+  if (splitk > 1) {
+    kchunk = ceil_div(ceil_div(K, splitk), BK) * BK;
+    splitk = (int)ceil_div(K, kchunk);
+  } else {
+    splitk = 1;
+  }
+  dim3 grid((unsigned)ceil_div(N, BN), (unsigned)ceil_div(M, BM), (unsigned)splitk);
+  gemm_kernel<TA, TB><<<grid, dim3(256), 0, s>>>(A, B, C, M, N, K, lda, ldb, ldc, bias, act, amask, mask_act, kchunk,
+                                                (splitk > 1 || force_atomic) ? 1 : 0);
+  return (int)hipGetLastError();
+}
+
+}  // namespace gngf
+
+using namespace gngf;
+
+// Y[M,N] = act(X[M,K] * W[N,K]^T + b)          nn.Linear + activation (models.py:84-85, 386-389)
+extern "C" int gngf_linear_fwd(const float* X, const float* W, const float* b, float* Y, int64_t M, int N, int K, int act,
+                               void* stream) {
+  GNGF_CHECK_ARG(M >= 0 && N > 0 && K > 0 && act >= 0 && act <= 3);
+  if (M == 0) return 0;
+  GNGF_CHECK_ARG(X && W && Y);
+  return launch_gemm<false, true>(X, W, Y, M, N, K, K, K, N, b, act, nullptr, 0, 1, as_stream(stream));
+}
+
+// dX[M,K] = (dY .* act'(Y))[M,N] * W[N,K]      Y = the layer's activated output (NULL / act 0: no activation)
+extern "C" int gngf_linear_bwd_input(const float* dY, const float* Y, const float* W, float* dX, int64_t M, int N, int K,
+                                     int act, void* stream) {
+  GNGF_CHECK_ARG(M >= 0 && N > 0 && K > 0 && act >= 0 && act <= 3);
+  if (M == 0) return 0;
+  GNGF_CHECK_ARG(dY && W && dX && (act == 0 || Y));
+  return launch_gemm<false, false>(dY, W, dX, M, K, N, N, K, K, nullptr, 0, act ? Y : nullptr, act, 1, as_stream(stream));
+}
+
+// dW[N,K] += (dY .* act'(Y))^T * X ;  db[N] += colsum(dY .* act'(Y)).   dW and db must be zero-filled by the caller
+// when a fresh gradient is wanted (split over the M contraction, accumulated with float atomics).
+extern "C" int gngf_linear_bwd_weight(const float* dY, const float* Y, const float* X, float* dW, float* db, int64_t M, int N,
+                                      int K, int act, void* stream) {
+  GNGF_CHECK_ARG(M >= 0 && N > 0 && K > 0 && act >= 0 && act <= 3);
+  if (M == 0) return 0;
+  GNGF_CHECK_ARG(dY && X && dW && (act == 0 || Y));
+  const int64_t tiles = ceil_div(N, BM) * ceil_div(K, BN);
+  int splitk = (int)((1024 + tiles - 1) / tiles);
+  const int64_t max_split = ceil_div(M, 256);
+  if (splitk > max_split) splitk = (int)max_split;
+  int rc = launch_gemm<true, false>(dY, X, dW, N, K, M, N, K, K, nullptr, 0, act ? Y : nullptr, act, splitk, as_stream(stream),
+                                    /*force_atomic=*/true);
+  if (rc) return rc;
+  if (db) {
+    const int64_t rows_per_block = 2048;
+    dim3 grid((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, rows_per_block));
+    colsum_kernel<<<grid, dim3(256), 0, as_stream(stream)>>>(dY, act ? Y : nullptr, act, db, M, N, rows_per_block);
+  }
+  GNGF_RETURN_LAUNCH();
+}
+
+// General accumulate-GEMM used by the HPD path:  C[M,N] += opA(A) * opB(B), contraction length Kc split over
+// blocks (float atomics; C zero-filled by the caller for a fresh result).
+//   ta = 0: A is (M,Kc) row-major, ta = 1: A is (Kc,M) row-major;  tb = 0: B is (Kc,N), tb = 1: B is (N,Kc).
+extern "C" int gngf_gemm_acc(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kc, int ta, int tb,
+                             void* stream) {
+  GNGF_CHECK_ARG(M >= 0 && N >= 0 && Kc >= 0);
+  if (M == 0 || N == 0 || Kc == 0) return 0;
+  GNGF_CHECK_ARG(A && B && C);
+  const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
+  int splitk = (int)ceil_div(1024, tiles);
+  const int64_t max_split = ceil_div(Kc, 64);
+  if (splitk > max_split) splitk = (int)max_split;
+  if (splitk < 1) splitk = 1;
+  const int64_t lda = ta ? M : Kc, ldb = tb ? Kc : N;
+  hipStream_t s = as_stream(stream);
+  if (!ta && !tb) return launch_gemm<false, false>(A, B, C, M, N, Kc, lda, ldb, N, nullptr, 0, nullptr, 0, splitk, s, true);
+  if (!ta && tb) return launch_gemm<false, true>(A, B, C, M, N, Kc, lda, ldb, N, nullptr, 0, nullptr, 0, splitk, s, true);
+  if (ta && !tb) return launch_gemm<true, false>(A, B, C, M, N, Kc, lda, ldb, N, nullptr, 0, nullptr, 0, splitk, s, true);
+  return launch_gemm<true, true>(A, B, C, M, N, Kc, lda, ldb, N, nullptr, 0, nullptr, 0, splitk, s, true);
+}

@@ -1,0 +1,332 @@
+"""Drop-in module classes for the reference's hot path (reference models.py), backed by gfx950 HIP kernels.
+
+Same class names, constructor signatures, forward signatures, return contracts and state-dict keys as the
+reference:
+    DifferentiableTopk         models.py:5-42
+    HashProbDistribution       models.py:45-123
+    MultiResHashEncoding       models.py:126-236
+    GeneralNeuralGaugeFields   models.py:239-655
+Behaviour switches are module globals read at call time, as in the reference (see params.py).
+
+What is different inside: GeneralNeuralGaugeFields.forward never builds per-instance tensors.
+HashProbDistribution is evaluated once per DISTINCT grid vertex (its input is the integer vertex only,
+models.py:416-418), the top-K of each vertex becomes a per-vertex table, and one fused kernel does
+corners + lookup + blend + bilinear interpolation.  The reference-shaped outputs (probs, indices) are
+expanded from the per-vertex tables on request.  There is no CPU path: forward on CPU tensors raises.
+"""
+from typing import Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .params import *  # noqa: F401,F403  (module-global behaviour switches, as in the reference)
+
+device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
+# Largest reference-shaped dense tensor the module materialises on request (the (P,L,4,T) distribution).
+DENSE_OUTPUT_LIMIT_BYTES = 4 << 30
+# Row-chunk budget of the per-vertex (rows, T) distribution scratch.
+HPD_CHUNK_BYTES = 4 << 30
+
+
+def level_resolutions(n_min: int, n_max: int, num_levels: int) -> np.ndarray:
+    """reference models.py:305-317 — identical float64 numpy expression (4096 -> 4095 at the last level)."""
+    b = np.exp((np.log(n_max) - np.log(n_min)) / (num_levels - 1))
+    return np.array([np.floor(n_min * b ** l) for l in range(num_levels)]).astype(np.int32)
+
+
+class DifferentiableTopk(torch.autograd.Function):
+    """reference models.py:5-42: torch.topk forward; backward scatters the K gradients into a zero tensor.
+    Kept for API compatibility on small (rows, T) inputs; the hot path folds this into softmax backward."""
+
+    @staticmethod
+    def forward(ctx, input: torch.Tensor, k: int, dim: int):
+        if dim not in (-1, input.dim() - 1):
+            raise ValueError("DifferentiableTopk: only the last dimension is supported")
+        x = input.reshape(-1, input.shape[-1]).contiguous()
+        U, T = x.shape
+        vals = torch.empty((U, k), dtype=torch.float32, device=x.device)
+        idx = torch.empty((U, k), dtype=torch.int32, device=x.device)
+        ops.call("gngf_topk", ops.ptr(x, torch.float32, "input"), ops.ptr(vals), ops.ptr(idx), U, T, k, ops.stream_ptr())
+        idx64 = idx.to(torch.int64).reshape(*input.shape[:-1], k)
+        ctx.save_for_backward(idx64)
+        ctx.in_shape = input.shape
+        ctx.mark_non_differentiable(idx64)
+        return vals.reshape(*input.shape[:-1], k), idx64
+
+    @staticmethod
+    def backward(ctx, grad_values, grad_indices):
+        (idx,) = ctx.saved_tensors
+        g = torch.zeros(ctx.in_shape, dtype=grad_values.dtype, device=grad_values.device)
+        g.scatter_(-1, idx, grad_values)
+        return g, None, None
+
+
+class HashProbDistribution(nn.Module):
+    """reference models.py:45-123.  Same parameters / state-dict keys (module_list.{i}.0.{weight,bias})."""
+
+    def __init__(self, hidden_layers_widths: list, in_features: int = 2, out_features: int = 2 ** 14, k: int = 1,
+                 topk_dim: int = -1, should_log: bool = False):
+        super().__init__()
+        self.out_features = out_features
+        self._k = k
+        self._topk_dim = topk_dim
+        self._should_log = should_log
+        widths = [in_features, *hidden_layers_widths, out_features]
+        self.module_list = nn.ModuleList([
+            nn.Sequential(nn.Linear(widths[i], widths[i + 1]),
+                          nn.ReLU() if i < len(widths) - 2 else nn.Softmax(dim=-1))
+            for i in range(len(widths) - 1)
+        ])
+
+    def flat_params(self):
+        out = []
+        for seq in self.module_list:
+            out += [seq[0].weight, seq[0].bias]
+        return out
+
+    def forward(self, x: torch.Tensor) -> Tuple:
+        """x (..., in_features) -> (probs (..., T), topk_probs (..., K), topk_indices (..., K) int64) — the
+        per-row formulation of the reference (dense distribution), on the HIP GEMM / softmax / top-K kernels."""
+        lead = x.shape[:-1]
+        rows = x.reshape(-1, x.shape[-1])
+        n = len(self.module_list)
+        acts = tuple([ops.ACT_RELU] * (n - 1) + [ops.ACT_NONE])
+        logits = ops.MlpFunction.apply(rows, acts, *self.flat_params())
+        probs, tp, ti = ops.SoftmaxTopkFunction.apply(logits, self._k)
+        T = probs.shape[-1]
+        return probs.reshape(*lead, T), tp.reshape(*lead, self._k), ti.to(torch.int64).reshape(*lead, self._k)
+
+
+class MultiResHashEncoding(nn.Module):
+    """reference models.py:126-236.  L tables (T,F) addressable as `_hash_tables[l].weight`
+    (state-dict keys `_hash_tables.{l}.weight`), stored as views of ONE contiguous (L,T,F) buffer so that the
+    kernels see a single base pointer."""
+
+    def __init__(self, hash_table_size: int, num_levels: int, feature_dim: int = 2, topk_k: int = 4,
+                 should_log: bool = False) -> None:
+        super().__init__()
+        self._hash_table_size = hash_table_size
+        self._num_levels = num_levels
+        self._feature_dim = feature_dim
+        self._topk_k = topk_k
+        self._should_log = should_log
+        base = torch.empty((num_levels, hash_table_size, feature_dim), dtype=torch.float32, device=device)
+        base.uniform_(-10.0 ** (-4), 10.0 ** (-4))                       # models.py:169
+        self._hash_tables = nn.ModuleList([nn.Embedding(hash_table_size, feature_dim, _weight=base[l])
+                                           for l in range(num_levels)])
+        self._base = base
+
+    def _apply_init(self, init_func, *args):
+        for i in range(self._num_levels):
+            init_func(self._hash_tables[i].weight, *args)
+
+    def packed_tables(self) -> torch.Tensor:
+        """The contiguous (L,T,F) storage behind the L parameters; re-packs (keeping the Parameter objects,
+        hence optimizer state) if something — .to(), .cuda(), load with assign — split the storage."""
+        ws = [m.weight for m in self._hash_tables]
+        L, T, F = self._num_levels, self._hash_table_size, self._feature_dim
+        base = self._base
+        stride = T * F * 4
+        ok = (base.device == ws[0].device and base.is_contiguous()
+              and all(w.data_ptr() == base.data_ptr() + l * stride and w.is_contiguous() for l, w in enumerate(ws)))
+        if not ok:
+            base = torch.stack([w.detach() for w in ws]).contiguous()
+            for l, w in enumerate(ws):
+                w.data = base[l]
+            self._base = base
+        return base
+
+    def forward(self, hashed_indices: torch.Tensor, hashed_probs_topk: torch.Tensor, should_calc_counts: bool = False):
+        """hashed_indices (P,L,4) [hash] or (P,L,4,K) [GNGF] int64; hashed_probs_topk (P,L,4,K) | None -> (P,F,L,4)."""
+        base = self.packed_tables()
+        tables = ops.TableViewFunction.apply(base, *[m.weight for m in self._hash_tables])
+        if should_use_hash_function:
+            if hashed_indices.dim() != 3:
+                raise ValueError("hash mode expects indices of shape (P, L, 4)")
+            return ops.MrheFunction.apply(tables, hashed_indices, None, 0)
+        if hashed_indices.dim() != 4:
+            raise ValueError("GNGF mode expects indices of shape (P, L, 4, K)")
+        return ops.MrheFunction.apply(tables, hashed_indices, hashed_probs_topk, ops.BLEND_CODES[should_softmax_topk_features])
+
+
+class VertexDistribution:
+    """Compact stand-in for the reference's dense (P,L,4,T) `probs` when it would not fit in memory:
+    per-vertex rows are never expanded; `pbar` (L,T) is the batch-mean distribution the loss needs
+    (reference utils.py:138,159).  `shape` mirrors the dense tensor's shape."""
+
+    def __init__(self, shape, pbar, topk_probs):
+        self.shape = torch.Size(shape)
+        self.pbar = pbar
+        self.topk_probs = topk_probs
+
+    def clone(self):
+        return self
+
+
+class GeneralNeuralGaugeFields(nn.Module):
+    """reference models.py:239-655 — same constructor, forward(x, batch_percentage, should_calc_counts) and
+    4-tuple return.  Extra (keyword-only, optional) attributes control what the reference-shaped outputs cost:
+        return_indices   (default True)  materialise the (P,L,4[,K]) int64 index tensor of the return contract
+        dense_probs      (default 'auto') materialise the (P,L,4,T) distribution when it fits DENSE_OUTPUT_LIMIT_BYTES
+        coord_bounds     (default None)  (max_row, max_col) of the coordinates if known: skips one device sync/step
+    """
+
+    def __init__(self, input_dim, hash_table_size: int, num_levels: int, n_min: int, n_max: int,
+                 MLP_hidden_layers_widths: list, HPD_hidden_layers_widths: list, HPD_out_features: int = 1,
+                 feature_dim: int = 2, topk_k: int = 4, should_keep_topk_only: bool = False, should_bw: bool = False,
+                 should_log: bool = False, HPD_weights_path: str = None, encoding_weights_path: str = None):
+        super().__init__()
+        if input_dim != 2:
+            raise ValueError("the gfx950 path implements the reference's 2-D image case (input_dim == 2)")
+        self._hash_table_size = hash_table_size
+        self._num_levels = num_levels
+        self._n_min = n_min
+        self._n_max = n_max
+        self._feature_dim = feature_dim
+        self._input_dim = input_dim
+        self._topk_k = topk_k
+        self._should_log = should_log
+        self._should_keep_topk_only = should_keep_topk_only
+
+        b = np.exp((np.log(n_max) - np.log(n_min)) / (num_levels - 1))
+        if b > 2 or b <= 1:                                                # models.py:306-309
+            print(f"The between level scale is recommended to be <= 2 and needs to be > 1 but was {b:.4f}.")
+        self._n_ls = torch.from_numpy(level_resolutions(n_min, n_max, num_levels)).reshape(1, 1, -1, 1).to(device).int()
+        cube = np.array([[0, 1, 0, 1], [0, 0, 1, 1]], dtype=np.int32)       # models.py:322-331
+        self._voxels_helper_hypercube = torch.from_numpy(cube).unsqueeze(0).unsqueeze(2).to(device).int()
+
+        self._batch_norm = nn.BatchNorm1d(input_dim)
+        if should_use_hash_function:
+            self._prime_numbers = nn.Parameter(torch.from_numpy(np.array([1, 2654435761, 805459861])).to(device), False)
+        else:
+            self.HPD = HashProbDistribution(HPD_hidden_layers_widths, in_features=input_dim,
+                                            out_features=HPD_out_features, k=topk_k, topk_dim=-1)
+            if HPD_weights_path is not None:                               # models.py:364-371
+                self.HPD.load_state_dict(torch.load(HPD_weights_path))
+                for _name, param in self.HPD.named_parameters():
+                    param.requires_grad = False
+        self.encoding = MultiResHashEncoding(hash_table_size, num_levels, feature_dim, topk_k, should_log)
+        widths = [num_levels * feature_dim, *MLP_hidden_layers_widths, (3 if not should_bw else 1)]
+        self._MLP_hidden_layers_widths = widths
+        self.mlp = nn.ModuleList([
+            nn.Sequential(nn.Linear(widths[i], widths[i + 1]),
+                          (nn.LeakyReLU() if should_leaky_relu else nn.ReLU()) if i < len(widths) - 2 else nn.Sigmoid())
+            for i in range(len(widths) - 1)
+        ])
+        self._hash_mode = bool(should_use_hash_function)
+        self._leaky = bool(should_leaky_relu)
+        self.return_indices = True
+        self.dense_probs = "auto"
+        self.coord_bounds = None
+        self._frozen_table = None          # cached per-vertex (idx, w, q) when the HPD is frozen
+        self.to(device)
+
+    # ------------------------------------------------------------------ helpers
+    def _n_ls_flat(self, dev):
+        if self._n_ls.device != dev:
+            self._n_ls = self._n_ls.to(dev)
+        return self._n_ls.reshape(-1)
+
+    def _decoder_params(self):
+        out = []
+        for seq in self.mlp:
+            out += [seq[0].weight, seq[0].bias]
+        return out
+
+    def _decode(self, enc):
+        n = len(self.mlp)
+        hidden = ops.ACT_LEAKY if self._leaky else ops.ACT_RELU
+        return ops.decoder_apply(enc, tuple([hidden] * (n - 1) + [ops.ACT_SIGMOID]), self._decoder_params())
+
+    def _vertex_extent(self, x):
+        """(vstride, NV) of the dense per-vertex table covering every corner of every level for this batch."""
+        if self.coord_bounds is not None:
+            mx, my = self.coord_bounds
+        else:
+            mx, my = x.amax(0).tolist()                                     # one host sync
+        gx_hi = int(np.floor(np.float32(mx) * np.float32(self._n_max))) + 1
+        gy_hi = int(np.floor(np.float32(my) * np.float32(self._n_max))) + 1
+        return gx_hi + 1, (gx_hi + 1) * (gy_hi + 1)
+
+    def hpd_is_frozen(self):
+        return all(not p.requires_grad for p in self.HPD.parameters())
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, batch_percentage: float = 1.0, should_calc_counts: bool = False):
+        if should_batchnorm_data:
+            x = self._batch_norm(x)
+        x = x.contiguous()
+        dev = x.device
+        n_ls = self._n_ls_flat(dev)
+        base = self.encoding.packed_tables()
+        tables = ops.TableViewFunction.apply(base, *[m.weight for m in self.encoding._hash_tables])
+        P, L, T, K = x.shape[0], self._num_levels, self._hash_table_size, self._topk_k
+
+        if self._hash_mode:
+            enc = ops.encode_apply(x, n_ls, tables, None, None, 0)
+            rgb = self._decode(enc)
+            idx = ops.hash_indices(x.detach(), n_ls, T) if (self.return_indices or should_calc_counts) else None
+            counts = self._calc_counts_per_level(idx, x, n_ls) if should_calc_counts else []
+            return rgb, None, idx, counts
+
+        vstride, NV = self._vertex_extent(x.detach())
+        keep_topk = self._should_keep_topk_only
+        dense_bytes = P * L * 4 * T * 4
+        want_dense = (not keep_topk) and (self.dense_probs is True or (self.dense_probs == "auto" and dense_bytes <= DENSE_OUTPUT_LIMIT_BYTES))
+        need_pbar = (not keep_topk) and not want_dense
+        mw = ops.vertex_multiplicity_weights(x.detach(), n_ls, vstride, NV) if need_pbar else None
+        tv, ti, pbar, probs_u = ops.HpdVertexFunction.apply(NV, vstride, K, mw, want_dense, HPD_CHUNK_BYTES,
+                                                            *self.HPD.flat_params())
+        w = ops.BlendFunction.apply(tv, ops.BLEND_CODES[should_softmax_topk_features])
+        enc = ops.encode_apply(x, n_ls, tables, ti, w, vstride)
+        rgb = self._decode(enc)
+
+        need_vid = want_dense or keep_topk or should_calc_counts
+        vid, idx64, _ = ops.expand_vertex_table(x.detach(), n_ls, vstride, NV,
+                                                src_idx=ti if (self.return_indices or should_calc_counts) else None,
+                                                want_vid=need_vid)
+        if keep_topk:
+            to_return_probs = tv[vid]                                       # (P,L,4,K), differentiable gather
+        elif want_dense:
+            to_return_probs = probs_u[vid]                                  # (P,L,4,T), differentiable gather
+        else:
+            to_return_probs = VertexDistribution((P, L, 4, T), pbar, tv)
+        counts = self._calc_counts_per_level(idx64[..., 0], x, n_ls) if should_calc_counts else []
+        return rgb, to_return_probs, idx64, counts
+
+    # ------------------------------------------------------------------ diagnostics (no-grad statistics, not kernels)
+    @torch.no_grad()
+    def _calc_counts_per_level(self, hash_idx, x, n_ls):
+        """reference models.py:530-566: per level, Counter of the slot of the first corner... of the DISTINCT cells."""
+        from collections import Counter
+        vid, _, _ = ops.expand_vertex_table(x, n_ls, self._n_max + 2, (self._n_max + 2) ** 2, want_vid=True)
+        out = []
+        for l in range(self._num_levels):
+            cells = vid[:, l, :].cpu().numpy()
+            _, first = np.unique(cells, axis=0, return_index=True)
+            out.append(dict(Counter(hash_idx[:, l].reshape(hash_idx.shape[0], -1)[first].reshape(-1).cpu().numpy().tolist())))
+        return out
+
+    @torch.no_grad()
+    def calc_hash_collisions(self, indices: torch.Tensor):
+        """reference models.py:568-619: (#vertices of the level) - (#distinct slots used), per level."""
+        n = self._n_ls.reshape(-1).cpu().numpy().astype(np.int64)
+        nverts = 4 + (n + 1 - 2) * 4 + (n + 1 - 2) ** 2                      # = (N_l + 1)^2
+        L = self._num_levels
+        if self._hash_mode:
+            per_level = indices.permute(1, 0, 2).reshape(L, -1)
+            coll = torch.tensor([int(nverts[i]) - int(torch.unique(per_level[i]).numel()) for i in range(L)])
+        else:
+            Kk = indices.shape[-1]
+            coll = torch.empty((Kk, L), device=indices.device)
+            for k in range(Kk):
+                per_level = indices[..., k].permute(1, 0, 2).reshape(L, -1)
+                coll[k] = torch.tensor([float(int(nverts[i]) - int(torch.unique(per_level[i]).numel())) for i in range(L)])
+            coll = coll.mean(0)
+            coll[coll < 0] = 0
+        min_possible = torch.tensor(nverts - self._hash_table_size).to(indices.device)
+        min_possible[min_possible < 0] = 0
+        return coll, min_possible

@@ -110,3 +110,254 @@ class EncodeDirectFunction(torch.autograd.Function):
         call("gngf_encode_bwd", ptr(xy), ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc, _f32, "grad"),
              ptr(dtables), ptr(dvw), P, L, F, T, K, mode, vstride, NV, stream_ptr())
         return None, None, dtables, None, dvw, None
+
+
+# ------------------------------------------------------------------------------------------------ dense layers
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
+
+
+def linear_fwd(x, w, b, act):
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=_f32, device=x.device)
+    call("gngf_linear_fwd", ptr(x, _f32, "x"), ptr(w, _f32, "weight"), ptr(b, _f32, "bias"), ptr(y), M, N, K, act, stream_ptr())
+    return y
+
+
+def linear_bwd_input(dy, y, w, act):
+    M, N = dy.shape
+    K = w.shape[1]
+    dx = torch.empty((M, K), dtype=_f32, device=dy.device)
+    call("gngf_linear_bwd_input", ptr(dy, _f32), ptr(y if act else None, _f32), ptr(w, _f32), ptr(dx), M, N, K, act, stream_ptr())
+    return dx
+
+
+def linear_bwd_weight(dy, y, x, dw, db, act):
+    """Accumulates into dw (N,K) and db (N,)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    call("gngf_linear_bwd_weight", ptr(dy, _f32), ptr(y if act else None, _f32), ptr(x, _f32), ptr(dw, _f32), ptr(db, _f32),
+         M, N, K, act, stream_ptr())
+
+
+def gemm_acc(a, b, c, M, N, Kc, ta, tb):
+    call("gngf_gemm_acc", ptr(a, _f32), ptr(b, _f32), ptr(c, _f32), M, N, Kc, int(ta), int(tb), stream_ptr())
+
+
+class MlpFunction(torch.autograd.Function):
+    """Chain of nn.Linear + activation on the generic MFMA GEMM (reference models.py:382-392 / 80-88).
+    apply(x, acts, w0, b0, w1, b1, ...) with acts a tuple of ACT_* codes, one per layer."""
+
+    @staticmethod
+    def forward(ctx, x, acts, *params):
+        x = _c(x)
+        hs = [x]
+        for i, act in enumerate(acts):
+            hs.append(linear_fwd(hs[-1], _c(params[2 * i]), _c(params[2 * i + 1]), act))
+        ctx.acts = acts
+        ctx.save_for_backward(*hs, *params)
+        return hs[-1]
+
+    @staticmethod
+    def backward(ctx, gy):
+        n = len(ctx.acts)
+        hs, params = ctx.saved_tensors[: n + 1], ctx.saved_tensors[n + 1:]
+        g = _c(gy)
+        grads = [None] * (2 * n)
+        for i in range(n - 1, -1, -1):
+            w = _c(params[2 * i])
+            dw, db = torch.zeros_like(w), torch.zeros_like(params[2 * i + 1])
+            linear_bwd_weight(g, hs[i + 1], hs[i], dw, db, ctx.acts[i])
+            grads[2 * i], grads[2 * i + 1] = dw, db
+            if i > 0 or ctx.needs_input_grad[0]:
+                g = linear_bwd_input(g, hs[i + 1], w, ctx.acts[i])
+        return (g if ctx.needs_input_grad[0] else None, None, *grads)
+
+
+# ------------------------------------------------------------------------------------------------ HPD per distinct vertex
+def vertex_coords(u0, count, vstride, device):
+    v = torch.empty((count, 2), dtype=_f32, device=device)
+    call("gngf_vertex_coords", ptr(v), u0, count, vstride, stream_ptr())
+    return v
+
+
+def vertex_multiplicity_weights(xy, n_ls, vstride, NV):
+    """mw (NV, L) = (#instances of vertex u at level l) / (4 P): weights of the batch-mean distribution."""
+    xy = _c(xy)
+    P, L = xy.shape[0], n_ls.numel()
+    counts = torch.zeros((L, NV), dtype=_i32, device=xy.device)
+    call("gngf_vertex_multiplicity", ptr(xy, _f32), ptr(n_ls, _i32), ptr(counts), P, L, vstride, NV, stream_ptr())
+    mw = torch.empty((NV, L), dtype=_f32, device=xy.device)
+    call("gngf_multiplicity_weights", ptr(counts), ptr(mw), NV, L, float(4 * P), stream_ptr())
+    return mw
+
+
+def expand_vertex_table(xy, n_ls, vstride, NV, src_idx=None, src_val=None, want_vid=False):
+    """(P,L,4[,K]) reference-shaped tensors from per-vertex (NV,K) tables (reference return contract models.py:478-484)."""
+    xy = _c(xy)
+    P, L = xy.shape[0], n_ls.numel()
+    K = src_idx.shape[1] if src_idx is not None else (src_val.shape[1] if src_val is not None else 0)
+    dev = xy.device
+    vid = torch.empty((P, L, 4), dtype=_i64, device=dev) if want_vid else None
+    oi = torch.empty((P, L, 4, K), dtype=_i64, device=dev) if src_idx is not None else None
+    ov = torch.empty((P, L, 4, K), dtype=_f32, device=dev) if src_val is not None else None
+    call("gngf_expand_vertex_table", ptr(xy, _f32), ptr(n_ls, _i32), ptr(src_idx, _i32), ptr(src_val, _f32), ptr(vid), ptr(oi),
+         ptr(ov), P, L, K, vstride, NV, stream_ptr())
+    return vid, oi, ov
+
+
+class HpdVertexFunction(torch.autograd.Function):
+    """HashProbDistribution (reference models.py:45-123) evaluated ONCE PER DISTINCT VERTEX u (vid = gy*vstride+gx,
+    u in [0, NV)), in row chunks so that the (rows, T) distribution never exceeds `chunk_bytes`.
+
+    apply(NV, vstride, K, mw, keep_probs, chunk_bytes, *params) ->
+        topk_val (NV,K), topk_idx (NV,K) int32, pbar (L,T) | None, probs (NV,T) | None
+    pbar_l = sum_u mw[u,l] * probs[u]  is the batch-mean distribution of utils.py:138,159 (mw = multiplicity/(4P)).
+    Backward recomputes each chunk (hidden layers, logits, softmax) and folds the top-K gradient and the
+    low-rank p-bar gradient into the softmax backward: the dense (P,L,4,T) zero-filled scatter of
+    models.py:27-35 never exists."""
+
+    @staticmethod
+    def _hidden(verts, params, n_layers):
+        hs = [verts]
+        for i in range(n_layers - 1):
+            hs.append(linear_fwd(hs[-1], params[2 * i], params[2 * i + 1], ACT_RELU))
+        return hs
+
+    @staticmethod
+    def forward(ctx, NV, vstride, K, mw, keep_probs, chunk_bytes, *params):
+        params = tuple(_c(p) for p in params)
+        n_layers = len(params) // 2
+        W_last, b_last = params[-2], params[-1]
+        T = W_last.shape[0]
+        dev = W_last.device
+        rows = int(max(64, min(NV, chunk_bytes // (4 * T))))
+        tv = torch.empty((NV, K), dtype=_f32, device=dev)
+        ti = torch.empty((NV, K), dtype=_i32, device=dev)
+        probs = torch.empty((NV, T), dtype=_f32, device=dev) if keep_probs else None
+        pbar = None
+        if mw is not None:
+            mw = _c(mw)
+            L = mw.shape[1]
+            pbar = torch.zeros((L, T), dtype=_f32, device=dev)
+        scratch = None if keep_probs else torch.empty((min(rows, NV), T), dtype=_f32, device=dev)
+        for u0 in range(0, NV, rows):
+            n = min(rows, NV - u0)
+            hs = HpdVertexFunction._hidden(vertex_coords(u0, n, vstride, dev), params, n_layers)
+            z = probs[u0:u0 + n] if keep_probs else scratch[:n]
+            call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(z), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
+            call("gngf_softmax_topk", ptr(z), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), n, T, K, stream_ptr())
+            if pbar is not None:
+                gemm_acc(mw[u0:u0 + n], z, pbar, L, T, n, ta=True, tb=False)
+        ctx.cfg = (NV, vstride, K, rows, n_layers, T, keep_probs)
+        ctx.save_for_backward(ti, mw, probs, *params)
+        ctx.mark_non_differentiable(ti)
+        return tv, ti, pbar, probs
+
+    @staticmethod
+    def backward(ctx, g_tv, g_ti, g_pbar, g_probs):
+        NV, vstride, K, rows, n_layers, T, keep_probs = ctx.cfg
+        ti, mw, probs = ctx.saved_tensors[:3]
+        params = ctx.saved_tensors[3:]
+        W_last, b_last = params[-2], params[-1]
+        dev = W_last.device
+        grads = [torch.zeros_like(p) for p in params]
+        g_tv = _c(g_tv) if g_tv is not None else None
+        g_pbar = _c(g_pbar) if (g_pbar is not None and mw is not None) else None
+        g_probs = _c(g_probs) if g_probs is not None else None
+        L = mw.shape[1] if mw is not None else 0
+        dz_buf = torch.empty((min(rows, NV), T), dtype=_f32, device=dev)
+        for u0 in range(0, NV, rows):
+            n = min(rows, NV - u0)
+            hs = HpdVertexFunction._hidden(vertex_coords(u0, n, vstride, dev), params, n_layers)
+            dz = dz_buf[:n]
+            if keep_probs:
+                p_chunk = probs[u0:u0 + n]
+            else:   # recompute logits + softmax in the scratch (top-K indices are the saved ones)
+                call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(dz), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
+                tv_tmp = torch.empty((n, K), dtype=_f32, device=dev)
+                ti_tmp = torch.empty((n, K), dtype=_i32, device=dev)
+                call("gngf_softmax_topk", ptr(dz), ptr(tv_tmp), ptr(ti_tmp), n, T, K, stream_ptr())
+                p_chunk = dz
+            call("gngf_softmax_bwd", ptr(p_chunk), ptr(g_tv[u0:u0 + n] if g_tv is not None else None), ptr(ti[u0:u0 + n]),
+                 ptr(g_probs[u0:u0 + n] if g_probs is not None else None),
+                 ptr(mw[u0:u0 + n] if g_pbar is not None else None), ptr(g_pbar), L, ptr(dz), n, T,
+                 K if g_tv is not None else 0, stream_ptr())
+            linear_bwd_weight(dz, None, hs[-1], grads[-2], grads[-1], ACT_NONE)
+            g = torch.zeros((n, W_last.shape[1]), dtype=_f32, device=dev)
+            gemm_acc(dz, W_last, g, n, W_last.shape[1], T, ta=False, tb=False)     # dh = dz @ W_last, split over T
+            for i in range(n_layers - 2, -1, -1):
+                linear_bwd_weight(g, hs[i + 1], hs[i], grads[2 * i], grads[2 * i + 1], ACT_RELU)
+                if i > 0:
+                    g = linear_bwd_input(g, hs[i + 1], params[2 * i], ACT_RELU)
+        return (None, None, None, None, None, None, *grads)
+
+
+class BlendFunction(torch.autograd.Function):
+    """w = blend(q) over the K top slots of each vertex (reference models.py:212-217)."""
+
+    @staticmethod
+    def forward(ctx, q, blend_code):
+        q = _c(q)
+        w = torch.empty_like(q)
+        call("gngf_blend_fwd", ptr(q, _f32), ptr(w), q.shape[0], q.shape[1], blend_code, stream_ptr())
+        ctx.save_for_backward(q)
+        ctx.blend_code = blend_code
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        (q,) = ctx.saved_tensors
+        dq = torch.empty_like(q)
+        call("gngf_blend_bwd", ptr(q), ptr(_c(dw), _f32), ptr(dq), q.shape[0], q.shape[1], ctx.blend_code, stream_ptr())
+        return dq, None
+
+
+class SoftmaxTopkFunction(torch.autograd.Function):
+    """Softmax(dim=-1) + nan_to_num + top-K on dense rows (reference models.py:85,111,116) for the standalone
+    HashProbDistribution.forward.  apply(logits (U,T), K) -> probs (U,T), topk_probs (U,K), topk_idx (U,K) int32."""
+
+    @staticmethod
+    def forward(ctx, logits, K):
+        probs = logits.detach().clone().contiguous()
+        U, T = probs.shape
+        tv = torch.empty((U, K), dtype=_f32, device=probs.device)
+        ti = torch.empty((U, K), dtype=_i32, device=probs.device)
+        call("gngf_softmax_topk", ptr(probs, _f32, "logits"), ptr(tv), ptr(ti), U, T, K, stream_ptr())
+        ctx.save_for_backward(probs, ti)
+        ctx.mark_non_differentiable(ti)
+        return probs, tv, ti
+
+    @staticmethod
+    def backward(ctx, g_probs, g_tv, g_ti):
+        probs, ti = ctx.saved_tensors
+        U, T = probs.shape
+        K = ti.shape[1]
+        dz = torch.empty_like(probs)
+        call("gngf_softmax_bwd", ptr(probs), ptr(_c(g_tv) if g_tv is not None else None, _f32), ptr(ti),
+             ptr(_c(g_probs) if g_probs is not None else None, _f32), ptr(None), ptr(None), 0, ptr(dz), U, T,
+             K if g_tv is not None else 0, stream_ptr())
+        return dz, None
+
+
+class TableViewFunction(torch.autograd.Function):
+    """Presents the L per-level Parameters (`_hash_tables.{l}.weight`, views of one buffer) to the kernels as ONE
+    (L,T,F) tensor and routes the (L,T,F) gradient back to the L parameters as views (no copies)."""
+
+    @staticmethod
+    def forward(ctx, base, *weights):
+        return base.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, *[g[l] for l in range(g.shape[0])])
+
+
+def encode_apply(xy, n_ls, tables, vert_idx, vert_w, vstride):
+    """Fused encoder dispatch (direct form; the tiled/LDS form takes over for levels it can stage)."""
+    return EncodeDirectFunction.apply(xy, n_ls, tables, vert_idx, vert_w, vstride)
+
+
+def decoder_apply(enc, acts, params):
+    """Decoder MLP dispatch (reference models.py:382-392,469-470)."""
+    return MlpFunction.apply(enc, acts, *params)

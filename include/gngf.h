@@ -70,6 +70,46 @@ int gngf_encode_bwd(const float* xy, const float* tables, const int32_t* vert_id
                     const int32_t* n_ls, const float* genc, float* dtables, float* dvert_w,
                     int64_t P, int L, int F, int64_t T, int K, int mode, int vstride, int64_t NV, void* stream);
 
+/* ---- dense layers on the matrix cores (exact-fp32 MFMA).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.01), 3 Sigmoid.
+ * nn.Linear + activation of HashProbDistribution (models.py:80-88,105-106) and of the decoder (models.py:382-392). */
+int gngf_linear_fwd(const float* X, const float* W, const float* b, float* Y, int64_t M, int N, int K, int act, void* stream);
+/* dX[M,K] = (dY .* act'(Y)) W ;  Y = activated output of the layer (may be NULL when act == 0) */
+int gngf_linear_bwd_input(const float* dY, const float* Y, const float* W, float* dX, int64_t M, int N, int K, int act,
+                          void* stream);
+/* dW[N,K] += (dY .* act'(Y))^T X ; db[N] += column sums.  Accumulates (float atomics): zero-fill for a fresh gradient. */
+int gngf_linear_bwd_weight(const float* dY, const float* Y, const float* X, float* dW, float* db, int64_t M, int N, int K,
+                           int act, void* stream);
+/* C[M,N] += opA(A) opB(B), contraction Kc split over blocks.  ta: A stored (Kc,M); tb: B stored (N,Kc). */
+int gngf_gemm_acc(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kc, int ta, int tb, void* stream);
+
+/* ---- a7/a8 tail, per DISTINCT vertex: Softmax(dim=-1) + nan_to_num + top-K (models.py:85,111,116; 5-19).
+ * logits_probs (U,T): logits in, probabilities out (in place).  topk_val (U,K) sorted descending, topk_idx (U,K) int32;
+ * ties resolve to the LOWER slot index (torch.topk leaves tie order unspecified). */
+int gngf_softmax_topk(float* logits_probs, float* topk_val, int32_t* topk_idx, int64_t U, int64_t T, int K, void* stream);
+/* DifferentiableTopk.forward alone (models.py:11) on arbitrary rows x (U,T); same ordering rules. */
+int gngf_topk(const float* x, float* topk_val, int32_t* topk_idx, int64_t U, int64_t T, int K, void* stream);
+/* backward of the above without the dense zero-filled scatter of models.py:27-35:
+ *   g = gdense (U,T, optional) + mw (U,L) * G (L,T) (optional low-rank term of the batch-mean loss) + dq at topk_idx
+ *   dlogits = p .* (g - <p, g>)        dlogits may alias probs. */
+int gngf_softmax_bwd(const float* probs, const float* dq, const int32_t* topk_idx, const float* gdense, const float* mw,
+                     const float* G, int L, float* dlogits, int64_t U, int64_t T, int K, void* stream);
+
+/* verts[i] = (gx, gy) fp32 of vertex id u0+i (vid = gy*vstride + gx): the raw-integer HPD input of models.py:416-418 */
+int gngf_vertex_coords(float* verts, int64_t u0, int64_t count, int vstride, void* stream);
+/* blend weights of the K rows (models.py:212-217) on the per-vertex table, and their backward (dw -> dq) */
+int gngf_blend_fwd(const float* q, float* w, int64_t U, int K, int blend, void* stream);
+int gngf_blend_bwd(const float* q, const float* dw, float* dq, int64_t U, int K, int blend, void* stream);
+/* counts (L,NV) int32 += number of (pixel, corner) instances of each vertex per level (caller zero-fills);
+ * mw (NV,L) = counts / denom : weights of the batch-mean distribution p-bar_l (utils.py:138,159). */
+int gngf_vertex_multiplicity(const float* xy, const int32_t* n_ls, int32_t* counts, int64_t P, int L, int vstride, int64_t NV,
+                             void* stream);
+int gngf_multiplicity_weights(const int32_t* counts, float* mw, int64_t NV, int L, float denom, void* stream);
+/* reference-shaped outputs rebuilt from the per-vertex table: vid_out (P,L,4) int64, out_idx (P,L,4,K) int64,
+ * out_val (P,L,4,K) fp32 (any of the three may be NULL) — models.py:478-484 return contract. */
+int gngf_expand_vertex_table(const float* xy, const int32_t* n_ls, const int32_t* src_idx, const float* src_val,
+                             int64_t* vid_out, int64_t* out_idx, float* out_val, int64_t P, int L, int K, int vstride,
+                             int64_t NV, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
