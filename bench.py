@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpixel/s forward+backward of the hash-grid encoder path (coords -> encoder -> decoder ->
+MSE gradient -> decoder/table gradients) at L=16, F=2, T=2^19, batch 2^20 pixels per GPU (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W            # N>1: launched by torch.distributed.run, one rank per GPU
+
+One JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP-event timed on the
+launch stream) and `cpu_baseline` (CPU oracle timed on the host cores, bounded sample, rank 0, N=1 only).
+
+Modes (all at the same shape; --mode picks the headline, the others are reported in the same line under "modes"):
+  gngf_frozen    GNGF indexing with a frozen HashProbDistribution (the reference's -hwp mode, models.py:364-371):
+                 the per-vertex top-K table is a function of frozen weights and is rebuilt only when they change.
+  gngf_learning  GNGF indexing with a trainable HPD: every step re-evaluates the HPD on every distinct vertex
+                 (MFMA-bound: U x 128 x T contraction) and back-propagates into it.
+  hash           plain spatial-hash indexing (should_use_hash_function=True), BASELINE.json configs[2] shape.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+L, F, T, K_TOP = 16, 2, 2 ** 19, 4
+N_MIN, N_MAX = 16, 512
+P_PER_GPU = 2 ** 20
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
+
+
+def algorithmic_bytes(mode):
+    """algorithmic bytes per pixel (fp32, ~0 reuse assumed)."""
+    sf = 4
+    Ke = 1 if mode == "hash" else K_TOP
+    J = 0 if mode == "hash" else 8 * K_TOP
+    b_fwd = 8 + L * 4 * Ke * F * sf + L * 4 * J + L * F * 4
+    b_bwd = 8 + L * F * 4 + L * 4 * J + 2 * L * 4 * Ke * F * sf + (L * 4 * K_TOP * F * sf if mode != "hash" else 0)
+    return b_fwd, b_bwd
+
+
+def strawberry_batch(P, rank, dev):
+    """cfg2 input: the 339x508 strawberry pixel list (coords = (row,col)/507, main.py:50-51), shuffled and repeated
+    to P pixels (the image has only 172 212 pixels)."""
+    img = np.load(os.path.join(ROOT, "tests", "golden", "strawberry_rgb.npz"))["img"]
+    h, w = img.shape[:2]
+    g = torch.Generator().manual_seed(65535 + rank)
+    sel = torch.cat([torch.randperm(h * w, generator=g) for _ in range(-(-P // (h * w)))])[:P]
+    rows, cols = sel // w, sel % w
+    xy = torch.stack([rows, cols], 1).float() / (max(w, h) - 1)
+    rgb = torch.from_numpy(img.reshape(-1, 3))[sel].float() / 255
+    return xy.to(dev).contiguous(), rgb.to(dev).contiguous(), (h, w)
+
+
+def build_model(mode, dev):
+    from collision_handling_in_instantngp_amd import models
+    models.should_use_hash_function = (mode == "hash")
+    torch.manual_seed(65535)
+    net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=T, num_levels=L, n_min=N_MIN, n_max=N_MAX,
+                                          MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
+                                          HPD_out_features=T, feature_dim=F, topk_k=K_TOP).to(dev)
+    net.return_indices = False          # the (P,L,4,K) int64 diagnostics tensor (2 GiB/step) is not part of fwd+bwd
+    net.dense_probs = False             # the dense (P,L,4,T) tensor is 128 MiB *per pixel* at this shape
+    if mode == "gngf_frozen":
+        for p in net.HPD.parameters():
+            p.requires_grad = False
+        net.compute_pbar = False        # the KL/JS term has no trainable input when the HPD is frozen
+    if mode == "gngf_learning":
+        net.coord_bounds = (1.0, 338.0 / 507.0)
+    return net, models
+
+
+def make_step(net, models, mode, xy, target, world):
+    from collision_handling_in_instantngp_amd import train, parallel
+    loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
+    params = [p for p in net.parameters() if p.requires_grad]
+    empty = torch.tensor([], device=xy.device)
+
+    def step():
+        for p in params:
+            p.grad = None
+        rgb, probs, _idx, _c = net(xy, 1.0)
+        if mode == "gngf_learning":
+            mse, kls, coll = loss_fn(rgb, target, T, probs, empty, empty)
+            loss = train.assemble_loss(mse, kls, coll, 1, 1, 1e-3)
+        else:
+            loss = torch.nn.functional.mse_loss(rgb, target)
+        loss.backward()
+        if world > 1:
+            parallel.allreduce_gradients(net, world)
+    return step
+
+
+def timed(step, steps, warmup, world):
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    return dt
+
+
+def kernel_times(net, models, mode, xy, n=20):
+    """HIP-event timing (on the launch stream = torch's current stream) of each hot kernel launched alone."""
+    from collision_handling_in_instantngp_amd import ops
+    dev = xy.device
+    n_ls = net._n_ls_flat(dev)
+    tables = net.encoding.packed_tables()
+    P = xy.shape[0]
+    if mode == "hash":
+        ti = w = None
+        vstride = 0
+    else:
+        with torch.no_grad():
+            _tv, ti, w, vstride, _NV = net._frozen_vertex_table(0) if net.hpd_is_frozen() else (None,) * 5
+        if ti is None:
+            return {}
+    genc = torch.randn((P, L * F), device=dev)
+    out = {}
+
+    def ev(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3
+
+    for name, fn in ops.encode_kernels(xy, n_ls, tables, ti, w, vstride, genc).items():
+        out[name] = ev(fn)
+    return out
+
+
+def cpu_baseline(mode, sample_pixels):
+    """The CPU oracle (oracle/gngf_oracle.py, kind 'port') timed on this host: forward + backward of the same path
+    on a bounded sample of the same workload.  Checker code is only timed here, never used by the product."""
+    from oracle import gngf_oracle as orc
+    rng = np.random.default_rng(0)
+    img = np.load(os.path.join(ROOT, "tests", "golden", "strawberry_rgb.npz"))["img"]
+    h, w = img.shape[:2]
+    sel = rng.permutation(h * w)[:sample_pixels]
+    x = (np.stack([sel // w, sel % w], 1) / np.float32(max(w, h) - 1)).astype(np.float32)
+    y = (img.reshape(-1, 3)[sel] / 255).astype(np.float32)
+    n_ls = orc.level_resolutions(N_MIN, N_MAX, L)
+    tables = ((rng.random((L, T, F), dtype=np.float32) - 0.5) * 2e-4).astype(np.float32)
+    dims = [L * F, 64, 64, 3]
+    dw = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(3)]
+    db = [np.zeros(dims[i + 1], np.float32) for i in range(3)]
+    vstride = N_MAX + 2
+    if mode != "hash":
+        vidx = rng.integers(0, T, (vstride * vstride, K_TOP)).astype(np.int64)
+        vw = rng.random((vstride * vstride, K_TOP), dtype=np.float32)
+    t0 = time.perf_counter()
+    _, grid = orc.scale_to_grid(x, n_ls)
+    if mode == "hash":
+        idx = orc.spatial_hash(grid.astype(np.int32), T)
+        probs = None
+    else:
+        gi = grid.astype(np.int64)
+        vid = gi[:, 1] * vstride + gi[:, 0]
+        idx, probs = vidx[vid], vw[vid]
+    feats = orc.encoding_forward(tables, idx, probs, None)
+    enc = orc.bilinear_forward(x, n_ls, feats)
+    rgb = orc.decoder_forward(enc, dw, db)
+    grgb = (2.0 / rgb.size) * (rgb - y)
+    genc, _, _ = orc.decoder_backward(enc, dw, db, grgb)
+    orc.encoding_backward(tables, idx, probs, None, orc.bilinear_backward(x, n_ls, genc, F))
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([d.get("num_threads", 1) for d in threadpool_info()] + [1])
+    except Exception:
+        cores = 1
+    return {"value": sample_pixels / dt / 1e6, "unit": "Mpixel/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_pixels} strawberry pixels, fwd+bwd, {mode} indexing (index table given), numpy oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="gngf_frozen", choices=["gngf_frozen", "gngf_learning", "hash"])
+    ap.add_argument("--pixels", type=int, default=P_PER_GPU, help="pixels per GPU per step")
+    ap.add_argument("--no-extra-modes", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2 ** 15)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    P = a.pixels
+    xy, target, (h, w) = strawberry_batch(P, rank, dev)
+
+    results = {}
+    order = [a.mode] + ([m for m in ("gngf_learning", "hash", "gngf_frozen") if m != a.mode] if not a.no_extra_modes else [])
+    kt = {}
+    for mode in order:
+        head = mode == a.mode
+        steps, warmup = (a.steps, a.warmup) if head else ((2, 1) if mode == "gngf_learning" else (max(5, a.steps // 2), 2))
+        if mode == "gngf_learning" and head:
+            steps, warmup = min(a.steps, 5), min(a.warmup, 1)
+        net, models = build_model(mode, dev)
+        step = make_step(net, models, mode, xy, target, world)
+        dt = timed(step, steps, warmup, world)
+        results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup}
+        if head and rank == 0:
+            try:
+                kt = kernel_times(net, models, mode, xy)
+            except Exception as e:  # pragma: no cover
+                kt = {"error": repr(e)}
+        models.should_use_hash_function = False
+        del net, step
+        torch.cuda.empty_cache()
+
+    if rank == 0:
+        head = results[a.mode]
+        b_fwd, b_bwd = algorithmic_bytes(a.mode)
+        roof = None
+        times = {k: v for k, v in kt.items() if isinstance(v, float)}
+        if times:
+            dom = max(times, key=times.get)
+            per_px = {"encode_fwd": b_fwd, "encode_bwd": b_bwd}.get(dom.split(":")[0])
+            if per_px is not None:
+                ach = per_px * P / times[dom] / 1e9
+                roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": times[dom] * 1e3,
+                        "algorithmic_bytes_per_pixel": per_px}
+            else:
+                flops = {"decoder_fwd": 2 * (L * F * 64 + 64 * 64 + 64 * 3), "decoder_bwd": 4 * (L * F * 64 + 64 * 64 + 64 * 3)}.get(dom.split(":")[0], 0)
+                ach = flops * P / times[dom] / 1e12
+                roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": times[dom] * 1e3}
+            tr_path = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.isfile(tr_path):
+                roof["traffic"] = json.load(open(tr_path)).get(dom)
+        line = {
+            "metric": "Mpixels/sec fwd+bwd at L=16,F=2,T=2^19", "value": head["mpix_s"], "unit": "Mpixel/s",
+            "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"], "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg2: strawberry.jpeg 339x508 pixel list shuffled+repeated to 2^20 px/GPU, L=16 F=2 T=2^19 "
+                                   f"K=4 N 16->512, {a.mode} indexing, random-init weights, MSE loss, fwd+bwd (no optimizer)",
+                       "mode": a.mode, "pixels_per_gpu": P, "parallelism": f"dp{world}"},
+            "modes": results, "kernel_ms": {k: (v * 1e3 if isinstance(v, float) else v) for k, v in kt.items()},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.mode, a.cpu_sample)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -118,6 +118,7 @@ class MultiResHashEncoding(nn.Module):
         self._hash_tables = nn.ModuleList([nn.Embedding(hash_table_size, feature_dim, _weight=base[l])
                                            for l in range(num_levels)])
         self._base = base
+        self._grad_base = None          # (L,T,F) gradient buffer behind the L `.grad` views (set by backward)
 
     def _apply_init(self, init_func, *args):
         for i in range(self._num_levels):
@@ -142,7 +143,7 @@ class MultiResHashEncoding(nn.Module):
     def forward(self, hashed_indices: torch.Tensor, hashed_probs_topk: torch.Tensor, should_calc_counts: bool = False):
         """hashed_indices (P,L,4) [hash] or (P,L,4,K) [GNGF] int64; hashed_probs_topk (P,L,4,K) | None -> (P,F,L,4)."""
         base = self.packed_tables()
-        tables = ops.TableViewFunction.apply(base, *[m.weight for m in self._hash_tables])
+        tables = ops.TableViewFunction.apply(base, self, *[m.weight for m in self._hash_tables])
         if should_use_hash_function:
             if hashed_indices.dim() != 3:
                 raise ValueError("hash mode expects indices of shape (P, L, 4)")
@@ -172,6 +173,7 @@ class GeneralNeuralGaugeFields(nn.Module):
         return_indices   (default True)  materialise the (P,L,4[,K]) int64 index tensor of the return contract
         dense_probs      (default 'auto') materialise the (P,L,4,T) distribution when it fits DENSE_OUTPUT_LIMIT_BYTES
         coord_bounds     (default None)  (max_row, max_col) of the coordinates if known: skips one device sync/step
+        compute_pbar     (default True)  when probs is returned compact, also reduce the batch-mean distribution
     """
 
     def __init__(self, input_dim, hash_table_size: int, num_levels: int, n_min: int, n_max: int,
@@ -221,6 +223,7 @@ class GeneralNeuralGaugeFields(nn.Module):
         self.return_indices = True
         self.dense_probs = "auto"
         self.coord_bounds = None
+        self.compute_pbar = True           # batch-mean distribution for the loss when probs is returned compact
         self._frozen_table = None          # cached per-vertex (idx, w, q) when the HPD is frozen
         self.to(device)
 
@@ -254,6 +257,18 @@ class GeneralNeuralGaugeFields(nn.Module):
     def hpd_is_frozen(self):
         return all(not p.requires_grad for p in self.HPD.parameters())
 
+    @torch.no_grad()
+    def _frozen_vertex_table(self, blend_code):
+        params = self.HPD.flat_params()
+        key = (tuple((p.data_ptr(), p._version) for p in params), blend_code, self._topk_k)
+        if self._frozen_table is None or self._frozen_table[0] != key:
+            vstride = self._n_max + 2
+            NV = vstride * vstride
+            tv, ti, _, _ = ops.HpdVertexFunction.apply(NV, vstride, self._topk_k, None, False, HPD_CHUNK_BYTES, *params)
+            w = ops.BlendFunction.apply(tv, blend_code)
+            self._frozen_table = (key, tv, ti, w, vstride, NV)
+        return self._frozen_table[1:]
+
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, batch_percentage: float = 1.0, should_calc_counts: bool = False):
         if should_batchnorm_data:
@@ -262,7 +277,7 @@ class GeneralNeuralGaugeFields(nn.Module):
         dev = x.device
         n_ls = self._n_ls_flat(dev)
         base = self.encoding.packed_tables()
-        tables = ops.TableViewFunction.apply(base, *[m.weight for m in self.encoding._hash_tables])
+        tables = ops.TableViewFunction.apply(base, self.encoding, *[m.weight for m in self.encoding._hash_tables])
         P, L, T, K = x.shape[0], self._num_levels, self._hash_table_size, self._topk_k
 
         if self._hash_mode:
@@ -272,15 +287,22 @@ class GeneralNeuralGaugeFields(nn.Module):
             counts = self._calc_counts_per_level(idx, x, n_ls) if should_calc_counts else []
             return rgb, None, idx, counts
 
-        vstride, NV = self._vertex_extent(x.detach())
         keep_topk = self._should_keep_topk_only
         dense_bytes = P * L * 4 * T * 4
         want_dense = (not keep_topk) and (self.dense_probs is True or (self.dense_probs == "auto" and dense_bytes <= DENSE_OUTPUT_LIMIT_BYTES))
-        need_pbar = (not keep_topk) and not want_dense
-        mw = ops.vertex_multiplicity_weights(x.detach(), n_ls, vstride, NV) if need_pbar else None
-        tv, ti, pbar, probs_u = ops.HpdVertexFunction.apply(NV, vstride, K, mw, want_dense, HPD_CHUNK_BYTES,
-                                                            *self.HPD.flat_params())
-        w = ops.BlendFunction.apply(tv, ops.BLEND_CODES[should_softmax_topk_features])
+        need_pbar = (not keep_topk) and (not want_dense) and self.compute_pbar
+        blend_code = ops.BLEND_CODES[should_softmax_topk_features]
+        if self.hpd_is_frozen() and not want_dense and not need_pbar:
+            # frozen HPD (-hwp mode, models.py:364-371): the per-vertex table is a pure function of the frozen
+            # weights, so it is rebuilt only when they change (version counters), over the whole [0,1]^2 domain.
+            tv, ti, w, vstride, NV = self._frozen_vertex_table(blend_code)
+            pbar = probs_u = None
+        else:
+            vstride, NV = self._vertex_extent(x.detach())
+            mw = ops.vertex_multiplicity_weights(x.detach(), n_ls, vstride, NV) if need_pbar else None
+            tv, ti, pbar, probs_u = ops.HpdVertexFunction.apply(NV, vstride, K, mw, want_dense, HPD_CHUNK_BYTES,
+                                                                *self.HPD.flat_params())
+            w = ops.BlendFunction.apply(tv, blend_code)
         enc = ops.encode_apply(x, n_ls, tables, ti, w, vstride)
         rgb = self._decode(enc)
 

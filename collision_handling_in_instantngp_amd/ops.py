@@ -342,15 +342,34 @@ class SoftmaxTopkFunction(torch.autograd.Function):
 
 class TableViewFunction(torch.autograd.Function):
     """Presents the L per-level Parameters (`_hash_tables.{l}.weight`, views of one buffer) to the kernels as ONE
-    (L,T,F) tensor and routes the (L,T,F) gradient back to the L parameters as views (no copies)."""
+    (L,T,F) tensor, and hands the (L,T,F) gradient buffer to the L parameters as views WITHOUT copies:
+    `.grad` of level l becomes g[l] directly (autograd's AccumulateGrad would clone each view), and the owner
+    module keeps `_grad_base = g` so that data-parallel training all-reduces ONE contiguous buffer."""
 
     @staticmethod
-    def forward(ctx, base, *weights):
+    def forward(ctx, base, owner, *weights):
+        ctx.owner = owner
+        ctx.weights = weights
         return base.detach()
 
     @staticmethod
     def backward(ctx, g):
-        return (None, *[g[l] for l in range(g.shape[0])])
+        ws = ctx.weights
+        if all(w.grad is None for w in ws):
+            g = g.contiguous()
+            for l, w in enumerate(ws):
+                if w.requires_grad:
+                    w.grad = g[l]
+            ctx.owner._grad_base = g
+        else:                      # gradient accumulation across several backward passes
+            for l, w in enumerate(ws):
+                if w.requires_grad:
+                    if w.grad is None:
+                        w.grad = g[l].clone()
+                    else:
+                        w.grad.add_(g[l])
+            ctx.owner._grad_base = None
+        return (None, None, *([None] * len(ws)))
 
 
 def encode_apply(xy, n_ls, tables, vert_idx, vert_w, vstride):
@@ -361,3 +380,27 @@ def encode_apply(xy, n_ls, tables, vert_idx, vert_w, vstride):
 def decoder_apply(enc, acts, params):
     """Decoder MLP dispatch (reference models.py:382-392,469-470)."""
     return MlpFunction.apply(enc, acts, *params)
+
+
+# ------------------------------------------------------------------------------------------------ per-kernel launch closures
+def encode_kernels(xy, n_ls, tables, vert_idx, vert_w, vstride, genc):
+    """{name: zero-arg launcher} for the encoder kernels the current dispatch uses (bench.py times each one alone
+    with HIP events on the launch stream)."""
+    L, T, F = tables.shape
+    P = xy.shape[0]
+    mode = MODE_HASH if vert_idx is None else MODE_VERTEX_TABLE
+    K = 0 if vert_idx is None else vert_idx.shape[1]
+    NV = 0 if vert_idx is None else vert_idx.shape[0]
+    enc = torch.empty((P, L * F), dtype=_f32, device=xy.device)
+    dtables = torch.zeros_like(tables)
+    s = stream_ptr
+
+    def fwd():
+        call("gngf_encode_fwd", ptr(xy), ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(enc), P, L, F, T, K, mode,
+             vstride, NV, s())
+
+    def bwd():
+        call("gngf_encode_bwd", ptr(xy), ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc), ptr(dtables), ptr(None),
+             P, L, F, T, K, mode, vstride, NV, s())
+
+    return {"encode_fwd:direct": fwd, "encode_bwd:direct": bwd}

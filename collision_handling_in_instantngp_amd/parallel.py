@@ -1,0 +1,55 @@
+"""Data-parallel training over RCCL/xGMI (one process per GPU): pixels shard across ranks, parameters replicate,
+one gradient exchange per step (the reference has no counterpart).
+
+Exchange layout, sized for point-to-point xGMI links:
+  * the hash-table gradient is ONE contiguous (L,T,F) buffer (`encoding._grad_base`, see ops.TableViewFunction):
+    a single large all-reduce, no per-level launches, no flatten copy;
+  * every other gradient (decoder, HPD) is packed into one small flat bucket.
+Losses are means over the LOCAL batch, so summed gradients are divided by world size (equal shards)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_batch(n_items: int, rank: int, world: int):
+    """Contiguous equal shards (the last rank takes the remainder)."""
+    per = n_items // world
+    lo = rank * per
+    hi = n_items if rank == world - 1 else lo + per
+    return lo, hi
+
+
+def allreduce_gradients(net, world: int, group=None):
+    if world <= 1:
+        return
+    inv = 1.0 / world
+    handled = set()
+    enc = getattr(net, "encoding", None)
+    base = getattr(enc, "_grad_base", None) if enc is not None else None
+    work = []
+    if base is not None:
+        work.append(dist.all_reduce(base, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        handled = {id(m.weight) for m in enc._hash_tables}
+    rest = [p for p in net.parameters() if p.requires_grad and p.grad is not None and id(p) not in handled]
+    flat = None
+    if rest:
+        flat = torch.cat([p.grad.reshape(-1) for p in rest])
+        work.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for w in work:
+        w.wait()
+    if base is not None:
+        base.mul_(inv)
+    if flat is not None:
+        flat.mul_(inv)
+        off = 0
+        for p in rest:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+
+
+def broadcast_parameters(net, src: int = 0, group=None):
+    """Replicas must start identical (same seed does it too; this makes it explicit)."""
+    for p in net.parameters():
+        dist.broadcast(p.data, src=src, group=group)
+    for b in net.buffers():
+        dist.broadcast(b.data, src=src, group=group)
