@@ -145,7 +145,7 @@ def kernel_times(net, models, mode, xy, n=20):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e-3
 
-    for name, fn in ops.encode_kernels(xy, n_ls, tables, ti, w, vstride, genc).items():
+    for name, fn in ops.encode_kernels(xy, n_ls, net._n_ls_host, tables, ti, w, vstride, genc).items():
         out[name] = ev(fn)
     return out
 

@@ -194,11 +194,11 @@ __global__ void __launch_bounds__(kBlock)
 encode_fwd_kernel(const float2* __restrict__ xy, const float* __restrict__ tables,
                   const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
                   const int32_t* __restrict__ n_ls, float* __restrict__ enc,
-                  int64_t total, int L, int64_t T, int K, int vstride, int64_t NV, bool pow2) {
+                  int64_t total, int L, int l0, int nl, int64_t T, int K, int vstride, int64_t NV, bool pow2) {
   const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (gid >= total) return;
-  const int64_t p = gid / L;
-  const int l = (int)(gid - p * L);
+  const int64_t p = gid / nl;
+  const int l = l0 + (int)(gid - p * nl);
   const float2 c = xy[p];
   const Cell cell = make_cell(c.x, c.y, n_ls[l]);
   const float* tab = tables + (int64_t)l * T * F;
@@ -225,7 +225,7 @@ encode_fwd_kernel(const float2* __restrict__ xy, const float* __restrict__ table
   }
 #pragma unroll
   for (int f = 0; f < F; ++f)
-    enc[gid * F + f] = ((feat[0][f] * cell.c[0] + feat[1][f] * cell.c[1]) + feat[2][f] * cell.c[2]) + feat[3][f] * cell.c[3];
+    enc[(p * L + l) * F + f] = ((feat[0][f] * cell.c[0] + feat[1][f] * cell.c[1]) + feat[2][f] * cell.c[2]) + feat[3][f] * cell.c[3];
 }
 
 template <int F, bool VT>
@@ -234,18 +234,18 @@ encode_bwd_kernel(const float2* __restrict__ xy, const float* __restrict__ table
                   const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
                   const int32_t* __restrict__ n_ls, const float* __restrict__ genc,
                   float* __restrict__ dtables, float* __restrict__ dvert_w,
-                  int64_t total, int L, int64_t T, int K, int vstride, int64_t NV, bool pow2) {
+                  int64_t total, int L, int l0, int nl, int64_t T, int K, int vstride, int64_t NV, bool pow2) {
   const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (gid >= total) return;
-  const int64_t p = gid / L;
-  const int l = (int)(gid - p * L);
+  const int64_t p = gid / nl;
+  const int l = l0 + (int)(gid - p * nl);
   const float2 c = xy[p];
   const Cell cell = make_cell(c.x, c.y, n_ls[l]);
   const float* tab = tables + (int64_t)l * T * F;
   float* dtab = dtables + (int64_t)l * T * F;
   float g[F];
 #pragma unroll
-  for (int f = 0; f < F; ++f) g[f] = genc[gid * F + f];
+  for (int f = 0; f < F; ++f) g[f] = genc[(p * L + l) * F + f];
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int gx = cell.gx + (v & 1), gy = cell.gy + (v >> 1);
@@ -347,21 +347,22 @@ extern "C" int gngf_bilinear_bwd(const float* xy, const int32_t* n_ls, const flo
 
 extern "C" int gngf_encode_fwd(const float* xy, const float* tables, const int32_t* vert_idx, const float* vert_w,
                                const int32_t* n_ls, float* enc, int64_t P, int L, int F, int64_t T, int K,
-                               int mode, int vstride, int64_t NV, void* stream) {
-  GNGF_CHECK_ARG(P >= 0 && L > 0 && L <= GNGF_MAX_LEVELS && T > 0);
+                               int mode, int vstride, int64_t NV, int l0, int l1, void* stream) {
+  GNGF_CHECK_ARG(P >= 0 && L > 0 && L <= GNGF_MAX_LEVELS && T > 0 && l0 >= 0 && l0 <= l1 && l1 <= L);
   GNGF_CHECK_ARG(mode == GNGF_MODE_HASH || mode == GNGF_MODE_VERTEX_TABLE);
-  if (P == 0) return 0;
+  if (P == 0 || l0 == l1) return 0;
   GNGF_CHECK_ARG(xy && tables && n_ls && enc);
-  const int64_t total = P * L;
+  const int nl = l1 - l0;
+  const int64_t total = P * nl;
   const dim3 grid((unsigned)ceil_div(total, kBlock)), block(kBlock);
   const bool pow2 = (T & (T - 1)) == 0;
   if (mode == GNGF_MODE_HASH) {
     DISPATCH_F(F, (encode_fwd_kernel<kF, false><<<grid, block, 0, as_stream(stream)>>>(
-                      reinterpret_cast<const float2*>(xy), tables, nullptr, nullptr, n_ls, enc, total, L, T, 0, 0, 0, pow2)));
+                      reinterpret_cast<const float2*>(xy), tables, nullptr, nullptr, n_ls, enc, total, L, l0, nl, T, 0, 0, 0, pow2)));
   } else {
     GNGF_CHECK_ARG(vert_idx && vert_w && K > 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0);
     DISPATCH_F(F, (encode_fwd_kernel<kF, true><<<grid, block, 0, as_stream(stream)>>>(
-                      reinterpret_cast<const float2*>(xy), tables, vert_idx, vert_w, n_ls, enc, total, L, T, K, vstride, NV, pow2)));
+                      reinterpret_cast<const float2*>(xy), tables, vert_idx, vert_w, n_ls, enc, total, L, l0, nl, T, K, vstride, NV, pow2)));
   }
   GNGF_RETURN_LAUNCH();
 }
@@ -369,23 +370,24 @@ extern "C" int gngf_encode_fwd(const float* xy, const float* tables, const int32
 extern "C" int gngf_encode_bwd(const float* xy, const float* tables, const int32_t* vert_idx, const float* vert_w,
                                const int32_t* n_ls, const float* genc, float* dtables, float* dvert_w,
                                int64_t P, int L, int F, int64_t T, int K, int mode, int vstride, int64_t NV,
-                               void* stream) {
-  GNGF_CHECK_ARG(P >= 0 && L > 0 && L <= GNGF_MAX_LEVELS && T > 0);
+                               int l0, int l1, void* stream) {
+  GNGF_CHECK_ARG(P >= 0 && L > 0 && L <= GNGF_MAX_LEVELS && T > 0 && l0 >= 0 && l0 <= l1 && l1 <= L);
   GNGF_CHECK_ARG(mode == GNGF_MODE_HASH || mode == GNGF_MODE_VERTEX_TABLE);
-  if (P == 0) return 0;
+  if (P == 0 || l0 == l1) return 0;
   GNGF_CHECK_ARG(xy && tables && n_ls && genc && dtables);
-  const int64_t total = P * L;
+  const int nl = l1 - l0;
+  const int64_t total = P * nl;
   const dim3 grid((unsigned)ceil_div(total, kBlock)), block(kBlock);
   const bool pow2 = (T & (T - 1)) == 0;
   if (mode == GNGF_MODE_HASH) {
     DISPATCH_F(F, (encode_bwd_kernel<kF, false><<<grid, block, 0, as_stream(stream)>>>(
                       reinterpret_cast<const float2*>(xy), tables, nullptr, nullptr, n_ls, genc, dtables, nullptr,
-                      total, L, T, 0, 0, 0, pow2)));
+                      total, L, l0, nl, T, 0, 0, 0, pow2)));
   } else {
     GNGF_CHECK_ARG(vert_idx && vert_w && K > 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0);
     DISPATCH_F(F, (encode_bwd_kernel<kF, true><<<grid, block, 0, as_stream(stream)>>>(
                       reinterpret_cast<const float2*>(xy), tables, vert_idx, vert_w, n_ls, genc, dtables, dvert_w,
-                      total, L, T, K, vstride, NV, pow2)));
+                      total, L, l0, nl, T, K, vstride, NV, pow2)));
   }
   GNGF_RETURN_LAUNCH();
 }

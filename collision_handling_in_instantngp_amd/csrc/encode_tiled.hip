@@ -1,0 +1,479 @@
+// Tiled / LDS-privatised form of the encoder hot path — the fast path whenever a level's vertex grid is
+// small enough to stage (all 16 levels at N_max = 512, T = 2^19).
+//
+// The indices of BOTH index sources depend only on (level, vertex): the spatial hash by definition
+// (reference models.py:504-528) and the GNGF top-K because the HPD input is the integer vertex alone
+// (models.py:416-418).  So the work splits into
+//   vertex stage  G_l[gy][gx][f] = E_l[hash(gx,gy)][f]            or  sum_k w_k(v) E_l[idx_k(v)][f]
+//                 (once per DISTINCT vertex: ~0.7 M rows instead of 67 M per-instance gathers at P = 2^20)
+//   pixel stage   enc[p][l][f] = sum_v c_v(p,l) G_l[cell(p,l)+v][f]   — dense-grid bilinear interpolation,
+// and backward mirrors it: the pixel stage accumulates dG, the vertex stage scatters dG into dE (and dL/dw).
+//
+// Pixel stage layout for gfx950: pixels are binned by spatial tile (2^tile_shift tiles per axis); one
+// 256-thread workgroup owns one (tile, chunk of pixels) work item, stages the tile's sub-grid of EVERY level in
+// LDS (~10 KB), and then runs one lane per (pixel, level): 4 x ds_read_b64 forward, 8 x ds_add_f32 backward.
+// The 16 level-lanes of a pixel read / write one contiguous 128-byte row of enc / d enc.  Gradients leave the
+// workgroup once per touched vertex instead of once per (pixel, corner): the 134 M global float atomics of the
+// direct form become ~2 M row-contiguous ones.
+#include "gngf_common.h"
+
+namespace gngf {
+
+constexpr int kTB = 256;        // pixel-stage workgroup
+constexpr int kBinThreads = 1024;
+
+__device__ __forceinline__ int tile_of(float x, float y, int tile_shift) {
+  const int TS = 1 << tile_shift;
+  int tx = (int)(x * (float)TS), ty = (int)(y * (float)TS);      // exact: TS is a power of two
+  tx = tx < 0 ? 0 : (tx >= TS ? TS - 1 : tx);
+  ty = ty < 0 ? 0 : (ty >= TS ? TS - 1 : ty);
+  return (ty << tile_shift) | tx;
+}
+
+// ---------------------------------------------------------------------------------------------- binning
+// K1: per-block histogram over a contiguous pixel range -> blockhist[tile][block]
+__global__ void __launch_bounds__(kBinThreads)
+bin_count_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB,
+                 int32_t* __restrict__ blockhist) {
+  extern __shared__ int hist[];
+  const int ntiles = 1 << (2 * tile_shift);
+  for (int i = threadIdx.x; i < ntiles; i += kBinThreads) hist[i] = 0;
+  __syncthreads();
+  const int64_t lo = (int64_t)blockIdx.x * per_block;
+  const int64_t hi = lo + per_block < P ? lo + per_block : P;
+  for (int64_t p = lo + threadIdx.x; p < hi; p += kBinThreads) {
+    const float2 c = xy[p];
+    atomicAdd(&hist[tile_of(c.x, c.y, tile_shift)], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ntiles; i += kBinThreads) blockhist[(int64_t)i * NB + blockIdx.x] = hist[i];
+}
+
+// K2 (one block): per-tile totals, exclusive scan over tiles, per-(tile, block) offsets, and the work-item table.
+__global__ void __launch_bounds__(kBinThreads)
+bin_scan_kernel(int32_t* __restrict__ blockhist, int NB, int tile_shift, int chunk, int32_t* __restrict__ tile_off,
+                int4* __restrict__ items, int32_t* __restrict__ n_items) {
+  __shared__ int wsum[kBinThreads / 64];
+  __shared__ int wsum2[kBinThreads / 64];
+  __shared__ int carry[2];
+  const int ntiles = 1 << (2 * tile_shift);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) { carry[0] = 0; carry[1] = 0; }
+  __syncthreads();
+  for (int base = 0; base < ntiles; base += kBinThreads) {
+    const int t = base + tid;
+    int total = 0;
+    if (t < ntiles) {
+      int32_t* row = blockhist + (int64_t)t * NB;
+      for (int b = 0; b < NB; ++b) { const int c = row[b]; row[b] = total; total += c; }   // exclusive within tile
+    }
+    const int nit = (total + chunk - 1) / chunk;
+    // block-wide exclusive scan of (total, nit)
+    int a = total, n2 = nit;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int ua = __shfl_up(a, o, 64), un = __shfl_up(n2, o, 64);
+      if (lane >= o) { a += ua; n2 += un; }
+    }
+    if (lane == 63) { wsum[wave] = a; wsum2[wave] = n2; }
+    __syncthreads();
+    int wa = 0, wn = 0;
+    for (int w = 0; w < wave; ++w) { wa += wsum[w]; wn += wsum2[w]; }
+    const int off = carry[0] + wa + a - total;      // exclusive prefix of pixel counts
+    const int ioff = carry[1] + wn + n2 - nit;      // exclusive prefix of item counts
+    if (t < ntiles) {
+      tile_off[t] = off;
+      int32_t* row = blockhist + (int64_t)t * NB;
+      for (int b = 0; b < NB; ++b) row[b] += off;
+      for (int j = 0; j < nit; ++j) {
+        const int cnt = (total - j * chunk) < chunk ? (total - j * chunk) : chunk;
+        items[ioff + j] = make_int4(off + j * chunk, cnt, t, 0);
+      }
+    }
+    __syncthreads();
+    if (tid == kBinThreads - 1) { carry[0] = off + total; carry[1] = ioff + nit; }
+    __syncthreads();
+  }
+  if (tid == 0) { tile_off[ntiles] = carry[0]; *n_items = carry[1]; }
+}
+
+// K3: scatter (x, y, original index) into tile order.  Same pixel->block partition as K1.
+__global__ void __launch_bounds__(kBinThreads)
+bin_scatter_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB,
+                   const int32_t* __restrict__ blockhist, float4* __restrict__ sorted) {
+  extern __shared__ int cursor[];
+  const int ntiles = 1 << (2 * tile_shift);
+  for (int i = threadIdx.x; i < ntiles; i += kBinThreads) cursor[i] = blockhist[(int64_t)i * NB + blockIdx.x];
+  __syncthreads();
+  const int64_t lo = (int64_t)blockIdx.x * per_block;
+  const int64_t hi = lo + per_block < P ? lo + per_block : P;
+  for (int64_t p = lo + threadIdx.x; p < hi; p += kBinThreads) {
+    const float2 c = xy[p];
+    const int pos = atomicAdd(&cursor[tile_of(c.x, c.y, tile_shift)], 1);
+    sorted[pos] = make_float4(c.x, c.y, __int_as_float((int)p), 0.f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- vertex stage
+// grid = (ceil(maxverts/256), Ls): one lane per (level, vertex).  Level grids are stored back to back:
+// G[(goff_l + gy*(N_l+2) + gx) * F + f], goff_l = sum_{j<l} (N_j+2)^2.
+__device__ __forceinline__ int64_t level_offset(const int32_t* n_ls, int l) {
+  int64_t o = 0;
+  for (int j = 0; j < l; ++j) { const int64_t g = n_ls[j] + 2; o += g * g; }
+  return o;
+}
+
+template <int F, bool VT>
+__global__ void __launch_bounds__(256)
+vertex_fwd_kernel(const float* __restrict__ tables, const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
+                  const int32_t* __restrict__ n_ls, float* __restrict__ G, int64_t T, int K, int vstride, int64_t NV,
+                  bool pow2) {
+  const int l = blockIdx.y;
+  const int gw = n_ls[l] + 2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= gw * gw) return;
+  const int gy = i / gw, gx = i - gy * gw;
+  const float* tab = tables + (int64_t)l * T * F;
+  float acc[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) acc[f] = 0.f;
+  if constexpr (!VT) {
+    const float* r = tab + spatial_hash(gx, gy, T, pow2) * F;
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = r[f];
+  } else {
+    const int64_t vid = (int64_t)gy * vstride + gx;
+    if (gx < vstride && vid < NV) {
+      for (int k = 0; k < K; ++k) {
+        const float w = vert_w[vid * K + k];
+        const float* r = tab + (int64_t)vert_idx[vid * K + k] * F;
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f] += r[f] * w;
+      }
+    }
+  }
+  float* o = G + (level_offset(n_ls, l) + i) * F;
+#pragma unroll
+  for (int f = 0; f < F; ++f) o[f] = acc[f];
+}
+
+template <int F, bool VT>
+__global__ void __launch_bounds__(256)
+vertex_bwd_kernel(const float* __restrict__ tables, const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
+                  const int32_t* __restrict__ n_ls, const float* __restrict__ dG, float* __restrict__ dtables,
+                  float* __restrict__ dvert_w, int64_t T, int K, int vstride, int64_t NV, bool pow2) {
+  const int l = blockIdx.y;
+  const int gw = n_ls[l] + 2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= gw * gw) return;
+  const float* gp = dG + (level_offset(n_ls, l) + i) * F;
+  float g[F];
+  bool any = false;
+#pragma unroll
+  for (int f = 0; f < F; ++f) { g[f] = gp[f]; any |= (g[f] != 0.f); }
+  if (!any) return;                               // vertices no pixel touched
+  const int gy = i / gw, gx = i - gy * gw;
+  const float* tab = tables + (int64_t)l * T * F;
+  float* dtab = dtables + (int64_t)l * T * F;
+  if constexpr (!VT) {
+    float* r = dtab + spatial_hash(gx, gy, T, pow2) * F;
+#pragma unroll
+    for (int f = 0; f < F; ++f) atomicAdd(r + f, g[f]);
+  } else {
+    const int64_t vid = (int64_t)gy * vstride + gx;
+    if (gx >= vstride || vid >= NV) return;
+    for (int k = 0; k < K; ++k) {
+      const float w = vert_w[vid * K + k];
+      const int64_t row = vert_idx[vid * K + k];
+      float dot = 0.f;
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        dot += g[f] * tab[row * F + f];
+        atomicAdd(dtab + row * F + f, g[f] * w);
+      }
+      if (dvert_w) atomicAdd(dvert_w + vid * K + k, dot);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- pixel stage
+struct TileMeta {          // per-level placement of the tile's sub-grid (in LDS)
+  int n[GNGF_MAX_LEVELS], gw[GNGF_MAX_LEVELS], cx[GNGF_MAX_LEVELS], cy[GNGF_MAX_LEVELS], wx[GNGF_MAX_LEVELS],
+      wy[GNGF_MAX_LEVELS], loff[GNGF_MAX_LEVELS];
+  int64_t goff[GNGF_MAX_LEVELS];
+};
+
+// Fills meta for tile (tx,ty).  A level whose sub-grid does not fit the provided LDS gets wx = 0 (global fallback).
+__device__ __forceinline__ void setup_tile(TileMeta& m, const int32_t* n_ls, int Ls, int tx, int ty, int tile_shift, int F,
+                                           int lds_floats) {
+  const int tid = threadIdx.x;
+  if (tid < Ls) {
+    const int n = n_ls[tid];
+    m.n[tid] = n;
+    m.gw[tid] = n + 2;
+    const int cx = (tx * n) >> tile_shift, cy = (ty * n) >> tile_shift;
+    int hx = (((tx + 1) * n) >> tile_shift) + 1, hy = (((ty + 1) * n) >> tile_shift) + 1;
+    hx = hx > n + 1 ? n + 1 : hx;
+    hy = hy > n + 1 ? n + 1 : hy;
+    m.cx[tid] = cx; m.cy[tid] = cy; m.wx[tid] = hx - cx + 1; m.wy[tid] = hy - cy + 1;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int64_t go = 0;
+    int lo = 0;
+    for (int l = 0; l < Ls; ++l) {
+      m.goff[l] = go;
+      go += (int64_t)m.gw[l] * m.gw[l];
+      const int sz = m.wx[l] * m.wy[l] * F;
+      if (lo + sz <= lds_floats) { m.loff[l] = lo; lo += sz; } else { m.wx[l] = 0; m.loff[l] = 0; }
+    }
+  }
+  __syncthreads();
+}
+
+template <int F>
+__global__ void __launch_bounds__(kTB)
+tiled_fwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ items, const int32_t* __restrict__ n_items,
+                 const int32_t* __restrict__ n_ls, const float* __restrict__ G, float* __restrict__ enc, int L, int Ls,
+                 int tile_shift, int lds_floats) {
+  extern __shared__ float lds[];
+  __shared__ TileMeta m;
+  if ((int)blockIdx.x >= *n_items) return;
+  const int4 it = items[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int TSm = (1 << tile_shift) - 1;
+  setup_tile(m, n_ls, Ls, it.z & TSm, it.z >> tile_shift, tile_shift, F, lds_floats);
+  for (int l = 0; l < Ls; ++l) {
+    const int wx = m.wx[l], sz = wx * m.wy[l];
+    const float* src = G + (m.goff[l] + (int64_t)m.cy[l] * m.gw[l] + m.cx[l]) * F;
+    float* dst = lds + m.loff[l];
+    for (int i = tid; i < sz; i += kTB) {
+      const int iy = i / wx, ix = i - iy * wx;
+      const float* s = src + ((int64_t)iy * m.gw[l] + ix) * F;
+#pragma unroll
+      for (int f = 0; f < F; ++f) dst[i * F + f] = s[f];
+    }
+  }
+  __syncthreads();
+  const int ppp = kTB / Ls;                     // pixels per pass: one lane per (pixel, level)
+  const int lp = tid / Ls, l = tid - lp * Ls;
+  if (lp >= ppp) return;
+  const int n = m.n[l], cx = m.cx[l], cy = m.cy[l], wx = m.wx[l], wy = m.wy[l], gw = m.gw[l];
+  const float* sub = lds + m.loff[l];
+  const float* Gl = G + m.goff[l] * F;
+  const int LF = L * F;
+  for (int j = lp; j < it.y; j += ppp) {
+    const float4 s = sorted[it.x + j];
+    const int64_t p = (int64_t)__float_as_int(s.z);
+    const Cell c = make_cell(s.x, s.y, n);
+    const int lx = c.gx - cx, ly = c.gy - cy;
+    float v[4][F];
+    if (lx >= 0 && ly >= 0 && lx + 1 < wx && ly + 1 < wy) {
+      const float* a = sub + (ly * wx + lx) * F;
+      const float* b = a + wx * F;
+#pragma unroll
+      for (int f = 0; f < F; ++f) { v[0][f] = a[f]; v[1][f] = a[F + f]; v[2][f] = b[f]; v[3][f] = b[F + f]; }
+    } else {                                     // outside the staged sub-grid (never for in-domain coords): global
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int gx = c.gx + (q & 1), gy = c.gy + (q >> 1);
+        gx = gx < 0 ? 0 : (gx > n + 1 ? n + 1 : gx);
+        gy = gy < 0 ? 0 : (gy > n + 1 ? n + 1 : gy);
+#pragma unroll
+        for (int f = 0; f < F; ++f) v[q][f] = Gl[((int64_t)gy * gw + gx) * F + f];
+      }
+    }
+    float* o = enc + p * LF + l * F;
+#pragma unroll
+    for (int f = 0; f < F; ++f) o[f] = ((v[0][f] * c.c[0] + v[1][f] * c.c[1]) + v[2][f] * c.c[2]) + v[3][f] * c.c[3];
+  }
+}
+
+template <int F>
+__global__ void __launch_bounds__(kTB)
+tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ items, const int32_t* __restrict__ n_items,
+                 const int32_t* __restrict__ n_ls, const float* __restrict__ genc, float* __restrict__ dG, int L, int Ls,
+                 int tile_shift, int lds_floats) {
+  extern __shared__ float lds[];
+  __shared__ TileMeta m;
+  if ((int)blockIdx.x >= *n_items) return;
+  const int4 it = items[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int TSm = (1 << tile_shift) - 1;
+  setup_tile(m, n_ls, Ls, it.z & TSm, it.z >> tile_shift, tile_shift, F, lds_floats);
+  int used = 0;
+  for (int l = 0; l < Ls; ++l) used += m.wx[l] * m.wy[l] * F;
+  for (int i = tid; i < used; i += kTB) lds[i] = 0.f;
+  __syncthreads();
+  const int ppp = kTB / Ls;
+  const int lp = tid / Ls, l = tid - lp * Ls;
+  if (lp < ppp) {
+    const int n = m.n[l], cx = m.cx[l], cy = m.cy[l], wx = m.wx[l], wy = m.wy[l], gw = m.gw[l];
+    float* sub = lds + m.loff[l];
+    float* dGl = dG + m.goff[l] * F;
+    const int LF = L * F;
+    for (int j = lp; j < it.y; j += ppp) {
+      const float4 s = sorted[it.x + j];
+      const int64_t p = (int64_t)__float_as_int(s.z);
+      const Cell c = make_cell(s.x, s.y, n);
+      const int lx = c.gx - cx, ly = c.gy - cy;
+      float g[F];
+      const float* gi = genc + p * LF + l * F;
+#pragma unroll
+      for (int f = 0; f < F; ++f) g[f] = gi[f];
+      if (lx >= 0 && ly >= 0 && lx + 1 < wx && ly + 1 < wy) {
+        float* a = sub + (ly * wx + lx) * F;
+        float* b = a + wx * F;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          atomicAdd(a + f, g[f] * c.c[0]);
+          atomicAdd(a + F + f, g[f] * c.c[1]);
+          atomicAdd(b + f, g[f] * c.c[2]);
+          atomicAdd(b + F + f, g[f] * c.c[3]);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int gx = c.gx + (q & 1), gy = c.gy + (q >> 1);
+          gx = gx < 0 ? 0 : (gx > n + 1 ? n + 1 : gx);
+          gy = gy < 0 ? 0 : (gy > n + 1 ? n + 1 : gy);
+#pragma unroll
+          for (int f = 0; f < F; ++f) atomicAdd(dGl + ((int64_t)gy * gw + gx) * F + f, g[f] * c.c[q]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // flush: one global atomic per touched sub-grid entry, row segments contiguous in dG
+  for (int ll = 0; ll < Ls; ++ll) {
+    const int wx = m.wx[ll], sz = wx * m.wy[ll] * F;
+    const float* src = lds + m.loff[ll];
+    float* dst = dG + (m.goff[ll] + (int64_t)m.cy[ll] * m.gw[ll] + m.cx[ll]) * F;
+    const int rowf = wx * F;
+    for (int i = tid; i < sz; i += kTB) {
+      const float v = src[i];
+      if (v != 0.f) {
+        const int iy = i / rowf, r = i - iy * rowf;
+        atomicAdd(dst + (int64_t)iy * m.gw[ll] * F + r, v);
+      }
+    }
+  }
+}
+
+}  // namespace gngf
+
+using namespace gngf;
+
+#define DISPATCH_F(F, ...)                          \
+  switch (F) {                                      \
+    case 1: { constexpr int kF = 1; __VA_ARGS__; } break; \
+    case 2: { constexpr int kF = 2; __VA_ARGS__; } break; \
+    case 4: { constexpr int kF = 4; __VA_ARGS__; } break; \
+    case 8: { constexpr int kF = 8; __VA_ARGS__; } break; \
+    default: return (int)hipErrorInvalidValue;      \
+  }
+
+// Bins P pixels into 4^tile_shift spatial tiles.  NB = number of binning blocks (<= 1024), chunk = max pixels per
+// work item.  Outputs: sorted (P float4 = x, y, bits(original index), 0), items (max_items int4 = start, count,
+// tile, 0; max_items >= ceil(P/chunk) + 4^tile_shift), n_items (1), tile_off (4^tile_shift + 1),
+// blockhist (4^tile_shift * NB scratch).
+extern "C" int gngf_bin_pixels(const float* xy, int64_t P, int tile_shift, int NB, int chunk, int32_t* blockhist,
+                               int32_t* tile_off, int32_t* items, int32_t* n_items, float* sorted, void* stream) {
+  GNGF_CHECK_ARG(P >= 0 && P < (1ll << 31) && tile_shift >= 0 && tile_shift <= 6 && NB > 0 && NB <= 1024 && chunk > 0);
+  GNGF_CHECK_ARG(xy && blockhist && tile_off && items && n_items && sorted);
+  const int ntiles = 1 << (2 * tile_shift);
+  const int64_t per_block = ceil_div(ceil_div(P, NB), kBinThreads) * kBinThreads;
+  hipStream_t s = as_stream(stream);
+  const size_t smem = (size_t)ntiles * sizeof(int);
+  bin_count_kernel<<<dim3(NB), dim3(kBinThreads), smem, s>>>(reinterpret_cast<const float2*>(xy), P, per_block, tile_shift, NB,
+                                                             blockhist);
+  bin_scan_kernel<<<dim3(1), dim3(kBinThreads), 0, s>>>(blockhist, NB, tile_shift, chunk, tile_off,
+                                                         reinterpret_cast<int4*>(items), n_items);
+  bin_scatter_kernel<<<dim3(NB), dim3(kBinThreads), smem, s>>>(reinterpret_cast<const float2*>(xy), P, per_block, tile_shift, NB,
+                                                               blockhist, reinterpret_cast<float4*>(sorted));
+  GNGF_RETURN_LAUNCH();
+}
+
+static int max_grid_side(const int32_t* n_ls_host, int Ls) {
+  int m = 0;
+  for (int l = 0; l < Ls; ++l) m = n_ls_host[l] + 2 > m ? n_ls_host[l] + 2 : m;
+  return m;
+}
+
+// Vertex stage forward: G (sum_l (N_l+2)^2, F) for levels [0, Ls).  n_ls_host mirrors n_ls on the host (grid sizing).
+extern "C" int gngf_vertex_grid_fwd(const float* tables, const int32_t* vert_idx, const float* vert_w, const int32_t* n_ls,
+                                    const int32_t* n_ls_host, float* G, int Ls, int F, int64_t T, int K, int mode,
+                                    int vstride, int64_t NV, void* stream) {
+  GNGF_CHECK_ARG(Ls > 0 && Ls <= GNGF_MAX_LEVELS && T > 0 && tables && n_ls && n_ls_host && G);
+  GNGF_CHECK_ARG(mode == GNGF_MODE_HASH || (vert_idx && vert_w && K > 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0));
+  const int side = max_grid_side(n_ls_host, Ls);
+  dim3 grid((unsigned)ceil_div((int64_t)side * side, 256), (unsigned)Ls), block(256);
+  const bool pow2 = (T & (T - 1)) == 0;
+  if (mode == GNGF_MODE_HASH) {
+    DISPATCH_F(F, (vertex_fwd_kernel<kF, false><<<grid, block, 0, as_stream(stream)>>>(tables, nullptr, nullptr, n_ls, G, T, 0, 0,
+                                                                                       0, pow2)));
+  } else {
+    DISPATCH_F(F, (vertex_fwd_kernel<kF, true><<<grid, block, 0, as_stream(stream)>>>(tables, vert_idx, vert_w, n_ls, G, T, K,
+                                                                                      vstride, NV, pow2)));
+  }
+  GNGF_RETURN_LAUNCH();
+}
+
+// Vertex stage backward: dG -> dtables (accumulated, caller zero-fills) and dvert_w (accumulated, may be NULL).
+extern "C" int gngf_vertex_grid_bwd(const float* tables, const int32_t* vert_idx, const float* vert_w, const int32_t* n_ls,
+                                    const int32_t* n_ls_host, const float* dG, float* dtables, float* dvert_w, int Ls, int F,
+                                    int64_t T, int K, int mode, int vstride, int64_t NV, void* stream) {
+  GNGF_CHECK_ARG(Ls > 0 && Ls <= GNGF_MAX_LEVELS && T > 0 && tables && n_ls && n_ls_host && dG && dtables);
+  GNGF_CHECK_ARG(mode == GNGF_MODE_HASH || (vert_idx && vert_w && K > 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0));
+  const int side = max_grid_side(n_ls_host, Ls);
+  dim3 grid((unsigned)ceil_div((int64_t)side * side, 256), (unsigned)Ls), block(256);
+  const bool pow2 = (T & (T - 1)) == 0;
+  if (mode == GNGF_MODE_HASH) {
+    DISPATCH_F(F, (vertex_bwd_kernel<kF, false><<<grid, block, 0, as_stream(stream)>>>(tables, nullptr, nullptr, n_ls, dG, dtables,
+                                                                                       nullptr, T, 0, 0, 0, pow2)));
+  } else {
+    DISPATCH_F(F, (vertex_bwd_kernel<kF, true><<<grid, block, 0, as_stream(stream)>>>(tables, vert_idx, vert_w, n_ls, dG, dtables,
+                                                                                      dvert_w, T, K, vstride, NV, pow2)));
+  }
+  GNGF_RETURN_LAUNCH();
+}
+
+// Pixel stage.  enc / genc are (P, L*F) rows; levels [0, Ls) are produced / consumed here (the remaining levels, if any,
+// by the direct form).  lds_bytes = dynamic LDS for the per-tile sub-grids (levels that do not fit fall back to global).
+extern "C" int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
+                                     const int32_t* n_ls, const float* G, float* enc, int L, int Ls, int F, int tile_shift,
+                                     int lds_bytes, void* stream) {
+  GNGF_CHECK_ARG(max_items >= 0 && L > 0 && Ls > 0 && Ls <= L && L <= GNGF_MAX_LEVELS && lds_bytes >= 0 && lds_bytes <= 128 * 1024);
+  if (max_items == 0) return 0;
+  GNGF_CHECK_ARG(sorted && items && n_items && n_ls && G && enc);
+  DISPATCH_F(F, {
+    if (lds_bytes > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiled_fwd_kernel<kF>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      if (e != hipSuccess) return (int)e;
+    }
+    tiled_fwd_kernel<kF><<<dim3((unsigned)max_items), dim3(kTB), (size_t)lds_bytes, as_stream(stream)>>>(
+        reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, n_ls, G, enc, L, Ls, tile_shift,
+        lds_bytes / 4);
+  });
+  GNGF_RETURN_LAUNCH();
+}
+
+extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
+                                     const int32_t* n_ls, const float* genc, float* dG, int L, int Ls, int F, int tile_shift,
+                                     int lds_bytes, void* stream) {
+  GNGF_CHECK_ARG(max_items >= 0 && L > 0 && Ls > 0 && Ls <= L && L <= GNGF_MAX_LEVELS && lds_bytes >= 0 && lds_bytes <= 128 * 1024);
+  if (max_items == 0) return 0;
+  GNGF_CHECK_ARG(sorted && items && n_items && n_ls && genc && dG);
+  DISPATCH_F(F, {
+    if (lds_bytes > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiled_bwd_kernel<kF>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      if (e != hipSuccess) return (int)e;
+    }
+    tiled_bwd_kernel<kF><<<dim3((unsigned)max_items), dim3(kTB), (size_t)lds_bytes, as_stream(stream)>>>(
+        reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, n_ls, genc, dG, L, Ls, tile_shift,
+        lds_bytes / 4);
+  });
+  GNGF_RETURN_LAUNCH();
+}

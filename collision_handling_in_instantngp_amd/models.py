@@ -196,6 +196,7 @@ class GeneralNeuralGaugeFields(nn.Module):
         b = np.exp((np.log(n_max) - np.log(n_min)) / (num_levels - 1))
         if b > 2 or b <= 1:                                                # models.py:306-309
             print(f"The between level scale is recommended to be <= 2 and needs to be > 1 but was {b:.4f}.")
+        self._n_ls_host = [int(n) for n in level_resolutions(n_min, n_max, num_levels)]
         self._n_ls = torch.from_numpy(level_resolutions(n_min, n_max, num_levels)).reshape(1, 1, -1, 1).to(device).int()
         cube = np.array([[0, 1, 0, 1], [0, 0, 1, 1]], dtype=np.int32)       # models.py:322-331
         self._voxels_helper_hypercube = torch.from_numpy(cube).unsqueeze(0).unsqueeze(2).to(device).int()
@@ -281,7 +282,7 @@ class GeneralNeuralGaugeFields(nn.Module):
         P, L, T, K = x.shape[0], self._num_levels, self._hash_table_size, self._topk_k
 
         if self._hash_mode:
-            enc = ops.encode_apply(x, n_ls, tables, None, None, 0)
+            enc = ops.encode_apply(x, n_ls, self._n_ls_host, tables, None, None, 0)
             rgb = self._decode(enc)
             idx = ops.hash_indices(x.detach(), n_ls, T) if (self.return_indices or should_calc_counts) else None
             counts = self._calc_counts_per_level(idx, x, n_ls) if should_calc_counts else []
@@ -303,7 +304,7 @@ class GeneralNeuralGaugeFields(nn.Module):
             tv, ti, pbar, probs_u = ops.HpdVertexFunction.apply(NV, vstride, K, mw, want_dense, HPD_CHUNK_BYTES,
                                                                 *self.HPD.flat_params())
             w = ops.BlendFunction.apply(tv, blend_code)
-        enc = ops.encode_apply(x, n_ls, tables, ti, w, vstride)
+        enc = ops.encode_apply(x, n_ls, self._n_ls_host, tables, ti, w, vstride)
         rgb = self._decode(enc)
 
         need_vid = want_dense or keep_topk or should_calc_counts

@@ -94,7 +94,7 @@ class EncodeDirectFunction(torch.autograd.Function):
         NV = 0 if vert_idx is None else vert_idx.shape[0]
         enc = torch.empty((P, L * F), dtype=_f32, device=tables.device)
         call("gngf_encode_fwd", ptr(xy, _f32, "xy"), ptr(tables, _f32, "tables"), ptr(vert_idx, _i32, "vert_idx"),
-             ptr(vert_w, _f32, "vert_w"), ptr(n_ls, _i32, "n_ls"), ptr(enc), P, L, F, T, K, mode, vstride, NV,
+             ptr(vert_w, _f32, "vert_w"), ptr(n_ls, _i32, "n_ls"), ptr(enc), P, L, F, T, K, mode, vstride, NV, 0, L,
              stream_ptr())
         ctx.save_for_backward(xy, n_ls, tables, vert_idx, vert_w)
         ctx.cfg = (P, L, F, T, K, mode, vstride, NV)
@@ -108,7 +108,7 @@ class EncodeDirectFunction(torch.autograd.Function):
         dtables = torch.zeros_like(tables)
         dvw = torch.zeros_like(vert_w) if (vert_w is not None and ctx.needs_input_grad[4]) else None
         call("gngf_encode_bwd", ptr(xy), ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc, _f32, "grad"),
-             ptr(dtables), ptr(dvw), P, L, F, T, K, mode, vstride, NV, stream_ptr())
+             ptr(dtables), ptr(dvw), P, L, F, T, K, mode, vstride, NV, 0, L, stream_ptr())
         return None, None, dtables, None, dvw, None
 
 
@@ -372,9 +372,144 @@ class TableViewFunction(torch.autograd.Function):
         return (None, None, *([None] * len(ws)))
 
 
-def encode_apply(xy, n_ls, tables, vert_idx, vert_w, vstride):
-    """Fused encoder dispatch (direct form; the tiled/LDS form takes over for levels it can stage)."""
-    return EncodeDirectFunction.apply(xy, n_ls, tables, vert_idx, vert_w, vstride)
+# ------------------------------------------------------------------------------------------------ tiled encoder
+import ctypes as _ct
+import math as _math
+
+ENCODE_PATH = "auto"        # "auto" | "direct" | "tiled"  (tests force a path; auto = tiled when it pays)
+TILED_CHUNK = 1024          # max pixels per (tile, chunk) work item
+TILED_MIN_PIXELS = 1 << 14  # below this the binning overhead is not worth it
+TILED_LDS_LIMIT = 64 * 1024
+
+
+class EncodePlan:
+    """Host-side geometry of the tiled form for one (batch size, level set): which levels are staged, the tile
+    grid, LDS budget, workspace sizes.  Pure integer arithmetic (unit-tested on CPU)."""
+
+    def __init__(self, P, n_ls_host, F, path=None):
+        path = path or ENCODE_PATH
+        self.P, self.F = int(P), int(F)
+        self.n_ls_host = [int(n) for n in n_ls_host]
+        L = len(self.n_ls_host)
+        self.L = L
+        Ls = 0
+        if path != "direct" and (path == "tiled" or P >= TILED_MIN_PIXELS):
+            for n in self.n_ls_host:          # resolutions ascend: stage the leading levels that are dense enough
+                dense_enough = n * n <= max(P, 1)          # >= 1 pixel per cell: privatisation pays
+                small_enough = (n + 2) * (n + 2) * F * 4 <= (64 << 20)
+                if dense_enough and small_enough:
+                    Ls += 1
+                else:
+                    break
+        self.Ls = Ls
+        if Ls == 0:
+            return
+        nmax = max(self.n_ls_host[:Ls])
+        shift = max(0, min(6, int(_math.ceil(_math.log2(max(nmax / 16.0, 1.0))))))
+        while True:
+            TS = 1 << shift
+            lds = sum((n // TS + 3) ** 2 for n in self.n_ls_host[:Ls]) * F * 4
+            if lds <= TILED_LDS_LIMIT or shift == 6:
+                break
+            shift += 1
+        if lds > TILED_LDS_LIMIT:      # drop the finest staged levels until the sub-grids fit
+            while Ls > 0 and sum((n // TS + 3) ** 2 for n in self.n_ls_host[:Ls]) * F * 4 > TILED_LDS_LIMIT:
+                Ls -= 1
+            self.Ls = Ls
+            if Ls == 0:
+                return
+            lds = sum((n // TS + 3) ** 2 for n in self.n_ls_host[:Ls]) * F * 4
+        self.tile_shift = shift
+        self.ntiles = 1 << (2 * shift)
+        self.lds_bytes = int(lds)
+        self.chunk = TILED_CHUNK
+        self.NB = max(1, min(128, -(-P // 8192)))
+        self.max_items = -(-P // self.chunk) + self.ntiles
+        self.vtot = sum((n + 2) ** 2 for n in self.n_ls_host[:Ls])
+        self.n_ls_c = (_ct.c_int32 * L)(*self.n_ls_host)
+
+
+class TiledWorkspace:
+    """Device buffers of one forward/backward pair (binning result is shared by both)."""
+
+    def __init__(self, plan, xy):
+        dev = xy.device
+        P = plan.P
+        self.blockhist = torch.empty((plan.ntiles * plan.NB,), dtype=_i32, device=dev)
+        self.tile_off = torch.empty((plan.ntiles + 1,), dtype=_i32, device=dev)
+        self.items = torch.empty((plan.max_items, 4), dtype=_i32, device=dev)
+        self.n_items = torch.empty((1,), dtype=_i32, device=dev)
+        self.sorted = torch.empty((max(P, 1), 4), dtype=_f32, device=dev)
+        call("gngf_bin_pixels", ptr(xy, _f32, "xy"), P, plan.tile_shift, plan.NB, plan.chunk, ptr(self.blockhist),
+             ptr(self.tile_off), ptr(self.items), ptr(self.n_items), ptr(self.sorted), stream_ptr())
+
+
+def _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G):
+    L, T, F = tables.shape
+    mode = MODE_HASH if vert_idx is None else MODE_VERTEX_TABLE
+    call("gngf_vertex_grid_fwd", ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), plan.n_ls_c, ptr(G), plan.Ls, F, T,
+         0 if vert_idx is None else vert_idx.shape[1], mode, vstride, 0 if vert_idx is None else vert_idx.shape[0], stream_ptr())
+
+
+def _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw):
+    L, T, F = tables.shape
+    mode = MODE_HASH if vert_idx is None else MODE_VERTEX_TABLE
+    call("gngf_vertex_grid_bwd", ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), plan.n_ls_c, ptr(dG), ptr(dtables), ptr(dvw),
+         plan.Ls, F, T, 0 if vert_idx is None else vert_idx.shape[1], mode, vstride,
+         0 if vert_idx is None else vert_idx.shape[0], stream_ptr())
+
+
+class EncodeFunction(torch.autograd.Function):
+    """Fused coords -> (P, L*F) encoder.  Levels [0, plan.Ls) run through the tiled form (vertex stage + binned,
+    LDS-privatised pixel stage), levels [plan.Ls, L) through the direct form.  Same inputs / gradients as
+    EncodeDirectFunction (reference models.py:486-528, 173-229, 621-655 and their autograd backward)."""
+
+    @staticmethod
+    def forward(ctx, xy, n_ls, plan, tables, vert_idx, vert_w, vstride):
+        xy, tables = _c(xy), _c(tables)
+        L, T, F = tables.shape
+        P = xy.shape[0]
+        mode = MODE_HASH if vert_idx is None else MODE_VERTEX_TABLE
+        K = 0 if vert_idx is None else vert_idx.shape[1]
+        NV = 0 if vert_idx is None else vert_idx.shape[0]
+        enc = torch.empty((P, L * F), dtype=_f32, device=tables.device)
+        ws = None
+        if plan.Ls > 0 and P > 0:
+            ws = TiledWorkspace(plan, xy)
+            G = torch.empty((plan.vtot, F), dtype=_f32, device=tables.device)
+            _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G)
+            call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), ptr(G),
+                 ptr(enc), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, stream_ptr())
+        if plan.Ls < L:
+            call("gngf_encode_fwd", ptr(xy, _f32, "xy"), ptr(tables, _f32, "tables"), ptr(vert_idx, _i32, "vert_idx"),
+                 ptr(vert_w, _f32, "vert_w"), ptr(n_ls, _i32, "n_ls"), ptr(enc), P, L, F, T, K, mode, vstride, NV, plan.Ls, L,
+                 stream_ptr())
+        ctx.save_for_backward(xy, n_ls, tables, vert_idx, vert_w)
+        ctx.cfg = (P, L, F, T, K, mode, vstride, NV, plan, ws)
+        return enc
+
+    @staticmethod
+    def backward(ctx, genc):
+        xy, n_ls, tables, vert_idx, vert_w = ctx.saved_tensors
+        P, L, F, T, K, mode, vstride, NV, plan, ws = ctx.cfg
+        genc = _c(genc)
+        dtables = torch.zeros_like(tables)
+        dvw = torch.zeros_like(vert_w) if (vert_w is not None and ctx.needs_input_grad[5]) else None
+        if plan.Ls > 0 and P > 0:
+            dG = torch.zeros((plan.vtot, F), dtype=_f32, device=tables.device)
+            call("gngf_encode_tiled_bwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls),
+                 ptr(genc, _f32, "grad"), ptr(dG), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, stream_ptr())
+            _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw)
+        if plan.Ls < L:
+            call("gngf_encode_bwd", ptr(xy), ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc, _f32, "grad"),
+                 ptr(dtables), ptr(dvw), P, L, F, T, K, mode, vstride, NV, plan.Ls, L, stream_ptr())
+        return None, None, None, dtables, None, dvw, None
+
+
+def encode_apply(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, path=None):
+    """Fused encoder dispatch: tiled form for the levels it can stage, direct form for the rest."""
+    plan = EncodePlan(xy.shape[0], n_ls_host, tables.shape[2], path)
+    return EncodeFunction.apply(xy, n_ls, plan, tables, vert_idx, vert_w, vstride)
 
 
 def decoder_apply(enc, acts, params):
@@ -383,7 +518,7 @@ def decoder_apply(enc, acts, params):
 
 
 # ------------------------------------------------------------------------------------------------ per-kernel launch closures
-def encode_kernels(xy, n_ls, tables, vert_idx, vert_w, vstride, genc):
+def encode_kernels(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, genc, path=None):
     """{name: zero-arg launcher} for the encoder kernels the current dispatch uses (bench.py times each one alone
     with HIP events on the launch stream)."""
     L, T, F = tables.shape
@@ -393,14 +528,27 @@ def encode_kernels(xy, n_ls, tables, vert_idx, vert_w, vstride, genc):
     NV = 0 if vert_idx is None else vert_idx.shape[0]
     enc = torch.empty((P, L * F), dtype=_f32, device=xy.device)
     dtables = torch.zeros_like(tables)
+    plan = EncodePlan(P, n_ls_host, F, path)
     s = stream_ptr
-
-    def fwd():
-        call("gngf_encode_fwd", ptr(xy), ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(enc), P, L, F, T, K, mode,
-             vstride, NV, s())
-
-    def bwd():
-        call("gngf_encode_bwd", ptr(xy), ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc), ptr(dtables), ptr(None),
-             P, L, F, T, K, mode, vstride, NV, s())
-
-    return {"encode_fwd:direct": fwd, "encode_bwd:direct": bwd}
+    out = {}
+    if plan.Ls > 0:
+        ws = TiledWorkspace(plan, xy)
+        G = torch.empty((plan.vtot, F), dtype=_f32, device=xy.device)
+        dG = torch.zeros_like(G)
+        _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G)
+        out["bin_pixels"] = lambda: TiledWorkspace(plan, xy)
+        out["vertex_fwd"] = lambda: _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G)
+        out["encode_fwd:tiled"] = lambda: call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items),
+                                               plan.max_items, ptr(n_ls), ptr(G), ptr(enc), L, plan.Ls, F, plan.tile_shift,
+                                               plan.lds_bytes, s())
+        out["encode_bwd:tiled"] = lambda: call("gngf_encode_tiled_bwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items),
+                                               plan.max_items, ptr(n_ls), ptr(genc), ptr(dG), L, plan.Ls, F, plan.tile_shift,
+                                               plan.lds_bytes, s())
+        out["vertex_bwd"] = lambda: _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, None)
+    if plan.Ls < L:
+        out["encode_fwd:direct"] = lambda: call("gngf_encode_fwd", ptr(xy), ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls),
+                                                ptr(enc), P, L, F, T, K, mode, vstride, NV, plan.Ls, L, s())
+        out["encode_bwd:direct"] = lambda: call("gngf_encode_bwd", ptr(xy), ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls),
+                                                ptr(genc), ptr(dtables), ptr(None), P, L, F, T, K, mode, vstride, NV, plan.Ls,
+                                                L, s())
+    return out

@@ -58,17 +58,45 @@ int gngf_bilinear_bwd(const float* xy, const int32_t* n_ls, const float* genc, f
                       int64_t P, int L, int F, void* stream);
 
 /* ---- a5..a12 fused, "direct" form: one lane per (pixel, level); table rows gathered straight from HBM/L2.
+ * Only levels [l0, l1) are produced / consumed (enc rows stay (P, L*F)); the tiled form below covers the others.
  * mode HASH: vert_idx/vert_w NULL, K ignored.
  * mode VERTEX_TABLE: vert_idx (NV,K) int32 slots and vert_w (NV,K) blend weights per grid vertex
  *   (vid = gy*vstride + gx), i.e. HPD(top-K) evaluated once per DISTINCT vertex instead of per instance. */
 int gngf_encode_fwd(const float* xy, const float* tables, const int32_t* vert_idx, const float* vert_w,
                     const int32_t* n_ls, float* enc, int64_t P, int L, int F, int64_t T, int K,
-                    int mode, int vstride, int64_t NV, void* stream);
+                    int mode, int vstride, int64_t NV, int l0, int l1, void* stream);
 /* backward: dtables (L,T,F) accumulated (caller zero-fills); dvert_w (NV,K) accumulated (caller zero-fills),
  * = sum over instances of c_v * <g, E_l[idx_k]>  (gradient w.r.t. the blend WEIGHT, before the blend's own backward). */
 int gngf_encode_bwd(const float* xy, const float* tables, const int32_t* vert_idx, const float* vert_w,
                     const int32_t* n_ls, const float* genc, float* dtables, float* dvert_w,
-                    int64_t P, int L, int F, int64_t T, int K, int mode, int vstride, int64_t NV, void* stream);
+                    int64_t P, int L, int F, int64_t T, int K, int mode, int vstride, int64_t NV, int l0, int l1,
+                    void* stream);
+
+/* ---- a5..a12 fused, "tiled" form: vertex stage + spatially binned, LDS-privatised pixel stage.
+ * gngf_bin_pixels: bins P pixels into 4^tile_shift tiles of [0,1]^2.  NB binning blocks (<= 1024); `chunk` = max pixels
+ *   per work item.  Outputs: sorted (P,4) fp32 = x, y, bits(original index), 0;  items (max_items,4) int32 = start, count,
+ *   tile, 0 with max_items >= ceil(P/chunk) + 4^tile_shift;  n_items (1);  tile_off (4^tile_shift + 1);
+ *   blockhist: scratch of 4^tile_shift * NB int32. */
+int gngf_bin_pixels(const float* xy, int64_t P, int tile_shift, int NB, int chunk, int32_t* blockhist, int32_t* tile_off,
+                    int32_t* items, int32_t* n_items, float* sorted, void* stream);
+/* vertex stage: G[(goff_l + gy*(N_l+2) + gx)*F + f] for levels [0, Ls), goff_l = sum_{j<l} (N_j+2)^2.
+ * n_ls_host mirrors n_ls on the host (grid sizing only). */
+int gngf_vertex_grid_fwd(const float* tables, const int32_t* vert_idx, const float* vert_w, const int32_t* n_ls,
+                         const int32_t* n_ls_host, float* G, int Ls, int F, int64_t T, int K, int mode, int vstride,
+                         int64_t NV, void* stream);
+/* dG -> dtables (L,T,F) accumulated (caller zero-fills) and dvert_w (NV,K) accumulated (NULL when not needed). */
+int gngf_vertex_grid_bwd(const float* tables, const int32_t* vert_idx, const float* vert_w, const int32_t* n_ls,
+                         const int32_t* n_ls_host, const float* dG, float* dtables, float* dvert_w, int Ls, int F, int64_t T,
+                         int K, int mode, int vstride, int64_t NV, void* stream);
+/* pixel stage over the work items of gngf_bin_pixels: enc / genc rows are (P, L*F); levels [0, Ls) handled here.
+ * lds_bytes: dynamic LDS for the per-tile sub-grids (a level that does not fit falls back to global memory).
+ * bwd ACCUMULATES into dG (caller zero-fills). */
+int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
+                          const int32_t* n_ls, const float* G, float* enc, int L, int Ls, int F, int tile_shift, int lds_bytes,
+                          void* stream);
+int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
+                          const int32_t* n_ls, const float* genc, float* dG, int L, int Ls, int F, int tile_shift, int lds_bytes,
+                          void* stream);
 
 /* ---- dense layers on the matrix cores (exact-fp32 MFMA).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.01), 3 Sigmoid.
  * nn.Linear + activation of HashProbDistribution (models.py:80-88,105-106) and of the decoder (models.py:382-392). */

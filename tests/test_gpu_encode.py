@@ -134,3 +134,86 @@ def test_empty_batch_and_bad_args(ops):
         ops.EncodeDirectFunction.apply(torch.zeros((4, 2), device=DEV), n_ls, torch.zeros((4, 256, 3), device=DEV), None, None, 0)
     with pytest.raises(Exception):         # CPU tensors never fall back
         ops.hash_indices(torch.zeros((4, 2)), n_ls.cpu(), 256)
+
+
+# ------------------------------------------------------------------------------------------------ tiled form
+def _oracle_hash(x, n_ls, tables, g):
+    L, T, F = tables.shape
+    _, grid = orc.scale_to_grid(x, n_ls)
+    idx = orc.spatial_hash(grid.astype(np.int32), T)
+    want = orc.bilinear_forward(x, n_ls, orc.encoding_forward(tables, idx))
+    dt, _ = orc.encoding_backward(tables, idx, None, True, orc.bilinear_backward(x, n_ls, g, F))
+    return want, dt
+
+
+@pytest.mark.parametrize("cfg", [(8, 32, 4, 2, 256, 3001), (16, 512, 16, 2, 2 ** 14, 40000), (16, 128, 5, 4, 1000, 20000),
+                                 (4, 64, 3, 1, 64, 5000), (16, 512, 16, 2, 2 ** 12, 3001), (16, 256, 8, 8, 4096, 70001)])
+def test_tiled_encode_hash_vs_oracle(ops, cfg):
+    """tiled form (all staged, or staged + direct levels mixed when the batch is sparse at the fine levels)"""
+    n_min, n_max, L, F, T, P = cfg
+    rng = np.random.default_rng(P)
+    x = _coords(P, rng)
+    x[100:200] = x[100]                                  # many pixels in one cell: LDS atomics on one address
+    tables = (rng.random((L, T, F), dtype=np.float32) - 0.5) * 2e-4
+    n_ls = orc.level_resolutions(n_min, n_max, L)
+    g = rng.standard_normal((P, L * F)).astype(np.float32)
+    want, dt = _oracle_hash(x, n_ls, tables, g)
+    tt = t(tables).requires_grad_()
+    enc = ops.encode_apply(t(x), t(n_ls, torch.int32), [int(n) for n in n_ls], tt, None, None, 0, path="tiled")
+    close(enc, want, 1e-6, 1e-9)
+    enc.backward(t(g))
+    close(tt.grad, dt, 2e-4, 2e-6)
+    # and the two forms agree bit-for-bit in the forward direction
+    enc_d = ops.encode_apply(t(x), t(n_ls, torch.int32), [int(n) for n in n_ls], t(tables), None, None, 0, path="direct")
+    assert torch.equal(enc_d, enc.detach())
+
+
+@pytest.mark.parametrize("cfg", [(8, 32, 4, 2, 256, 4, 5000), (16, 128, 8, 2, 4096, 4, 30000), (8, 64, 5, 4, 512, 1, 9000),
+                                 (16, 512, 16, 2, 2 ** 13, 4, 2500)])
+def test_tiled_encode_vertex_table_vs_oracle(ops, cfg):
+    n_min, n_max, L, F, T, K, P = cfg
+    rng = np.random.default_rng(P + 1)
+    x = _coords(P, rng)
+    tables = (rng.random((L, T, F), dtype=np.float32) - 0.5) * 2e-4
+    n_ls = orc.level_resolutions(n_min, n_max, L)
+    vstride = n_max + 2
+    NV = vstride * vstride
+    vidx = rng.integers(0, T, (NV, K)).astype(np.int32)
+    vw = rng.random((NV, K), dtype=np.float32)
+    _, grid = orc.scale_to_grid(x, n_ls)
+    gi = grid.astype(np.int64)
+    vid = gi[:, 1] * vstride + gi[:, 0]
+    idx_inst, w_inst = vidx[vid].astype(np.int64), vw[vid]
+    want = orc.bilinear_forward(x, n_ls, orc.encoding_forward(tables, idx_inst, w_inst, None))
+    tt, tw = t(tables).requires_grad_(), t(vw).requires_grad_()
+    enc = ops.encode_apply(t(x), t(n_ls, torch.int32), [int(n) for n in n_ls], tt, t(vidx), tw, vstride, path="tiled")
+    close(enc, want, 2e-6, 1e-9)
+    g = rng.standard_normal(want.shape).astype(np.float32)
+    enc.backward(t(g))
+    dt, dw_inst = orc.encoding_backward(tables, idx_inst, w_inst, None, orc.bilinear_backward(x, n_ls, g, F))
+    close(tt.grad, dt, 2e-4, 2e-6)
+    dvw = np.zeros((NV, K), np.float64)
+    np.add.at(dvw, vid.reshape(-1), dw_inst.reshape(-1, K).astype(np.float64))
+    close(tw.grad, dvw, 2e-4, 2e-7)
+
+
+def test_binning_is_a_permutation_grouped_by_tile(ops):
+    rng = np.random.default_rng(9)
+    P = 50000
+    x = _coords(P, rng)
+    plan = ops.EncodePlan(P, [16, 64, 512], 2, "tiled")
+    ws = ops.TiledWorkspace(plan, t(x))
+    srt = ws.sorted.cpu().numpy()
+    ids = srt[:, 2].copy().view(np.int32)
+    assert np.array_equal(np.sort(ids), np.arange(P))                      # every pixel exactly once
+    assert np.array_equal(srt[:, :2], x[ids])                              # coordinates travel with their index
+    TS = 1 << plan.tile_shift
+    tile = np.minimum((srt[:, 1] * TS).astype(np.int64), TS - 1) * TS + np.minimum((srt[:, 0] * TS).astype(np.int64), TS - 1)
+    assert np.all(np.diff(tile) >= 0)                                      # sorted by tile
+    n_items = int(ws.n_items.item())
+    items = ws.items.cpu().numpy()[:n_items]
+    assert items[:, 1].sum() == P and items[:, 1].max() <= plan.chunk and items[:, 1].min() > 0
+    for s_, c_, t_, _ in items[:: max(1, n_items // 50)]:
+        assert np.all(tile[s_:s_ + c_] == t_)
+    off = ws.tile_off.cpu().numpy()
+    assert off[-1] == P and np.array_equal(np.bincount(tile, minlength=TS * TS), np.diff(off))

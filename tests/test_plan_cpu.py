@@ -1,0 +1,43 @@
+"""CPU: host-side geometry of the tiled encoder (pure integer logic) and level resolutions vs goldens."""
+import numpy as np
+
+from collision_handling_in_instantngp_amd import ops, models
+
+
+def test_product_level_resolutions_match_reference(golden):
+    g = golden("G1_level_resolutions")
+    i = 0
+    while f"case{i}" in g:
+        a, b, L = (int(v) for v in g[f"case{i}"])
+        assert np.array_equal(models.level_resolutions(a, b, L), g[f"n_ls{i}"])
+        i += 1
+
+
+def test_plan_cfg2_stages_every_level():
+    n = [int(v) for v in models.level_resolutions(16, 512, 16)]
+    pl = ops.EncodePlan(2 ** 20, n, 2)
+    assert pl.Ls == 16 and pl.tile_shift == 5 and pl.lds_bytes <= ops.TILED_LDS_LIMIT
+    assert pl.max_items >= 2 ** 20 // pl.chunk + pl.ntiles
+    assert pl.vtot == sum((v + 2) ** 2 for v in n)
+    # every tile's sub-grid fits the LDS bound used for the launch
+    TS = 1 << pl.tile_shift
+    for tx in (0, 1, TS // 2, TS - 1):
+        tot = 0
+        for v in n:
+            cx = (tx * v) >> pl.tile_shift
+            hx = min((((tx + 1) * v) >> pl.tile_shift) + 1, v + 1)
+            tot += (hx - cx + 1) ** 2
+        assert tot * 2 * 4 <= pl.lds_bytes
+
+
+def test_plan_sparse_fine_levels_go_direct():
+    n = [int(v) for v in models.level_resolutions(16, 4096, 16)]
+    pl = ops.EncodePlan(2 ** 20, n, 2)
+    assert 0 < pl.Ls < 16 and all(v * v <= 2 ** 20 for v in n[:pl.Ls]) and n[pl.Ls] ** 2 > 2 ** 20
+
+
+def test_plan_small_batches_use_direct_form():
+    pl = ops.EncodePlan(1000, [8, 12, 20, 32], 2)
+    assert pl.Ls == 0
+    assert ops.EncodePlan(1000, [8, 12, 20, 32], 2, "tiled").Ls == 4
+    assert ops.EncodePlan(2 ** 20, [8, 12, 20, 32], 2, "direct").Ls == 0
