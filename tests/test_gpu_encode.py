@@ -162,7 +162,7 @@ def test_tiled_encode_hash_vs_oracle(ops, cfg):
     enc = ops.encode_apply(t(x), t(n_ls, torch.int32), [int(n) for n in n_ls], tt, None, None, 0, path="tiled")
     close(enc, want, 1e-6, 1e-9)
     enc.backward(t(g))
-    close(tt.grad, dt, 2e-4, 2e-6)
+    close(tt.grad, dt, 2e-4, 2e-6 * max(1.0, float(np.abs(dt).max())))   # fp32 sums of ~P/cells terms, any order
     # and the two forms agree bit-for-bit in the forward direction
     enc_d = ops.encode_apply(t(x), t(n_ls, torch.int32), [int(n) for n in n_ls], t(tables), None, None, 0, path="direct")
     assert torch.equal(enc_d, enc.detach())
@@ -191,10 +191,10 @@ def test_tiled_encode_vertex_table_vs_oracle(ops, cfg):
     g = rng.standard_normal(want.shape).astype(np.float32)
     enc.backward(t(g))
     dt, dw_inst = orc.encoding_backward(tables, idx_inst, w_inst, None, orc.bilinear_backward(x, n_ls, g, F))
-    close(tt.grad, dt, 2e-4, 2e-6)
+    close(tt.grad, dt, 2e-4, 2e-6 * max(1.0, float(np.abs(dt).max())))
     dvw = np.zeros((NV, K), np.float64)
     np.add.at(dvw, vid.reshape(-1), dw_inst.reshape(-1, K).astype(np.float64))
-    close(tw.grad, dvw, 2e-4, 2e-7)
+    close(tw.grad, dvw, 2e-4, 2e-6 * max(1e-1, float(np.abs(dvw).max())))
 
 
 def test_binning_is_a_permutation_grouped_by_tile(ops):

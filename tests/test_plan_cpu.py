@@ -39,5 +39,5 @@ def test_plan_sparse_fine_levels_go_direct():
 def test_plan_small_batches_use_direct_form():
     pl = ops.EncodePlan(1000, [8, 12, 20, 32], 2)
     assert pl.Ls == 0
-    assert ops.EncodePlan(1000, [8, 12, 20, 32], 2, "tiled").Ls == 4
+    assert ops.EncodePlan(2000, [8, 12, 20, 32], 2, "tiled").Ls == 4
     assert ops.EncodePlan(2 ** 20, [8, 12, 20, 32], 2, "direct").Ls == 0
