@@ -32,6 +32,10 @@ SIGNATURES = {
     "gngf_vertex_grid_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L, _P],
     "gngf_encode_tiled_fwd": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gngf_encode_tiled_bwd": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gngf_decoder_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "gngf_decoder_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "gngf_decoder_bwd_slabs": [_L],
+    "gngf_decoder_slab_floats": [_I, _I],
     "gngf_linear_fwd": [_P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gngf_linear_bwd_input": [_P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gngf_linear_bwd_weight": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
@@ -93,6 +97,11 @@ def ptr(t, dtype=None, name="tensor"):
     if not t.is_contiguous():
         raise ValueError(f"{name} must be contiguous")
     return _P(t.data_ptr())
+
+
+def query(name, *args):
+    """Entry points that return a size rather than a hipError_t."""
+    return getattr(load(), name)(*args)
 
 
 def call(name, *args):

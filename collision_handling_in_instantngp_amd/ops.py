@@ -512,8 +512,52 @@ def encode_apply(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, path=No
     return EncodeFunction.apply(xy, n_ls, plan, tables, vert_idx, vert_w, vstride)
 
 
-def decoder_apply(enc, acts, params):
-    """Decoder MLP dispatch (reference models.py:382-392,469-470)."""
+class DecoderFunction(torch.autograd.Function):
+    """The reference's default decoder (in -> 64 -> 64 -> out, ReLU|LeakyReLU, Sigmoid; models.py:382-392) as ONE fused
+    MFMA kernel per direction (csrc/decoder.hip).  apply(enc, leaky, W0, b0, W1, b1, W2, b2) -> rgb."""
+
+    @staticmethod
+    def forward(ctx, enc, leaky, W0, b0, W1, b1, W2, b2):
+        enc = _c(enc)
+        ws = [_c(w) for w in (W0, b0, W1, b1, W2, b2)]
+        P, in_dim = enc.shape
+        out_dim = ws[4].shape[0]
+        rgb = torch.empty((P, out_dim), dtype=_f32, device=enc.device)
+        call("gngf_decoder_fwd", ptr(enc, _f32, "enc"), *[ptr(w, _f32) for w in ws], ptr(rgb), P, in_dim, out_dim, int(leaky),
+             stream_ptr())
+        ctx.save_for_backward(enc, rgb, *ws)
+        ctx.cfg = (P, in_dim, out_dim, int(leaky))
+        return rgb
+
+    @staticmethod
+    def backward(ctx, drgb):
+        enc, rgb, W0, b0, W1, b1, W2, b2 = ctx.saved_tensors
+        P, in_dim, out_dim, leaky = ctx.cfg
+        drgb = _c(drgb)
+        dev = enc.device
+        denc = torch.empty_like(enc)
+        grads = [torch.empty_like(w) for w in (W0, b0, W1, b1, W2, b2)]
+        slabs = torch.empty((_lib.query("gngf_decoder_bwd_slabs", P) * _lib.query("gngf_decoder_slab_floats", in_dim, out_dim),),
+                            dtype=_f32, device=dev)
+        call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb, _f32, "grad"), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2),
+             ptr(denc), *[ptr(g) for g in grads], ptr(slabs), P, in_dim, out_dim, leaky, stream_ptr())
+        return (denc, None, *grads)
+
+
+def decoder_fused_ok(acts, params):
+    if len(acts) != 3 or acts[2] != ACT_SIGMOID or acts[0] != acts[1] or acts[0] not in (ACT_RELU, ACT_LEAKY):
+        return False
+    W0, _, W1, _, W2, _ = params
+    return W0.shape[0] == 64 and tuple(W1.shape) == (64, 64) and W2.shape[1] == 64 and W0.shape[1] <= 64 and W2.shape[0] <= 4
+
+
+def decoder_apply(enc, acts, params, fused=None):
+    """Decoder MLP dispatch (reference models.py:382-392,469-470): the fused kernel for the default 64/64 widths,
+    the generic MFMA linear chain otherwise."""
+    if (fused is None or fused) and decoder_fused_ok(acts, params):
+        return DecoderFunction.apply(enc, acts[0] == ACT_LEAKY, *params)
+    if fused:
+        raise ValueError("fused decoder needs hidden widths [64, 64], in <= 64, out <= 4")
     return MlpFunction.apply(enc, acts, *params)
 
 

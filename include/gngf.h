@@ -110,6 +110,18 @@ int gngf_linear_bwd_weight(const float* dY, const float* Y, const float* X, floa
 /* C[M,N] += opA(A) opB(B), contraction Kc split over blocks.  ta: A stored (Kc,M); tb: B stored (N,Kc). */
 int gngf_gemm_acc(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kc, int ta, int tb, void* stream);
 
+/* ---- a13: the decoder MLP fused (models.py:382-392,469-470): Linear(in,64)+act, Linear(64,64)+act, Linear(64,out)+Sigmoid,
+ * act = ReLU (leaky = 0) or LeakyReLU(0.01) (leaky = 1); in_dim <= 64, out_dim <= 4.  W* are (out,in) like nn.Linear. */
+int gngf_decoder_fwd(const float* enc, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                     const float* b2, float* rgb, int64_t P, int in_dim, int out_dim, int leaky, void* stream);
+/* backward: denc (P,in_dim) and the six parameter gradients, each WRITTEN (not accumulated); rgb = the forward output.
+ * slabs: workspace of gngf_decoder_bwd_slabs(P) * gngf_decoder_slab_floats(in_dim, out_dim) floats. */
+int gngf_decoder_bwd(const float* enc, const float* rgb, const float* drgb, const float* W0, const float* b0, const float* W1,
+                     const float* b1, const float* W2, float* denc, float* dW0, float* db0, float* dW1, float* db1, float* dW2,
+                     float* db2, float* slabs, int64_t P, int in_dim, int out_dim, int leaky, void* stream);
+int gngf_decoder_bwd_slabs(int64_t P);
+int gngf_decoder_slab_floats(int in_dim, int out_dim);
+
 /* ---- a7/a8 tail, per DISTINCT vertex: Softmax(dim=-1) + nan_to_num + top-K (models.py:85,111,116; 5-19).
  * logits_probs (U,T): logits in, probabilities out (in place).  topk_val (U,K) sorted descending, topk_idx (U,K) int32;
  * ties resolve to the LOWER slot index (torch.topk leaves tie order unspecified). */

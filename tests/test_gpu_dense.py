@@ -155,3 +155,49 @@ def test_differentiable_topk_standalone():
     want = np.zeros_like(x)
     np.put_along_axis(want, wi, g, -1)
     assert np.array_equal(xt.grad.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("tag", ["cfg1", "cfg2", "bw_leaky"])
+@pytest.mark.parametrize("fused", [True, False])
+def test_decoder_vs_reference_golden(ops, golden, tag, fused):
+    """decoder MLP (fused MFMA kernel and generic chain) vs the reference's own forward / backward (G9)."""
+    g = golden("G9_decoder")
+    L, Fd, bw, leaky = (int(v) for v in g[f"{tag}_cfg"])
+    params = []
+    for i in range(3):
+        params += [t(g[f"{tag}_w_{i}_0_weight"]).requires_grad_(), t(g[f"{tag}_w_{i}_0_bias"]).requires_grad_()]
+    hid = ops.ACT_LEAKY if leaky else ops.ACT_RELU
+    x = t(g[f"{tag}_x"]).requires_grad_()
+    y = ops.decoder_apply(x, (hid, hid, ops.ACT_SIGMOID), params, fused=fused)
+    close(y, g[f"{tag}_y"], 1e-5, 1e-6)
+    y.backward(t(g[f"{tag}_gy"]))
+    close(x.grad, g[f"{tag}_dx"], 1e-4, 1e-6)
+    for i in range(3):
+        close(params[2 * i].grad, g[f"{tag}_g_{i}_0_weight"], 1e-4, 1e-5)
+        close(params[2 * i + 1].grad, g[f"{tag}_g_{i}_0_bias"], 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("P,in_dim,out_dim,leaky", [(1, 32, 3, 0), (127, 32, 3, 0), (129, 8, 3, 0), (40000, 32, 3, 0),
+                                                     (5000, 64, 1, 1), (333, 24, 4, 0), (70000, 16, 3, 1)])
+def test_fused_decoder_vs_numpy(ops, P, in_dim, out_dim, leaky):
+    rng = np.random.default_rng(P + in_dim)
+    dims = [in_dim, 64, 64, out_dim]
+    W = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(3)]
+    B = [(rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32) for i in range(3)]
+    x = rng.standard_normal((P, in_dim)).astype(np.float32)
+    gy = rng.standard_normal((P, out_dim)).astype(np.float32)
+    y = orc.decoder_forward(x, W, B, bool(leaky))
+    dx, dW, dB = orc.decoder_backward(x, W, B, gy, bool(leaky))
+    params = []
+    for i in range(3):
+        params += [t(W[i]).requires_grad_(), t(B[i]).requires_grad_()]
+    xt = t(x).requires_grad_()
+    hid = ops.ACT_LEAKY if leaky else ops.ACT_RELU
+    yg = ops.decoder_apply(xt, (hid, hid, ops.ACT_SIGMOID), params, fused=True)
+    close(yg, y, 1e-5, 1e-6)
+    yg.backward(t(gy))
+    close(xt.grad, dx, 1e-4, 2e-6)
+    for i in range(3):
+        scale = max(1.0, float(np.abs(dW[i]).max()))
+        close(params[2 * i].grad, dW[i], 2e-4, 2e-5 * scale)
+        close(params[2 * i + 1].grad, dB[i], 2e-4, 2e-5 * scale)
