@@ -128,7 +128,7 @@ def kernel_times(net, models, mode, xy, n=20):
         vstride = 0
     else:
         with torch.no_grad():
-            _tv, ti, w, vstride, _NV = net._frozen_vertex_table(0) if net.hpd_is_frozen() else (None,) * 5
+            _tv, ti, w, vstride, _NV, _o = net._frozen_vertex_table(0) if net.hpd_is_frozen() else (None,) * 6
         if ti is None:
             return {}
     genc = torch.randn((P, L * F), device=dev)

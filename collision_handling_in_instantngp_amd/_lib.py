@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgngf_hip.so")
+LIB_PATH = os.environ.get("GNGF_LIB_PATH") or os.path.join(_HERE, "libgngf_hip.so")   # override: experiments only
 
 _c = ctypes
 _P = _c.c_void_p
@@ -27,11 +27,12 @@ SIGNATURES = {
     "gngf_bilinear_bwd": [_P, _P, _P, _P, _L, _I, _I, _P],
     "gngf_encode_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _L, _I, _I, _P],
     "gngf_encode_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _L, _I, _I, _P],
-    "gngf_bin_pixels": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "gngf_bin_pixels": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "gngf_vertex_grid_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L, _P],
     "gngf_vertex_grid_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L, _P],
     "gngf_encode_tiled_fwd": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "gngf_encode_tiled_bwd": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gngf_encode_tiled_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gngf_vertex_grid_bwd_sorted": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _L, _P],
     "gngf_decoder_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gngf_decoder_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gngf_decoder_bwd_slabs": [_L],

@@ -22,6 +22,8 @@ namespace gngf {
 constexpr int kTB = 256;        // pixel-stage workgroup
 constexpr int kBinThreads = 1024;
 
+__device__ __forceinline__ int g_max0(int v) { return v < 0 ? 0 : v; }
+
 __device__ __forceinline__ int tile_of(float x, float y, int tile_shift) {
   const int TS = 1 << tile_shift;
   int tx = (int)(x * (float)TS), ty = (int)(y * (float)TS);      // exact: TS is a power of two
@@ -49,52 +51,72 @@ bin_count_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, in
   for (int i = threadIdx.x; i < ntiles; i += kBinThreads) blockhist[(int64_t)i * NB + blockIdx.x] = hist[i];
 }
 
-// K2 (one block): per-tile totals, exclusive scan over tiles, per-(tile, block) offsets, and the work-item table.
+// K2 (one block of 16 waves): per-tile totals, exclusive scan over tiles, per-(tile, block) offsets, work-item table.
+// blockhist is [tile][NB] with NB <= 128: one WAVE scans one tile row (2 entries per lane) with shuffles.
 __global__ void __launch_bounds__(kBinThreads)
 bin_scan_kernel(int32_t* __restrict__ blockhist, int NB, int tile_shift, int chunk, int32_t* __restrict__ tile_off,
-                int4* __restrict__ items, int32_t* __restrict__ n_items) {
-  __shared__ int wsum[kBinThreads / 64];
-  __shared__ int wsum2[kBinThreads / 64];
-  __shared__ int carry[2];
+                int32_t* __restrict__ tile_item_base, int4* __restrict__ items, int32_t* __restrict__ n_items) {
+  __shared__ int tot[4096];
+  __shared__ int wsum[kBinThreads / 64], wsum2[kBinThreads / 64];
   const int ntiles = 1 << (2 * tile_shift);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) { carry[0] = 0; carry[1] = 0; }
-  __syncthreads();
-  for (int base = 0; base < ntiles; base += kBinThreads) {
-    const int t = base + tid;
-    int total = 0;
-    if (t < ntiles) {
-      int32_t* row = blockhist + (int64_t)t * NB;
-      for (int b = 0; b < NB; ++b) { const int c = row[b]; row[b] = total; total += c; }   // exclusive within tile
-    }
-    const int nit = (total + chunk - 1) / chunk;
-    // block-wide exclusive scan of (total, nit)
-    int a = total, n2 = nit;
+  constexpr int kWaves = kBinThreads / 64;
+  // phase A: exclusive scan inside each tile row, row totals to LDS
+  for (int t = wave; t < ntiles; t += kWaves) {
+    int32_t* row = blockhist + (int64_t)t * NB;
+    const int b0 = 2 * lane, b1 = 2 * lane + 1;
+    const int v0 = b0 < NB ? row[b0] : 0, v1 = b1 < NB ? row[b1] : 0;
+    int incl = v0 + v1;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int ua = __shfl_up(a, o, 64), un = __shfl_up(n2, o, 64);
-      if (lane >= o) { a += ua; n2 += un; }
-    }
-    if (lane == 63) { wsum[wave] = a; wsum2[wave] = n2; }
-    __syncthreads();
-    int wa = 0, wn = 0;
-    for (int w = 0; w < wave; ++w) { wa += wsum[w]; wn += wsum2[w]; }
-    const int off = carry[0] + wa + a - total;      // exclusive prefix of pixel counts
-    const int ioff = carry[1] + wn + n2 - nit;      // exclusive prefix of item counts
-    if (t < ntiles) {
-      tile_off[t] = off;
-      int32_t* row = blockhist + (int64_t)t * NB;
-      for (int b = 0; b < NB; ++b) row[b] += off;
-      for (int j = 0; j < nit; ++j) {
-        const int cnt = (total - j * chunk) < chunk ? (total - j * chunk) : chunk;
-        items[ioff + j] = make_int4(off + j * chunk, cnt, t, 0);
-      }
-    }
-    __syncthreads();
-    if (tid == kBinThreads - 1) { carry[0] = off + total; carry[1] = ioff + nit; }
-    __syncthreads();
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+    const int ex = incl - (v0 + v1);
+    if (b0 < NB) row[b0] = ex;
+    if (b1 < NB) row[b1] = ex + v0;
+    if (lane == 63) tot[t] = incl;
   }
-  if (tid == 0) { tile_off[ntiles] = carry[0]; *n_items = carry[1]; }
+  __syncthreads();
+  // phase B: block-wide exclusive scan over tiles of (pixels, items); each thread owns `per` consecutive tiles
+  const int per = (ntiles + kBinThreads - 1) / kBinThreads;
+  int mytot = 0, myit = 0;
+  for (int q = 0; q < per; ++q) {
+    const int t = tid * per + q;
+    if (t < ntiles) { mytot += tot[t]; myit += (tot[t] + chunk - 1) / chunk; }
+  }
+  int a = mytot, n2 = myit;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int ua = __shfl_up(a, o, 64), un = __shfl_up(n2, o, 64);
+    if (lane >= o) { a += ua; n2 += un; }
+  }
+  if (lane == 63) { wsum[wave] = a; wsum2[wave] = n2; }
+  __syncthreads();
+  int off = a - mytot, ioff = n2 - myit;
+  for (int w = 0; w < wave; ++w) { off += wsum[w]; ioff += wsum2[w]; }
+  for (int q = 0; q < per; ++q) {
+    const int t = tid * per + q;
+    if (t < ntiles) {
+      const int total = tot[t];
+      const int nit = (total + chunk - 1) / chunk;
+      tile_off[t] = off;
+      tile_item_base[t] = ioff;
+      for (int jj = 0; jj < nit; ++jj) {
+        const int cnt = (total - jj * chunk) < chunk ? (total - jj * chunk) : chunk;
+        items[ioff + jj] = make_int4(off + jj * chunk, cnt, t, nit);
+      }
+      tot[t] = off;                 // reuse: tile offset for phase C
+      off += total;
+      ioff += nit;
+    }
+  }
+  if (tid == kBinThreads - 1) { tile_off[ntiles] = off; tile_item_base[ntiles] = ioff; *n_items = ioff; }
+  __syncthreads();
+  // phase C: add the tile offset to every (tile, block) entry
+  for (int t = wave; t < ntiles; t += kWaves) {
+    int32_t* row = blockhist + (int64_t)t * NB;
+    const int o = tot[t];
+    if (2 * lane < NB) row[2 * lane] += o;
+    if (2 * lane + 1 < NB) row[2 * lane + 1] += o;
+  }
 }
 
 // K3: scatter (x, y, original index) into tile order.  Same pixel->block partition as K1.
@@ -289,13 +311,31 @@ tiled_fwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
   }
 }
 
+// fp32 term -> 64-bit fixed point with 2^S fractional scaling, by integer arithmetic on the float's bits
+// (truncation toward zero: error < 2^-S per term).  S is chosen per work item so that no sum can overflow.
+__device__ __forceinline__ long long to_fixed(float t, int S) {
+  const unsigned bits = __float_as_uint(t);
+  const int e = (int)((bits >> 23) & 0xffu);
+  const long long m = (long long)((bits & 0x7fffffu) | (e ? 0x800000u : 0u));
+  const int sh = (e ? e : 1) - 150 + S;
+  long long q = sh >= 0 ? (m << sh) : (sh > -64 ? (m >> (-sh)) : 0ll);
+  return (bits >> 31) ? -q : q;
+}
+
+// Backward pixel stage.  gfx950's LDS float atomic (ds_add_f32) retires ~3 cycles PER LANE (193 cycles per
+// wave-instruction, measured: tools/micro/lds_atomic.cpp) while ds_add_u64 takes 7-12 cycles per wave-instruction,
+// so the privatised sub-grids accumulate in 64-bit FIXED POINT: every term g*c (one fp32 multiply, as in the
+// reference) is scaled by 2^S, S = 61 - ceil(log2(chunk)) - exponent(max |g| over the item's pixels), which makes
+// overflow impossible and the quantisation (2^-S per term, ~2^-49 of the item's largest gradient) far below one fp32
+// ulp of any partial sum.  Integer adds commute: the per-item image is bitwise reproducible.
 template <int F>
 __global__ void __launch_bounds__(kTB)
 tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ items, const int32_t* __restrict__ n_items,
-                 const int32_t* __restrict__ n_ls, const float* __restrict__ genc, float* __restrict__ dG, int L, int Ls,
-                 int tile_shift, int lds_floats) {
-  extern __shared__ float lds[];
+                 const int32_t* __restrict__ n_ls, const float* __restrict__ genc, float* __restrict__ dG,
+                 float* __restrict__ partials, int L, int Ls, int tile_shift, int lds_floats, int log2_chunk) {
+  extern __shared__ unsigned long long acc64[];
   __shared__ TileMeta m;
+  __shared__ float wmax[kTB / 64];
   if ((int)blockIdx.x >= *n_items) return;
   const int4 it = items[blockIdx.x];
   const int tid = threadIdx.x;
@@ -303,15 +343,34 @@ tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
   setup_tile(m, n_ls, Ls, it.z & TSm, it.z >> tile_shift, tile_shift, F, lds_floats);
   int used = 0;
   for (int l = 0; l < Ls; ++l) used += m.wx[l] * m.wy[l] * F;
-  for (int i = tid; i < used; i += kTB) lds[i] = 0.f;
-  __syncthreads();
+  for (int i = tid; i < used; i += kTB) acc64[i] = 0ull;
   const int ppp = kTB / Ls;
   const int lp = tid / Ls, l = tid - lp * Ls;
-  if (lp < ppp) {
+  const int LF = L * F;
+  // pass 1: largest |gradient| over the item's pixels (these rows are re-read from L2 in pass 2)
+  float gmax = 0.f;
+  if (lp < ppp)
+    for (int j = lp; j < it.y; j += ppp) {
+      const int64_t p = (int64_t)__float_as_int(sorted[it.x + j].z);
+      const float* gi = genc + p * LF + l * F;
+#pragma unroll
+      for (int f = 0; f < F; ++f) { const float a = fabsf(gi[f]); gmax = (a > gmax || a != a) ? a : gmax; }   // NaN sticks
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const float ov = __shfl_xor(gmax, o, 64); gmax = (ov > gmax || ov != ov) ? ov : gmax; }
+  if ((tid & 63) == 0) wmax[tid >> 6] = gmax;
+  __syncthreads();
+  gmax = wmax[0];
+#pragma unroll
+  for (int w = 1; w < kTB / 64; ++w) gmax = (wmax[w] > gmax || wmax[w] != wmax[w]) ? wmax[w] : gmax;
+  const bool finite = gmax < INFINITY;                     // false for inf and NaN
+  int eg = 0;
+  if (finite && gmax > 0.f) (void)frexpf(gmax, &eg);        // gmax < 2^eg
+  const int S = 61 - log2_chunk - eg;
+  if (lp < ppp && finite) {
     const int n = m.n[l], cx = m.cx[l], cy = m.cy[l], wx = m.wx[l], wy = m.wy[l], gw = m.gw[l];
-    float* sub = lds + m.loff[l];
+    unsigned long long* sub = acc64 + m.loff[l];
     float* dGl = dG + m.goff[l] * F;
-    const int LF = L * F;
     for (int j = lp; j < it.y; j += ppp) {
       const float4 s = sorted[it.x + j];
       const int64_t p = (int64_t)__float_as_int(s.z);
@@ -322,14 +381,14 @@ tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
 #pragma unroll
       for (int f = 0; f < F; ++f) g[f] = gi[f];
       if (lx >= 0 && ly >= 0 && lx + 1 < wx && ly + 1 < wy) {
-        float* a = sub + (ly * wx + lx) * F;
-        float* b = a + wx * F;
+        unsigned long long* a = sub + (ly * wx + lx) * F;
+        unsigned long long* b = a + wx * F;
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-          atomicAdd(a + f, g[f] * c.c[0]);
-          atomicAdd(a + F + f, g[f] * c.c[1]);
-          atomicAdd(b + f, g[f] * c.c[2]);
-          atomicAdd(b + F + f, g[f] * c.c[3]);
+          atomicAdd(a + f, (unsigned long long)to_fixed(g[f] * c.c[0], S));
+          atomicAdd(a + F + f, (unsigned long long)to_fixed(g[f] * c.c[1], S));
+          atomicAdd(b + f, (unsigned long long)to_fixed(g[f] * c.c[2], S));
+          atomicAdd(b + F + f, (unsigned long long)to_fixed(g[f] * c.c[3], S));
         }
       } else {
 #pragma unroll
@@ -344,20 +403,135 @@ tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
     }
   }
   __syncthreads();
-  // flush: one global atomic per touched sub-grid entry, row segments contiguous in dG
-  for (int ll = 0; ll < Ls; ++ll) {
-    const int wx = m.wx[ll], sz = wx * m.wy[ll] * F;
-    const float* src = lds + m.loff[ll];
-    float* dst = dG + (m.goff[ll] + (int64_t)m.cy[ll] * m.gw[ll] + m.cx[ll]) * F;
-    const int rowf = wx * F;
-    for (int i = tid; i < sz; i += kTB) {
-      const float v = src[i];
-      if (v != 0.f) {
-        const int iy = i / rowf, r = i - iy * rowf;
-        atomicAdd(dst + (int64_t)iy * m.gw[ll] * F + r, v);
+  // store pass: the item's privatised sub-grid image goes out as fp32 with plain coalesced stores; the gather pass
+  // sums, per destination vertex, the images of the (few) items that cover it — no global float atomics at all.
+  float* part = partials + (int64_t)blockIdx.x * lds_floats;
+  const double inv = finite ? ldexp(1.0, -S) : 0.0;
+  for (int i = tid; i < used; i += kTB)
+    part[i] = finite ? (float)((double)(long long)acc64[i] * inv) : __int_as_float(0x7fc00000);
+}
+
+// Gather pass: dG[(l, gx, gy)] += sum over the items whose tile sub-grid contains the vertex.
+// grid = (ceil(maxverts/256), Ls).  Re-derives each covering tile's LDS layout (same rule as setup_tile).
+template <int F>
+__global__ void __launch_bounds__(256)
+gather_partials_kernel(const float* __restrict__ partials, const int32_t* __restrict__ tile_item_base,
+                       const int32_t* __restrict__ n_ls, float* __restrict__ dG, int Ls, int tile_shift, int lds_floats) {
+  __shared__ int s_n[GNGF_MAX_LEVELS];
+  if (threadIdx.x < Ls) s_n[threadIdx.x] = n_ls[threadIdx.x];
+  __syncthreads();
+  const int l = blockIdx.y;
+  const int n = s_n[l], gw = n + 2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= gw * gw) return;
+  const int gy = i / gw, gx = i - gy * gw;
+  const int TS = 1 << tile_shift;
+  // tiles whose [cx, hx] range can contain gx:  cx(t) = (t*n)>>s <= gx   and   hx(t) = min(((t+1)*n>>s)+1, n+1) >= gx
+  auto lo_of = [&](int g) { int t = (int)((((int64_t)(g - 1) << tile_shift) + n - 1) / n) - 1; return t < 0 ? 0 : t; };
+  auto hi_of = [&](int g) { int t = (int)((((int64_t)(g + 1) << tile_shift) + n - 1) / n) - 1; return t > TS - 1 ? TS - 1 : t; };
+  const int tx0 = g_max0(lo_of(gx)), tx1 = hi_of(gx), ty0 = g_max0(lo_of(gy)), ty1 = hi_of(gy);
+  float acc[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) acc[f] = 0.f;
+  for (int ty = ty0; ty <= ty1; ++ty)
+    for (int tx = tx0; tx <= tx1; ++tx) {
+      const int t = (ty << tile_shift) | tx;
+      const int it0 = tile_item_base[t], it1 = tile_item_base[t + 1];
+      if (it0 == it1) continue;
+      // layout of this tile's sub-grids up to level l
+      int lo = 0, cx = 0, cy = 0, wx = 0, wy = 0;
+      bool fits = false;
+      for (int j = 0; j <= l; ++j) {
+        const int nj = s_n[j];
+        const int cxj = (tx * nj) >> tile_shift, cyj = (ty * nj) >> tile_shift;
+        int hxj = (((tx + 1) * nj) >> tile_shift) + 1, hyj = (((ty + 1) * nj) >> tile_shift) + 1;
+        hxj = hxj > nj + 1 ? nj + 1 : hxj;
+        hyj = hyj > nj + 1 ? nj + 1 : hyj;
+        const int wxj = hxj - cxj + 1, wyj = hyj - cyj + 1, sz = wxj * wyj * F;
+        const bool fj = lo + sz <= lds_floats;
+        if (j == l) { cx = cxj; cy = cyj; wx = wxj; wy = wyj; fits = fj; }
+        else if (fj) lo += sz;
+      }
+      const int lx = gx - cx, ly = gy - cy;
+      if (!fits || lx < 0 || ly < 0 || lx >= wx || ly >= wy) continue;
+      const int64_t o = lo + (ly * wx + lx) * F;
+      for (int it = it0; it < it1; ++it) {
+        const float* p = partials + (int64_t)it * lds_floats + o;
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f] += p[f];
       }
     }
+  int64_t goff = 0;
+  for (int j = 0; j < l; ++j) goff += (int64_t)(s_n[j] + 2) * (s_n[j] + 2);
+  float* d = dG + (goff + i) * F;
+#pragma unroll
+  for (int f = 0; f < F; ++f) d[f] += acc[f];      // += : the out-of-sub-grid fallback may already have added (atomically, earlier kernel)
+}
+
+// Vertex stage backward for the vertex-table index source, contention-free for ANY slot distribution (a freshly
+// initialised HPD maps most vertices to a handful of slots): the (vertex,k) entries are visited in SLOT order
+// (`order` = argsort of vert_idx), each lane takes one entry and walks the levels it belongs to, and equal slots —
+// adjacent lanes — are combined with a wave-level segmented scan before the one atomic per (wave, run).
+// dvert_w needs no atomics at all: every entry is owned by exactly one lane.
+template <int F>
+__global__ void __launch_bounds__(256)
+vertex_bwd_sorted_kernel(const float* __restrict__ tables, const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
+                         const int32_t* __restrict__ order, const int32_t* __restrict__ n_ls, const float* __restrict__ dG,
+                         float* __restrict__ dtables, float* __restrict__ dvert_w, int Ls, int64_t T, int K, int vstride,
+                         int64_t NE) {
+  __shared__ int s_n[GNGF_MAX_LEVELS];
+  __shared__ int64_t s_goff[GNGF_MAX_LEVELS];
+  if (threadIdx.x < Ls) s_n[threadIdx.x] = n_ls[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) { int64_t o = 0; for (int l = 0; l < Ls; ++l) { s_goff[l] = o; o += (int64_t)(s_n[l] + 2) * (s_n[l] + 2); } }
+  __syncthreads();
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool live = j < NE;
+  const int e = live ? order[j] : 0;
+  const int slot = live ? vert_idx[e] : -1 - lane;          // dead lanes never merge with anything
+  const float w = live ? vert_w[e] : 0.f;
+  const int vid = e / K;
+  const int gy = vid / vstride, gx = vid - gy * vstride;
+  const int slot_up = __shfl_up(slot, 1, 64), slot_dn = __shfl_down(slot, 1, 64);
+  const bool run_tail = (lane == 63) || (slot_dn != slot);
+  (void)slot_up;
+  float dw_acc = 0.f;
+  for (int l = 0; l < Ls; ++l) {
+    const int n = s_n[l];
+    const bool in = live && gx <= n + 1 && gy <= n + 1;
+    float v[F];
+    float dot = 0.f;
+    if (in) {
+      const float* g = dG + (s_goff[l] + (int64_t)gy * (n + 2) + gx) * F;
+      const float* r = tables + ((int64_t)l * T + slot) * F;
+#pragma unroll
+      for (int f = 0; f < F; ++f) { const float gv = g[f]; v[f] = gv * w; dot += gv * r[f]; }
+    } else {
+#pragma unroll
+      for (int f = 0; f < F; ++f) v[f] = 0.f;
+    }
+    dw_acc += dot;
+    // the whole wave skips a level none of its lanes belongs to (coarse levels: almost always)
+    if (__ballot(in) == 0ull) continue;
+    // segmented inclusive scan over equal-slot runs
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int os = __shfl_up(slot, o, 64);
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const float ov = __shfl_up(v[f], o, 64);
+        if (lane >= o && os == slot) v[f] += ov;
+      }
+    }
+    if (run_tail && live) {
+      float* d = dtables + ((int64_t)l * T + slot) * F;
+#pragma unroll
+      for (int f = 0; f < F; ++f)
+        if (v[f] != 0.f) atomicAdd(d + f, v[f]);
+    }
   }
+  if (live && dvert_w) dvert_w[e] = dw_acc;
 }
 
 }  // namespace gngf
@@ -373,21 +547,22 @@ using namespace gngf;
     default: return (int)hipErrorInvalidValue;      \
   }
 
-// Bins P pixels into 4^tile_shift spatial tiles.  NB = number of binning blocks (<= 1024), chunk = max pixels per
+// Bins P pixels into 4^tile_shift spatial tiles.  NB = number of binning blocks (<= 128), chunk = max pixels per
 // work item.  Outputs: sorted (P float4 = x, y, bits(original index), 0), items (max_items int4 = start, count,
-// tile, 0; max_items >= ceil(P/chunk) + 4^tile_shift), n_items (1), tile_off (4^tile_shift + 1),
-// blockhist (4^tile_shift * NB scratch).
+// tile, items of that tile; max_items >= ceil(P/chunk) + 4^tile_shift), n_items (1), tile_off and tile_item_base
+// (4^tile_shift + 1 each: exclusive prefixes of pixels / items per tile), blockhist (4^tile_shift * NB scratch).
 extern "C" int gngf_bin_pixels(const float* xy, int64_t P, int tile_shift, int NB, int chunk, int32_t* blockhist,
-                               int32_t* tile_off, int32_t* items, int32_t* n_items, float* sorted, void* stream) {
-  GNGF_CHECK_ARG(P >= 0 && P < (1ll << 31) && tile_shift >= 0 && tile_shift <= 6 && NB > 0 && NB <= 1024 && chunk > 0);
-  GNGF_CHECK_ARG(xy && blockhist && tile_off && items && n_items && sorted);
+                               int32_t* tile_off, int32_t* tile_item_base, int32_t* items, int32_t* n_items, float* sorted,
+                               void* stream) {
+  GNGF_CHECK_ARG(P >= 0 && P < (1ll << 31) && tile_shift >= 0 && tile_shift <= 6 && NB > 0 && NB <= 128 && chunk > 0);
+  GNGF_CHECK_ARG(xy && blockhist && tile_off && tile_item_base && items && n_items && sorted);
   const int ntiles = 1 << (2 * tile_shift);
   const int64_t per_block = ceil_div(ceil_div(P, NB), kBinThreads) * kBinThreads;
   hipStream_t s = as_stream(stream);
   const size_t smem = (size_t)ntiles * sizeof(int);
   bin_count_kernel<<<dim3(NB), dim3(kBinThreads), smem, s>>>(reinterpret_cast<const float2*>(xy), P, per_block, tile_shift, NB,
                                                              blockhist);
-  bin_scan_kernel<<<dim3(1), dim3(kBinThreads), 0, s>>>(blockhist, NB, tile_shift, chunk, tile_off,
+  bin_scan_kernel<<<dim3(1), dim3(kBinThreads), 0, s>>>(blockhist, NB, tile_shift, chunk, tile_off, tile_item_base,
                                                          reinterpret_cast<int4*>(items), n_items);
   bin_scatter_kernel<<<dim3(NB), dim3(kBinThreads), smem, s>>>(reinterpret_cast<const float2*>(xy), P, per_block, tile_shift, NB,
                                                                blockhist, reinterpret_cast<float4*>(sorted));
@@ -460,20 +635,41 @@ extern "C" int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, 
 }
 
 extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
-                                     const int32_t* n_ls, const float* genc, float* dG, int L, int Ls, int F, int tile_shift,
-                                     int lds_bytes, void* stream) {
-  GNGF_CHECK_ARG(max_items >= 0 && L > 0 && Ls > 0 && Ls <= L && L <= GNGF_MAX_LEVELS && lds_bytes >= 0 && lds_bytes <= 128 * 1024);
+                                     const int32_t* tile_item_base, const int32_t* n_ls, const int32_t* n_ls_host,
+                                     const float* genc, float* dG, float* partials, int L, int Ls, int F, int tile_shift,
+                                     int lds_bytes, int chunk, void* stream) {
+  GNGF_CHECK_ARG(max_items >= 0 && L > 0 && Ls > 0 && Ls <= L && L <= GNGF_MAX_LEVELS && lds_bytes >= 0 && lds_bytes <= 64 * 1024);
+  GNGF_CHECK_ARG(chunk > 0 && chunk <= (1 << 20));
+  int log2_chunk = 0;
+  while ((1 << log2_chunk) < chunk) ++log2_chunk;
   if (max_items == 0) return 0;
-  GNGF_CHECK_ARG(sorted && items && n_items && n_ls && genc && dG);
+  GNGF_CHECK_ARG(sorted && items && n_items && tile_item_base && n_ls && n_ls_host && genc && dG && partials);
+  const int side = max_grid_side(n_ls_host, Ls);
   DISPATCH_F(F, {
-    if (lds_bytes > 48 * 1024) {
+    if (2 * lds_bytes > 48 * 1024) {       // 64-bit accumulators: twice the forward image
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiled_bwd_kernel<kF>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * lds_bytes);
       if (e != hipSuccess) return (int)e;
     }
-    tiled_bwd_kernel<kF><<<dim3((unsigned)max_items), dim3(kTB), (size_t)lds_bytes, as_stream(stream)>>>(
-        reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, n_ls, genc, dG, L, Ls, tile_shift,
-        lds_bytes / 4);
+    tiled_bwd_kernel<kF><<<dim3((unsigned)max_items), dim3(kTB), (size_t)2 * lds_bytes, as_stream(stream)>>>(
+        reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, n_ls, genc, dG, partials, L, Ls,
+        tile_shift, lds_bytes / 4, log2_chunk);
+    gather_partials_kernel<kF><<<dim3((unsigned)ceil_div((int64_t)side * side, 256), (unsigned)Ls), dim3(256), 0,
+                                 as_stream(stream)>>>(partials, tile_item_base, n_ls, dG, Ls, tile_shift, lds_bytes / 4);
   });
+  GNGF_RETURN_LAUNCH();
+}
+
+// Vertex stage backward, vertex-table source, slot-ordered and contention-free (see vertex_bwd_sorted_kernel).
+// order (NV*K) int32 = argsort of vert_idx viewed flat.  dtables accumulated; dvert_w (NV,K) WRITTEN (may be NULL).
+extern "C" int gngf_vertex_grid_bwd_sorted(const float* tables, const int32_t* vert_idx, const float* vert_w,
+                                           const int32_t* order, const int32_t* n_ls, const float* dG, float* dtables,
+                                           float* dvert_w, int Ls, int F, int64_t T, int K, int vstride, int64_t NV,
+                                           void* stream) {
+  GNGF_CHECK_ARG(Ls > 0 && Ls <= GNGF_MAX_LEVELS && T > 0 && K > 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0);
+  GNGF_CHECK_ARG(tables && vert_idx && vert_w && order && n_ls && dG && dtables && NV * K < (1ll << 31));
+  const int64_t NE = NV * K;
+  DISPATCH_F(F, (vertex_bwd_sorted_kernel<kF><<<dim3((unsigned)ceil_div(NE, 256)), dim3(256), 0, as_stream(stream)>>>(
+                    tables, vert_idx, vert_w, order, n_ls, dG, dtables, dvert_w, Ls, T, K, vstride, NE)));
   GNGF_RETURN_LAUNCH();
 }

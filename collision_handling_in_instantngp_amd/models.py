@@ -267,7 +267,7 @@ class GeneralNeuralGaugeFields(nn.Module):
             NV = vstride * vstride
             tv, ti, _, _ = ops.HpdVertexFunction.apply(NV, vstride, self._topk_k, None, False, HPD_CHUNK_BYTES, *params)
             w = ops.BlendFunction.apply(tv, blend_code)
-            self._frozen_table = (key, tv, ti, w, vstride, NV)
+            self._frozen_table = (key, tv, ti, w, vstride, NV, ops.slot_order(ti))
         return self._frozen_table[1:]
 
     # ------------------------------------------------------------------ forward
@@ -296,7 +296,7 @@ class GeneralNeuralGaugeFields(nn.Module):
         if self.hpd_is_frozen() and not want_dense and not need_pbar:
             # frozen HPD (-hwp mode, models.py:364-371): the per-vertex table is a pure function of the frozen
             # weights, so it is rebuilt only when they change (version counters), over the whole [0,1]^2 domain.
-            tv, ti, w, vstride, NV = self._frozen_vertex_table(blend_code)
+            tv, ti, w, vstride, NV, order = self._frozen_vertex_table(blend_code)
             pbar = probs_u = None
         else:
             vstride, NV = self._vertex_extent(x.detach())
@@ -304,13 +304,16 @@ class GeneralNeuralGaugeFields(nn.Module):
             tv, ti, pbar, probs_u = ops.HpdVertexFunction.apply(NV, vstride, K, mw, want_dense, HPD_CHUNK_BYTES,
                                                                 *self.HPD.flat_params())
             w = ops.BlendFunction.apply(tv, blend_code)
-        enc = ops.encode_apply(x, n_ls, self._n_ls_host, tables, ti, w, vstride)
+            order = None
+        enc = ops.encode_apply(x, n_ls, self._n_ls_host, tables, ti, w, vstride, order=order)
         rgb = self._decode(enc)
 
         need_vid = want_dense or keep_topk or should_calc_counts
-        vid, idx64, _ = ops.expand_vertex_table(x.detach(), n_ls, vstride, NV,
-                                                src_idx=ti if (self.return_indices or should_calc_counts) else None,
-                                                want_vid=need_vid)
+        need_idx = self.return_indices or should_calc_counts
+        vid = idx64 = None
+        if need_vid or need_idx:
+            vid, idx64, _ = ops.expand_vertex_table(x.detach(), n_ls, vstride, NV, src_idx=ti if need_idx else None,
+                                                    want_vid=need_vid)
         if keep_topk:
             to_return_probs = tv[vid]                                       # (P,L,4,K), differentiable gather
         elif want_dense:

@@ -379,7 +379,7 @@ import math as _math
 ENCODE_PATH = "auto"        # "auto" | "direct" | "tiled"  (tests force a path; auto = tiled when it pays)
 TILED_CHUNK = 1024          # max pixels per (tile, chunk) work item
 TILED_MIN_PIXELS = 1 << 14  # below this the binning overhead is not worth it
-TILED_LDS_LIMIT = 64 * 1024
+TILED_LDS_LIMIT = 48 * 1024    # forward image; the backward image (64-bit accumulators) is twice this
 
 
 class EncodePlan:
@@ -437,11 +437,12 @@ class TiledWorkspace:
         P = plan.P
         self.blockhist = torch.empty((plan.ntiles * plan.NB,), dtype=_i32, device=dev)
         self.tile_off = torch.empty((plan.ntiles + 1,), dtype=_i32, device=dev)
+        self.tile_item_base = torch.empty((plan.ntiles + 1,), dtype=_i32, device=dev)
         self.items = torch.empty((plan.max_items, 4), dtype=_i32, device=dev)
         self.n_items = torch.empty((1,), dtype=_i32, device=dev)
         self.sorted = torch.empty((max(P, 1), 4), dtype=_f32, device=dev)
         call("gngf_bin_pixels", ptr(xy, _f32, "xy"), P, plan.tile_shift, plan.NB, plan.chunk, ptr(self.blockhist),
-             ptr(self.tile_off), ptr(self.items), ptr(self.n_items), ptr(self.sorted), stream_ptr())
+             ptr(self.tile_off), ptr(self.tile_item_base), ptr(self.items), ptr(self.n_items), ptr(self.sorted), stream_ptr())
 
 
 def _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G):
@@ -451,8 +452,25 @@ def _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G):
          0 if vert_idx is None else vert_idx.shape[1], mode, vstride, 0 if vert_idx is None else vert_idx.shape[0], stream_ptr())
 
 
-def _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw):
+def slot_order(vert_idx):
+    """argsort of the per-vertex slot table viewed flat (int32): the visiting order of the contention-free vertex
+    backward.  One device sort per table build (frozen HPD: once; learning: once per step, next to the HPD GEMMs)."""
+    return torch.sort(vert_idx.reshape(-1), stable=True)[1].to(_i32)
+
+
+def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F):
+    partials = torch.empty((plan.max_items * (plan.lds_bytes // 4),), dtype=_f32, device=genc.device)
+    call("gngf_encode_tiled_bwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(ws.tile_item_base),
+         ptr(n_ls), plan.n_ls_c, ptr(genc, _f32, "grad"), ptr(dG), ptr(partials), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes,
+         plan.chunk, stream_ptr())
+
+
+def _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw, order=None):
     L, T, F = tables.shape
+    if vert_idx is not None and order is not None:
+        call("gngf_vertex_grid_bwd_sorted", ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(order, _i32, "order"), ptr(n_ls), ptr(dG),
+             ptr(dtables), ptr(dvw), plan.Ls, F, T, vert_idx.shape[1], vstride, vert_idx.shape[0], stream_ptr())
+        return
     mode = MODE_HASH if vert_idx is None else MODE_VERTEX_TABLE
     call("gngf_vertex_grid_bwd", ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), plan.n_ls_c, ptr(dG), ptr(dtables), ptr(dvw),
          plan.Ls, F, T, 0 if vert_idx is None else vert_idx.shape[1], mode, vstride,
@@ -465,7 +483,7 @@ class EncodeFunction(torch.autograd.Function):
     EncodeDirectFunction (reference models.py:486-528, 173-229, 621-655 and their autograd backward)."""
 
     @staticmethod
-    def forward(ctx, xy, n_ls, plan, tables, vert_idx, vert_w, vstride):
+    def forward(ctx, xy, n_ls, plan, tables, vert_idx, vert_w, vstride, order=None):
         xy, tables = _c(xy), _c(tables)
         L, T, F = tables.shape
         P = xy.shape[0]
@@ -474,6 +492,8 @@ class EncodeFunction(torch.autograd.Function):
         NV = 0 if vert_idx is None else vert_idx.shape[0]
         enc = torch.empty((P, L * F), dtype=_f32, device=tables.device)
         ws = None
+        if vert_idx is not None and order is None and plan.Ls > 0 and P > 0 and ctx.needs_input_grad[3]:
+            order = slot_order(vert_idx)
         if plan.Ls > 0 and P > 0:
             ws = TiledWorkspace(plan, xy)
             G = torch.empty((plan.vtot, F), dtype=_f32, device=tables.device)
@@ -484,32 +504,42 @@ class EncodeFunction(torch.autograd.Function):
             call("gngf_encode_fwd", ptr(xy, _f32, "xy"), ptr(tables, _f32, "tables"), ptr(vert_idx, _i32, "vert_idx"),
                  ptr(vert_w, _f32, "vert_w"), ptr(n_ls, _i32, "n_ls"), ptr(enc), P, L, F, T, K, mode, vstride, NV, plan.Ls, L,
                  stream_ptr())
-        ctx.save_for_backward(xy, n_ls, tables, vert_idx, vert_w)
+        ctx.save_for_backward(xy, n_ls, tables, vert_idx, vert_w, order)
         ctx.cfg = (P, L, F, T, K, mode, vstride, NV, plan, ws)
         return enc
 
     @staticmethod
     def backward(ctx, genc):
-        xy, n_ls, tables, vert_idx, vert_w = ctx.saved_tensors
+        xy, n_ls, tables, vert_idx, vert_w, order = ctx.saved_tensors
         P, L, F, T, K, mode, vstride, NV, plan, ws = ctx.cfg
         genc = _c(genc)
         dtables = torch.zeros_like(tables)
         dvw = torch.zeros_like(vert_w) if (vert_w is not None and ctx.needs_input_grad[5]) else None
         if plan.Ls > 0 and P > 0:
             dG = torch.zeros((plan.vtot, F), dtype=_f32, device=tables.device)
-            call("gngf_encode_tiled_bwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls),
-                 ptr(genc, _f32, "grad"), ptr(dG), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, stream_ptr())
-            _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw)
+            _pixel_bwd(plan, ws, n_ls, genc, dG, L, F)
+            if order is not None and dvw is not None and plan.Ls < L:
+                # the sorted kernel WRITES dvert_w; the direct levels below accumulate into the same buffer
+                dvw_t = torch.empty_like(dvw)
+                _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw_t, order)
+            else:
+                dvw_t = None
+                _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw, order)
+        else:
+            dvw_t = None
         if plan.Ls < L:
             call("gngf_encode_bwd", ptr(xy), ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc, _f32, "grad"),
                  ptr(dtables), ptr(dvw), P, L, F, T, K, mode, vstride, NV, plan.Ls, L, stream_ptr())
-        return None, None, None, dtables, None, dvw, None
+        if dvw_t is not None:
+            dvw = dvw + dvw_t
+        return None, None, None, dtables, None, dvw, None, None
 
 
-def encode_apply(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, path=None):
-    """Fused encoder dispatch: tiled form for the levels it can stage, direct form for the rest."""
+def encode_apply(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, path=None, order=None):
+    """Fused encoder dispatch: tiled form for the levels it can stage, direct form for the rest.
+    order: optional cached slot_order(vert_idx) (frozen tables)."""
     plan = EncodePlan(xy.shape[0], n_ls_host, tables.shape[2], path)
-    return EncodeFunction.apply(xy, n_ls, plan, tables, vert_idx, vert_w, vstride)
+    return EncodeFunction.apply(xy, n_ls, plan, tables, vert_idx, vert_w, vstride, order)
 
 
 class DecoderFunction(torch.autograd.Function):
@@ -585,10 +615,9 @@ def encode_kernels(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, genc,
         out["encode_fwd:tiled"] = lambda: call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items),
                                                plan.max_items, ptr(n_ls), ptr(G), ptr(enc), L, plan.Ls, F, plan.tile_shift,
                                                plan.lds_bytes, s())
-        out["encode_bwd:tiled"] = lambda: call("gngf_encode_tiled_bwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items),
-                                               plan.max_items, ptr(n_ls), ptr(genc), ptr(dG), L, plan.Ls, F, plan.tile_shift,
-                                               plan.lds_bytes, s())
-        out["vertex_bwd"] = lambda: _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, None)
+        order = slot_order(vert_idx) if vert_idx is not None else None
+        out["encode_bwd:tiled"] = lambda: _pixel_bwd(plan, ws, n_ls, genc, dG, L, F)
+        out["vertex_bwd"] = lambda: _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, None, order)
     if plan.Ls < L:
         out["encode_fwd:direct"] = lambda: call("gngf_encode_fwd", ptr(xy), ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls),
                                                 ptr(enc), P, L, F, T, K, mode, vstride, NV, plan.Ls, L, s())

@@ -75,10 +75,11 @@ int gngf_encode_bwd(const float* xy, const float* tables, const int32_t* vert_id
 /* ---- a5..a12 fused, "tiled" form: vertex stage + spatially binned, LDS-privatised pixel stage.
  * gngf_bin_pixels: bins P pixels into 4^tile_shift tiles of [0,1]^2.  NB binning blocks (<= 1024); `chunk` = max pixels
  *   per work item.  Outputs: sorted (P,4) fp32 = x, y, bits(original index), 0;  items (max_items,4) int32 = start, count,
- *   tile, 0 with max_items >= ceil(P/chunk) + 4^tile_shift;  n_items (1);  tile_off (4^tile_shift + 1);
- *   blockhist: scratch of 4^tile_shift * NB int32. */
+ *   tile, items-of-tile with max_items >= ceil(P/chunk) + 4^tile_shift;  n_items (1);  tile_off and tile_item_base
+ *   (4^tile_shift + 1 each: exclusive prefixes of pixels / items per tile);  blockhist: scratch of 4^tile_shift * NB
+ *   int32, NB <= 128. */
 int gngf_bin_pixels(const float* xy, int64_t P, int tile_shift, int NB, int chunk, int32_t* blockhist, int32_t* tile_off,
-                    int32_t* items, int32_t* n_items, float* sorted, void* stream);
+                    int32_t* tile_item_base, int32_t* items, int32_t* n_items, float* sorted, void* stream);
 /* vertex stage: G[(goff_l + gy*(N_l+2) + gx)*F + f] for levels [0, Ls), goff_l = sum_{j<l} (N_j+2)^2.
  * n_ls_host mirrors n_ls on the host (grid sizing only). */
 int gngf_vertex_grid_fwd(const float* tables, const int32_t* vert_idx, const float* vert_w, const int32_t* n_ls,
@@ -90,13 +91,23 @@ int gngf_vertex_grid_bwd(const float* tables, const int32_t* vert_idx, const flo
                          int K, int mode, int vstride, int64_t NV, void* stream);
 /* pixel stage over the work items of gngf_bin_pixels: enc / genc rows are (P, L*F); levels [0, Ls) handled here.
  * lds_bytes: dynamic LDS for the per-tile sub-grids (a level that does not fit falls back to global memory).
- * bwd ACCUMULATES into dG (caller zero-fills). */
+ * bwd ACCUMULATES into dG (caller zero-fills) in two passes with no global float atomics: every work item stores its
+ * privatised sub-grid image to partials (max_items * lds_bytes/4 floats), then a gather pass sums, per vertex, the
+ * images of the items that cover it.  Inside a work item the sub-grids accumulate in 64-bit fixed point (LDS float
+ * atomics are ~20x slower than 64-bit integer ones on gfx950); `chunk` = the binning chunk (bounds the term count). */
 int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
                           const int32_t* n_ls, const float* G, float* enc, int L, int Ls, int F, int tile_shift, int lds_bytes,
                           void* stream);
 int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
-                          const int32_t* n_ls, const float* genc, float* dG, int L, int Ls, int F, int tile_shift, int lds_bytes,
+                          const int32_t* tile_item_base, const int32_t* n_ls, const int32_t* n_ls_host, const float* genc,
+                          float* dG, float* partials, int L, int Ls, int F, int tile_shift, int lds_bytes, int chunk,
                           void* stream);
+/* vertex stage backward for the vertex-table source in SLOT order (order (NV*K) int32 = argsort of vert_idx, flat):
+ * contention-free for any slot distribution (wave-level segmented reduction, one atomic per (wave, slot run));
+ * dtables accumulated, dvert_w (NV,K) written without atomics (NULL when not needed). */
+int gngf_vertex_grid_bwd_sorted(const float* tables, const int32_t* vert_idx, const float* vert_w, const int32_t* order,
+                                const int32_t* n_ls, const float* dG, float* dtables, float* dvert_w, int Ls, int F, int64_t T,
+                                int K, int vstride, int64_t NV, void* stream);
 
 /* ---- dense layers on the matrix cores (exact-fp32 MFMA).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.01), 3 Sigmoid.
  * nn.Linear + activation of HashProbDistribution (models.py:80-88,105-106) and of the decoder (models.py:382-392). */
