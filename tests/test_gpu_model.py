@@ -119,3 +119,27 @@ def test_compact_distribution_equals_dense(golden):
     for k in outs[True][1]:
         scale = np.abs(outs[True][1][k]).max() + 1e-30
         close(outs[False][1][k], outs[True][1][k], 2e-3, 1e-4 * scale, k)
+
+
+def test_training_curve_matches_reference_three_epochs(golden):
+    """cfg1 (BASELINE configs[0]: strawberry.jpeg, params-ID 4061, L=4 T=2^8 K=4, 3 batches/epoch): MSE and PSNR of the
+    first three epochs vs the reference's own train_step run (G8).  PSNR must agree within 0.01 dB (north-star bar)."""
+    from collision_handling_in_instantngp_amd import train
+    net, g7, models, _ = build(golden, "gngf")
+    g = golden("G8_train_curve")
+    img = golden("strawberry_rgb")["img"]
+    X, Y, h, w = strawberry(golden)
+    shuffled = t(g["shuffled"].astype(np.int64))
+    loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
+    opt = train.get_optimizer(net, 1e-4, 1e-3, 1e-3, 0, 1e-6, 1e-6)
+    for e in range(3):
+        loss, mse, outputs = train.train_step(net, loss_fn, opt, X, Y, w, h, 1, 1, 1e-3, batch_percentage=1 / 3,
+                                              should_shuffle=True, shuffled_indices=shuffled)
+        n = outputs.shape[0] // 3 * 3                      # reference quirk: int(1/3 * shape) * 3 pixels are visited
+        out_img = torch.zeros_like(outputs)
+        out_img[shuffled[:n]] = outputs[:n]
+        show = (out_img * 255).reshape(h, w, 3).int().cpu().numpy()
+        if n == outputs.shape[0]:
+            psnr = train.calc_psnr(show, img)
+            assert abs(psnr - float(g["psnr"][e])) < 0.01, (e, psnr, float(g["psnr"][e]))
+        np.testing.assert_allclose(mse, float(g["mse"][e]), rtol=2e-3)
