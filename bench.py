@@ -96,6 +96,22 @@ def make_step(net, models, mode, xy, target, world):
     return step
 
 
+def graphed(step, warm=3):
+    """Capture one whole step (forward + backward, every launch of ours and torch's) into a hipGraph: the step is
+    ~15 short kernels, so eager launch gaps and Python dispatch are a visible fraction of a ~1 ms step."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(warm):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    return g.replay
+
+
 def timed(step, steps, warmup, world):
     for _ in range(warmup):
         step()
@@ -202,6 +218,7 @@ def main():
     ap.add_argument("--mode", default="gngf_frozen", choices=["gngf_frozen", "gngf_learning", "hash"])
     ap.add_argument("--pixels", type=int, default=P_PER_GPU, help="pixels per GPU per step")
     ap.add_argument("--no-extra-modes", action="store_true")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2 ** 15)
     a = ap.parse_args()
@@ -230,8 +247,17 @@ def main():
             steps, warmup = min(a.steps, 5), min(a.warmup, 1)
         net, models = build_model(mode, dev)
         step = make_step(net, models, mode, xy, target, world)
+        launch = "eager"
+        if a.graph and world == 1 and mode != "gngf_learning":
+            try:
+                step = graphed(step)
+                launch = "hipGraph"
+            except Exception as e:  # pragma: no cover
+                print(f"[bench] graph capture failed ({e!r}); running eagerly", file=sys.stderr)
+                step = make_step(net, models, mode, xy, target, world)
         dt = timed(step, steps, warmup, world)
-        results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup}
+        results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+                         "launch": launch}
         if head and rank == 0:
             try:
                 kt = kernel_times(net, models, mode, xy)

@@ -121,30 +121,50 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
   using FF = FwdFrags<KIN>;
   __shared__ float A0[FF::kA0];
   __shared__ float A1[FF::kA1];
-  __shared__ float A2[FF::kA2];
   __shared__ float bs[2 * kH + 32];
   const bool leaky = leaky_i != 0;
-  fill_fwd_frags<KIN>(A0, A1, A2, W0, W1, W2, in_dim, out_dim, true);
+  fill_fwd_frags<KIN>(A0, A1, nullptr, W0, W1, W2, in_dim, out_dim, false);
   for (int e = threadIdx.x; e < 2 * kH + 32; e += kDecThreads)
     bs[e] = e < kH ? b0[e] : (e < 2 * kH ? b1[e - kH] : ((e - 2 * kH) < out_dim ? b2[e - 2 * kH] : 0.f));
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
   const int64_t ntiles = (P + 127) / 128;
+  // output layer on the VALU: 3-4 outputs do not fill a 32-row MFMA tile.  Each lane keeps the W2 entries of the 32
+  // features it owns (registers, loaded once); the two halves of a pixel are combined with one cross-half shuffle.
+  float w2r[4][32];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int q = 0; q < 32; ++q) w2r[c][q] = c < out_dim ? W2[c * kH + 32 * (q >> 4) + crow(q & 15, h)] : 0.f;
+  float xn[KIN / 2];
+  {
+    const int64_t pix0 = (int64_t)blockIdx.x * 128 + wave * 32 + i;
+    load_x<KIN>(X, pix0, pix0 < P && (int64_t)blockIdx.x < ntiles, in_dim, h, xn);
+  }
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t pix = tile * 128 + wave * 32 + i;
     const bool valid = pix < P;
     float xr[KIN / 2];
-    load_x<KIN>(X, pix, valid, in_dim, h, xr);
-    f32x16 acc1[2], acc2[2], acc3;
+#pragma unroll
+    for (int s = 0; s < KIN / 2; ++s) xr[s] = xn[s];
+    {                                                     // prefetch the next tile's rows under this tile's MFMAs
+      const int64_t npix = (tile + gridDim.x) * 128 + wave * 32 + i;
+      load_x<KIN>(X, npix, npix < P && tile + gridDim.x < ntiles, in_dim, h, xn);
+    }
+    f32x16 acc1[2], acc2[2];
     hidden_layers<KIN>(A0, A1, bs, bs + kH, xr, lane, h, leaky, acc1, acc2);
+    float y[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc3[r] = bs[2 * kH + crow(r, h)];      // zero beyond out_dim
+    for (int c = 0; c < 4; ++c) {
+      float a = 0.f;
 #pragma unroll
-    for (int s2 = 0; s2 < 32; ++s2) acc3 = MFMA(A2[s2 * 64 + lane], acc2[s2 >> 4][s2 & 15], acc3);
-    if (valid && h == 0) {                                               // output rows 0..3 live in regs 0..3 of half 0
+      for (int q = 0; q < 32; ++q) a = fmaf(w2r[c][q], acc2[q >> 4][q & 15], a);
+      y[c] = a + __shfl_xor(a, 32, 64) + bs[2 * kH + c];
+    }
+    if (valid && h == 0) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        if (c < out_dim) Y[pix * out_dim + c] = 1.0f / (1.0f + expf(-acc3[c]));
+        if (c < out_dim) Y[pix * out_dim + c] = 1.0f / (1.0f + expf(-y[c]));
     }
   }
 }
@@ -217,9 +237,6 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     const bool valid = pix < P;
     float xr[S0];
     load_x<KIN>(X, pix, valid, in_dim, h, xr);
-    f32x16 acc1[2], acc2[2];
-    hidden_layers<KIN>(A0, A1, bs, bs + kH, xr, lane, h, leaky, acc1, acc2);
-
     // dz3 = dY * y (1 - y)   (Sigmoid backward), zero for padding pixels: they then contribute nothing anywhere
     float dz3[4];
 #pragma unroll
@@ -229,6 +246,9 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
       dz3[c] = v;
       if (h == 0) db2acc[c] += v;
     }
+    f32x16 acc1[2], acc2[2];
+    hidden_layers<KIN>(A0, A1, bs, bs + kH, xr, lane, h, leaky, acc1, acc2);
+
     // ---- dW2 += dz3^T h2 : images  dz3T -> imgA rows 0..3,  h2T -> imgB
     if (h == 0) {
 #pragma unroll
@@ -372,15 +392,22 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   for (int e = threadIdx.x; e < nslab; e += kDecThreads) out[e] = acc_lds[e];
 }
 
-// sums the per-workgroup slabs and writes the six gradient tensors
-__global__ void __launch_bounds__(256)
+// sums the per-workgroup slabs and writes the six gradient tensors.  64 elements x 16 slab-groups per block.
+__global__ void __launch_bounds__(1024)
 decoder_reduce_kernel(const float* __restrict__ slabs, int nslabs, int nslab, int in_dim, int out_dim,
                       float* __restrict__ dW0, float* __restrict__ db0, float* __restrict__ dW1, float* __restrict__ db1,
                       float* __restrict__ dW2, float* __restrict__ db2) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= nslab) return;
+  __shared__ float red[16][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + c;
   float s = 0.f;
-  for (int b = 0; b < nslabs; ++b) s += slabs[(int64_t)b * nslab + e];
+  if (e < nslab)
+    for (int b = q; b < nslabs; b += 16) s += slabs[(int64_t)b * nslab + e];
+  red[q][c] = s;
+  __syncthreads();
+  if (q != 0 || e >= nslab) return;
+#pragma unroll
+  for (int k = 1; k < 16; ++k) s += red[k][c];
   const int o0 = kH * in_dim, o1 = o0 + kH * kH, o2 = o1 + out_dim * kH, o3 = o2 + kH, o4 = o3 + kH;
   if (e < o0) dW0[e] = s;
   else if (e < o1) dW1[e - o0] = s;
@@ -455,7 +482,7 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
-  decoder_reduce_kernel<<<dim3((unsigned)((nslab + 255) / 256)), dim3(256), 0, s>>>(slabs, nslabs, nslab, in_dim, out_dim, dW0,
+  decoder_reduce_kernel<<<dim3((unsigned)((nslab + 63) / 64)), dim3(1024), 0, s>>>(slabs, nslabs, nslab, in_dim, out_dim, dW0,
                                                                                    db0, dW1, db1, dW2, db2);
   GNGF_RETURN_LAUNCH();
 }

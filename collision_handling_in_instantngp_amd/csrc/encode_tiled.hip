@@ -51,36 +51,37 @@ bin_count_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, in
   for (int i = threadIdx.x; i < ntiles; i += kBinThreads) blockhist[(int64_t)i * NB + blockIdx.x] = hist[i];
 }
 
-// K2 (one block of 16 waves): per-tile totals, exclusive scan over tiles, per-(tile, block) offsets, work-item table.
-// blockhist is [tile][NB] with NB <= 128: one WAVE scans one tile row (2 entries per lane) with shuffles.
+// K2a: one WAVE per tile row of blockhist [tile][NB] (NB <= 128: 2 entries per lane): exclusive scan inside the row,
+// row total to tot[tile].  grid = ceil(ntiles / 4) blocks of 4 waves.
+__global__ void __launch_bounds__(256)
+bin_rowscan_kernel(int32_t* __restrict__ blockhist, int NB, int ntiles, int32_t* __restrict__ tot) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= ntiles) return;
+  int32_t* row = blockhist + (int64_t)t * NB;
+  const int b0 = 2 * lane, b1 = 2 * lane + 1;
+  const int v0 = b0 < NB ? row[b0] : 0, v1 = b1 < NB ? row[b1] : 0;
+  int incl = v0 + v1;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+  const int ex = incl - (v0 + v1);
+  if (b0 < NB) row[b0] = ex;
+  if (b1 < NB) row[b1] = ex + v0;
+  if (lane == 63) tot[t] = incl;
+}
+
+// K2b (one block): exclusive scan over tiles of (pixels, items); tile_off, tile_item_base, work-item table.
 __global__ void __launch_bounds__(kBinThreads)
-bin_scan_kernel(int32_t* __restrict__ blockhist, int NB, int tile_shift, int chunk, int32_t* __restrict__ tile_off,
+bin_scan_kernel(const int32_t* __restrict__ tot, int tile_shift, int chunk, int32_t* __restrict__ tile_off,
                 int32_t* __restrict__ tile_item_base, int4* __restrict__ items, int32_t* __restrict__ n_items) {
-  __shared__ int tot[4096];
   __shared__ int wsum[kBinThreads / 64], wsum2[kBinThreads / 64];
   const int ntiles = 1 << (2 * tile_shift);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int kWaves = kBinThreads / 64;
-  // phase A: exclusive scan inside each tile row, row totals to LDS
-  for (int t = wave; t < ntiles; t += kWaves) {
-    int32_t* row = blockhist + (int64_t)t * NB;
-    const int b0 = 2 * lane, b1 = 2 * lane + 1;
-    const int v0 = b0 < NB ? row[b0] : 0, v1 = b1 < NB ? row[b1] : 0;
-    int incl = v0 + v1;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
-    const int ex = incl - (v0 + v1);
-    if (b0 < NB) row[b0] = ex;
-    if (b1 < NB) row[b1] = ex + v0;
-    if (lane == 63) tot[t] = incl;
-  }
-  __syncthreads();
-  // phase B: block-wide exclusive scan over tiles of (pixels, items); each thread owns `per` consecutive tiles
-  const int per = (ntiles + kBinThreads - 1) / kBinThreads;
+  const int per = (ntiles + kBinThreads - 1) / kBinThreads;      // consecutive tiles per thread
   int mytot = 0, myit = 0;
   for (int q = 0; q < per; ++q) {
     const int t = tid * per + q;
-    if (t < ntiles) { mytot += tot[t]; myit += (tot[t] + chunk - 1) / chunk; }
+    if (t < ntiles) { const int c = tot[t]; mytot += c; myit += (c + chunk - 1) / chunk; }
   }
   int a = mytot, n2 = myit;
 #pragma unroll
@@ -103,29 +104,20 @@ bin_scan_kernel(int32_t* __restrict__ blockhist, int NB, int tile_shift, int chu
         const int cnt = (total - jj * chunk) < chunk ? (total - jj * chunk) : chunk;
         items[ioff + jj] = make_int4(off + jj * chunk, cnt, t, nit);
       }
-      tot[t] = off;                 // reuse: tile offset for phase C
       off += total;
       ioff += nit;
     }
   }
   if (tid == kBinThreads - 1) { tile_off[ntiles] = off; tile_item_base[ntiles] = ioff; *n_items = ioff; }
-  __syncthreads();
-  // phase C: add the tile offset to every (tile, block) entry
-  for (int t = wave; t < ntiles; t += kWaves) {
-    int32_t* row = blockhist + (int64_t)t * NB;
-    const int o = tot[t];
-    if (2 * lane < NB) row[2 * lane] += o;
-    if (2 * lane + 1 < NB) row[2 * lane + 1] += o;
-  }
 }
 
 // K3: scatter (x, y, original index) into tile order.  Same pixel->block partition as K1.
 __global__ void __launch_bounds__(kBinThreads)
 bin_scatter_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB,
-                   const int32_t* __restrict__ blockhist, float4* __restrict__ sorted) {
+                   const int32_t* __restrict__ blockhist, const int32_t* __restrict__ tile_off, float4* __restrict__ sorted) {
   extern __shared__ int cursor[];
   const int ntiles = 1 << (2 * tile_shift);
-  for (int i = threadIdx.x; i < ntiles; i += kBinThreads) cursor[i] = blockhist[(int64_t)i * NB + blockIdx.x];
+  for (int i = threadIdx.x; i < ntiles; i += kBinThreads) cursor[i] = tile_off[i] + blockhist[(int64_t)i * NB + blockIdx.x];
   __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * per_block;
   const int64_t hi = lo + per_block < P ? lo + per_block : P;
@@ -550,7 +542,7 @@ using namespace gngf;
 // Bins P pixels into 4^tile_shift spatial tiles.  NB = number of binning blocks (<= 128), chunk = max pixels per
 // work item.  Outputs: sorted (P float4 = x, y, bits(original index), 0), items (max_items int4 = start, count,
 // tile, items of that tile; max_items >= ceil(P/chunk) + 4^tile_shift), n_items (1), tile_off and tile_item_base
-// (4^tile_shift + 1 each: exclusive prefixes of pixels / items per tile), blockhist (4^tile_shift * NB scratch).
+// (4^tile_shift + 1 each: exclusive prefixes of pixels / items per tile), blockhist (4^tile_shift * (NB + 1) scratch).
 extern "C" int gngf_bin_pixels(const float* xy, int64_t P, int tile_shift, int NB, int chunk, int32_t* blockhist,
                                int32_t* tile_off, int32_t* tile_item_base, int32_t* items, int32_t* n_items, float* sorted,
                                void* stream) {
@@ -562,10 +554,13 @@ extern "C" int gngf_bin_pixels(const float* xy, int64_t P, int tile_shift, int N
   const size_t smem = (size_t)ntiles * sizeof(int);
   bin_count_kernel<<<dim3(NB), dim3(kBinThreads), smem, s>>>(reinterpret_cast<const float2*>(xy), P, per_block, tile_shift, NB,
                                                              blockhist);
-  bin_scan_kernel<<<dim3(1), dim3(kBinThreads), 0, s>>>(blockhist, NB, tile_shift, chunk, tile_off, tile_item_base,
+  // row totals live behind the NB columns of blockhist: the caller's scratch is 4^tile_shift * (NB + 1) int32
+  int32_t* tot = blockhist + (int64_t)ntiles * NB;
+  bin_rowscan_kernel<<<dim3((unsigned)ceil_div(ntiles, 4)), dim3(256), 0, s>>>(blockhist, NB, ntiles, tot);
+  bin_scan_kernel<<<dim3(1), dim3(kBinThreads), 0, s>>>(tot, tile_shift, chunk, tile_off, tile_item_base,
                                                          reinterpret_cast<int4*>(items), n_items);
   bin_scatter_kernel<<<dim3(NB), dim3(kBinThreads), smem, s>>>(reinterpret_cast<const float2*>(xy), P, per_block, tile_shift, NB,
-                                                               blockhist, reinterpret_cast<float4*>(sorted));
+                                                               blockhist, tile_off, reinterpret_cast<float4*>(sorted));
   GNGF_RETURN_LAUNCH();
 }
 

@@ -435,7 +435,7 @@ class TiledWorkspace:
     def __init__(self, plan, xy):
         dev = xy.device
         P = plan.P
-        self.blockhist = torch.empty((plan.ntiles * plan.NB,), dtype=_i32, device=dev)
+        self.blockhist = torch.empty((plan.ntiles * (plan.NB + 1),), dtype=_i32, device=dev)
         self.tile_off = torch.empty((plan.ntiles + 1,), dtype=_i32, device=dev)
         self.tile_item_base = torch.empty((plan.ntiles + 1,), dtype=_i32, device=dev)
         self.items = torch.empty((plan.max_items, 4), dtype=_i32, device=dev)
