@@ -32,6 +32,27 @@ __device__ __forceinline__ float hidden_dact(float y, bool leaky) { return y > 0
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// Coalesced copy of the raw weights into LDS with a +1 padded row stride (conflict-free strided reads afterwards):
+//   W0s [64][in_dim+1] | W1s [64][65] | W2s [4][65] | b0 [64] | b1 [64] | b2 [4]
+struct RawOff { int w0, w1, w2, b0, b1, b2, total; };
+__host__ __device__ inline RawOff raw_offsets(int in_dim) {
+  RawOff o;
+  o.w0 = 0; o.w1 = o.w0 + kH * (in_dim + 1); o.w2 = o.w1 + kH * 65; o.b0 = o.w2 + 4 * 65; o.b1 = o.b0 + kH; o.b2 = o.b1 + kH;
+  o.total = o.b2 + 4;
+  return o;
+}
+__device__ __forceinline__ void stage_raw(float* raw, const float* __restrict__ W0, const float* __restrict__ b0,
+                                          const float* __restrict__ W1, const float* __restrict__ b1,
+                                          const float* __restrict__ W2, const float* __restrict__ b2, int in_dim, int out_dim) {
+  const RawOff o = raw_offsets(in_dim);
+  for (int e = threadIdx.x; e < kH * in_dim; e += kDecThreads) raw[o.w0 + (e / in_dim) * (in_dim + 1) + e % in_dim] = W0[e];
+  for (int e = threadIdx.x; e < kH * kH; e += kDecThreads) raw[o.w1 + (e >> 6) * 65 + (e & 63)] = W1[e];
+  for (int e = threadIdx.x; e < 4 * kH; e += kDecThreads) raw[o.w2 + (e >> 6) * 65 + (e & 63)] = (e >> 6) < out_dim ? W2[e] : 0.f;
+  for (int e = threadIdx.x; e < kH; e += kDecThreads) { raw[o.b0 + e] = b0[e]; raw[o.b1 + e] = b1[e]; }
+  if (threadIdx.x < 4) raw[o.b2 + threadIdx.x] = (b2 && (int)threadIdx.x < out_dim) ? b2[threadIdx.x] : 0.f;
+  __syncthreads();
+}
+
 // LDS fragment images.  frag[(tile * S + s) * 64 + lane].
 template <int KIN>
 struct FwdFrags {
@@ -40,38 +61,34 @@ struct FwdFrags {
 };
 
 template <int KIN>
-__device__ __forceinline__ void fill_fwd_frags(float* A0, float* A1, float* A2, const float* __restrict__ W0,
-                                               const float* __restrict__ W1, const float* __restrict__ W2, int in_dim,
-                                               int out_dim, bool need_a2) {
+__device__ __forceinline__ void fill_fwd_frags(float* A0, float* A1, const float* raw, int in_dim) {
   constexpr int S0 = KIN / 2;
+  const RawOff o = raw_offsets(in_dim);
   for (int e = threadIdx.x; e < 2 * S0 * 64; e += kDecThreads) {
     const int lane = e & 63, s = (e >> 6) % S0, t = (e >> 6) / S0;
     const int i = lane & 31, h = lane >> 5, k = h * S0 + s;
-    A0[e] = k < in_dim ? W0[(32 * t + i) * in_dim + k] : 0.f;
+    A0[e] = k < in_dim ? raw[o.w0 + (32 * t + i) * (in_dim + 1) + k] : 0.f;
   }
   for (int e = threadIdx.x; e < 2 * 32 * 64; e += kDecThreads) {
     const int lane = e & 63, s2 = (e >> 6) & 31, t = e >> 11;
     const int i = lane & 31, h = lane >> 5;
-    A1[e] = W1[(32 * t + i) * kH + kmapC(s2, h)];
+    A1[e] = raw[o.w1 + (32 * t + i) * 65 + kmapC(s2, h)];
   }
-  if (need_a2)
-    for (int e = threadIdx.x; e < 32 * 64; e += kDecThreads) {
-      const int lane = e & 63, s2 = e >> 6;
-      const int i = lane & 31, h = lane >> 5;
-      A2[e] = i < out_dim ? W2[i * kH + kmapC(s2, h)] : 0.f;
-    }
 }
 
-// Loads the lane's slice of its pixel's input row: xr[s] = X[pix][h*KIN/2 + s].
+// Loads the lane's slice of its pixel's input row: xr[s] = X[pix][h*KIN/2 + s].  Branch-free on the fast path (the pixel
+// index is clamped into range and the result masked) so that the loads can stay in flight across the loop back-edge.
 template <int KIN>
-__device__ __forceinline__ void load_x(const float* __restrict__ X, int64_t pix, bool valid, int in_dim, int h, float* xr) {
+__device__ __forceinline__ void load_x(const float* __restrict__ X, int64_t pix, bool valid, int in_dim, int h, float* xr,
+                                       int64_t P) {
   constexpr int S0 = KIN / 2;
-  if (valid && in_dim == KIN) {
-    const float4* src = reinterpret_cast<const float4*>(X + pix * KIN + h * S0);
+  if (in_dim == KIN) {
+    const int64_t q = pix < P ? pix : P - 1;
+    const float4* src = reinterpret_cast<const float4*>(X + q * KIN + h * S0);
 #pragma unroll
-    for (int q = 0; q < S0 / 4; ++q) {
-      const float4 v = src[q];
-      xr[4 * q] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
+    for (int k = 0; k < S0 / 4; ++k) {      // raw values: the caller masks padding pixels when it CONSUMES them
+      const float4 v = src[k];
+      xr[4 * k] = v.x; xr[4 * k + 1] = v.y; xr[4 * k + 2] = v.z; xr[4 * k + 3] = v.w;
     }
   } else {
 #pragma unroll
@@ -91,20 +108,32 @@ __device__ __forceinline__ void hidden_layers(const float* A0, const float* A1, 
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc1[t][r] = b0s[32 * t + crow(r, h)]; acc2[t][r] = b1s[32 * t + crow(r, h)]; }
+  // Fragments are burst-loaded into registers BEFORE each MFMA run (one exposed LDS latency per run): left to itself
+  // hipcc issues each ds_read one or two MFMAs ahead of its use and stalls the matrix pipe on lgkmcnt every step.
+  {
+    float f0[2][S0];
 #pragma unroll
-  for (int s = 0; s < S0; ++s) {
-    acc1[0] = MFMA(A0[(0 * S0 + s) * 64 + lane], xr[s], acc1[0]);
-    acc1[1] = MFMA(A0[(1 * S0 + s) * 64 + lane], xr[s], acc1[1]);
+    for (int s = 0; s < S0; ++s) { f0[0][s] = A0[(0 * S0 + s) * 64 + lane]; f0[1][s] = A0[(1 * S0 + s) * 64 + lane]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < S0; ++s) {
+      acc1[0] = MFMA(f0[0][s], xr[s], acc1[0]);
+      acc1[1] = MFMA(f0[1][s], xr[s], acc1[1]);
+    }
   }
+  float f1[2][32];
+#pragma unroll
+  for (int s2 = 0; s2 < 32; ++s2) { f1[0][s2] = A1[(0 * 32 + s2) * 64 + lane]; f1[1][s2] = A1[(1 * 32 + s2) * 64 + lane]; }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[t][r] = hidden_act(acc1[t][r], leaky);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int s2 = 0; s2 < 32; ++s2) {
     const float b = acc1[s2 >> 4][s2 & 15];
-    acc2[0] = MFMA(A1[(0 * 32 + s2) * 64 + lane], b, acc2[0]);
-    acc2[1] = MFMA(A1[(1 * 32 + s2) * 64 + lane], b, acc2[1]);
+    acc2[0] = MFMA(f1[0][s2], b, acc2[0]);
+    acc2[1] = MFMA(f1[1][s2], b, acc2[1]);
   }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -113,59 +142,108 @@ __device__ __forceinline__ void hidden_layers(const float* A0, const float* A1, 
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// One wave per SIMD (the whole 512-entry register file): every weight fragment and bias lives in registers for the
+// lifetime of the persistent workgroup, so a tile is: 4 x 16-byte loads (prefetched one tile ahead), 32 + 64 f32 MFMAs
+// chained through the accumulators, and the 3-4 wide output layer on v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4 pixels:
+// the lane's own accumulator register is the B operand, the lane's (channel = lane%4) weight the A operand; the two
+// lane halves hold different features of the same pixel and are combined with one cross-half shuffle).
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
 template <int KIN>
 __global__ void __launch_bounds__(kDecThreads, 1)
 decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, const float* __restrict__ b0,
                    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
                    const float* __restrict__ b2, float* __restrict__ Y, int64_t P, int in_dim, int out_dim, int leaky_i) {
-  using FF = FwdFrags<KIN>;
-  __shared__ float A0[FF::kA0];
-  __shared__ float A1[FF::kA1];
-  __shared__ float bs[2 * kH + 32];
+  constexpr int S0 = KIN / 2;
   const bool leaky = leaky_i != 0;
-  fill_fwd_frags<KIN>(A0, A1, nullptr, W0, W1, W2, in_dim, out_dim, false);
-  for (int e = threadIdx.x; e < 2 * kH + 32; e += kDecThreads)
-    bs[e] = e < kH ? b0[e] : (e < 2 * kH ? b1[e - kH] : ((e - 2 * kH) < out_dim ? b2[e - 2 * kH] : 0.f));
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
   const int64_t ntiles = (P + 127) / 128;
-  // output layer on the VALU: 3-4 outputs do not fill a 32-row MFMA tile.  Each lane keeps the W2 entries of the 32
-  // features it owns (registers, loaded once); the two halves of a pixel are combined with one cross-half shuffle.
-  float w2r[4][32];
+  // register-resident operands, gathered from a coalesced LDS copy of the raw weights
+  extern __shared__ float raw[];
+  stage_raw(raw, W0, b0, W1, b1, W2, b2, in_dim, out_dim);
+  const RawOff o = raw_offsets(in_dim);
+  float a0r[2][S0], a1r[2][32], w2a[32];
+  f32x16 b0v[2], b1v[2];
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int t = 0; t < 2; ++t) {
 #pragma unroll
-    for (int q = 0; q < 32; ++q) w2r[c][q] = c < out_dim ? W2[c * kH + 32 * (q >> 4) + crow(q & 15, h)] : 0.f;
-  float xn[KIN / 2];
+    for (int s = 0; s < S0; ++s) { const int k = h * S0 + s; a0r[t][s] = k < in_dim ? raw[o.w0 + (32 * t + i) * (in_dim + 1) + k] : 0.f; }
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) a1r[t][s2] = raw[o.w1 + (32 * t + i) * 65 + kmapC(s2, h)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { b0v[t][r] = raw[o.b0 + 32 * t + crow(r, h)]; b1v[t][r] = raw[o.b1 + 32 * t + crow(r, h)]; }
+  }
+  const int ch = lane & 3;
+#pragma unroll
+  for (int s2 = 0; s2 < 32; ++s2) w2a[s2] = raw[o.w2 + ch * 65 + kmapC(s2, h)];
+  float b2v[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) b2v[c] = raw[o.b2 + c];
+
+  float xn[S0];
   {
     const int64_t pix0 = (int64_t)blockIdx.x * 128 + wave * 32 + i;
-    load_x<KIN>(X, pix0, pix0 < P && (int64_t)blockIdx.x < ntiles, in_dim, h, xn);
+    load_x<KIN>(X, pix0, pix0 < P && (int64_t)blockIdx.x < ntiles, in_dim, h, xn, P);
   }
+  // Stores are software-pipelined one tile late: CDNA4's vmcnt counts stores too and hipcc waits vmcnt(0) at the first
+  // use of the prefetched row, so a store issued at the END of a tile would put its full write latency on the critical
+  // path of the next tile.  Issued right after that wait instead, it retires under the next tile's MFMAs.
+  float yprev[4] = {0.f, 0.f, 0.f, 0.f};
+  int64_t pixprev = -1;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t pix = tile * 128 + wave * 32 + i;
     const bool valid = pix < P;
-    float xr[KIN / 2];
+    float xr[S0];
 #pragma unroll
-    for (int s = 0; s < KIN / 2; ++s) xr[s] = xn[s];
-    {                                                     // prefetch the next tile's rows under this tile's MFMAs
-      const int64_t npix = (tile + gridDim.x) * 128 + wave * 32 + i;
-      load_x<KIN>(X, npix, npix < P && tile + gridDim.x < ntiles, in_dim, h, xn);
-    }
-    f32x16 acc1[2], acc2[2];
-    hidden_layers<KIN>(A0, A1, bs, bs + kH, xr, lane, h, leaky, acc1, acc2);
-    float y[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float a = 0.f;
-#pragma unroll
-      for (int q = 0; q < 32; ++q) a = fmaf(w2r[c][q], acc2[q >> 4][q & 15], a);
-      y[c] = a + __shfl_xor(a, 32, 64) + bs[2 * kH + c];
-    }
-    if (valid && h == 0) {
+    for (int s = 0; s < S0; ++s) { xr[s] = valid ? xn[s] : 0.f; asm volatile("" : "+v"(xr[s])); }
+    // hipcc waits vmcnt(0) at the first use of a value loaded in the previous iteration; pin that use ABOVE the
+    // next tile's loads so the wait retires only the old loads and the new ones fly under this tile's MFMAs.
+    __builtin_amdgcn_sched_barrier(0);
+    if (pixprev >= 0 && h == 0) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        if (c < out_dim) Y[pix * out_dim + c] = 1.0f / (1.0f + expf(-y[c]));
+        if (c < out_dim) Y[pixprev * out_dim + c] = yprev[c];
     }
+    {
+      const int64_t npix = (tile + gridDim.x) * 128 + wave * 32 + i;
+      load_x<KIN>(X, npix, npix < P && tile + gridDim.x < ntiles, in_dim, h, xn, P);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc1[2], acc2[2];
+    acc1[0] = MFMA(a0r[0][0], xr[0], b0v[0]);
+    acc1[1] = MFMA(a0r[1][0], xr[0], b0v[1]);
+#pragma unroll
+    for (int s = 1; s < S0; ++s) {
+      acc1[0] = MFMA(a0r[0][s], xr[s], acc1[0]);
+      acc1[1] = MFMA(a0r[1][s], xr[s], acc1[1]);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[t][r] = hidden_act(acc1[t][r], leaky);
+    acc2[0] = MFMA(a1r[0][0], acc1[0][0], b1v[0]);
+    acc2[1] = MFMA(a1r[1][0], acc1[0][0], b1v[1]);
+#pragma unroll
+    for (int s2 = 1; s2 < 32; ++s2) {
+      const float b = acc1[s2 >> 4][s2 & 15];
+      acc2[0] = MFMA(a1r[0][s2], b, acc2[0]);
+      acc2[1] = MFMA(a1r[1][s2], b, acc2[1]);
+    }
+    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2)
+      d = __builtin_amdgcn_mfma_f32_4x4x1f32(w2a[s2], hidden_act(acc2[s2 >> 4][s2 & 15], leaky), d, 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float z = d[c] + __shfl_xor(d[c], 32, 64) + b2v[c];
+      yprev[c] = 1.0f / (1.0f + expf(-z));
+    }
+    pixprev = valid ? pix : -1;
+  }
+  if (pixprev >= 0 && h == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < out_dim) Y[pixprev * out_dim + c] = yprev[c];
   }
 }
 
@@ -173,7 +251,15 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
 // slab layout (floats): dW0 [64*in_dim] | dW1 [64*64] | dW2 [out_dim*64] | db0 [64] | db1 [64] | db2 [out_dim]
 __host__ __device__ inline int slab_size(int in_dim, int out_dim) { return kH * in_dim + kH * kH + out_dim * kH + 2 * kH + out_dim; }
 
-constexpr int kImgStride = 33;
+#if defined(GNGF_STAMPS)   // diagnostic build only (tools/perf_decoder.py --stamps): per-phase cycle shares of the backward loop
+__device__ unsigned long long g_stamps[16];
+#define STAMP(k) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    ph[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+constexpr int kImgStride = 34;   // 8-byte aligned rows: ds_read_b64 of two consecutive pixels, conflict-free (34*i mod 64)
 constexpr int kImgFloats = 64 * kImgStride;
 
 template <int KIN>
@@ -193,26 +279,28 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   float* A0T = A1T + 2 * 32 * 64;                        // [t(TX)][s2(32)][64]: W0[kmapC(s2,h)][32t+i]
   float* bs = A0T + TX * 32 * 64;                        // b0 | b1
   float* img = bs + 2 * kH;                              // per wave: imgA [64][33], imgB [64][33]
-  float* acc_lds = img;                                  // workgroup slab accumulator: reuses the images after the loop
   const bool leaky = leaky_i != 0;
   const int nslab = slab_size(in_dim, out_dim);
 
-  fill_fwd_frags<KIN>(A0, A1, nullptr, W0, W1, W2, in_dim, out_dim, false);
+  float* raw = img;                                      // the image area is free until the main loop starts
+  stage_raw(raw, W0, b0, W1, b1, W2, nullptr, in_dim, out_dim);
+  const RawOff ro = raw_offsets(in_dim);
+  fill_fwd_frags<KIN>(A0, A1, raw, in_dim);
   for (int e = threadIdx.x; e < 2 * 2 * 64; e += kDecThreads) {
     const int lane = e & 63, s = (e >> 6) & 1, t = e >> 7;
     const int c = 2 * s + (lane >> 5);
-    A2T[e] = c < out_dim ? W2[c * kH + 32 * t + (lane & 31)] : 0.f;
+    A2T[e] = raw[ro.w2 + c * 65 + 32 * t + (lane & 31)];
   }
   for (int e = threadIdx.x; e < 2 * 32 * 64; e += kDecThreads) {
     const int lane = e & 63, s2 = (e >> 6) & 31, t = e >> 11;
-    A1T[e] = W1[kmapC(s2, lane >> 5) * kH + 32 * t + (lane & 31)];
+    A1T[e] = raw[ro.w1 + kmapC(s2, lane >> 5) * 65 + 32 * t + (lane & 31)];
   }
   for (int e = threadIdx.x; e < TX * 32 * 64; e += kDecThreads) {
     const int lane = e & 63, s2 = (e >> 6) & 31, t = e >> 11;
     const int j = 32 * t + (lane & 31);
-    A0T[e] = j < in_dim ? W0[kmapC(s2, lane >> 5) * in_dim + j] : 0.f;
+    A0T[e] = j < in_dim ? raw[ro.w0 + kmapC(s2, lane >> 5) * (in_dim + 1) + j] : 0.f;
   }
-  for (int e = threadIdx.x; e < 2 * kH; e += kDecThreads) bs[e] = e < kH ? b0[e] : b1[e - kH];
+  for (int e = threadIdx.x; e < 2 * kH; e += kDecThreads) bs[e] = e < kH ? raw[ro.b0 + e] : raw[ro.b1 + e - kH];
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
@@ -232,22 +320,51 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   }
 
   const int64_t ntiles = (P + 127) / 128;
+  // next-tile prefetch of the input row, the forward output and its gradient (raw values; masked when consumed)
+  float xn[S0], yn[4], dyn[4];
+  auto fetch = [&](int64_t t) {
+    int64_t q = t * 128 + wave * 32 + i;
+    q = q < P ? q : P - 1;
+    load_x<KIN>(X, q, true, in_dim, h, xn, P);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int cc = c < out_dim ? c : 0;
+      yn[c] = Yout[q * out_dim + cc];
+      dyn[c] = dY[q * out_dim + cc];
+    }
+  };
+  // Software pipeline: the rows of tile t+1 are CONSUMED (vmcnt wait) at the END of tile t, before tile t's d-enc stores
+  // are issued and before the loads of tile t+2 — so neither the store latency nor the load latency is ever waited for
+  // at the top of a tile (CDNA4's vmcnt counts stores; hipcc waits vmcnt(0) at the first use of a prefetched value).
+  float xr[S0], dz3[4];
+  auto consume = [&](int64_t t) {
+    const int64_t q = t * 128 + wave * 32 + i;
+    const bool ok = t < ntiles && q < P;
+#pragma unroll
+    for (int s = 0; s < S0; ++s) { xr[s] = (ok && (in_dim == KIN || h * S0 + s < in_dim)) ? xn[s] : 0.f; asm volatile("" : "+v"(xr[s])); }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      // dz3 = dY * y (1 - y)   (Sigmoid backward), zero for padding pixels: they then contribute nothing anywhere
+      dz3[c] = (ok && c < out_dim) ? dyn[c] * (yn[c] * (1.f - yn[c])) : 0.f;
+      asm volatile("" : "+v"(dz3[c]));
+      if (h == 0) db2acc[c] += dz3[c];
+    }
+  };
+  fetch(blockIdx.x);
+  consume(blockIdx.x);
+  __builtin_amdgcn_sched_barrier(0);
+  fetch((int64_t)blockIdx.x + gridDim.x < ntiles ? (int64_t)blockIdx.x + gridDim.x : blockIdx.x);
+#if defined(GNGF_STAMPS)
+  unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
+#endif
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t pix = tile * 128 + wave * 32 + i;
     const bool valid = pix < P;
-    float xr[S0];
-    load_x<KIN>(X, pix, valid, in_dim, h, xr);
-    // dz3 = dY * y (1 - y)   (Sigmoid backward), zero for padding pixels: they then contribute nothing anywhere
-    float dz3[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float v = 0.f;
-      if (valid && c < out_dim) { const float y = Yout[pix * out_dim + c]; v = dY[pix * out_dim + c] * (y * (1.f - y)); }
-      dz3[c] = v;
-      if (h == 0) db2acc[c] += v;
-    }
+    STAMP(0);
     f32x16 acc1[2], acc2[2];
     hidden_layers<KIN>(A0, A1, bs, bs + kH, xr, lane, h, leaky, acc1, acc2);
+    STAMP(1);
 
     // ---- dW2 += dz3^T h2 : images  dz3T -> imgA rows 0..3,  h2T -> imgB
     if (h == 0) {
@@ -258,12 +375,26 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) imgB[(32 * t + crow(r, h)) * kImgStride + i] = acc2[t][r];
+    {   // operands for all 16 k-steps first (pixel k = 16h + s, two per ds_read_b64), THEN the MFMAs: issued one by one
+        // behind each MFMA the reads expose the full LDS latency 32 times per phase (measured: ~50 % MFMA idle)
+      float2 av[8], b0p[8], b1p[8];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const float a = i < 4 ? imgA[i * kImgStride + 2 * s + h] : 0.f;
-      dW2acc[0] = MFMA(a, imgB[(i) * kImgStride + 2 * s + h], dW2acc[0]);
-      dW2acc[1] = MFMA(a, imgB[(32 + i) * kImgStride + 2 * s + h], dW2acc[1]);
+      for (int q = 0; q < 8; ++q) {
+        av[q] = *reinterpret_cast<const float2*>(imgA + (i & 3) * kImgStride + 16 * h + 2 * q);
+        b0p[q] = *reinterpret_cast<const float2*>(imgB + i * kImgStride + 16 * h + 2 * q);
+        b1p[q] = *reinterpret_cast<const float2*>(imgB + (32 + i) * kImgStride + 16 * h + 2 * q);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float a0 = i < 4 ? av[q].x : 0.f, a1 = i < 4 ? av[q].y : 0.f;
+        dW2acc[0] = MFMA(a0, b0p[q].x, dW2acc[0]);
+        dW2acc[1] = MFMA(a0, b1p[q].x, dW2acc[1]);
+        dW2acc[0] = MFMA(a1, b0p[q].y, dW2acc[0]);
+        dW2acc[1] = MFMA(a1, b1p[q].y, dW2acc[1]);
+      }
     }
+    STAMP(2);
     // ---- dh2^T = W2^T dz3^T  (k = output channel, padded to 4)
     f32x16 d2[2];
     d2[0] = 0; d2[1] = 0;
@@ -277,6 +408,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { d2[t][r] *= hidden_dact(acc2[t][r], leaky); db1acc[t][r] += d2[t][r]; }
+    STAMP(3);
     // ---- dW1 += dz2^T h1 : dz2T -> imgA, h1T -> imgB
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -285,28 +417,49 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
         imgA[(32 * t + crow(r, h)) * kImgStride + i] = d2[t][r];
         imgB[(32 * t + crow(r, h)) * kImgStride + i] = acc1[t][r];
       }
+    {
+      float2 a0p[8], a1p[8], b0p[8], b1p[8];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const float a0 = imgA[i * kImgStride + 2 * s + h], a1 = imgA[(32 + i) * kImgStride + 2 * s + h];
-      const float b0v = imgB[i * kImgStride + 2 * s + h], b1v = imgB[(32 + i) * kImgStride + 2 * s + h];
-      dW1acc[0][0] = MFMA(a0, b0v, dW1acc[0][0]);
-      dW1acc[0][1] = MFMA(a0, b1v, dW1acc[0][1]);
-      dW1acc[1][0] = MFMA(a1, b0v, dW1acc[1][0]);
-      dW1acc[1][1] = MFMA(a1, b1v, dW1acc[1][1]);
+      for (int q = 0; q < 8; ++q) {
+        a0p[q] = *reinterpret_cast<const float2*>(imgA + i * kImgStride + 16 * h + 2 * q);
+        a1p[q] = *reinterpret_cast<const float2*>(imgA + (32 + i) * kImgStride + 16 * h + 2 * q);
+        b0p[q] = *reinterpret_cast<const float2*>(imgB + i * kImgStride + 16 * h + 2 * q);
+        b1p[q] = *reinterpret_cast<const float2*>(imgB + (32 + i) * kImgStride + 16 * h + 2 * q);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        dW1acc[0][0] = MFMA(a0p[q].x, b0p[q].x, dW1acc[0][0]);
+        dW1acc[0][1] = MFMA(a0p[q].x, b1p[q].x, dW1acc[0][1]);
+        dW1acc[1][0] = MFMA(a1p[q].x, b0p[q].x, dW1acc[1][0]);
+        dW1acc[1][1] = MFMA(a1p[q].x, b1p[q].x, dW1acc[1][1]);
+        dW1acc[0][0] = MFMA(a0p[q].y, b0p[q].y, dW1acc[0][0]);
+        dW1acc[0][1] = MFMA(a0p[q].y, b1p[q].y, dW1acc[0][1]);
+        dW1acc[1][0] = MFMA(a1p[q].y, b0p[q].y, dW1acc[1][0]);
+        dW1acc[1][1] = MFMA(a1p[q].y, b1p[q].y, dW1acc[1][1]);
+      }
     }
+    STAMP(4);
     // ---- dh1^T = W1^T dz2^T
     f32x16 d1[2];
     d1[0] = 0; d1[1] = 0;
+    {
+      float ft[2][32];
 #pragma unroll
-    for (int s2 = 0; s2 < 32; ++s2) {
-      const float b = d2[s2 >> 4][s2 & 15];
-      d1[0] = MFMA(A1T[(0 * 32 + s2) * 64 + lane], b, d1[0]);
-      d1[1] = MFMA(A1T[(1 * 32 + s2) * 64 + lane], b, d1[1]);
+      for (int s2 = 0; s2 < 32; ++s2) { ft[0][s2] = A1T[(0 * 32 + s2) * 64 + lane]; ft[1][s2] = A1T[(1 * 32 + s2) * 64 + lane]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s2 = 0; s2 < 32; ++s2) {
+        const float b = d2[s2 >> 4][s2 & 15];
+        d1[0] = MFMA(ft[0][s2], b, d1[0]);
+        d1[1] = MFMA(ft[1][s2], b, d1[1]);
+      }
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { d1[t][r] *= hidden_dact(acc1[t][r], leaky); db0acc[t][r] += d1[t][r]; }
+    STAMP(5);
     // ---- dW0 += dz1^T x : dz1T -> imgA, xT -> imgB (rows = input features)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -317,45 +470,82 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     if (KIN < 32) {
       for (int rr = KIN + h; rr < 32; rr += 2) imgB[rr * kImgStride + i] = 0.f;
     }
+    {
+      float2 a0p[8], a1p[8], bp[TX][8];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const float a0 = imgA[i * kImgStride + 2 * s + h], a1 = imgA[(32 + i) * kImgStride + 2 * s + h];
+      for (int q = 0; q < 8; ++q) {
+        a0p[q] = *reinterpret_cast<const float2*>(imgA + i * kImgStride + 16 * h + 2 * q);
+        a1p[q] = *reinterpret_cast<const float2*>(imgA + (32 + i) * kImgStride + 16 * h + 2 * q);
 #pragma unroll
-      for (int tx = 0; tx < TX; ++tx) {
-        const float bv = imgB[(32 * tx + i) * kImgStride + 2 * s + h];
-        dW0acc[0][tx] = MFMA(a0, bv, dW0acc[0][tx]);
-        dW0acc[1][tx] = MFMA(a1, bv, dW0acc[1][tx]);
+        for (int tx = 0; tx < TX; ++tx) bp[tx][q] = *reinterpret_cast<const float2*>(imgB + (32 * tx + i) * kImgStride + 16 * h + 2 * q);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int tx = 0; tx < TX; ++tx) {
+          dW0acc[0][tx] = MFMA(a0p[q].x, bp[tx][q].x, dW0acc[0][tx]);
+          dW0acc[1][tx] = MFMA(a1p[q].x, bp[tx][q].x, dW0acc[1][tx]);
+          dW0acc[0][tx] = MFMA(a0p[q].y, bp[tx][q].y, dW0acc[0][tx]);
+          dW0acc[1][tx] = MFMA(a1p[q].y, bp[tx][q].y, dW0acc[1][tx]);
+        }
     }
-    // ---- d enc^T = W0^T dz1^T ; regs 4g..4g+3 are 4 consecutive input features
+    STAMP(6);
+    // ---- d enc^T = W0^T dz1^T ; regs 4g..4g+3 are 4 consecutive input features.  Two accumulator chains per tile.
+    f32x16 dxv[TX];
 #pragma unroll
     for (int tx = 0; tx < TX; ++tx) {
-      f32x16 dx;
-      dx = 0;
+      f32x16 dxa, dxb;
+      dxa = 0; dxb = 0;
+      float ft[32];
 #pragma unroll
-      for (int s2 = 0; s2 < 32; ++s2) dx = MFMA(A0T[(tx * 32 + s2) * 64 + lane], d1[s2 >> 4][s2 & 15], dx);
-      if (valid) {
+      for (int s2 = 0; s2 < 32; ++s2) ft[s2] = A0T[(tx * 32 + s2) * 64 + lane];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s2 = 0; s2 < 32; s2 += 2) {
+        dxa = MFMA(ft[s2], d1[s2 >> 4][s2 & 15], dxa);
+        dxb = MFMA(ft[s2 + 1], d1[(s2 + 1) >> 4][(s2 + 1) & 15], dxb);
+      }
+      dxv[tx] = dxa + dxb;
+    }
+    // end of tile: consume tile t+1's rows (their loads were issued a whole tile ago), THEN store, THEN prefetch t+2
+    consume(tile + gridDim.x);
+    __builtin_amdgcn_sched_barrier(0);
+    if (valid) {
+#pragma unroll
+      for (int tx = 0; tx < TX; ++tx)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int col = 32 * tx + 8 * g + 4 * h;
           if (in_dim == KIN) {
             if (32 * tx + 8 * g + 8 <= KIN)            // KIN = 16: only g = 0, 1 are real input features
-              *reinterpret_cast<float4*>(dX + pix * KIN + col) = make_float4(dx[4 * g], dx[4 * g + 1], dx[4 * g + 2], dx[4 * g + 3]);
+              *reinterpret_cast<float4*>(dX + pix * KIN + col) =
+                  make_float4(dxv[tx][4 * g], dxv[tx][4 * g + 1], dxv[tx][4 * g + 2], dxv[tx][4 * g + 3]);
           } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              if (col + q < in_dim) dX[pix * in_dim + col + q] = dx[4 * g + q];
+              if (col + q < in_dim) dX[pix * in_dim + col + q] = dxv[tx][4 * g + q];
           }
         }
-      }
     }
+    {
+      const int64_t t2 = tile + 2 * (int64_t)gridDim.x;
+      fetch(t2 < ntiles ? t2 : tile);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(7);
   }
 
-  // ---- wave accumulators -> workgroup slab (LDS atomics), then one plain-store slab per workgroup
-  __syncthreads();                                       // every wave is done with its transposition images
-  for (int e = threadIdx.x; e < nslab; e += kDecThreads) acc_lds[e] = 0.f;
-  __syncthreads();
-  float* sW0 = acc_lds;
+#if defined(GNGF_STAMPS)
+  if (blockIdx.x == 7 && threadIdx.x == 0)
+    for (int k = 0; k < 10; ++k) g_stamps[k] = ph[k];
+#endif
+  // ---- wave accumulators -> workgroup slab.  No LDS float atomics (ds_add_f32 costs ~190 cycles per wave-instruction
+  // on gfx950): every wave stores its tiles into its own LDS region, bias partials are reduced over the 32 pixel lanes
+  // with shuffles, then the four regions are summed into ONE plain-store slab per workgroup.
+  __syncthreads();                                       // every wave is done with the images and fragments
+  float* region = smem + wave * nslab;                   // 4 regions; the fragment + image areas are dead now
+  float* sW0 = region;
   float* sW1 = sW0 + kH * in_dim;
   float* sW2 = sW1 + kH * kH;
   float* sb0 = sW2 + out_dim * kH;
@@ -367,29 +557,33 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     for (int r = 0; r < 16; ++r) {
       const int row = 32 * ti + crow(r, h);
 #pragma unroll
-      for (int tj = 0; tj < 2; ++tj) atomicAdd(sW1 + row * kH + 32 * tj + i, dW1acc[ti][tj][r]);
+      for (int tj = 0; tj < 2; ++tj) sW1[row * kH + 32 * tj + i] = dW1acc[ti][tj][r];
 #pragma unroll
       for (int tx = 0; tx < TX; ++tx)
-        if (32 * tx + i < in_dim) atomicAdd(sW0 + row * in_dim + 32 * tx + i, dW0acc[ti][tx][r]);
-      // bias partials: every lane of a half holds a different pixel's share of the same feature
-      atomicAdd(sb0 + row, db0acc[ti][r]);
-      atomicAdd(sb1 + row, db1acc[ti][r]);
+        if (32 * tx + i < in_dim) sW0[row * in_dim + 32 * tx + i] = dW0acc[ti][tx][r];
+      float v0 = db0acc[ti][r], v1 = db1acc[ti][r];       // every lane of a half holds one pixel's share
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o, 64); v1 += __shfl_xor(v1, o, 64); }
+      if (i == 0) { sb0[row] = v0; sb1[row] = v1; }
     }
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = crow(r, h);
-      if (row < out_dim) atomicAdd(sW2 + row * kH + 32 * tj + i, dW2acc[tj][r]);
+      if (row < out_dim) sW2[row * kH + 32 * tj + i] = dW2acc[tj][r];
     }
-  if (h == 0) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (c < out_dim) atomicAdd(sb2 + c, db2acc[c]);
+  for (int c = 0; c < 4; ++c) {
+    float v = h == 0 ? db2acc[c] : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0 && c < out_dim) sb2[c] = v;
   }
   __syncthreads();
   float* out = slabs + (int64_t)blockIdx.x * nslab;
-  for (int e = threadIdx.x; e < nslab; e += kDecThreads) out[e] = acc_lds[e];
+  for (int e = threadIdx.x; e < nslab; e += kDecThreads)
+    out[e] = (smem[e] + smem[nslab + e]) + (smem[2 * nslab + e] + smem[3 * nslab + e]);
 }
 
 // sums the per-workgroup slabs and writes the six gradient tensors.  64 elements x 16 slab-groups per block.
@@ -422,7 +616,9 @@ static size_t bwd_smem_bytes(int in_dim, int out_dim) {
   using FF = FwdFrags<KIN>;
   constexpr int TX = (KIN + 31) / 32;
   const int img = 4 * 2 * kImgFloats, slab = slab_size(in_dim, out_dim);
-  return sizeof(float) * (size_t)(FF::kA0 + FF::kA1 + 2 * 2 * 64 + 2 * 32 * 64 + TX * 32 * 64 + 2 * kH + (img > slab ? img : slab));
+  const size_t main_loop = (size_t)(FF::kA0 + FF::kA1 + 2 * 2 * 64 + 2 * 32 * 64 + TX * 32 * 64 + 2 * kH + img);
+  const size_t epilogue = (size_t)4 * slab;            // four per-wave regions over the dead fragment/image areas
+  return sizeof(float) * (main_loop > epilogue ? main_loop : epilogue);
 }
 
 }  // namespace gngf
@@ -449,8 +645,9 @@ extern "C" int gngf_decoder_fwd(const float* enc, const float* W0, const float* 
   if (P == 0) return 0;
   GNGF_CHECK_ARG(enc && W0 && b0 && W1 && b1 && W2 && b2 && rgb);
   const int64_t tiles = (P + 127) / 128;
-  const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);
-  DISPATCH_KIN(in_dim, (decoder_fwd_kernel<kKIN><<<dim3(grid), dim3(kDecThreads), 0, as_stream(stream)>>>(
+  const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);       // one persistent workgroup per CU
+  const size_t smem = sizeof(float) * (size_t)raw_offsets(in_dim).total;
+  DISPATCH_KIN(in_dim, (decoder_fwd_kernel<kKIN><<<dim3(grid), dim3(kDecThreads), smem, as_stream(stream)>>>(
                            enc, W0, b0, W1, b1, W2, b2, rgb, P, in_dim, out_dim, leaky)));
   GNGF_RETURN_LAUNCH();
 }
@@ -486,3 +683,9 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
                                                                                    db0, dW1, db1, dW2, db2);
   GNGF_RETURN_LAUNCH();
 }
+
+#if defined(GNGF_STAMPS)
+extern "C" int gngf_debug_read_stamps(unsigned long long* host16) {
+  return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(gngf::g_stamps), 16 * sizeof(unsigned long long));
+}
+#endif

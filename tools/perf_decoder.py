@@ -24,3 +24,14 @@ for name, fn in (("decoder_fwd", fwd), ("decoder_bwd", bwd)):
     us = e0.elapsed_time(e1) / 10 * 1e3
     fl = {"decoder_fwd": 2 * (32 * 64 + 64 * 64 + 64 * 3), "decoder_bwd": 0}[name]
     print(f"{name:14s} {us:8.1f} us  {P/us:8.1f} Mpx/s")
+if os.environ.get("GNGF_LIB_PATH", "").endswith("stamps.so"):
+    import ctypes
+    buf = (ctypes.c_uint64 * 16)()
+    _lib.load().gngf_debug_read_stamps.argtypes = [ctypes.c_void_p]
+    torch.cuda.synchronize()
+    print("rc", _lib.load().gngf_debug_read_stamps(buf))
+    names = ["load/copy", "recompute L1+L2", "img+dW2", "dh2+dact", "img+dW1", "dh1+dact", "img+dW0", "dX+store"]
+    tot = sum(buf[:8])
+    for n, v in zip(names, buf[:8]):
+        print(f"  {n:18s} {v/32:9.0f} cycles/tile  {100*v/max(tot,1):5.1f}%")
+    print("  total per tile", tot / 32)
