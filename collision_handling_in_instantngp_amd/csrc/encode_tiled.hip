@@ -276,30 +276,39 @@ tiled_fwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
   const float* sub = lds + m.loff[l];
   const float* Gl = G + m.goff[l] * F;
   const int LF = L * F;
-  for (int j = lp; j < it.y; j += ppp) {
-    const float4 s = sorted[it.x + j];
-    const int64_t p = (int64_t)__float_as_int(s.z);
-    const Cell c = make_cell(s.x, s.y, n);
-    const int lx = c.gx - cx, ly = c.gy - cy;
-    float v[4][F];
-    if (lx >= 0 && ly >= 0 && lx + 1 < wx && ly + 1 < wy) {
-      const float* a = sub + (ly * wx + lx) * F;
-      const float* b = a + wx * F;
+  // 4 pixels per lane per trip, their (dependent) loads issued together: the loop is latency-bound otherwise
+  constexpr int U = 4;
+  for (int j0 = lp; j0 < it.y; j0 += U * ppp) {
+    float4 sv[U];
 #pragma unroll
-      for (int f = 0; f < F; ++f) { v[0][f] = a[f]; v[1][f] = a[F + f]; v[2][f] = b[f]; v[3][f] = b[F + f]; }
-    } else {                                     // outside the staged sub-grid (never for in-domain coords): global
+    for (int u = 0; u < U; ++u) { const int j = j0 + u * ppp; sv[u] = sorted[it.x + (j < it.y ? j : it.y - 1)]; }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int gx = c.gx + (q & 1), gy = c.gy + (q >> 1);
-        gx = gx < 0 ? 0 : (gx > n + 1 ? n + 1 : gx);
-        gy = gy < 0 ? 0 : (gy > n + 1 ? n + 1 : gy);
+    for (int u = 0; u < U; ++u) {
+      if (j0 + u * ppp >= it.y) break;
+      const float4 s = sv[u];
+      const int64_t p = (int64_t)__float_as_int(s.z);
+      const Cell c = make_cell(s.x, s.y, n);
+      const int lx = c.gx - cx, ly = c.gy - cy;
+      float v[4][F];
+      if (lx >= 0 && ly >= 0 && lx + 1 < wx && ly + 1 < wy) {
+        const float* a = sub + (ly * wx + lx) * F;
+        const float* b = a + wx * F;
 #pragma unroll
-        for (int f = 0; f < F; ++f) v[q][f] = Gl[((int64_t)gy * gw + gx) * F + f];
+        for (int f = 0; f < F; ++f) { v[0][f] = a[f]; v[1][f] = a[F + f]; v[2][f] = b[f]; v[3][f] = b[F + f]; }
+      } else {                                     // outside the staged sub-grid (never for in-domain coords): global
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int gx = c.gx + (q & 1), gy = c.gy + (q >> 1);
+          gx = gx < 0 ? 0 : (gx > n + 1 ? n + 1 : gx);
+          gy = gy < 0 ? 0 : (gy > n + 1 ? n + 1 : gy);
+#pragma unroll
+          for (int f = 0; f < F; ++f) v[q][f] = Gl[((int64_t)gy * gw + gx) * F + f];
+        }
       }
-    }
-    float* o = enc + p * LF + l * F;
+      float* o = enc + p * LF + l * F;
 #pragma unroll
-    for (int f = 0; f < F; ++f) o[f] = ((v[0][f] * c.c[0] + v[1][f] * c.c[1]) + v[2][f] * c.c[2]) + v[3][f] * c.c[3];
+      for (int f = 0; f < F; ++f) o[f] = ((v[0][f] * c.c[0] + v[1][f] * c.c[1]) + v[2][f] * c.c[2]) + v[3][f] * c.c[3];
+    }
   }
 }
 
@@ -341,12 +350,21 @@ tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
   const int LF = L * F;
   // pass 1: largest |gradient| over the item's pixels (these rows are re-read from L2 in pass 2)
   float gmax = 0.f;
+  constexpr int U = 4;                                     // 4 pixels per lane per trip: loads issued together
   if (lp < ppp)
-    for (int j = lp; j < it.y; j += ppp) {
-      const int64_t p = (int64_t)__float_as_int(sorted[it.x + j].z);
-      const float* gi = genc + p * LF + l * F;
+    for (int j0 = lp; j0 < it.y; j0 += U * ppp) {
+      int64_t pp[U];
 #pragma unroll
-      for (int f = 0; f < F; ++f) { const float a = fabsf(gi[f]); gmax = (a > gmax || a != a) ? a : gmax; }   // NaN sticks
+      for (int u = 0; u < U; ++u) { const int j = j0 + u * ppp; pp[u] = (int64_t)__float_as_int(sorted[it.x + (j < it.y ? j : it.y - 1)].z); }
+      float gv[U][F];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int f = 0; f < F; ++f) gv[u][f] = genc[pp[u] * LF + l * F + f];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int f = 0; f < F; ++f) { const float a = fabsf(gv[u][f]); gmax = (a > gmax || a != a) ? a : gmax; }   // NaN sticks
     }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { const float ov = __shfl_xor(gmax, o, 64); gmax = (ov > gmax || ov != ov) ? ov : gmax; }
@@ -363,33 +381,43 @@ tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
     const int n = m.n[l], cx = m.cx[l], cy = m.cy[l], wx = m.wx[l], wy = m.wy[l], gw = m.gw[l];
     unsigned long long* sub = acc64 + m.loff[l];
     float* dGl = dG + m.goff[l] * F;
-    for (int j = lp; j < it.y; j += ppp) {
-      const float4 s = sorted[it.x + j];
-      const int64_t p = (int64_t)__float_as_int(s.z);
-      const Cell c = make_cell(s.x, s.y, n);
-      const int lx = c.gx - cx, ly = c.gy - cy;
-      float g[F];
-      const float* gi = genc + p * LF + l * F;
+    for (int j0 = lp; j0 < it.y; j0 += U * ppp) {
+      float4 sv[U];
 #pragma unroll
-      for (int f = 0; f < F; ++f) g[f] = gi[f];
-      if (lx >= 0 && ly >= 0 && lx + 1 < wx && ly + 1 < wy) {
-        unsigned long long* a = sub + (ly * wx + lx) * F;
-        unsigned long long* b = a + wx * F;
+      for (int u = 0; u < U; ++u) { const int j = j0 + u * ppp; sv[u] = sorted[it.x + (j < it.y ? j : it.y - 1)]; }
+      float gv[U][F];
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
-          atomicAdd(a + f, (unsigned long long)to_fixed(g[f] * c.c[0], S));
-          atomicAdd(a + F + f, (unsigned long long)to_fixed(g[f] * c.c[1], S));
-          atomicAdd(b + f, (unsigned long long)to_fixed(g[f] * c.c[2], S));
-          atomicAdd(b + F + f, (unsigned long long)to_fixed(g[f] * c.c[3], S));
-        }
-      } else {
+      for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          int gx = c.gx + (q & 1), gy = c.gy + (q >> 1);
-          gx = gx < 0 ? 0 : (gx > n + 1 ? n + 1 : gx);
-          gy = gy < 0 ? 0 : (gy > n + 1 ? n + 1 : gy);
+        for (int f = 0; f < F; ++f) gv[u][f] = genc[(int64_t)__float_as_int(sv[u].z) * LF + l * F + f];
 #pragma unroll
-          for (int f = 0; f < F; ++f) atomicAdd(dGl + ((int64_t)gy * gw + gx) * F + f, g[f] * c.c[q]);
+      for (int u = 0; u < U; ++u) {
+        if (j0 + u * ppp >= it.y) break;
+        const float4 s = sv[u];
+        const Cell c = make_cell(s.x, s.y, n);
+        const int lx = c.gx - cx, ly = c.gy - cy;
+        float g[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) g[f] = gv[u][f];
+        if (lx >= 0 && ly >= 0 && lx + 1 < wx && ly + 1 < wy) {
+          unsigned long long* a = sub + (ly * wx + lx) * F;
+          unsigned long long* b = a + wx * F;
+#pragma unroll
+          for (int f = 0; f < F; ++f) {
+            atomicAdd(a + f, (unsigned long long)to_fixed(g[f] * c.c[0], S));
+            atomicAdd(a + F + f, (unsigned long long)to_fixed(g[f] * c.c[1], S));
+            atomicAdd(b + f, (unsigned long long)to_fixed(g[f] * c.c[2], S));
+            atomicAdd(b + F + f, (unsigned long long)to_fixed(g[f] * c.c[3], S));
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            int gx = c.gx + (q & 1), gy = c.gy + (q >> 1);
+            gx = gx < 0 ? 0 : (gx > n + 1 ? n + 1 : gx);
+            gy = gy < 0 ? 0 : (gy > n + 1 ? n + 1 : gy);
+#pragma unroll
+            for (int f = 0; f < F; ++f) atomicAdd(dGl + ((int64_t)gy * gw + gx) * F + f, g[f] * c.c[q]);
+          }
         }
       }
     }
@@ -489,22 +517,34 @@ vertex_bwd_sorted_kernel(const float* __restrict__ tables, const int32_t* __rest
   const bool run_tail = (lane == 63) || (slot_dn != slot);
   (void)slot_up;
   float dw_acc = 0.f;
-  for (int l = 0; l < Ls; ++l) {
+  // first level this lane's vertex belongs to (levels ascend, so it belongs to every later one); the wave starts at
+  // the smallest such level among its lanes — with the (first level, slot) visiting order that is the lanes' own.
+  int lmin = Ls;
+  if (live) { const int mg = gx > gy ? gx : gy; lmin = 0; while (lmin < Ls && mg > s_n[lmin] + 1) ++lmin; }
+  int lstart = lmin;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int ov = __shfl_xor(lstart, o, 64); lstart = ov < lstart ? ov : lstart; }
+  for (int l = lstart; l < Ls; ++l) {
     const int n = s_n[l];
-    const bool in = live && gx <= n + 1 && gy <= n + 1;
+    const bool in = live && l >= lmin;
     float v[F];
     float dot = 0.f;
     if (in) {
       const float* g = dG + (s_goff[l] + (int64_t)gy * (n + 2) + gx) * F;
-      const float* r = tables + ((int64_t)l * T + slot) * F;
+      if (dvert_w) {                       // the table row is only needed for d w (trainable HPD)
+        const float* r = tables + ((int64_t)l * T + slot) * F;
 #pragma unroll
-      for (int f = 0; f < F; ++f) { const float gv = g[f]; v[f] = gv * w; dot += gv * r[f]; }
+        for (int f = 0; f < F; ++f) { const float gv = g[f]; v[f] = gv * w; dot += gv * r[f]; }
+      } else {
+#pragma unroll
+        for (int f = 0; f < F; ++f) v[f] = g[f] * w;
+      }
     } else {
 #pragma unroll
       for (int f = 0; f < F; ++f) v[f] = 0.f;
     }
     dw_acc += dot;
-    // the whole wave skips a level none of its lanes belongs to (coarse levels: almost always)
+    // the whole wave skips a level none of its lanes belongs to
     if (__ballot(in) == 0ull) continue;
     // segmented inclusive scan over equal-slot runs
 #pragma unroll

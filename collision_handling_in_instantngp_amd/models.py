@@ -267,7 +267,7 @@ class GeneralNeuralGaugeFields(nn.Module):
             NV = vstride * vstride
             tv, ti, _, _ = ops.HpdVertexFunction.apply(NV, vstride, self._topk_k, None, False, HPD_CHUNK_BYTES, *params)
             w = ops.BlendFunction.apply(tv, blend_code)
-            self._frozen_table = (key, tv, ti, w, vstride, NV, ops.slot_order(ti))
+            self._frozen_table = (key, tv, ti, w, vstride, NV, ops.slot_order(ti, self._n_ls_host, vstride))
         return self._frozen_table[1:]
 
     # ------------------------------------------------------------------ forward

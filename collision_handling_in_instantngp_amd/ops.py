@@ -452,10 +452,21 @@ def _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G):
          0 if vert_idx is None else vert_idx.shape[1], mode, vstride, 0 if vert_idx is None else vert_idx.shape[0], stream_ptr())
 
 
-def slot_order(vert_idx):
-    """argsort of the per-vertex slot table viewed flat (int32): the visiting order of the contention-free vertex
-    backward.  One device sort per table build (frozen HPD: once; learning: once per step, next to the HPD GEMMs)."""
-    return torch.sort(vert_idx.reshape(-1), stable=True)[1].to(_i32)
+def slot_order(vert_idx, n_ls_host=None, vstride=None):
+    """Visiting order of the contention-free vertex backward: (vertex,k) entries sorted by (first level the vertex
+    belongs to, slot).  Equal slots stay adjacent inside a level group (wave-level segmented reduction), and a wave
+    only walks the levels >= its group's first level (coarse levels contain few vertices).  One device sort per table
+    build (frozen HPD: once; learning: once per step, next to the HPD GEMMs).  Returns int32 (NV*K)."""
+    NV, K = vert_idx.shape
+    flat = vert_idx.reshape(-1).to(_i64)
+    if n_ls_host is not None and vstride:
+        T_bits = int(flat.max().item()).bit_length() if flat.numel() else 1
+        vid = torch.arange(NV, device=vert_idx.device, dtype=_i64)
+        m = torch.maximum(vid % vstride, vid // vstride)                 # max(gx, gy)
+        bounds = torch.tensor([n + 1 for n in n_ls_host], device=vert_idx.device, dtype=_i64)
+        lmin = torch.searchsorted(bounds, m)                             # first level with max(gx,gy) <= n_l + 1
+        flat = (lmin.repeat_interleave(K) << T_bits) | flat
+    return torch.sort(flat, stable=True)[1].to(_i32)
 
 
 def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F):
@@ -493,7 +504,7 @@ class EncodeFunction(torch.autograd.Function):
         enc = torch.empty((P, L * F), dtype=_f32, device=tables.device)
         ws = None
         if vert_idx is not None and order is None and plan.Ls > 0 and P > 0 and ctx.needs_input_grad[3]:
-            order = slot_order(vert_idx)
+            order = slot_order(vert_idx, plan.n_ls_host[:plan.Ls], vstride)
         if plan.Ls > 0 and P > 0:
             ws = TiledWorkspace(plan, xy)
             G = torch.empty((plan.vtot, F), dtype=_f32, device=tables.device)
@@ -615,7 +626,7 @@ def encode_kernels(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, genc,
         out["encode_fwd:tiled"] = lambda: call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items),
                                                plan.max_items, ptr(n_ls), ptr(G), ptr(enc), L, plan.Ls, F, plan.tile_shift,
                                                plan.lds_bytes, s())
-        order = slot_order(vert_idx) if vert_idx is not None else None
+        order = slot_order(vert_idx, plan.n_ls_host[:plan.Ls], vstride) if vert_idx is not None else None
         out["encode_bwd:tiled"] = lambda: _pixel_bwd(plan, ws, n_ls, genc, dG, L, F)
         out["vertex_bwd"] = lambda: _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, None, order)
     if plan.Ls < L:
