@@ -636,3 +636,26 @@ def encode_kernels(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, genc,
                                                 ptr(genc), ptr(dtables), ptr(None), P, L, F, T, K, mode, vstride, NV, plan.Ls,
                                                 L, s())
     return out
+
+
+def decoder_kernels(enc, params, leaky, drgb):
+    """{name: zero-arg launcher} for the fused decoder kernels (bench.py per-kernel timing)."""
+    W0, b0, W1, b1, W2, b2 = [_c(p.detach()) for p in params]
+    P, in_dim = enc.shape
+    out_dim = W2.shape[0]
+    rgb = torch.empty((P, out_dim), dtype=_f32, device=enc.device)
+    denc = torch.empty_like(enc)
+    grads = [torch.empty_like(w) for w in (W0, b0, W1, b1, W2, b2)]
+    slabs = torch.empty((_lib.query("gngf_decoder_bwd_slabs", P) * _lib.query("gngf_decoder_slab_floats", in_dim, out_dim),),
+                        dtype=_f32, device=enc.device)
+
+    def fwd():
+        call("gngf_decoder_fwd", ptr(enc), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(rgb), P, in_dim, out_dim,
+             int(leaky), stream_ptr())
+
+    def bwd():
+        call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(denc),
+             *[ptr(g) for g in grads], ptr(slabs), P, in_dim, out_dim, int(leaky), stream_ptr())
+
+    fwd()
+    return {"decoder_fwd": fwd, "decoder_bwd": bwd}
