@@ -377,6 +377,8 @@ import ctypes as _ct
 import math as _math
 
 ENCODE_PATH = "auto"        # "auto" | "direct" | "tiled"  (tests force a path; auto = tiled when it pays)
+DP_EXCHANGE = None          # data parallel: callable that sum-all-reduces + averages the vertex-grid gradient in place
+DP_TABLES_REDUCED = False   # set when the table gradient of the last backward came out of an exchanged dG
 TILED_CHUNK = 1024          # max pixels per (tile, chunk) work item
 TILED_MIN_PIXELS = 1 << 14  # below this the binning overhead is not worth it
 TILED_LDS_LIMIT = 48 * 1024    # forward image; the backward image (64-bit accumulators) is twice this
@@ -529,6 +531,9 @@ class EncodeFunction(torch.autograd.Function):
         if plan.Ls > 0 and P > 0:
             dG = torch.zeros((plan.vtot, F), dtype=_f32, device=tables.device)
             _pixel_bwd(plan, ws, n_ls, genc, dG, L, F)
+            if DP_EXCHANGE is not None and plan.Ls == L:
+                DP_EXCHANGE(dG)                     # one small all-reduce instead of the (L,T,F) table gradient
+                globals()["DP_TABLES_REDUCED"] = True
             if order is not None and dvw is not None and plan.Ls < L:
                 # the sorted kernel WRITES dvert_w; the direct levels below accumulate into the same buffer
                 dvw_t = torch.empty_like(dvw)

@@ -9,6 +9,28 @@ Losses are means over the LOCAL batch, so summed gradients are divided by world 
 import torch
 import torch.distributed as dist
 
+from . import ops
+
+
+def all_reduce_sum(t, group=None):
+    """Sum-all-reduce of a device tensor: RCCL when the backend is nccl; with gloo (CPU rehearsals / single-GPU tests
+    of the multi-rank logic) the tensor is staged through host memory."""
+    if dist.get_backend(group) == "nccl" or not t.is_cuda:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    else:
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+
+
+def enable_vertex_grid_exchange(world: int, group=None):
+    """Exchange the dense per-level VERTEX-GRID gradient (sum_l (N_l+2)^2 * F floats: 5.7 MB at N 16->512) inside the
+    encoder backward instead of the (L,T,F) table gradient (64 MiB at T = 2^19) afterwards: the vertex stage
+    dG -> dE is linear and identical on every rank, so reducing dG first gives the same table gradient with ~11x
+    fewer bytes on the xGMI links.  Applies when the tiled form covers every level; otherwise the table buffer is
+    all-reduced as before."""
+    ops.DP_EXCHANGE = None if world <= 1 else (lambda t: (all_reduce_sum(t, group), t.mul_(1.0 / world)))
+
 
 def shard_batch(n_items: int, rank: int, world: int):
     """Contiguous equal shards (the last rank takes the remainder)."""
@@ -26,7 +48,12 @@ def allreduce_gradients(net, world: int, group=None):
     enc = getattr(net, "encoding", None)
     base = getattr(enc, "_grad_base", None) if enc is not None else None
     work = []
-    if base is not None:
+    tables_done = ops.DP_TABLES_REDUCED          # set by the encoder backward when it exchanged dG (see above)
+    ops.DP_TABLES_REDUCED = False
+    if base is not None and tables_done:
+        handled = {id(m.weight) for m in enc._hash_tables}
+        base = None
+    elif base is not None:
         work.append(dist.all_reduce(base, op=dist.ReduceOp.SUM, group=group, async_op=True))
         handled = {id(m.weight) for m in enc._hash_tables}
     rest = [p for p in net.parameters() if p.requires_grad and p.grad is not None and id(p) not in handled]

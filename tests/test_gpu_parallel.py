@@ -1,0 +1,86 @@
+"""GPU, 2 ranks on ONE device over gloo (tensor staging through host): a 2-way pixel-sharded step with the
+vertex-grid gradient exchange equals the single-rank step on the concatenated batch (SURVEY.md §4 iv)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _grads(net):
+    return {k: p.grad.detach().cpu().numpy().copy() for k, p in net.named_parameters() if p.grad is not None}
+
+
+def _make(models, mode):
+    models.should_use_hash_function = (mode == "hash")
+    torch.manual_seed(7)
+    net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=2 ** 14, num_levels=8, n_min=16, n_max=128,
+                                          MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
+                                          HPD_out_features=2 ** 14, feature_dim=2, topk_k=4)
+    net.return_indices = False
+    net.dense_probs = False
+    if mode != "hash":
+        for p in net.HPD.parameters():
+            p.requires_grad = False
+        net.compute_pbar = False
+    return net
+
+
+def _worker(rank, world, port, mode, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from collision_handling_in_instantngp_amd import models, parallel, ops
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    P = 2 ** 15
+    xy = torch.rand((P, 2), generator=g).to(dev)
+    tgt = torch.rand((P, 3), generator=g).to(dev)
+    net = _make(models, mode)
+    parallel.broadcast_parameters(net)
+    # single-rank reference on the whole batch (rank 0 only)
+    ref = None
+    if rank == 0:
+        rgb, *_ = net(xy, 1.0)
+        torch.nn.functional.mse_loss(rgb, tgt).backward()
+        ref = _grads(net)
+        net.zero_grad()
+    parallel.enable_vertex_grid_exchange(world)
+    lo, hi = parallel.shard_batch(P, rank, world)
+    rgb, *_ = net(xy[lo:hi], 1.0)
+    torch.nn.functional.mse_loss(rgb, tgt[lo:hi]).backward()
+    reduced_flag = ops.DP_TABLES_REDUCED
+    parallel.allreduce_gradients(net, world)
+    got = _grads(net)
+    ok = True
+    if rank == 0:
+        for k in ref:
+            scale = np.abs(ref[k]).max() + 1e-30
+            ok &= bool(np.abs(got[k] - ref[k]).max() <= 2e-4 * scale)
+    ret[rank] = (ok, bool(reduced_flag))
+    parallel.enable_vertex_grid_exchange(1)
+    models.should_use_hash_function = False
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("mode", ["hash", "gngf_frozen"])
+def test_two_rank_sharded_step_equals_single_rank(mode):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), mode, ret), nprocs=2, join=True)
+    assert ret[0][0], "sharded gradients differ from the single-rank step"
+    assert ret[0][1] and ret[1][1], "the vertex-grid exchange did not engage"
