@@ -32,7 +32,7 @@ __device__ __forceinline__ bool beats(float av, int ai, float bv, int bi) { retu
 // nan_to_num maps the NaNs to 0.  Top-K is taken on the final fp32 probabilities; ties -> lower index.
 __global__ void __launch_bounds__(kRowBlock)
 softmax_topk_kernel(float* __restrict__ z, float* __restrict__ topv, int32_t* __restrict__ topi, int64_t T, int K,
-                    int do_softmax) {
+                    int do_softmax, float* __restrict__ rowstat) {
   extern __shared__ float smem[];            // K*256 values, K*256 indices, then 16 floats scratch
   float* lv = smem;
   int* li = reinterpret_cast<int*>(smem + (size_t)K * kRowBlock);
@@ -60,6 +60,10 @@ softmax_topk_kernel(float* __restrict__ z, float* __restrict__ topv, int32_t* __
     __syncthreads();
     s = (red[0] + red[1]) + (red[2] + red[3]);
     __syncthreads();
+    if (rowstat && tid == 0) {                 // (max, sum) of the row: lets backward rebuild p = exp(z - m) / s from logits
+      rowstat[2 * (int64_t)blockIdx.x] = m;
+      rowstat[2 * (int64_t)blockIdx.x + 1] = row_nan ? __int_as_float(0x7fc00000) : s;
+    }
   }
 
   for (int k = 0; k < K; ++k) { lv[k * kRowBlock + tid] = -INFINITY; li[k * kRowBlock + tid] = INT_MAX; }
@@ -147,6 +151,106 @@ softmax_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dq, co
   }
   __syncthreads();
   if (tid < K && dq) dz[topi[row * K + tid]] += pk[tid] * dq[row * K + tid];
+}
+
+// ---------------------------------------------------------------------------------------------- low-rank softmax backward
+// Backward of softmax + top-K + batch-mean loss from RECOMPUTED LOGITS, for the chunked per-vertex path:
+//   p = exp(z - m) / s (row stats saved by the forward),  g[r,t] = sum_l mw[r,l] G[l,t]  (+ dq_k at the top-K slots)
+//   dz[r,t] = p (g - dot_r),  dot_r = sum_t p g,   db[t] += sum_r dz[r,t]
+// Tiling: a block owns 64 rows x a range of columns; a thread owns one column at a time, keeps G[:,t] (L values) in
+// registers and reads mw / row stats from LDS, so G is read once per 64 rows instead of once per row (the first
+// version re-read all of G for every row: 10.6 ms per 2048-row chunk at T = 2^19; this form is bound by the two
+// streaming passes over z).
+constexpr int kSbRows = 64;
+constexpr int kSbCols = 8192;      // columns per block (32 trips of 256)
+
+__device__ __forceinline__ float prob_of(float z, float m, float s) {
+  const float q = expf(z - m) / s;
+  return (q != q) ? 0.f : (q > 3.4028234663852886e38f ? 3.4028234663852886e38f : q);   // nan_to_num; s = NaN marks a NaN row
+}
+
+template <bool APPLY>
+__global__ void __launch_bounds__(256)
+softmax_bwd_tile_kernel(float* __restrict__ Z, const float* __restrict__ rowstat, const float* __restrict__ mw,
+                        const float* __restrict__ G, int L, float* __restrict__ dot, float* __restrict__ db, int64_t U,
+                        int64_t T) {
+  __shared__ float mwS[kSbRows][GNGF_MAX_LEVELS];
+  __shared__ float mS[kSbRows], sS[kSbRows], dS[kSbRows];
+  __shared__ float red[4][kSbRows];
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * kSbRows;
+  const int nr = (int)((U - r0) < kSbRows ? (U - r0) : kSbRows);
+  for (int e = tid; e < kSbRows * L; e += 256) { const int r = e / L, l = e - r * L; mwS[r][l] = (r < nr && mw) ? mw[(r0 + r) * L + l] : 0.f; }
+  if (tid < kSbRows) {
+    const bool ok = tid < nr;
+    mS[tid] = ok ? rowstat[2 * (r0 + tid)] : 0.f;
+    sS[tid] = ok ? rowstat[2 * (r0 + tid) + 1] : 1.f;
+    dS[tid] = (ok && APPLY) ? dot[r0 + tid] : 0.f;
+  }
+  __syncthreads();
+  float acc[kSbRows];
+  if (!APPLY) {
+#pragma unroll
+    for (int r = 0; r < kSbRows; ++r) acc[r] = 0.f;
+  }
+  const int64_t c0 = (int64_t)blockIdx.x * kSbCols;
+  const int64_t c1 = (c0 + kSbCols < T) ? c0 + kSbCols : T;
+  for (int64_t t = c0 + tid; t < c1; t += 256) {
+    float Gc[GNGF_MAX_LEVELS];
+    for (int l = 0; l < L; ++l) Gc[l] = G[(int64_t)l * T + t];
+    float colsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < kSbRows; ++r) {            // fully unrolled: acc[r] must be a static register index
+      if (r >= nr) continue;
+      float* zp = Z + (r0 + r) * T + t;
+      const float p = prob_of(*zp, mS[r], sS[r]);
+      float g = 0.f;
+      for (int l = 0; l < L; ++l) g += mwS[r][l] * Gc[l];
+      if (APPLY) {
+        const float dz = p * (g - dS[r]);
+        *zp = dz;
+        colsum += dz;
+      } else {
+        acc[r] += p * g;
+      }
+    }
+    if (APPLY && db) atomicAdd(db + t, colsum);
+  }
+  if (!APPLY) {
+    // block reduction of the 64 row sums: wave shuffles, then 4 partials through LDS, one atomic per (block, row)
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int r = 0; r < kSbRows; ++r) {
+      float v = acc[r];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) red[wave][r] = v;
+    }
+    __syncthreads();
+    if (tid < nr) atomicAdd(dot + r0 + tid, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+  }
+}
+
+// top-K part of the row dots; stashes p at the top-K slots (the logits are overwritten by the apply pass)
+__global__ void softmax_bwd_topk_dot_kernel(const float* __restrict__ Z, const float* __restrict__ rowstat,
+                                            const float* __restrict__ dq, const int32_t* __restrict__ topi,
+                                            float* __restrict__ pk, float* __restrict__ dot, int64_t U, int64_t T, int K) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= U * K) return;
+  const int64_t r = e / K;
+  const float p = prob_of(Z[r * T + topi[e]], rowstat[2 * r], rowstat[2 * r + 1]);
+  pk[e] = p;
+  atomicAdd(dot + r, p * dq[e]);
+}
+
+__global__ void softmax_bwd_topk_fix_kernel(float* __restrict__ dZ, const float* __restrict__ dq, const int32_t* __restrict__ topi,
+                                            const float* __restrict__ pk, float* __restrict__ db, int64_t U, int64_t T, int K) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= U * K) return;
+  const int64_t r = e / K;
+  const float add = pk[e] * dq[e];
+  dZ[r * T + topi[e]] += add;                  // the K slots of a row are distinct: no race
+  if (db) atomicAdd(db + topi[e], add);
 }
 
 // verts[u] = (gx, gy) as fp32 with u = gy * vstride + gx   (the HPD input is the raw integer vertex, models.py:416-418)
@@ -257,8 +361,8 @@ expand_kernel(const float2* __restrict__ xy, const int32_t* __restrict__ n_ls, c
 
 using namespace gngf;
 
-extern "C" int gngf_softmax_topk(float* logits_probs, float* topk_val, int32_t* topk_idx, int64_t U, int64_t T, int K,
-                                 void* stream) {
+extern "C" int gngf_softmax_topk(float* logits_probs, float* topk_val, int32_t* topk_idx, float* rowstat, int64_t U, int64_t T,
+                                 int K, void* stream) {
   GNGF_CHECK_ARG(U >= 0 && T > 0 && K > 0 && K <= GNGF_MAX_TOPK && K <= T && T < INT_MAX);
   if (U == 0) return 0;
   GNGF_CHECK_ARG(logits_probs && topk_val && topk_idx);
@@ -268,7 +372,8 @@ extern "C" int gngf_softmax_topk(float* logits_probs, float* topk_val, int32_t* 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  softmax_topk_kernel<<<dim3((unsigned)U), dim3(kRowBlock), smem, as_stream(stream)>>>(logits_probs, topk_val, topk_idx, T, K, 1);
+  softmax_topk_kernel<<<dim3((unsigned)U), dim3(kRowBlock), smem, as_stream(stream)>>>(logits_probs, topk_val, topk_idx, T, K, 1,
+                                                                                       rowstat);
   GNGF_RETURN_LAUNCH();
 }
 
@@ -284,7 +389,7 @@ extern "C" int gngf_topk(const float* x, float* topk_val, int32_t* topk_idx, int
     if (e != hipSuccess) return (int)e;
   }
   softmax_topk_kernel<<<dim3((unsigned)U), dim3(kRowBlock), smem, as_stream(stream)>>>(const_cast<float*>(x), topk_val, topk_idx,
-                                                                                       T, K, 0);
+                                                                                       T, K, 0, nullptr);
   GNGF_RETURN_LAUNCH();
 }
 
@@ -296,6 +401,32 @@ extern "C" int gngf_softmax_bwd(const float* probs, const float* dq, const int32
   GNGF_CHECK_ARG(probs && dlogits && (K == 0 || topk_idx) && ((mw == nullptr) == (G == nullptr)));
   softmax_bwd_kernel<<<dim3((unsigned)U), dim3(kRowBlock), 0, as_stream(stream)>>>(probs, dq, topk_idx, gdense, mw, G, L,
                                                                                     dlogits, T, K);
+  GNGF_RETURN_LAUNCH();
+}
+
+// Softmax(+top-K, + batch-mean loss) backward from recomputed logits, in place: logits_dz (U,T) logits in, d logits out.
+// rowstat (U,2) from gngf_softmax_topk; dq/topk_idx (U,K) or K = 0; mw (U,L) and G (L,T) or L = 0;
+// db (T) += column sums of d logits (NULL: skipped); scratch: (U + U*K) floats.
+extern "C" int gngf_softmax_bwd_lowrank(float* logits_dz, const float* rowstat, const float* dq, const int32_t* topk_idx,
+                                        const float* mw, const float* G, int L, float* db, float* scratch, int64_t U, int64_t T,
+                                        int K, void* stream) {
+  GNGF_CHECK_ARG(U >= 0 && T > 0 && K >= 0 && K <= GNGF_MAX_TOPK && L >= 0 && L <= GNGF_MAX_LEVELS);
+  if (U == 0) return 0;
+  GNGF_CHECK_ARG(logits_dz && rowstat && scratch && (K == 0 || (dq && topk_idx)) && (L == 0 || (mw && G)));
+  hipStream_t s = as_stream(stream);
+  float* dot = scratch;
+  float* pk = scratch + U;
+  hipError_t e = hipMemsetAsync(dot, 0, sizeof(float) * (size_t)U, s);
+  if (e != hipSuccess) return (int)e;
+  const dim3 grid((unsigned)ceil_div(T, kSbCols), (unsigned)ceil_div(U, kSbRows));
+  if (L > 0)
+    softmax_bwd_tile_kernel<false><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, nullptr, U, T);
+  if (K > 0)
+    softmax_bwd_topk_dot_kernel<<<dim3((unsigned)ceil_div(U * K, 256)), dim3(256), 0, s>>>(logits_dz, rowstat, dq, topk_idx, pk,
+                                                                                          dot, U, T, K);
+  softmax_bwd_tile_kernel<true><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, db, U, T);
+  if (K > 0)
+    softmax_bwd_topk_fix_kernel<<<dim3((unsigned)ceil_div(U * K, 256)), dim3(256), 0, s>>>(logits_dz, dq, topk_idx, pk, db, U, T, K);
   GNGF_RETURN_LAUNCH();
 }
 

@@ -136,7 +136,8 @@ def linear_bwd_weight(dy, y, x, dw, db, act):
     """Accumulates into dw (N,K) and db (N,)."""
     M, N = dy.shape
     K = x.shape[1]
-    call("gngf_linear_bwd_weight", ptr(dy, _f32), ptr(y if act else None, _f32), ptr(x, _f32), ptr(dw, _f32), ptr(db, _f32),
+    call("gngf_linear_bwd_weight", ptr(dy, _f32), ptr(y if act else None, _f32), ptr(x, _f32), ptr(dw, _f32),
+         ptr(db, _f32) if db is not None else ptr(None),
          M, N, K, act, stream_ptr())
 
 
@@ -234,6 +235,7 @@ class HpdVertexFunction(torch.autograd.Function):
         rows = int(max(64, min(NV, chunk_bytes // (4 * T))))
         tv = torch.empty((NV, K), dtype=_f32, device=dev)
         ti = torch.empty((NV, K), dtype=_i32, device=dev)
+        rowstat = torch.empty((NV, 2), dtype=_f32, device=dev)
         probs = torch.empty((NV, T), dtype=_f32, device=dev) if keep_probs else None
         pbar = None
         if mw is not None:
@@ -246,19 +248,19 @@ class HpdVertexFunction(torch.autograd.Function):
             hs = HpdVertexFunction._hidden(vertex_coords(u0, n, vstride, dev), params, n_layers)
             z = probs[u0:u0 + n] if keep_probs else scratch[:n]
             call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(z), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
-            call("gngf_softmax_topk", ptr(z), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), n, T, K, stream_ptr())
+            call("gngf_softmax_topk", ptr(z), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), ptr(rowstat[u0:u0 + n]), n, T, K, stream_ptr())
             if pbar is not None:
                 gemm_acc(mw[u0:u0 + n], z, pbar, L, T, n, ta=True, tb=False)
         ctx.cfg = (NV, vstride, K, rows, n_layers, T, keep_probs)
-        ctx.save_for_backward(ti, mw, probs, *params)
+        ctx.save_for_backward(ti, mw, probs, rowstat, *params)
         ctx.mark_non_differentiable(ti)
         return tv, ti, pbar, probs
 
     @staticmethod
     def backward(ctx, g_tv, g_ti, g_pbar, g_probs):
         NV, vstride, K, rows, n_layers, T, keep_probs = ctx.cfg
-        ti, mw, probs = ctx.saved_tensors[:3]
-        params = ctx.saved_tensors[3:]
+        ti, mw, probs, rowstat = ctx.saved_tensors[:4]
+        params = ctx.saved_tensors[4:]
         W_last, b_last = params[-2], params[-1]
         dev = W_last.device
         grads = [torch.zeros_like(p) for p in params]
@@ -267,23 +269,34 @@ class HpdVertexFunction(torch.autograd.Function):
         g_probs = _c(g_probs) if g_probs is not None else None
         L = mw.shape[1] if mw is not None else 0
         dz_buf = torch.empty((min(rows, NV), T), dtype=_f32, device=dev)
+        lowrank = g_probs is None           # no dense gradient on the distribution: stream from recomputed logits
+        if lowrank:
+            scratch = torch.empty((min(rows, NV) * (1 + K),), dtype=_f32, device=dev)
         for u0 in range(0, NV, rows):
             n = min(rows, NV - u0)
             hs = HpdVertexFunction._hidden(vertex_coords(u0, n, vstride, dev), params, n_layers)
             dz = dz_buf[:n]
-            if keep_probs:
-                p_chunk = probs[u0:u0 + n]
-            else:   # recompute logits + softmax in the scratch (top-K indices are the saved ones)
+            if lowrank:
+                # logits again, then softmax / top-K / batch-mean backward in place; db of the last layer is fused in
                 call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(dz), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
-                tv_tmp = torch.empty((n, K), dtype=_f32, device=dev)
-                ti_tmp = torch.empty((n, K), dtype=_i32, device=dev)
-                call("gngf_softmax_topk", ptr(dz), ptr(tv_tmp), ptr(ti_tmp), n, T, K, stream_ptr())
-                p_chunk = dz
-            call("gngf_softmax_bwd", ptr(p_chunk), ptr(g_tv[u0:u0 + n] if g_tv is not None else None), ptr(ti[u0:u0 + n]),
-                 ptr(g_probs[u0:u0 + n] if g_probs is not None else None),
-                 ptr(mw[u0:u0 + n] if g_pbar is not None else None), ptr(g_pbar), L, ptr(dz), n, T,
-                 K if g_tv is not None else 0, stream_ptr())
-            linear_bwd_weight(dz, None, hs[-1], grads[-2], grads[-1], ACT_NONE)
+                call("gngf_softmax_bwd_lowrank", ptr(dz), ptr(rowstat[u0:u0 + n]),
+                     ptr(g_tv[u0:u0 + n] if g_tv is not None else None), ptr(ti[u0:u0 + n]),
+                     ptr(mw[u0:u0 + n] if g_pbar is not None else None), ptr(g_pbar), L if g_pbar is not None else 0,
+                     ptr(grads[-1]), ptr(scratch), n, T, K if g_tv is not None else 0, stream_ptr())
+                linear_bwd_weight(dz, None, hs[-1], grads[-2], None, ACT_NONE)
+            else:
+                if keep_probs:
+                    p_chunk = probs[u0:u0 + n]
+                else:   # recompute logits + softmax in the scratch (top-K indices are the saved ones)
+                    call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(dz), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
+                    tv_tmp = torch.empty((n, K), dtype=_f32, device=dev)
+                    ti_tmp = torch.empty((n, K), dtype=_i32, device=dev)
+                    call("gngf_softmax_topk", ptr(dz), ptr(tv_tmp), ptr(ti_tmp), ptr(None), n, T, K, stream_ptr())
+                    p_chunk = dz
+                call("gngf_softmax_bwd", ptr(p_chunk), ptr(g_tv[u0:u0 + n] if g_tv is not None else None), ptr(ti[u0:u0 + n]),
+                     ptr(g_probs[u0:u0 + n]), ptr(mw[u0:u0 + n] if g_pbar is not None else None), ptr(g_pbar), L, ptr(dz), n, T,
+                     K if g_tv is not None else 0, stream_ptr())
+                linear_bwd_weight(dz, None, hs[-1], grads[-2], grads[-1], ACT_NONE)
             g = torch.zeros((n, W_last.shape[1]), dtype=_f32, device=dev)
             gemm_acc(dz, W_last, g, n, W_last.shape[1], T, ta=False, tb=False)     # dh = dz @ W_last, split over T
             for i in range(n_layers - 2, -1, -1):
@@ -309,7 +322,8 @@ class BlendFunction(torch.autograd.Function):
     def backward(ctx, dw):
         (q,) = ctx.saved_tensors
         dq = torch.empty_like(q)
-        call("gngf_blend_bwd", ptr(q), ptr(_c(dw), _f32), ptr(dq), q.shape[0], q.shape[1], ctx.blend_code, stream_ptr())
+        dw = _c(dw)            # named: a temporary passed straight to ptr() could be freed (and its block reused) before the launch
+        call("gngf_blend_bwd", ptr(q), ptr(dw, _f32), ptr(dq), q.shape[0], q.shape[1], ctx.blend_code, stream_ptr())
         return dq, None
 
 
@@ -323,7 +337,7 @@ class SoftmaxTopkFunction(torch.autograd.Function):
         U, T = probs.shape
         tv = torch.empty((U, K), dtype=_f32, device=probs.device)
         ti = torch.empty((U, K), dtype=_i32, device=probs.device)
-        call("gngf_softmax_topk", ptr(probs, _f32, "logits"), ptr(tv), ptr(ti), U, T, K, stream_ptr())
+        call("gngf_softmax_topk", ptr(probs, _f32, "logits"), ptr(tv), ptr(ti), ptr(None), U, T, K, stream_ptr())
         ctx.save_for_backward(probs, ti)
         ctx.mark_non_differentiable(ti)
         return probs, tv, ti
@@ -334,8 +348,9 @@ class SoftmaxTopkFunction(torch.autograd.Function):
         U, T = probs.shape
         K = ti.shape[1]
         dz = torch.empty_like(probs)
-        call("gngf_softmax_bwd", ptr(probs), ptr(_c(g_tv) if g_tv is not None else None, _f32), ptr(ti),
-             ptr(_c(g_probs) if g_probs is not None else None, _f32), ptr(None), ptr(None), 0, ptr(dz), U, T,
+        g_tv = _c(g_tv) if g_tv is not None else None
+        g_probs = _c(g_probs) if g_probs is not None else None
+        call("gngf_softmax_bwd", ptr(probs), ptr(g_tv, _f32), ptr(ti), ptr(g_probs, _f32), ptr(None), ptr(None), 0, ptr(dz), U, T,
              K if g_tv is not None else 0, stream_ptr())
         return dz, None
 

@@ -135,8 +135,10 @@ int gngf_decoder_slab_floats(int in_dim, int out_dim);
 
 /* ---- a7/a8 tail, per DISTINCT vertex: Softmax(dim=-1) + nan_to_num + top-K (models.py:85,111,116; 5-19).
  * logits_probs (U,T): logits in, probabilities out (in place).  topk_val (U,K) sorted descending, topk_idx (U,K) int32;
- * ties resolve to the LOWER slot index (torch.topk leaves tie order unspecified). */
-int gngf_softmax_topk(float* logits_probs, float* topk_val, int32_t* topk_idx, int64_t U, int64_t T, int K, void* stream);
+ * ties resolve to the LOWER slot index (torch.topk leaves tie order unspecified).  rowstat (U,2) = (row max, row sum of
+ * exp(z - max); NaN marks a NaN-poisoned row), optional (NULL): lets the backward rebuild p from recomputed logits. */
+int gngf_softmax_topk(float* logits_probs, float* topk_val, int32_t* topk_idx, float* rowstat, int64_t U, int64_t T, int K,
+                      void* stream);
 /* DifferentiableTopk.forward alone (models.py:11) on arbitrary rows x (U,T); same ordering rules. */
 int gngf_topk(const float* x, float* topk_val, int32_t* topk_idx, int64_t U, int64_t T, int K, void* stream);
 /* backward of the above without the dense zero-filled scatter of models.py:27-35:
@@ -144,6 +146,12 @@ int gngf_topk(const float* x, float* topk_val, int32_t* topk_idx, int64_t U, int
  *   dlogits = p .* (g - <p, g>)        dlogits may alias probs. */
 int gngf_softmax_bwd(const float* probs, const float* dq, const int32_t* topk_idx, const float* gdense, const float* mw,
                      const float* G, int L, float* dlogits, int64_t U, int64_t T, int K, void* stream);
+
+/* the same backward from RECOMPUTED LOGITS, in place (logits in, d logits out), for the chunked per-vertex path:
+ * p = exp(z - rowstat.max) / rowstat.sum;  g = mw (U,L) * G (L,T) + dq at topk_idx;  dz = p .* (g - <p,g>);
+ * db (T) += column sums of dz (NULL: skipped).  scratch: U + U*K floats.  L = 0 / K = 0 drop the respective term. */
+int gngf_softmax_bwd_lowrank(float* logits_dz, const float* rowstat, const float* dq, const int32_t* topk_idx, const float* mw,
+                             const float* G, int L, float* db, float* scratch, int64_t U, int64_t T, int K, void* stream);
 
 /* verts[i] = (gx, gy) fp32 of vertex id u0+i (vid = gy*vstride + gx): the raw-integer HPD input of models.py:416-418 */
 int gngf_vertex_coords(float* verts, int64_t u0, int64_t count, int vstride, void* stream);

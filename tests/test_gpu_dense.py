@@ -201,3 +201,37 @@ def test_fused_decoder_vs_numpy(ops, P, in_dim, out_dim, leaky):
         scale = max(1.0, float(np.abs(dW[i]).max()))
         close(params[2 * i].grad, dW[i], 2e-4, 2e-5 * scale)
         close(params[2 * i + 1].grad, dB[i], 2e-4, 2e-5 * scale)
+
+
+@pytest.mark.parametrize("U,T,K,Lv", [(100, 700, 4, 5), (64, 8192 + 300, 3, 16), (130, 257, 0, 4), (70, 1000, 6, 0)])
+def test_softmax_bwd_lowrank_from_logits_vs_numpy(ops, U, T, K, Lv):
+    """streamed softmax / top-K / batch-mean backward from recomputed logits (chunked per-vertex path)"""
+    from collision_handling_in_instantngp_amd._lib import call, ptr, stream_ptr
+    rng = np.random.default_rng(U + T)
+    z = (rng.standard_normal((U, T)) * 2).astype(np.float32)
+    z[1, 7] = np.nan                                         # NaN row: probabilities are nan_to_num'ed to 0 -> zero gradient
+    probs, tv, ti = ops.SoftmaxTopkFunction.apply(t(z), max(K, 1))
+    zt = t(z)
+    tvb, tib = torch.empty((U, max(K, 1)), device=DEV), torch.empty((U, max(K, 1)), dtype=torch.int32, device=DEV)
+    rowstat = torch.empty((U, 2), device=DEV)
+    call("gngf_softmax_topk", ptr(zt), ptr(tvb), ptr(tib), ptr(rowstat), U, T, max(K, 1), stream_ptr())
+    p = zt.cpu().numpy().astype(np.float64)                  # probabilities (in place)
+    mw = rng.random((U, max(Lv, 1))).astype(np.float32)
+    G = rng.standard_normal((max(Lv, 1), T)).astype(np.float32)
+    dq = rng.standard_normal((U, max(K, 1))).astype(np.float32)
+    g = (mw.astype(np.float64) @ G.astype(np.float64)) if Lv else np.zeros((U, T))
+    tin = tib.cpu().numpy().astype(np.int64)
+    if K:
+        np.put_along_axis(g, tin[:, :K], np.take_along_axis(g, tin[:, :K], -1) + dq[:, :K], -1)
+    want = p * (g - (g * p).sum(-1, keepdims=True))
+    logits = t(z)                                            # fresh logits, as the backward recomputes them
+    db = torch.zeros((T,), device=DEV)
+    scratch = torch.empty((U * (1 + max(K, 1)),), device=DEV)
+    dq_t = t(dq[:, :K].copy()) if K else None                # keep every device tensor alive across the launch
+    ti_t = tib[:, :K].contiguous() if K else None
+    mw_t, G_t = (t(mw), t(G)) if Lv else (None, None)
+    call("gngf_softmax_bwd_lowrank", ptr(logits), ptr(rowstat), ptr(dq_t), ptr(ti_t), ptr(mw_t), ptr(G_t), Lv, ptr(db),
+         ptr(scratch), U, T, K, stream_ptr())
+    scale = np.abs(want).max()
+    close(logits, want, 2e-4, 2e-6 * scale)
+    close(db, want.sum(0), 2e-4, 2e-5 * scale)
