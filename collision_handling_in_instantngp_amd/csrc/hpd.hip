@@ -169,63 +169,76 @@ __device__ __forceinline__ float prob_of(float z, float m, float s) {
   return (q != q) ? 0.f : (q > 3.4028234663852886e38f ? 3.4028234663852886e38f : q);   // nan_to_num; s = NaN marks a NaN row
 }
 
-template <bool APPLY>
+template <bool APPLY, int LMAX>
 __global__ void __launch_bounds__(256)
 softmax_bwd_tile_kernel(float* __restrict__ Z, const float* __restrict__ rowstat, const float* __restrict__ mw,
                         const float* __restrict__ G, int L, float* __restrict__ dot, float* __restrict__ db, int64_t U,
                         int64_t T) {
-  __shared__ float mwS[kSbRows][GNGF_MAX_LEVELS];
-  __shared__ float mS[kSbRows], sS[kSbRows], dS[kSbRows];
+  // Row-wise operands (row max / sum / dot, the L multiplicity weights) are wave-UNIFORM: they are read straight from
+  // global memory with uniform indices, which hipcc turns into scalar loads (SGPR operands of the FMAs) — the first
+  // tiled version broadcast them out of LDS and was bound by 16+ ds_reads per element.  A thread owns CPT columns.
+  constexpr int CPT = 4;
   __shared__ float red[4][kSbRows];
   const int tid = threadIdx.x;
   const int64_t r0 = (int64_t)blockIdx.y * kSbRows;
   const int nr = (int)((U - r0) < kSbRows ? (U - r0) : kSbRows);
-  for (int e = tid; e < kSbRows * L; e += 256) { const int r = e / L, l = e - r * L; mwS[r][l] = (r < nr && mw) ? mw[(r0 + r) * L + l] : 0.f; }
-  if (tid < kSbRows) {
-    const bool ok = tid < nr;
-    mS[tid] = ok ? rowstat[2 * (r0 + tid)] : 0.f;
-    sS[tid] = ok ? rowstat[2 * (r0 + tid) + 1] : 1.f;
-    dS[tid] = (ok && APPLY) ? dot[r0 + tid] : 0.f;
-  }
-  __syncthreads();
-  float acc[kSbRows];
+  const int lane = tid & 63, wave = tid >> 6;
   if (!APPLY) {
-#pragma unroll
-    for (int r = 0; r < kSbRows; ++r) acc[r] = 0.f;
+    red[wave][lane] = 0.f;                       // kSbRows == 64: one entry per lane; each wave owns its row of `red`
+    __syncthreads();
   }
   const int64_t c0 = (int64_t)blockIdx.x * kSbCols;
   const int64_t c1 = (c0 + kSbCols < T) ? c0 + kSbCols : T;
-  for (int64_t t = c0 + tid; t < c1; t += 256) {
-    float Gc[GNGF_MAX_LEVELS];
-    for (int l = 0; l < L; ++l) Gc[l] = G[(int64_t)l * T + t];
-    float colsum = 0.f;
+  for (int64_t tb = c0; tb < c1; tb += 256 * CPT) {
+    int64_t tc[CPT];
+    bool okc[CPT];
+    float Gc[CPT][LMAX];
 #pragma unroll
-    for (int r = 0; r < kSbRows; ++r) {            // fully unrolled: acc[r] must be a static register index
-      if (r >= nr) continue;
-      float* zp = Z + (r0 + r) * T + t;
-      const float p = prob_of(*zp, mS[r], sS[r]);
-      float g = 0.f;
-      for (int l = 0; l < L; ++l) g += mwS[r][l] * Gc[l];
-      if (APPLY) {
-        const float dz = p * (g - dS[r]);
-        *zp = dz;
-        colsum += dz;
-      } else {
-        acc[r] += p * g;
+    for (int q = 0; q < CPT; ++q) {
+      tc[q] = tb + q * 256 + tid;
+      okc[q] = tc[q] < c1;
+      const int64_t ts = okc[q] ? tc[q] : c1 - 1;
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) Gc[q][l] = l < L ? G[(int64_t)l * T + ts] : 0.f;
+    }
+    float colsum[CPT] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < nr; ++r) {
+      const int64_t row = r0 + r;
+      const float m = rowstat[2 * row], sden = rowstat[2 * row + 1];       // uniform -> scalar loads
+      const float dr = APPLY ? dot[row] : 0.f;
+      float mwr[LMAX];
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) mwr[l] = (l < L) ? mw[row * L + l] : 0.f;
+      float part = 0.f;
+#pragma unroll
+      for (int q = 0; q < CPT; ++q) {
+        if (!okc[q]) continue;
+        float* zp = Z + row * T + tc[q];
+        const float p = prob_of(*zp, m, sden);
+        float g = 0.f;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) g += mwr[l] * Gc[q][l];
+        if (APPLY) {
+          const float dz = p * (g - dr);
+          *zp = dz;
+          colsum[q] += dz;
+        } else {
+          part += p * g;
+        }
+      }
+      if (!APPLY) {                              // wave-level sum of this trip's 256 columns, kept per (wave, row) in LDS
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if (lane == 0) red[wave][r] += part;
       }
     }
-    if (APPLY && db) atomicAdd(db + t, colsum);
+    if (APPLY && db) {
+#pragma unroll
+      for (int q = 0; q < CPT; ++q)
+        if (okc[q]) atomicAdd(db + tc[q], colsum[q]);
+    }
   }
   if (!APPLY) {
-    // block reduction of the 64 row sums: wave shuffles, then 4 partials through LDS, one atomic per (block, row)
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int r = 0; r < kSbRows; ++r) {
-      float v = acc[r];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) red[wave][r] = v;
-    }
     __syncthreads();
     if (tid < nr) atomicAdd(dot + r0 + tid, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
   }
@@ -419,12 +432,18 @@ extern "C" int gngf_softmax_bwd_lowrank(float* logits_dz, const float* rowstat, 
   hipError_t e = hipMemsetAsync(dot, 0, sizeof(float) * (size_t)U, s);
   if (e != hipSuccess) return (int)e;
   const dim3 grid((unsigned)ceil_div(T, kSbCols), (unsigned)ceil_div(U, kSbRows));
-  if (L > 0)
-    softmax_bwd_tile_kernel<false><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, nullptr, U, T);
+  const bool small = L <= 4;
+  if (L > 0) {
+    if (small) softmax_bwd_tile_kernel<false, 4><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, nullptr, U, T);
+    else if (L <= 16) softmax_bwd_tile_kernel<false, 16><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, nullptr, U, T);
+    else softmax_bwd_tile_kernel<false, 32><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, nullptr, U, T);
+  }
   if (K > 0)
     softmax_bwd_topk_dot_kernel<<<dim3((unsigned)ceil_div(U * K, 256)), dim3(256), 0, s>>>(logits_dz, rowstat, dq, topk_idx, pk,
                                                                                           dot, U, T, K);
-  softmax_bwd_tile_kernel<true><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, db, U, T);
+  if (small) softmax_bwd_tile_kernel<true, 4><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, db, U, T);
+  else if (L <= 16) softmax_bwd_tile_kernel<true, 16><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, db, U, T);
+  else softmax_bwd_tile_kernel<true, 32><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, db, U, T);
   if (K > 0)
     softmax_bwd_topk_fix_kernel<<<dim3((unsigned)ceil_div(U * K, 256)), dim3(256), 0, s>>>(logits_dz, dq, topk_idx, pk, db, U, T, K);
   GNGF_RETURN_LAUNCH();

@@ -94,6 +94,122 @@ gemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __r
   }
 }
 
+// 128x128 tile variant for the large HPD GEMMs (logits, dW_last, dh_last): 4 waves as 2x2, each wave a 64x64 sub-tile =
+// 2x2 MFMA accumulators, so every ds_read feeds two MFMAs; operands are staged k-major ([BK][128+4]) with 16-byte global
+// loads along whichever axis is contiguous in memory.
+constexpr int BM2 = 128, BN2 = 128, LDS2 = BM2 + 4;
+
+template <bool TRANS>   // TRANS: element (r, k) lives at src[k*ld + r] (contiguous along r); else src[r*ld + k]
+__device__ __forceinline__ void stage128(float* S, const float* __restrict__ src, const float* __restrict__ mask, int mask_act,
+                                         int64_t r0, int64_t R, int64_t k0, int64_t kend, int64_t ld, int tid) {
+  // 128 x 16 elements = 512 float4; 2 per thread
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int li = tid + e * 256;
+    if (TRANS) {
+      const int kk = li >> 5, rq = (li & 31) * 4;                  // 16 k rows x 32 float4 along r
+      const int64_t gr = r0 + rq, gk = k0 + kk;
+      float4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gk < kend) {
+        const int64_t o = gk * ld + gr;
+        if (gr + 3 < R && ((o & 3) == 0)) {
+          v = *reinterpret_cast<const float4*>(src + o);
+          if (mask) {
+            const float4 mv = *reinterpret_cast<const float4*>(mask + o);
+            v.x *= act_bwd_from_y(mv.x, mask_act); v.y *= act_bwd_from_y(mv.y, mask_act);
+            v.z *= act_bwd_from_y(mv.z, mask_act); v.w *= act_bwd_from_y(mv.w, mask_act);
+          }
+        } else {
+          float t4[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            t4[q] = (gr + q < R) ? src[o + q] : 0.f;
+            if (mask && gr + q < R) t4[q] *= act_bwd_from_y(mask[o + q], mask_act);
+          }
+          v = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        }
+      }
+      *reinterpret_cast<float4*>(S + kk * LDS2 + rq) = v;
+    } else {
+      const int rr = li >> 2, kq = (li & 3) * 4;                   // 128 rows x 4 float4 along k
+      const int64_t gr = r0 + rr, gk = k0 + kq;
+      float t4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (gr < R) {
+        const int64_t o = gr * ld + gk;
+        if (gk + 3 < kend && ((o & 3) == 0)) {
+          const float4 v = *reinterpret_cast<const float4*>(src + o);
+          t4[0] = v.x; t4[1] = v.y; t4[2] = v.z; t4[3] = v.w;
+          if (mask) {
+            const float4 mv = *reinterpret_cast<const float4*>(mask + o);
+            t4[0] *= act_bwd_from_y(mv.x, mask_act); t4[1] *= act_bwd_from_y(mv.y, mask_act);
+            t4[2] *= act_bwd_from_y(mv.z, mask_act); t4[3] *= act_bwd_from_y(mv.w, mask_act);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (gk + q < kend) { t4[q] = src[o + q]; if (mask) t4[q] *= act_bwd_from_y(mask[o + q], mask_act); }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) S[(kq + q) * LDS2 + rr] = t4[q];
+    }
+  }
+}
+
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256)
+gemm128_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+               int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+               const float* __restrict__ bias, int act, const float* __restrict__ amask, int mask_act,
+               int64_t kchunk, int atomic_out) {
+  __shared__ float As[BK * LDS2];
+  __shared__ float Bs[BK * LDS2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.y * BM2, n0 = (int64_t)blockIdx.x * BN2;
+  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = 0;
+  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+    // A(m,k): TA -> contiguous along m.   B(k,n): TB -> B[n*ldb + k] contiguous along k, else contiguous along n.
+    stage128<TA>(As, A, amask, mask_act, m0, M, k0, kend, lda, tid);
+    stage128<!TB>(Bs, B, nullptr, 0, n0, N, k0, kend, ldb, tid);
+    __syncthreads();
+    const float* ap = As + h * LDS2 + wm * 64 + i;
+    const float* bp = Bs + h * LDS2 + wn * 64 + i;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = ap[kk * LDS2], a1 = ap[kk * LDS2 + 32];
+      const float b0 = bp[kk * LDS2], b1 = bp[kk * LDS2 + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int64_t col = n0 + wn * 64 + tn * 32 + i;
+    if (col >= N) continue;
+    const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= M) continue;
+        const float v = acc[tm][tn][r] + bv;
+        if (atomic_out) atomicAdd(C + row * ldc + col, v);
+        else C[row * ldc + col] = act_fwd(v, act);
+      }
+  }
+}
+
 // column sums of dZ = dY * act'(Y):  db[n] = sum_m dZ[m][n].  grid.x = ceil(N/64), grid.y = row slices; atomics.
 __global__ void __launch_bounds__(256)
 colsum_kernel(const float* __restrict__ dY, const float* __restrict__ Ymask, int mask_act, float* __restrict__ db,
@@ -126,6 +242,12 @@ static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int6
     splitk = (int)ceil_div(K, kchunk);
   } else {
     splitk = 1;
+  }
+  if (M >= BM2 && N >= BN2) {          // large problems: 128x128 tiles, 2x2 accumulators per wave
+    dim3 grid2((unsigned)ceil_div(N, BN2), (unsigned)ceil_div(M, BM2), (unsigned)splitk);
+    gemm128_kernel<TA, TB><<<grid2, dim3(256), 0, s>>>(A, B, C, M, N, K, lda, ldb, ldc, bias, act, amask, mask_act, kchunk,
+                                                      (splitk > 1 || force_atomic) ? 1 : 0);
+    return (int)hipGetLastError();
   }
   dim3 grid((unsigned)ceil_div(N, BN), (unsigned)ceil_div(M, BM), (unsigned)splitk);
   gemm_kernel<TA, TB><<<grid, dim3(256), 0, s>>>(A, B, C, M, N, K, lda, ldb, ldc, bias, act, amask, mask_act, kchunk,
@@ -162,7 +284,8 @@ extern "C" int gngf_linear_bwd_weight(const float* dY, const float* Y, const flo
   GNGF_CHECK_ARG(M >= 0 && N > 0 && K > 0 && act >= 0 && act <= 3);
   if (M == 0) return 0;
   GNGF_CHECK_ARG(dY && X && dW && (act == 0 || Y));
-  const int64_t tiles = ceil_div(N, BM) * ceil_div(K, BN);
+  const int tsz = (N >= BM2 && K >= BN2) ? BM2 : BM;
+  const int64_t tiles = ceil_div(N, tsz) * ceil_div(K, tsz);
   int splitk = (int)((1024 + tiles - 1) / tiles);
   const int64_t max_split = ceil_div(M, 256);
   if (splitk > max_split) splitk = (int)max_split;
@@ -185,7 +308,8 @@ extern "C" int gngf_gemm_acc(const float* A, const float* B, float* C, int64_t M
   GNGF_CHECK_ARG(M >= 0 && N >= 0 && Kc >= 0);
   if (M == 0 || N == 0 || Kc == 0) return 0;
   GNGF_CHECK_ARG(A && B && C);
-  const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
+  const int tsz = (M >= BM2 && N >= BN2) ? BM2 : BM;
+  const int64_t tiles = ceil_div(M, tsz) * ceil_div(N, tsz);
   int splitk = (int)ceil_div(1024, tiles);
   const int64_t max_split = ceil_div(Kc, 64);
   if (splitk > max_split) splitk = (int)max_split;

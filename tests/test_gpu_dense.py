@@ -25,7 +25,7 @@ def ops():
 
 
 @pytest.mark.parametrize("M,N,K,act", [(1000, 64, 32, 1), (257, 3, 64, 3), (65, 128, 2, 1), (4096, 300, 128, 0), (1, 1, 1, 2),
-                                        (130, 70, 33, 2)])
+                                        (130, 70, 33, 2), (300, 257, 130, 1), (129, 128, 2, 3)])
 def test_linear_fwd_bwd_vs_numpy(ops, M, N, K, act):
     rng = np.random.default_rng(M + N)
     x = rng.standard_normal((M, K)).astype(np.float32)
@@ -46,10 +46,11 @@ def test_linear_fwd_bwd_vs_numpy(ops, M, N, K, act):
     close(db, dz.sum(0), 1e-4, 1e-5 * scale)
 
 
+@pytest.mark.parametrize("shape", [(16, 700, 5000), (256, 390, 3001), (130, 128, 70)])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-def test_gemm_acc_all_layouts(ops, ta, tb):
+def test_gemm_acc_all_layouts(ops, ta, tb, shape):
     rng = np.random.default_rng(3)
-    M, N, Kc = 16, 700, 5000
+    M, N, Kc = shape
     a = rng.standard_normal((Kc, M) if ta else (M, Kc)).astype(np.float32)
     b = rng.standard_normal((N, Kc) if tb else (Kc, N)).astype(np.float32)
     want = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
