@@ -250,7 +250,10 @@ class GeneralNeuralGaugeFields(nn.Module):
         if self.coord_bounds is not None:
             mx, my = self.coord_bounds
         else:
-            mx, my = x.amax(0).tolist()                                     # one host sync
+            b = x.amax(0)
+            if ops.DP_MAX is not None:
+                ops.DP_MAX(b)                                               # every rank must build the same vertex table
+            mx, my = b.tolist()                                             # one host sync
         gx_hi = int(np.floor(np.float32(mx) * np.float32(self._n_max))) + 1
         gy_hi = int(np.floor(np.float32(my) * np.float32(self._n_max))) + 1
         return gx_hi + 1, (gx_hi + 1) * (gy_hi + 1)

@@ -251,6 +251,8 @@ class HpdVertexFunction(torch.autograd.Function):
             call("gngf_softmax_topk", ptr(z), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), ptr(rowstat[u0:u0 + n]), n, T, K, stream_ptr())
             if pbar is not None:
                 gemm_acc(mw[u0:u0 + n], z, pbar, L, T, n, ta=True, tb=False)
+        if pbar is not None and DP_MEAN is not None:
+            DP_MEAN(pbar)      # the loss is a nonlinear function of the batch mean: average BEFORE the log (SURVEY §8e ii)
         ctx.cfg = (NV, vstride, K, rows, n_layers, T, keep_probs)
         ctx.save_for_backward(ti, mw, probs, rowstat, *params)
         ctx.mark_non_differentiable(ti)
@@ -394,6 +396,8 @@ import math as _math
 ENCODE_PATH = "auto"        # "auto" | "direct" | "tiled"  (tests force a path; auto = tiled when it pays)
 DP_EXCHANGE = None          # data parallel: callable that sum-all-reduces + averages the vertex-grid gradient in place
 DP_TABLES_REDUCED = False   # set when the table gradient of the last backward came out of an exchanged dG
+DP_MEAN = None              # data parallel: callable averaging a tensor over ranks in place (batch-mean distribution p-bar)
+DP_MAX = None               # data parallel: callable max-reducing a small tensor over ranks in place (coordinate bounds)
 TILED_CHUNK = 1024          # max pixels per (tile, chunk) work item
 TILED_MIN_PIXELS = 1 << 14  # below this the binning overhead is not worth it
 TILED_LDS_LIMIT = 48 * 1024    # forward image; the backward image (64-bit accumulators) is twice this

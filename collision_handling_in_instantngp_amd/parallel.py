@@ -29,7 +29,23 @@ def enable_vertex_grid_exchange(world: int, group=None):
     dG -> dE is linear and identical on every rank, so reducing dG first gives the same table gradient with ~11x
     fewer bytes on the xGMI links.  Applies when the tiled form covers every level; otherwise the table buffer is
     all-reduced as before."""
-    ops.DP_EXCHANGE = None if world <= 1 else (lambda t: (all_reduce_sum(t, group), t.mul_(1.0 / world)))
+    if world <= 1:
+        ops.DP_EXCHANGE = ops.DP_MEAN = ops.DP_MAX = None
+        return
+    ops.DP_EXCHANGE = lambda t: (all_reduce_sum(t, group), t.mul_(1.0 / world))
+    # GNGF with a trainable HPD: the KL/JS loss is a nonlinear function of the batch-mean distribution, so p-bar is
+    # averaged over ranks in the forward (exact single-GPU equivalence), and every rank builds its per-vertex table over
+    # the same vertex rectangle (max of the shards' coordinate bounds).
+    ops.DP_MEAN = ops.DP_EXCHANGE
+
+    def _max(t):
+        if dist.get_backend(group) == "nccl" or not t.is_cuda:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        else:
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+            t.copy_(h)
+    ops.DP_MAX = _max
 
 
 def shard_batch(n_items: int, rank: int, world: int):

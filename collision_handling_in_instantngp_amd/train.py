@@ -54,7 +54,10 @@ def get_optimizer(net, encoding_lr, HPD_lr, MLP_lr, encoding_weight_decay, HPD_w
     if not models.should_use_hash_function:
         groups.append({"params": net.HPD.parameters(), "lr": HPD_lr, "weight_decay": HPD_weight_decay})
     groups.append({"params": net.mlp.parameters(), "lr": MLP_lr, "weight_decay": MLP_weight_decay})
-    return torch.optim.Adam(groups, betas=betas, eps=eps)
+    # same update rule as the reference's torch.optim.Adam; the single-kernel ("fused") implementation moves the
+    # 64 MiB of tables + moments in ~0.1 ms per step at cfg2 instead of ~0.3 ms for the per-op default
+    on_gpu = all(p.is_cuda for p in net.parameters())
+    return torch.optim.Adam(groups, betas=betas, eps=eps, **({"fused": True} if on_gpu else {}))
 
 
 def assemble_loss(mse, kls, colls, l_mse, l_js_kl, l_collisions):
