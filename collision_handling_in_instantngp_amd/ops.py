@@ -400,6 +400,7 @@ DP_MEAN = None              # data parallel: callable averaging a tensor over ra
 DP_MAX = None               # data parallel: callable max-reducing a small tensor over ranks in place (coordinate bounds)
 TILED_CHUNK = 1024          # max pixels per (tile, chunk) work item
 TILED_MIN_PIXELS = 1 << 14  # below this the binning overhead is not worth it
+TILED_CELLS_PER_PIXEL = 4.0 # a level is staged while N_l^2 <= this * P (sparser levels: direct form)
 TILED_LDS_LIMIT = 48 * 1024    # forward image; the backward image (64-bit accumulators) is twice this
 
 
@@ -416,7 +417,7 @@ class EncodePlan:
         Ls = 0
         if path != "direct" and (path == "tiled" or P >= TILED_MIN_PIXELS):
             for n in self.n_ls_host:          # resolutions ascend: stage the leading levels that are dense enough
-                dense_enough = n * n <= max(P, 1)          # >= 1 pixel per cell: privatisation pays
+                dense_enough = n * n <= TILED_CELLS_PER_PIXEL * max(P, 1)
                 small_enough = (n + 2) * (n + 2) * F * 4 <= (64 << 20)
                 if dense_enough and small_enough:
                     Ls += 1

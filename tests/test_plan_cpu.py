@@ -33,11 +33,13 @@ def test_plan_cfg2_stages_every_level():
 def test_plan_sparse_fine_levels_go_direct():
     n = [int(v) for v in models.level_resolutions(16, 4096, 16)]
     pl = ops.EncodePlan(2 ** 20, n, 2)
-    assert 0 < pl.Ls < 16 and all(v * v <= 2 ** 20 for v in n[:pl.Ls]) and n[pl.Ls] ** 2 > 2 ** 20
+    c = ops.TILED_CELLS_PER_PIXEL
+    assert 0 < pl.Ls < 16 and all(v * v <= c * 2 ** 20 for v in n[:pl.Ls]) and n[pl.Ls] ** 2 > c * 2 ** 20
 
 
 def test_plan_small_batches_use_direct_form():
     pl = ops.EncodePlan(1000, [8, 12, 20, 32], 2)
     assert pl.Ls == 0
     assert ops.EncodePlan(2000, [8, 12, 20, 32], 2, "tiled").Ls == 4
+    assert ops.EncodePlan(100, [8, 12, 20, 32], 2, "tiled").Ls < 4           # too sparse at the finest level
     assert ops.EncodePlan(2 ** 20, [8, 12, 20, 32], 2, "direct").Ls == 0
