@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(kDecThreads, 1)
 decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, const float* __restrict__ dY,
                    const float* __restrict__ W0, const float* __restrict__ b0, const float* __restrict__ W1,
                    const float* __restrict__ b1, const float* __restrict__ W2, float* __restrict__ dX,
-                   float* __restrict__ slabs, int64_t P, int in_dim, int out_dim, int leaky_i) {
+                   float* __restrict__ slabs, float* __restrict__ absmax, int64_t P, int in_dim, int out_dim, int leaky_i) {
   using FF = FwdFrags<KIN>;
   constexpr int S0 = KIN / 2;
   constexpr int TX = (KIN + 31) / 32;                    // 32-row tiles of the input width
@@ -354,6 +354,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   consume(blockIdx.x);
   __builtin_amdgcn_sched_barrier(0);
   fetch((int64_t)blockIdx.x + gridDim.x < ntiles ? (int64_t)blockIdx.x + gridDim.x : blockIdx.x);
+  float dxmax = 0.f;                                     // largest |d enc| this lane produced (hint for the encoder backward)
 #if defined(GNGF_STAMPS)
   unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
@@ -507,6 +508,8 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
         dxb = MFMA(ft[s2 + 1], d1[(s2 + 1) >> 4][(s2 + 1) & 15], dxb);
       }
       dxv[tx] = dxa + dxb;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float a = fabsf(dxv[tx][r]); dxmax = (a > dxmax || a != a) ? a : dxmax; }   // NaN sticks
     }
     // end of tile: consume tile t+1's rows (their loads were issued a whole tile ago), THEN store, THEN prefetch t+2
     consume(tile + gridDim.x);
@@ -540,6 +543,11 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   if (blockIdx.x == 7 && threadIdx.x == 0)
     for (int k = 0; k < 10; ++k) g_stamps[k] = ph[k];
 #endif
+  if (absmax) {                                          // non-negative floats (and NaN > inf) order like their bit patterns
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float ov = __shfl_xor(dxmax, o, 64); dxmax = (ov > dxmax || ov != ov) ? ov : dxmax; }
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(dxmax));
+  }
   // ---- wave accumulators -> workgroup slab.  No LDS float atomics (ds_add_f32 costs ~190 cycles per wave-instruction
   // on gfx950): every wave stores its tiles into its own LDS region, bias partials are reduced over the 32 pixel lanes
   // with shuffles, then the four regions are summed into ONE plain-store slab per workgroup.
@@ -656,13 +664,17 @@ extern "C" int gngf_decoder_fwd(const float* enc, const float* W0, const float* 
 // slabs: workspace of gngf_decoder_bwd_slabs(P) * gngf_decoder_slab_floats(in_dim, out_dim) floats.
 extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float* drgb, const float* W0, const float* b0,
                                 const float* W1, const float* b1, const float* W2, float* denc, float* dW0, float* db0,
-                                float* dW1, float* db1, float* dW2, float* db2, float* slabs, int64_t P, int in_dim,
-                                int out_dim, int leaky, void* stream) {
+                                float* dW1, float* db1, float* dW2, float* db2, float* slabs, float* denc_absmax, int64_t P,
+                                int in_dim, int out_dim, int leaky, void* stream) {
   GNGF_CHECK_ARG(P >= 0 && in_dim > 0 && in_dim <= 64 && out_dim > 0 && out_dim <= 4);
   GNGF_CHECK_ARG(dW0 && db0 && dW1 && db1 && dW2 && db2 && slabs);
   const int nslab = slab_size(in_dim, out_dim);
   hipStream_t s = as_stream(stream);
   const int nslabs = gngf_decoder_bwd_slabs(P);
+  if (denc_absmax) {
+    hipError_t e = hipMemsetAsync(denc_absmax, 0, sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+  }
   if (P == 0) {
     hipError_t e = hipMemsetAsync(slabs, 0, sizeof(float) * (size_t)nslab, s);
     if (e != hipSuccess) return (int)e;
@@ -674,7 +686,7 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
       decoder_bwd_kernel<kKIN><<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc,
-                                                                                      slabs, P, in_dim, out_dim, leaky);
+                                                                                      slabs, denc_absmax, P, in_dim, out_dim, leaky);
     });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

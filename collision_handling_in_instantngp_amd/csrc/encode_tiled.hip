@@ -333,7 +333,8 @@ template <int F>
 __global__ void __launch_bounds__(kTB)
 tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ items, const int32_t* __restrict__ n_items,
                  const int32_t* __restrict__ n_ls, const float* __restrict__ genc, float* __restrict__ dG,
-                 float* __restrict__ partials, int L, int Ls, int tile_shift, int lds_floats, int log2_chunk) {
+                 float* __restrict__ partials, const float* __restrict__ gmax_hint, int L, int Ls, int tile_shift,
+                 int lds_floats, int log2_chunk) {
   extern __shared__ unsigned long long acc64[];
   __shared__ TileMeta m;
   __shared__ float wmax[kTB / 64];
@@ -348,10 +349,12 @@ tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
   const int ppp = kTB / Ls;
   const int lp = tid / Ls, l = tid - lp * Ls;
   const int LF = L * F;
-  // pass 1: largest |gradient| over the item's pixels (these rows are re-read from L2 in pass 2)
+  // pass 1: largest |gradient| over the item's pixels — skipped when the producer of genc handed over a bound on
+  // max |genc| (the fused decoder backward does): any bound >= the item's own maximum keeps the sums overflow-free.
   float gmax = 0.f;
   constexpr int U = 4;                                     // 4 pixels per lane per trip: loads issued together
-  if (lp < ppp)
+  if (gmax_hint) gmax = *gmax_hint;
+  if (lp < ppp && !gmax_hint)
     for (int j0 = lp; j0 < it.y; j0 += U * ppp) {
       int64_t pp[U];
 #pragma unroll
@@ -671,8 +674,8 @@ extern "C" int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, 
 
 extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
                                      const int32_t* tile_item_base, const int32_t* n_ls, const int32_t* n_ls_host,
-                                     const float* genc, float* dG, float* partials, int L, int Ls, int F, int tile_shift,
-                                     int lds_bytes, int chunk, void* stream) {
+                                     const float* genc, const float* genc_absmax, float* dG, float* partials, int L, int Ls,
+                                     int F, int tile_shift, int lds_bytes, int chunk, void* stream) {
   GNGF_CHECK_ARG(max_items >= 0 && L > 0 && Ls > 0 && Ls <= L && L <= GNGF_MAX_LEVELS && lds_bytes >= 0 && lds_bytes <= 64 * 1024);
   GNGF_CHECK_ARG(chunk > 0 && chunk <= (1 << 20));
   int log2_chunk = 0;
@@ -687,8 +690,8 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
       if (e != hipSuccess) return (int)e;
     }
     tiled_bwd_kernel<kF><<<dim3((unsigned)max_items), dim3(kTB), (size_t)2 * lds_bytes, as_stream(stream)>>>(
-        reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, n_ls, genc, dG, partials, L, Ls,
-        tile_shift, lds_bytes / 4, log2_chunk);
+        reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, n_ls, genc, dG, partials,
+        genc_absmax, L, Ls, tile_shift, lds_bytes / 4, log2_chunk);
     gather_partials_kernel<kF><<<dim3((unsigned)ceil_div((int64_t)side * side, 256), (unsigned)Ls), dim3(256), 0,
                                  as_stream(stream)>>>(partials, tile_item_base, n_ls, dG, Ls, tile_shift, lds_bytes / 4);
   });

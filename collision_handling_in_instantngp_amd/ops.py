@@ -491,11 +491,22 @@ def slot_order(vert_idx, n_ls_host=None, vstride=None):
     return torch.sort(flat, stable=True)[1].to(_i32)
 
 
-def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F):
+# max |d enc| handed from the fused decoder backward to the tiled encoder backward: {data_ptr: (absmax tensor, version)}
+_ABSMAX_HINTS = {}
+
+
+def _take_absmax_hint(genc):
+    h = _ABSMAX_HINTS.pop(genc.data_ptr(), None)
+    if len(_ABSMAX_HINTS) > 8:
+        _ABSMAX_HINTS.clear()
+    return h[0] if (h is not None and h[1] == genc._version) else None     # any in-place edit since invalidates the bound
+
+
+def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None):
     partials = torch.empty((plan.max_items * (plan.lds_bytes // 4),), dtype=_f32, device=genc.device)
     call("gngf_encode_tiled_bwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(ws.tile_item_base),
-         ptr(n_ls), plan.n_ls_c, ptr(genc, _f32, "grad"), ptr(dG), ptr(partials), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes,
-         plan.chunk, stream_ptr())
+         ptr(n_ls), plan.n_ls_c, ptr(genc, _f32, "grad"), ptr(absmax), ptr(dG), ptr(partials), L, plan.Ls, F, plan.tile_shift,
+         plan.lds_bytes, plan.chunk, stream_ptr())
 
 
 def _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw, order=None):
@@ -546,11 +557,12 @@ class EncodeFunction(torch.autograd.Function):
         xy, n_ls, tables, vert_idx, vert_w, order = ctx.saved_tensors
         P, L, F, T, K, mode, vstride, NV, plan, ws = ctx.cfg
         genc = _c(genc)
+        absmax = _take_absmax_hint(genc)
         dtables = torch.zeros_like(tables)
         dvw = torch.zeros_like(vert_w) if (vert_w is not None and ctx.needs_input_grad[5]) else None
         if plan.Ls > 0 and P > 0:
             dG = torch.zeros((plan.vtot, F), dtype=_f32, device=tables.device)
-            _pixel_bwd(plan, ws, n_ls, genc, dG, L, F)
+            _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax)
             if DP_EXCHANGE is not None and plan.Ls == L:
                 DP_EXCHANGE(dG)                     # one small all-reduce instead of the (L,T,F) table gradient
                 globals()["DP_TABLES_REDUCED"] = True
@@ -605,8 +617,10 @@ class DecoderFunction(torch.autograd.Function):
         grads = [torch.empty_like(w) for w in (W0, b0, W1, b1, W2, b2)]
         slabs = torch.empty((_lib.query("gngf_decoder_bwd_slabs", P) * _lib.query("gngf_decoder_slab_floats", in_dim, out_dim),),
                             dtype=_f32, device=dev)
+        absmax = torch.empty((1,), dtype=_f32, device=dev)
         call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb, _f32, "grad"), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2),
-             ptr(denc), *[ptr(g) for g in grads], ptr(slabs), P, in_dim, out_dim, leaky, stream_ptr())
+             ptr(denc), *[ptr(g) for g in grads], ptr(slabs), ptr(absmax), P, in_dim, out_dim, leaky, stream_ptr())
+        _ABSMAX_HINTS[denc.data_ptr()] = (absmax, denc._version)
         return (denc, None, *grads)
 
 
@@ -680,7 +694,7 @@ def decoder_kernels(enc, params, leaky, drgb):
 
     def bwd():
         call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(denc),
-             *[ptr(g) for g in grads], ptr(slabs), P, in_dim, out_dim, int(leaky), stream_ptr())
+             *[ptr(g) for g in grads], ptr(slabs), ptr(None), P, in_dim, out_dim, int(leaky), stream_ptr())
 
     fwd()
     return {"decoder_fwd": fwd, "decoder_bwd": bwd}

@@ -94,14 +94,16 @@ int gngf_vertex_grid_bwd(const float* tables, const int32_t* vert_idx, const flo
  * bwd ACCUMULATES into dG (caller zero-fills) in two passes with no global float atomics: every work item stores its
  * privatised sub-grid image to partials (max_items * lds_bytes/4 floats), then a gather pass sums, per vertex, the
  * images of the items that cover it.  Inside a work item the sub-grids accumulate in 64-bit fixed point (LDS float
- * atomics are ~20x slower than 64-bit integer ones on gfx950); `chunk` = the binning chunk (bounds the term count). */
+ * atomics are ~20x slower than 64-bit integer ones on gfx950); `chunk` = the binning chunk (bounds the term count).
+ * genc_absmax (1 float, optional): a bound >= max |genc| that fixes the fixed-point scale; NULL: each work item scans its
+ * own rows first. */
 int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
                           const int32_t* n_ls, const float* G, float* enc, int L, int Ls, int F, int tile_shift, int lds_bytes,
                           void* stream);
 int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
                           const int32_t* tile_item_base, const int32_t* n_ls, const int32_t* n_ls_host, const float* genc,
-                          float* dG, float* partials, int L, int Ls, int F, int tile_shift, int lds_bytes, int chunk,
-                          void* stream);
+                          const float* genc_absmax, float* dG, float* partials, int L, int Ls, int F, int tile_shift,
+                          int lds_bytes, int chunk, void* stream);
 /* vertex stage backward for the vertex-table source in SLOT order (order (NV*K) int32 = argsort of vert_idx, flat):
  * contention-free for any slot distribution (wave-level segmented reduction, one atomic per (wave, slot run));
  * dtables accumulated, dvert_w (NV,K) written without atomics (NULL when not needed). */
@@ -126,10 +128,12 @@ int gngf_gemm_acc(const float* A, const float* B, float* C, int64_t M, int64_t N
 int gngf_decoder_fwd(const float* enc, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
                      const float* b2, float* rgb, int64_t P, int in_dim, int out_dim, int leaky, void* stream);
 /* backward: denc (P,in_dim) and the six parameter gradients, each WRITTEN (not accumulated); rgb = the forward output.
- * slabs: workspace of gngf_decoder_bwd_slabs(P) * gngf_decoder_slab_floats(in_dim, out_dim) floats. */
+ * slabs: workspace of gngf_decoder_bwd_slabs(P) * gngf_decoder_slab_floats(in_dim, out_dim) floats.
+ * denc_absmax (1 float, optional): receives max |denc| (NaN if any element is NaN) — a bound the tiled encoder backward
+ * can take instead of scanning its input once more. */
 int gngf_decoder_bwd(const float* enc, const float* rgb, const float* drgb, const float* W0, const float* b0, const float* W1,
                      const float* b1, const float* W2, float* denc, float* dW0, float* db0, float* dW1, float* db1, float* dW2,
-                     float* db2, float* slabs, int64_t P, int in_dim, int out_dim, int leaky, void* stream);
+                     float* db2, float* slabs, float* denc_absmax, int64_t P, int in_dim, int out_dim, int leaky, void* stream);
 int gngf_decoder_bwd_slabs(int64_t P);
 int gngf_decoder_slab_floats(int in_dim, int out_dim);
 
