@@ -288,7 +288,7 @@ class GeneralNeuralGaugeFields(nn.Module):
             enc = ops.encode_apply(x, n_ls, self._n_ls_host, tables, None, None, 0)
             rgb = self._decode(enc)
             idx = ops.hash_indices(x.detach(), n_ls, T) if (self.return_indices or should_calc_counts) else None
-            counts = self._calc_counts_per_level(idx, x, n_ls) if should_calc_counts else []
+            counts = self._calc_counts_per_level(idx, x.detach(), n_ls) if should_calc_counts else []
             return rgb, None, idx, counts
 
         keep_topk = self._should_keep_topk_only
@@ -323,20 +323,28 @@ class GeneralNeuralGaugeFields(nn.Module):
             to_return_probs = probs_u[vid]                                  # (P,L,4,T), differentiable gather
         else:
             to_return_probs = VertexDistribution((P, L, 4, T), pbar, tv)
-        counts = self._calc_counts_per_level(idx64[..., 0], x, n_ls) if should_calc_counts else []
+        counts = self._calc_counts_per_level(idx64[..., 0], x.detach(), n_ls) if should_calc_counts else []
         return rgb, to_return_probs, idx64, counts
 
     # ------------------------------------------------------------------ diagnostics (no-grad statistics, not kernels)
     @torch.no_grad()
     def _calc_counts_per_level(self, hash_idx, x, n_ls):
-        """reference models.py:530-566: per level, Counter of the slot of the first corner... of the DISTINCT cells."""
+        """reference models.py:530-566, restated literally (a no-grad statistic with numpy round trips in the reference
+        too): per level, the pixels with distinct corner sets are found with np.unique(axis=0, return_index=True) and a
+        Counter is taken of `rearrange(hash, "p l v -> l (p v)")[level][unique_indices]` — including the reference's
+        indexing of the flattened (p v) axis with PIXEL indices."""
         from collections import Counter
-        vid, _, _ = ops.expand_vertex_table(x, n_ls, self._n_max + 2, (self._n_max + 2) ** 2, want_vid=True)
+        L = self._num_levels
+        P = x.shape[0]
+        scaled = x[:, :, None] * n_ls.to(torch.float32)[None, None, :]                       # (P,2,L)  models.py:492-495
+        cube = self._voxels_helper_hypercube.to(x.device).to(torch.float32).reshape(1, 2, 1, 4)
+        grid = torch.floor(scaled)[..., None] + cube                                           # (P,2,L,4)
+        rearranged = grid.permute(2, 0, 3, 1).reshape(L, P, 8).cpu().numpy()                   # "p xy l v -> l p (v xy)"
+        per_level = hash_idx.permute(1, 0, 2).reshape(L, P * 4).cpu().numpy()
         out = []
-        for l in range(self._num_levels):
-            cells = vid[:, l, :].cpu().numpy()
-            _, first = np.unique(cells, axis=0, return_index=True)
-            out.append(dict(Counter(hash_idx[:, l].reshape(hash_idx.shape[0], -1)[first].reshape(-1).cpu().numpy().tolist())))
+        for l in range(L):
+            _, first = np.unique(rearranged[l], axis=0, return_index=True)
+            out.append(dict(Counter(per_level[l][first].tolist())))
         return out
 
     @torch.no_grad()

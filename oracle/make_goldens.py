@@ -316,7 +316,32 @@ def g8(F_, U_, M, P_):
     save("G8_train_curve", **rec)
 
 
-GROUPS = {"G1": g1, "G2": g2_g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
+def g10(F_, U_, M, P_):
+    """Diagnostics contract: counts_per_level (models.py:530-566) and calc_hash_collisions (models.py:568-619)."""
+    mods = (F_, U_, M)
+    img, X, Y, h, w = load_strawberry()
+    torch.manual_seed(SEED)
+    sl = torch.randperm(h * w)[:4096]
+    out = {"sel": sl.numpy().astype(np.int64)}
+    for mode in ("hash", "gngf"):
+        net = make_net(M, mods, hash_mode=(mode == "hash"), T=256, L=4, n_min=8, n_max=32, K=4)
+        if mode == "gngf":
+            for k_, v_ in net.state_dict().items():
+                if k_.startswith("HPD."):
+                    out["gngf_init_" + k_.replace(".", "_")] = np32(v_)
+        rgb, probs, idx, counts = net(X[sl], 1 / 3, should_calc_counts=True)
+        for l, c in enumerate(counts):
+            ks = np.array(sorted(c.keys()), dtype=np.int64)
+            out[f"{mode}_counts_keys_{l}"] = ks
+            out[f"{mode}_counts_vals_{l}"] = np.array([c[k] for k in ks], dtype=np.int64)
+        coll, minc = net.calc_hash_collisions(idx)
+        out[f"{mode}_collisions"] = np32(coll)
+        out[f"{mode}_min_collisions"] = np32(minc)
+        out[f"{mode}_idx"] = np32(idx)
+    save("G10_diagnostics", **out)
+
+
+GROUPS = {"G10": g10, "G1": g1, "G2": g2_g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -143,3 +143,64 @@ def test_training_curve_matches_reference_three_epochs(golden):
             psnr = train.calc_psnr(show, img)
             assert abs(psnr - float(g["psnr"][e])) < 0.01, (e, psnr, float(g["psnr"][e]))
         np.testing.assert_allclose(mse, float(g["mse"][e]), rtol=2e-3)
+
+
+@pytest.mark.parametrize("mode", ["hash", "gngf"])
+def test_diagnostics_contract_matches_reference(golden, mode):
+    """forward(..., should_calc_counts=True) -> counts_per_level, and calc_hash_collisions (reference models.py:530-619)."""
+    from collision_handling_in_instantngp_amd import models
+    g = golden("G10_diagnostics")
+    models.should_use_hash_function = (mode == "hash")
+    try:
+        net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=256, num_levels=4, n_min=8, n_max=32,
+                                              MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
+                                              HPD_out_features=256, feature_dim=2, topk_k=4)
+        if mode == "gngf":
+            sd = net.state_dict()
+            for k in list(sd):
+                gk = "gngf_init_" + k.replace(".", "_")
+                if gk in g:
+                    sd[k] = t(g[gk])
+            net.load_state_dict(sd)
+        X, Y, h, w = strawberry(golden)
+        sel = t(g["sel"])
+        rgb, probs, idx, counts = net(X[sel], 1 / 3, should_calc_counts=True)
+        ref_idx = g[f"{mode}_idx"]
+        if mode == "hash":
+            assert np.array_equal(idx.cpu().numpy(), ref_idx)
+        same = np.array_equal(idx.cpu().numpy(), ref_idx)
+        assert len(counts) == 4
+        if same:                      # identical indices (always in hash mode; in GNGF mode unless a top-K tie resolved differently)
+            for l, c in enumerate(counts):
+                ks = np.array(sorted(c.keys()), dtype=np.int64)
+                assert np.array_equal(ks, g[f"{mode}_counts_keys_{l}"])
+                assert np.array_equal(np.array([c[k] for k in ks]), g[f"{mode}_counts_vals_{l}"])
+        coll, minc = net.calc_hash_collisions(t(ref_idx))
+        np.testing.assert_allclose(coll.cpu().numpy().astype(np.float64), g[f"{mode}_collisions"].astype(np.float64))
+        np.testing.assert_allclose(minc.cpu().numpy().astype(np.float64), g[f"{mode}_min_collisions"].astype(np.float64))
+    finally:
+        models.should_use_hash_function = False
+
+
+def test_keep_topk_only_bw_and_leaky_variants_run_and_differentiate(golden):
+    """constructor switches of the reference: should_keep_topk_only (probs = (P,L,4,K)), should_bw (1 output), LeakyReLU."""
+    from collision_handling_in_instantngp_amd import models, train
+    X, Y, h, w = strawberry(golden)
+    models.should_leaky_relu = True
+    try:
+        net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=512, num_levels=5, n_min=8, n_max=64,
+                                              MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
+                                              HPD_out_features=512, feature_dim=4, topk_k=3, should_keep_topk_only=True, should_bw=True)
+        rgb, probs, idx, counts = net(X[:3000], 1.0)
+        assert rgb.shape == (3000, 1) and probs.shape == (3000, 5, 4, 3) and idx.shape == (3000, 5, 4, 3)
+        loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
+        empty = torch.tensor([], device=DEV)
+        mse, kls, coll = loss_fn(rgb, Y[:3000, :1], probs.shape[-1], probs, empty, empty)
+        train.assemble_loss(mse, kls, coll, 1, 1, 1e-3).backward()
+        for k, p in net.named_parameters():
+            if k.startswith("_batch_norm"):        # unused unless should_batchnorm_data (as in the reference)
+                continue
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        assert float(net.HPD.module_list[3][0].weight.grad.abs().sum()) > 0
+    finally:
+        models.should_leaky_relu = False
