@@ -250,7 +250,7 @@ class GeneralNeuralGaugeFields(nn.Module):
         if self.coord_bounds is not None:
             mx, my = self.coord_bounds
         else:
-            b = x.amax(0)
+            b = x.amax(0) if x.shape[0] > 0 else torch.zeros((2,), dtype=x.dtype, device=x.device)   # empty batch
             if ops.DP_MAX is not None:
                 ops.DP_MAX(b)                                               # every rank must build the same vertex table
             mx, my = b.tolist()                                             # one host sync

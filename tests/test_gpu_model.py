@@ -204,3 +204,27 @@ def test_keep_topk_only_bw_and_leaky_variants_run_and_differentiate(golden):
         assert float(net.HPD.module_list[3][0].weight.grad.abs().sum()) > 0
     finally:
         models.should_leaky_relu = False
+
+
+@pytest.mark.parametrize("mode", ["hash", "gngf"])
+def test_edge_batches_empty_single_and_noncontiguous(golden, mode):
+    """empty batch, one pixel, a non-contiguous coordinate view and coordinates that require grad (the reference's
+    `rearranged_grid_coords.requires_grad_()` leaves coordinates without a gradient: _scale_to_grid is no_grad)."""
+    net, g, models, train = build(golden, mode)
+    try:
+        X, Y, h, w = strawberry(golden)
+        rgb, probs, idx, counts = net(X[:0], 1.0)
+        assert rgb.shape == (0, 3) and counts == []
+        rgb1, *_ = net(X[5:6], 1.0)
+        big = torch.stack([X[:1000, 0], torch.zeros(1000, device=DEV), X[:1000, 1]], 1)
+        view = big[:, ::2]                                      # stride-2 view of the coordinates
+        assert not view.is_contiguous()
+        xg = X[:1000].clone().requires_grad_()
+        a, *_ = net(view, 1.0)
+        b, *_ = net(xg, 1.0)
+        assert torch.equal(a, b)
+        assert torch.allclose(a[5], rgb1[0], rtol=0, atol=1e-7)
+        b.sum().backward()
+        assert xg.grad is None
+    finally:
+        models.should_use_hash_function = False
