@@ -27,8 +27,8 @@ __device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2
 // k index (feature of a 64-wide activation held as two accumulator tiles) consumed at chained k-step s2 by lane half h
 __device__ __forceinline__ int kmapC(int s2, int h) { return 32 * (s2 >> 4) + crow(s2 & 15, h); }
 
-__device__ __forceinline__ float hidden_act(float z, bool leaky) { return z > 0.f ? z : (leaky ? 0.01f * z : 0.f); }
-__device__ __forceinline__ float hidden_dact(float y, bool leaky) { return y > 0.f ? 1.f : (leaky ? 0.01f : 0.f); }
+template <bool LEAKY> __device__ __forceinline__ float hidden_act(float z) { return LEAKY ? (z > 0.f ? z : 0.01f * z) : fmaxf(z, 0.f); }
+template <bool LEAKY> __device__ __forceinline__ float hidden_dact(float y) { return y > 0.f ? 1.f : (LEAKY ? 0.01f : 0.f); }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -100,9 +100,9 @@ __device__ __forceinline__ void load_x(const float* __restrict__ X, int64_t pix,
 }
 
 // Layers 1 and 2 for one 32-pixel tile of this wave: acc1 = h1^T, acc2 = h2^T (both activated).
-template <int KIN>
+template <int KIN, bool LEAKY>
 __device__ __forceinline__ void hidden_layers(const float* A0, const float* A1, const float* b0s, const float* b1s,
-                                              const float* xr, int lane, int h, bool leaky, f32x16 (&acc1)[2], f32x16 (&acc2)[2]) {
+                                              const float* xr, int lane, int h, f32x16 (&acc1)[2], f32x16 (&acc2)[2]) {
   constexpr int S0 = KIN / 2;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -127,7 +127,7 @@ __device__ __forceinline__ void hidden_layers(const float* A0, const float* A1, 
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[t][r] = hidden_act(acc1[t][r], leaky);
+    for (int r = 0; r < 16; ++r) acc1[t][r] = hidden_act<LEAKY>(acc1[t][r]);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int s2 = 0; s2 < 32; ++s2) {
@@ -138,7 +138,7 @@ __device__ __forceinline__ void hidden_layers(const float* A0, const float* A1, 
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[t][r] = hidden_act(acc2[t][r], leaky);
+    for (int r = 0; r < 16; ++r) acc2[t][r] = hidden_act<LEAKY>(acc2[t][r]);
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -149,13 +149,12 @@ __device__ __forceinline__ void hidden_layers(const float* A0, const float* A1, 
 // lane halves hold different features of the same pixel and are combined with one cross-half shuffle).
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-template <int KIN>
+template <int KIN, bool LEAKY>
 __global__ void __launch_bounds__(kDecThreads, 1)
 decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, const float* __restrict__ b0,
                    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
-                   const float* __restrict__ b2, float* __restrict__ Y, int64_t P, int in_dim, int out_dim, int leaky_i) {
+                   const float* __restrict__ b2, float* __restrict__ Y, int64_t P, int in_dim, int out_dim) {
   constexpr int S0 = KIN / 2;
-  const bool leaky = leaky_i != 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
   const int64_t ntiles = (P + 127) / 128;
   // register-resident operands, gathered from a coalesced LDS copy of the raw weights
@@ -220,7 +219,7 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[t][r] = hidden_act(acc1[t][r], leaky);
+      for (int r = 0; r < 16; ++r) acc1[t][r] = hidden_act<LEAKY>(acc1[t][r]);
     acc2[0] = MFMA(a1r[0][0], acc1[0][0], b1v[0]);
     acc2[1] = MFMA(a1r[1][0], acc1[0][0], b1v[1]);
 #pragma unroll
@@ -232,7 +231,7 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
     f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s2 = 0; s2 < 32; ++s2)
-      d = __builtin_amdgcn_mfma_f32_4x4x1f32(w2a[s2], hidden_act(acc2[s2 >> 4][s2 & 15], leaky), d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_4x4x1f32(w2a[s2], hidden_act<LEAKY>(acc2[s2 >> 4][s2 & 15]), d, 0, 0, 0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float z = d[c] + __shfl_xor(d[c], 32, 64) + b2v[c];
@@ -262,12 +261,12 @@ __device__ unsigned long long g_stamps[16];
 constexpr int kImgStride = 34;   // 8-byte aligned rows: ds_read_b64 of two consecutive pixels, conflict-free (34*i mod 64)
 constexpr int kImgFloats = 64 * kImgStride;
 
-template <int KIN>
+template <int KIN, bool LEAKY>
 __global__ void __launch_bounds__(kDecThreads, 1)
 decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, const float* __restrict__ dY,
                    const float* __restrict__ W0, const float* __restrict__ b0, const float* __restrict__ W1,
                    const float* __restrict__ b1, const float* __restrict__ W2, float* __restrict__ dX,
-                   float* __restrict__ slabs, float* __restrict__ absmax, int64_t P, int in_dim, int out_dim, int leaky_i) {
+                   float* __restrict__ slabs, float* __restrict__ absmax, int64_t P, int in_dim, int out_dim) {
   using FF = FwdFrags<KIN>;
   constexpr int S0 = KIN / 2;
   constexpr int TX = (KIN + 31) / 32;                    // 32-row tiles of the input width
@@ -279,7 +278,6 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   float* A0T = A1T + 2 * 32 * 64;                        // [t(TX)][s2(32)][64]: W0[kmapC(s2,h)][32t+i]
   float* bs = A0T + TX * 32 * 64;                        // b0 | b1
   float* img = bs + 2 * kH;                              // per wave: imgA [64][33], imgB [64][33]
-  const bool leaky = leaky_i != 0;
   const int nslab = slab_size(in_dim, out_dim);
 
   float* raw = img;                                      // the image area is free until the main loop starts
@@ -364,7 +362,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     const bool valid = pix < P;
     STAMP(0);
     f32x16 acc1[2], acc2[2];
-    hidden_layers<KIN>(A0, A1, bs, bs + kH, xr, lane, h, leaky, acc1, acc2);
+    hidden_layers<KIN, LEAKY>(A0, A1, bs, bs + kH, xr, lane, h, acc1, acc2);
     STAMP(1);
 
     // ---- dW2 += dz3^T h2 : images  dz3T -> imgA rows 0..3,  h2T -> imgB
@@ -408,7 +406,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { d2[t][r] *= hidden_dact(acc2[t][r], leaky); db1acc[t][r] += d2[t][r]; }
+      for (int r = 0; r < 16; ++r) { d2[t][r] *= hidden_dact<LEAKY>(acc2[t][r]); db1acc[t][r] += d2[t][r]; }
     STAMP(3);
     // ---- dW1 += dz2^T h1 : dz2T -> imgA, h1T -> imgB
 #pragma unroll
@@ -459,7 +457,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { d1[t][r] *= hidden_dact(acc1[t][r], leaky); db0acc[t][r] += d1[t][r]; }
+      for (int r = 0; r < 16; ++r) { d1[t][r] *= hidden_dact<LEAKY>(acc1[t][r]); db0acc[t][r] += d1[t][r]; }
     STAMP(5);
     // ---- dW0 += dz1^T x : dz1T -> imgA, xT -> imgB (rows = input features)
 #pragma unroll
@@ -655,8 +653,10 @@ extern "C" int gngf_decoder_fwd(const float* enc, const float* W0, const float* 
   const int64_t tiles = (P + 127) / 128;
   const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);       // one persistent workgroup per CU
   const size_t smem = sizeof(float) * (size_t)raw_offsets(in_dim).total;
-  DISPATCH_KIN(in_dim, (decoder_fwd_kernel<kKIN><<<dim3(grid), dim3(kDecThreads), smem, as_stream(stream)>>>(
-                           enc, W0, b0, W1, b1, W2, b2, rgb, P, in_dim, out_dim, leaky)));
+  DISPATCH_KIN(in_dim, {
+    if (leaky) decoder_fwd_kernel<kKIN, true><<<dim3(grid), dim3(kDecThreads), smem, as_stream(stream)>>>(enc, W0, b0, W1, b1, W2, b2, rgb, P, in_dim, out_dim);
+    else decoder_fwd_kernel<kKIN, false><<<dim3(grid), dim3(kDecThreads), smem, as_stream(stream)>>>(enc, W0, b0, W1, b1, W2, b2, rgb, P, in_dim, out_dim);
+  });
   GNGF_RETURN_LAUNCH();
 }
 
@@ -682,11 +682,12 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
     GNGF_CHECK_ARG(enc && rgb && drgb && W0 && b0 && W1 && b1 && W2 && denc);
     DISPATCH_KIN(in_dim, {
       const size_t smem = bwd_smem_bytes<kKIN>(in_dim, out_dim);
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_kernel<kKIN>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      const void* fn = leaky ? reinterpret_cast<const void*>(decoder_bwd_kernel<kKIN, true>)
+                             : reinterpret_cast<const void*>(decoder_bwd_kernel<kKIN, false>);
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
-      decoder_bwd_kernel<kKIN><<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc,
-                                                                                      slabs, denc_absmax, P, in_dim, out_dim, leaky);
+      if (leaky) decoder_bwd_kernel<kKIN, true><<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, denc_absmax, P, in_dim, out_dim);
+      else decoder_bwd_kernel<kKIN, false><<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, denc_absmax, P, in_dim, out_dim);
     });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
