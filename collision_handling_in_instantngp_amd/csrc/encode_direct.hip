@@ -228,45 +228,46 @@ encode_fwd_kernel(const float2* __restrict__ xy, const float* __restrict__ table
     enc[(p * L + l) * F + f] = ((feat[0][f] * cell.c[0] + feat[1][f] * cell.c[1]) + feat[2][f] * cell.c[2]) + feat[3][f] * cell.c[3];
 }
 
+// Backward, direct form.  One lane per (pixel, level, FEATURE), feature fastest: the F lanes of a corner add to F
+// consecutive floats of one table row, so one wave-instruction's atomics fall into 64/F rows instead of 64 — the
+// memory-side atomic unit works in 64-byte requests and merges the lanes of a row (F = 4: 4x fewer requests).
 template <int F, bool VT>
 __global__ void __launch_bounds__(kBlock)
 encode_bwd_kernel(const float2* __restrict__ xy, const float* __restrict__ tables,
                   const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
                   const int32_t* __restrict__ n_ls, const float* __restrict__ genc,
                   float* __restrict__ dtables, float* __restrict__ dvert_w,
-                  int64_t total, int L, int l0, int nl, int64_t T, int K, int vstride, int64_t NV, bool pow2) {
+                  int64_t total /* P*nl*F */, int L, int l0, int nl, int64_t T, int K, int vstride, int64_t NV, bool pow2) {
   const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (gid >= total) return;
-  const int64_t p = gid / nl;
-  const int l = l0 + (int)(gid - p * nl);
+  const int f = (int)(gid % F);
+  const int64_t pl = gid / F;
+  const int64_t p = pl / nl;
+  const int l = l0 + (int)(pl - p * nl);
   const float2 c = xy[p];
   const Cell cell = make_cell(c.x, c.y, n_ls[l]);
   const float* tab = tables + (int64_t)l * T * F;
   float* dtab = dtables + (int64_t)l * T * F;
-  float g[F];
-#pragma unroll
-  for (int f = 0; f < F; ++f) g[f] = genc[(p * L + l) * F + f];
+  const float g = genc[(p * L + l) * F + f];
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int gx = cell.gx + (v & 1), gy = cell.gy + (v >> 1);
     const float cv = cell.c[v];
     if constexpr (!VT) {
-      float* r = dtab + spatial_hash(gx, gy, T, pow2) * F;
-#pragma unroll
-      for (int f = 0; f < F; ++f) atomicAdd(r + f, g[f] * cv);
+      atomicAdd(dtab + spatial_hash(gx, gy, T, pow2) * F + f, g * cv);
     } else {
       int64_t vid = (int64_t)gy * vstride + gx;
       vid = vid < 0 ? 0 : (vid >= NV ? NV - 1 : vid);
       for (int k = 0; k < K; ++k) {
         const float w = vert_w[vid * K + k];
         const int64_t row = vert_idx[vid * K + k];
-        float dot = 0.f;
+        atomicAdd(dtab + row * F + f, (g * cv) * w);
+        if (dvert_w) {                       // <g, E_l[row]> over the F feature lanes of this corner (adjacent lanes)
+          float dot = g * tab[row * F + f];
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
-          dot += g[f] * tab[row * F + f];
-          atomicAdd(dtab + row * F + f, (g[f] * cv) * w);
+          for (int o = 1; o < F; o <<= 1) dot += __shfl_xor(dot, o, 64);
+          if (f == 0) atomicAdd(dvert_w + vid * K + k, dot * cv);
         }
-        if (dvert_w) atomicAdd(dvert_w + vid * K + k, dot * cv);
       }
     }
   }
@@ -376,7 +377,7 @@ extern "C" int gngf_encode_bwd(const float* xy, const float* tables, const int32
   if (P == 0 || l0 == l1) return 0;
   GNGF_CHECK_ARG(xy && tables && n_ls && genc && dtables);
   const int nl = l1 - l0;
-  const int64_t total = P * nl;
+  const int64_t total = P * nl * F;                       // one lane per (pixel, level, feature)
   const dim3 grid((unsigned)ceil_div(total, kBlock)), block(kBlock);
   const bool pow2 = (T & (T - 1)) == 0;
   if (mode == GNGF_MODE_HASH) {
