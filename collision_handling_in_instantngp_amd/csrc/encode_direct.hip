@@ -189,9 +189,9 @@ bilinear_bwd_kernel(const float2* __restrict__ xy, const int32_t* __restrict__ n
 // ------------------------------------------------------------------------------------------------
 // Fused direct encoder: coords -> (P, L*F).  One lane per (pixel, level): the L lanes of a pixel write one
 // contiguous L*F*4-byte row (128 B at L=16, F=2).
-template <int F, bool VT>
+template <int F, bool VT, typename TT>
 __global__ void __launch_bounds__(kBlock)
-encode_fwd_kernel(const float2* __restrict__ xy, const float* __restrict__ tables,
+encode_fwd_kernel(const float2* __restrict__ xy, const TT* __restrict__ tables,
                   const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
                   const int32_t* __restrict__ n_ls, float* __restrict__ enc,
                   int64_t total, int L, int l0, int nl, int64_t T, int K, int vstride, int64_t NV, bool pow2) {
@@ -201,15 +201,15 @@ encode_fwd_kernel(const float2* __restrict__ xy, const float* __restrict__ table
   const int l = l0 + (int)(gid - p * nl);
   const float2 c = xy[p];
   const Cell cell = make_cell(c.x, c.y, n_ls[l]);
-  const float* tab = tables + (int64_t)l * T * F;
+  const TT* tab = tables + (int64_t)l * T * F;
   float feat[4][F];
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int gx = cell.gx + (v & 1), gy = cell.gy + (v >> 1);
     if constexpr (!VT) {
-      const float* r = tab + spatial_hash(gx, gy, T, pow2) * F;
+      const TT* r = tab + spatial_hash(gx, gy, T, pow2) * F;
 #pragma unroll
-      for (int f = 0; f < F; ++f) feat[v][f] = r[f];
+      for (int f = 0; f < F; ++f) feat[v][f] = tload(r + f);
     } else {
       int64_t vid = (int64_t)gy * vstride + gx;
       vid = vid < 0 ? 0 : (vid >= NV ? NV - 1 : vid);   // never fault on out-of-domain coordinates
@@ -217,9 +217,9 @@ encode_fwd_kernel(const float2* __restrict__ xy, const float* __restrict__ table
       for (int f = 0; f < F; ++f) feat[v][f] = 0.f;
       for (int k = 0; k < K; ++k) {
         const float w = vert_w[vid * K + k];
-        const float* r = tab + (int64_t)vert_idx[vid * K + k] * F;
+        const TT* r = tab + (int64_t)vert_idx[vid * K + k] * F;
 #pragma unroll
-        for (int f = 0; f < F; ++f) feat[v][f] += r[f] * w;
+        for (int f = 0; f < F; ++f) feat[v][f] += tload(r + f) * w;
       }
     }
   }
@@ -231,9 +231,9 @@ encode_fwd_kernel(const float2* __restrict__ xy, const float* __restrict__ table
 // Backward, direct form.  One lane per (pixel, level, FEATURE), feature fastest: the F lanes of a corner add to F
 // consecutive floats of one table row, so one wave-instruction's atomics fall into 64/F rows instead of 64 — the
 // memory-side atomic unit works in 64-byte requests and merges the lanes of a row (F = 4: 4x fewer requests).
-template <int F, bool VT>
+template <int F, bool VT, typename TT>
 __global__ void __launch_bounds__(kBlock)
-encode_bwd_kernel(const float2* __restrict__ xy, const float* __restrict__ tables,
+encode_bwd_kernel(const float2* __restrict__ xy, const TT* __restrict__ tables,
                   const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
                   const int32_t* __restrict__ n_ls, const float* __restrict__ genc,
                   float* __restrict__ dtables, float* __restrict__ dvert_w,
@@ -246,7 +246,7 @@ encode_bwd_kernel(const float2* __restrict__ xy, const float* __restrict__ table
   const int l = l0 + (int)(pl - p * nl);
   const float2 c = xy[p];
   const Cell cell = make_cell(c.x, c.y, n_ls[l]);
-  const float* tab = tables + (int64_t)l * T * F;
+  const TT* tab = tables + (int64_t)l * T * F;
   float* dtab = dtables + (int64_t)l * T * F;
   const float g = genc[(p * L + l) * F + f];
 #pragma unroll
@@ -263,7 +263,7 @@ encode_bwd_kernel(const float2* __restrict__ xy, const float* __restrict__ table
         const int64_t row = vert_idx[vid * K + k];
         atomicAdd(dtab + row * F + f, (g * cv) * w);
         if (dvert_w) {                       // <g, E_l[row]> over the F feature lanes of this corner (adjacent lanes)
-          float dot = g * tab[row * F + f];
+          float dot = g * tload(tab + row * F + f);
 #pragma unroll
           for (int o = 1; o < F; o <<= 1) dot += __shfl_xor(dot, o, 64);
           if (f == 0) atomicAdd(dvert_w + vid * K + k, dot * cv);
@@ -346,49 +346,56 @@ extern "C" int gngf_bilinear_bwd(const float* xy, const int32_t* n_ls, const flo
   GNGF_RETURN_LAUNCH();
 }
 
-extern "C" int gngf_encode_fwd(const float* xy, const float* tables, const int32_t* vert_idx, const float* vert_w,
+#define DISPATCH_TT(dt, ...)                                                          \
+  if ((dt) == GNGF_FEAT_F32) { using TT = float; __VA_ARGS__; }                       \
+  else if ((dt) == GNGF_FEAT_F16) { using TT = __half; __VA_ARGS__; }                 \
+  else return (int)hipErrorInvalidValue;
+
+extern "C" int gngf_encode_fwd(const float* xy, const void* tables_v, int feat_dtype, const int32_t* vert_idx, const float* vert_w,
                                const int32_t* n_ls, float* enc, int64_t P, int L, int F, int64_t T, int K,
                                int mode, int vstride, int64_t NV, int l0, int l1, void* stream) {
   GNGF_CHECK_ARG(P >= 0 && L > 0 && L <= GNGF_MAX_LEVELS && T > 0 && l0 >= 0 && l0 <= l1 && l1 <= L);
   GNGF_CHECK_ARG(mode == GNGF_MODE_HASH || mode == GNGF_MODE_VERTEX_TABLE);
   if (P == 0 || l0 == l1) return 0;
-  GNGF_CHECK_ARG(xy && tables && n_ls && enc);
+  GNGF_CHECK_ARG(xy && tables_v && n_ls && enc);
   const int nl = l1 - l0;
   const int64_t total = P * nl;
   const dim3 grid((unsigned)ceil_div(total, kBlock)), block(kBlock);
   const bool pow2 = (T & (T - 1)) == 0;
   if (mode == GNGF_MODE_HASH) {
-    DISPATCH_F(F, (encode_fwd_kernel<kF, false><<<grid, block, 0, as_stream(stream)>>>(
-                      reinterpret_cast<const float2*>(xy), tables, nullptr, nullptr, n_ls, enc, total, L, l0, nl, T, 0, 0, 0, pow2)));
+    DISPATCH_TT(feat_dtype, DISPATCH_F(F, (encode_fwd_kernel<kF, false, TT><<<grid, block, 0, as_stream(stream)>>>(
+                      reinterpret_cast<const float2*>(xy), static_cast<const TT*>(tables_v), nullptr, nullptr, n_ls, enc, total, L, l0,
+                      nl, T, 0, 0, 0, pow2))));
   } else {
     GNGF_CHECK_ARG(vert_idx && vert_w && K > 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0);
-    DISPATCH_F(F, (encode_fwd_kernel<kF, true><<<grid, block, 0, as_stream(stream)>>>(
-                      reinterpret_cast<const float2*>(xy), tables, vert_idx, vert_w, n_ls, enc, total, L, l0, nl, T, K, vstride, NV, pow2)));
+    DISPATCH_TT(feat_dtype, DISPATCH_F(F, (encode_fwd_kernel<kF, true, TT><<<grid, block, 0, as_stream(stream)>>>(
+                      reinterpret_cast<const float2*>(xy), static_cast<const TT*>(tables_v), vert_idx, vert_w, n_ls, enc, total, L,
+                      l0, nl, T, K, vstride, NV, pow2))));
   }
   GNGF_RETURN_LAUNCH();
 }
 
-extern "C" int gngf_encode_bwd(const float* xy, const float* tables, const int32_t* vert_idx, const float* vert_w,
+extern "C" int gngf_encode_bwd(const float* xy, const void* tables_v, int feat_dtype, const int32_t* vert_idx, const float* vert_w,
                                const int32_t* n_ls, const float* genc, float* dtables, float* dvert_w,
                                int64_t P, int L, int F, int64_t T, int K, int mode, int vstride, int64_t NV,
                                int l0, int l1, void* stream) {
   GNGF_CHECK_ARG(P >= 0 && L > 0 && L <= GNGF_MAX_LEVELS && T > 0 && l0 >= 0 && l0 <= l1 && l1 <= L);
   GNGF_CHECK_ARG(mode == GNGF_MODE_HASH || mode == GNGF_MODE_VERTEX_TABLE);
   if (P == 0 || l0 == l1) return 0;
-  GNGF_CHECK_ARG(xy && tables && n_ls && genc && dtables);
+  GNGF_CHECK_ARG(xy && tables_v && n_ls && genc && dtables);
   const int nl = l1 - l0;
   const int64_t total = P * nl * F;                       // one lane per (pixel, level, feature)
   const dim3 grid((unsigned)ceil_div(total, kBlock)), block(kBlock);
   const bool pow2 = (T & (T - 1)) == 0;
   if (mode == GNGF_MODE_HASH) {
-    DISPATCH_F(F, (encode_bwd_kernel<kF, false><<<grid, block, 0, as_stream(stream)>>>(
-                      reinterpret_cast<const float2*>(xy), tables, nullptr, nullptr, n_ls, genc, dtables, nullptr,
-                      total, L, l0, nl, T, 0, 0, 0, pow2)));
+    DISPATCH_TT(feat_dtype, DISPATCH_F(F, (encode_bwd_kernel<kF, false, TT><<<grid, block, 0, as_stream(stream)>>>(
+                      reinterpret_cast<const float2*>(xy), static_cast<const TT*>(tables_v), nullptr, nullptr, n_ls, genc, dtables,
+                      nullptr, total, L, l0, nl, T, 0, 0, 0, pow2))));
   } else {
     GNGF_CHECK_ARG(vert_idx && vert_w && K > 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0);
-    DISPATCH_F(F, (encode_bwd_kernel<kF, true><<<grid, block, 0, as_stream(stream)>>>(
-                      reinterpret_cast<const float2*>(xy), tables, vert_idx, vert_w, n_ls, genc, dtables, dvert_w,
-                      total, L, l0, nl, T, K, vstride, NV, pow2)));
+    DISPATCH_TT(feat_dtype, DISPATCH_F(F, (encode_bwd_kernel<kF, true, TT><<<grid, block, 0, as_stream(stream)>>>(
+                      reinterpret_cast<const float2*>(xy), static_cast<const TT*>(tables_v), vert_idx, vert_w, n_ls, genc, dtables,
+                      dvert_w, total, L, l0, nl, T, K, vstride, NV, pow2))));
   }
   GNGF_RETURN_LAUNCH();
 }

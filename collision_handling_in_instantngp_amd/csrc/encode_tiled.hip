@@ -137,9 +137,9 @@ __device__ __forceinline__ int64_t level_offset(const int32_t* n_ls, int l) {
   return o;
 }
 
-template <int F, bool VT>
+template <int F, bool VT, typename TT>
 __global__ void __launch_bounds__(256)
-vertex_fwd_kernel(const float* __restrict__ tables, const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
+vertex_fwd_kernel(const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
                   const int32_t* __restrict__ n_ls, float* __restrict__ G, int64_t T, int K, int vstride, int64_t NV,
                   bool pow2) {
   const int l = blockIdx.y;
@@ -147,22 +147,22 @@ vertex_fwd_kernel(const float* __restrict__ tables, const int32_t* __restrict__ 
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= gw * gw) return;
   const int gy = i / gw, gx = i - gy * gw;
-  const float* tab = tables + (int64_t)l * T * F;
+  const TT* tab = tables + (int64_t)l * T * F;
   float acc[F];
 #pragma unroll
   for (int f = 0; f < F; ++f) acc[f] = 0.f;
   if constexpr (!VT) {
-    const float* r = tab + spatial_hash(gx, gy, T, pow2) * F;
+    const TT* r = tab + spatial_hash(gx, gy, T, pow2) * F;
 #pragma unroll
-    for (int f = 0; f < F; ++f) acc[f] = r[f];
+    for (int f = 0; f < F; ++f) acc[f] = tload(r + f);
   } else {
     const int64_t vid = (int64_t)gy * vstride + gx;
     if (gx < vstride && vid < NV) {
       for (int k = 0; k < K; ++k) {
         const float w = vert_w[vid * K + k];
-        const float* r = tab + (int64_t)vert_idx[vid * K + k] * F;
+        const TT* r = tab + (int64_t)vert_idx[vid * K + k] * F;
 #pragma unroll
-        for (int f = 0; f < F; ++f) acc[f] += r[f] * w;
+        for (int f = 0; f < F; ++f) acc[f] += tload(r + f) * w;
       }
     }
   }
@@ -171,9 +171,9 @@ vertex_fwd_kernel(const float* __restrict__ tables, const int32_t* __restrict__ 
   for (int f = 0; f < F; ++f) o[f] = acc[f];
 }
 
-template <int F, bool VT>
+template <int F, bool VT, typename TT>
 __global__ void __launch_bounds__(256)
-vertex_bwd_kernel(const float* __restrict__ tables, const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
+vertex_bwd_kernel(const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
                   const int32_t* __restrict__ n_ls, const float* __restrict__ dG, float* __restrict__ dtables,
                   float* __restrict__ dvert_w, int64_t T, int K, int vstride, int64_t NV, bool pow2) {
   const int l = blockIdx.y;
@@ -187,7 +187,7 @@ vertex_bwd_kernel(const float* __restrict__ tables, const int32_t* __restrict__ 
   for (int f = 0; f < F; ++f) { g[f] = gp[f]; any |= (g[f] != 0.f); }
   if (!any) return;                               // vertices no pixel touched
   const int gy = i / gw, gx = i - gy * gw;
-  const float* tab = tables + (int64_t)l * T * F;
+  const TT* tab = tables + (int64_t)l * T * F;
   float* dtab = dtables + (int64_t)l * T * F;
   if constexpr (!VT) {
     float* r = dtab + spatial_hash(gx, gy, T, pow2) * F;
@@ -202,7 +202,7 @@ vertex_bwd_kernel(const float* __restrict__ tables, const int32_t* __restrict__ 
       float dot = 0.f;
 #pragma unroll
       for (int f = 0; f < F; ++f) {
-        dot += g[f] * tab[row * F + f];
+        dot += g[f] * tload(tab + row * F + f);
         atomicAdd(dtab + row * F + f, g[f] * w);
       }
       if (dvert_w) atomicAdd(dvert_w + vid * K + k, dot);
@@ -496,9 +496,9 @@ gather_partials_kernel(const float* __restrict__ partials, const int32_t* __rest
 // (`order` = argsort of vert_idx), each lane takes one entry and walks the levels it belongs to, and equal slots —
 // adjacent lanes — are combined with a wave-level segmented scan before the one atomic per (wave, run).
 // dvert_w needs no atomics at all: every entry is owned by exactly one lane.
-template <int F>
+template <int F, typename TT>
 __global__ void __launch_bounds__(256)
-vertex_bwd_sorted_kernel(const float* __restrict__ tables, const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
+vertex_bwd_sorted_kernel(const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
                          const int32_t* __restrict__ order, const int32_t* __restrict__ n_ls, const float* __restrict__ dG,
                          float* __restrict__ dtables, float* __restrict__ dvert_w, int Ls, int64_t T, int K, int vstride,
                          int64_t NE) {
@@ -535,9 +535,9 @@ vertex_bwd_sorted_kernel(const float* __restrict__ tables, const int32_t* __rest
     if (in) {
       const float* g = dG + (s_goff[l] + (int64_t)gy * (n + 2) + gx) * F;
       if (dvert_w) {                       // the table row is only needed for d w (trainable HPD)
-        const float* r = tables + ((int64_t)l * T + slot) * F;
+        const TT* r = tables + ((int64_t)l * T + slot) * F;
 #pragma unroll
-        for (int f = 0; f < F; ++f) { const float gv = g[f]; v[f] = gv * w; dot += gv * r[f]; }
+        for (int f = 0; f < F; ++f) { const float gv = g[f]; v[f] = gv * w; dot += gv * tload(r + f); }
       } else {
 #pragma unroll
         for (int f = 0; f < F; ++f) v[f] = g[f] * w;
@@ -572,6 +572,11 @@ vertex_bwd_sorted_kernel(const float* __restrict__ tables, const int32_t* __rest
 }  // namespace gngf
 
 using namespace gngf;
+
+#define DISPATCH_TT(dt, ...)                                                          \
+  if ((dt) == GNGF_FEAT_F32) { using TT = float; __VA_ARGS__; }                       \
+  else if ((dt) == GNGF_FEAT_F16) { using TT = __half; __VA_ARGS__; }                 \
+  else return (int)hipErrorInvalidValue;
 
 #define DISPATCH_F(F, ...)                          \
   switch (F) {                                      \
@@ -614,7 +619,7 @@ static int max_grid_side(const int32_t* n_ls_host, int Ls) {
 }
 
 // Vertex stage forward: G (sum_l (N_l+2)^2, F) for levels [0, Ls).  n_ls_host mirrors n_ls on the host (grid sizing).
-extern "C" int gngf_vertex_grid_fwd(const float* tables, const int32_t* vert_idx, const float* vert_w, const int32_t* n_ls,
+extern "C" int gngf_vertex_grid_fwd(const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w, const int32_t* n_ls,
                                     const int32_t* n_ls_host, float* G, int Ls, int F, int64_t T, int K, int mode,
                                     int vstride, int64_t NV, void* stream) {
   GNGF_CHECK_ARG(Ls > 0 && Ls <= GNGF_MAX_LEVELS && T > 0 && tables && n_ls && n_ls_host && G);
@@ -623,17 +628,17 @@ extern "C" int gngf_vertex_grid_fwd(const float* tables, const int32_t* vert_idx
   dim3 grid((unsigned)ceil_div((int64_t)side * side, 256), (unsigned)Ls), block(256);
   const bool pow2 = (T & (T - 1)) == 0;
   if (mode == GNGF_MODE_HASH) {
-    DISPATCH_F(F, (vertex_fwd_kernel<kF, false><<<grid, block, 0, as_stream(stream)>>>(tables, nullptr, nullptr, n_ls, G, T, 0, 0,
-                                                                                       0, pow2)));
+    DISPATCH_TT(feat_dtype, DISPATCH_F(F, (vertex_fwd_kernel<kF, false, TT><<<grid, block, 0, as_stream(stream)>>>(
+                                static_cast<const TT*>(tables), nullptr, nullptr, n_ls, G, T, 0, 0, 0, pow2))));
   } else {
-    DISPATCH_F(F, (vertex_fwd_kernel<kF, true><<<grid, block, 0, as_stream(stream)>>>(tables, vert_idx, vert_w, n_ls, G, T, K,
-                                                                                      vstride, NV, pow2)));
+    DISPATCH_TT(feat_dtype, DISPATCH_F(F, (vertex_fwd_kernel<kF, true, TT><<<grid, block, 0, as_stream(stream)>>>(
+                                static_cast<const TT*>(tables), vert_idx, vert_w, n_ls, G, T, K, vstride, NV, pow2))));
   }
   GNGF_RETURN_LAUNCH();
 }
 
 // Vertex stage backward: dG -> dtables (accumulated, caller zero-fills) and dvert_w (accumulated, may be NULL).
-extern "C" int gngf_vertex_grid_bwd(const float* tables, const int32_t* vert_idx, const float* vert_w, const int32_t* n_ls,
+extern "C" int gngf_vertex_grid_bwd(const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w, const int32_t* n_ls,
                                     const int32_t* n_ls_host, const float* dG, float* dtables, float* dvert_w, int Ls, int F,
                                     int64_t T, int K, int mode, int vstride, int64_t NV, void* stream) {
   GNGF_CHECK_ARG(Ls > 0 && Ls <= GNGF_MAX_LEVELS && T > 0 && tables && n_ls && n_ls_host && dG && dtables);
@@ -642,11 +647,12 @@ extern "C" int gngf_vertex_grid_bwd(const float* tables, const int32_t* vert_idx
   dim3 grid((unsigned)ceil_div((int64_t)side * side, 256), (unsigned)Ls), block(256);
   const bool pow2 = (T & (T - 1)) == 0;
   if (mode == GNGF_MODE_HASH) {
-    DISPATCH_F(F, (vertex_bwd_kernel<kF, false><<<grid, block, 0, as_stream(stream)>>>(tables, nullptr, nullptr, n_ls, dG, dtables,
-                                                                                       nullptr, T, 0, 0, 0, pow2)));
+    DISPATCH_TT(feat_dtype, DISPATCH_F(F, (vertex_bwd_kernel<kF, false, TT><<<grid, block, 0, as_stream(stream)>>>(
+                                static_cast<const TT*>(tables), nullptr, nullptr, n_ls, dG, dtables, nullptr, T, 0, 0, 0, pow2))));
   } else {
-    DISPATCH_F(F, (vertex_bwd_kernel<kF, true><<<grid, block, 0, as_stream(stream)>>>(tables, vert_idx, vert_w, n_ls, dG, dtables,
-                                                                                      dvert_w, T, K, vstride, NV, pow2)));
+    DISPATCH_TT(feat_dtype, DISPATCH_F(F, (vertex_bwd_kernel<kF, true, TT><<<grid, block, 0, as_stream(stream)>>>(
+                                static_cast<const TT*>(tables), vert_idx, vert_w, n_ls, dG, dtables, dvert_w, T, K, vstride, NV,
+                                pow2))));
   }
   GNGF_RETURN_LAUNCH();
 }
@@ -700,14 +706,16 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
 
 // Vertex stage backward, vertex-table source, slot-ordered and contention-free (see vertex_bwd_sorted_kernel).
 // order (NV*K) int32 = argsort of vert_idx viewed flat.  dtables accumulated; dvert_w (NV,K) WRITTEN (may be NULL).
-extern "C" int gngf_vertex_grid_bwd_sorted(const float* tables, const int32_t* vert_idx, const float* vert_w,
+extern "C" int gngf_vertex_grid_bwd_sorted(const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w,
                                            const int32_t* order, const int32_t* n_ls, const float* dG, float* dtables,
                                            float* dvert_w, int Ls, int F, int64_t T, int K, int vstride, int64_t NV,
                                            void* stream) {
   GNGF_CHECK_ARG(Ls > 0 && Ls <= GNGF_MAX_LEVELS && T > 0 && K > 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0);
   GNGF_CHECK_ARG(tables && vert_idx && vert_w && order && n_ls && dG && dtables && NV * K < (1ll << 31));
   const int64_t NE = NV * K;
-  DISPATCH_F(F, (vertex_bwd_sorted_kernel<kF><<<dim3((unsigned)ceil_div(NE, 256)), dim3(256), 0, as_stream(stream)>>>(
-                    tables, vert_idx, vert_w, order, n_ls, dG, dtables, dvert_w, Ls, T, K, vstride, NE)));
+  DISPATCH_TT(feat_dtype, DISPATCH_F(F, (vertex_bwd_sorted_kernel<kF, TT><<<dim3((unsigned)ceil_div(NE, 256)), dim3(256), 0,
+                                                                          as_stream(stream)>>>(
+                              static_cast<const TT*>(tables), vert_idx, vert_w, order, n_ls, dG, dtables, dvert_w, Ls, T, K,
+                              vstride, NE))));
   GNGF_RETURN_LAUNCH();
 }

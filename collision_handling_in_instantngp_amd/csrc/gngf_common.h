@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels.  Wave = 64 lanes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 #include "../../include/gngf.h"
 
@@ -8,6 +9,10 @@
 #define GNGF_RETURN_LAUNCH() return (int)hipGetLastError()
 
 namespace gngf {
+
+// Table element type: fp32 (the reference) or fp16 storage (BASELINE config 5); arithmetic is always fp32.
+__device__ __forceinline__ float tload(const float* p) { return *p; }
+__device__ __forceinline__ float tload(const __half* p) { return __half2float(*p); }
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -106,7 +106,10 @@ class MultiResHashEncoding(nn.Module):
     kernels see a single base pointer."""
 
     def __init__(self, hash_table_size: int, num_levels: int, feature_dim: int = 2, topk_k: int = 4,
-                 should_log: bool = False) -> None:
+                 should_log: bool = False, table_dtype: torch.dtype = torch.float32) -> None:
+        """table_dtype (extension, not in the reference): torch.float16 stores the level tables in half precision
+        (BASELINE.json config 5); interpolation arithmetic and gradient accumulation stay fp32, the gradient handed to
+        the fp16 parameters is rounded once at the end (use loss scaling as in any fp16 training)."""
         super().__init__()
         self._hash_table_size = hash_table_size
         self._num_levels = num_levels
@@ -115,6 +118,7 @@ class MultiResHashEncoding(nn.Module):
         self._should_log = should_log
         base = torch.empty((num_levels, hash_table_size, feature_dim), dtype=torch.float32, device=device)
         base.uniform_(-10.0 ** (-4), 10.0 ** (-4))                       # models.py:169
+        base = base.to(table_dtype)
         self._hash_tables = nn.ModuleList([nn.Embedding(hash_table_size, feature_dim, _weight=base[l])
                                            for l in range(num_levels)])
         self._base = base
@@ -130,7 +134,7 @@ class MultiResHashEncoding(nn.Module):
         ws = [m.weight for m in self._hash_tables]
         L, T, F = self._num_levels, self._hash_table_size, self._feature_dim
         base = self._base
-        stride = T * F * 4
+        stride = T * F * base.element_size()
         ok = (base.device == ws[0].device and base.is_contiguous()
               and all(w.data_ptr() == base.data_ptr() + l * stride and w.is_contiguous() for l, w in enumerate(ws)))
         if not ok:
@@ -144,6 +148,9 @@ class MultiResHashEncoding(nn.Module):
         """hashed_indices (P,L,4) [hash] or (P,L,4,K) [GNGF] int64; hashed_probs_topk (P,L,4,K) | None -> (P,F,L,4)."""
         base = self.packed_tables()
         tables = ops.TableViewFunction.apply(base, self, *[m.weight for m in self._hash_tables])
+        if base.dtype != torch.float32:
+            raise TypeError("MultiResHashEncoding.forward (the per-instance module boundary) is fp32 only; fp16 tables run "
+                            "through GeneralNeuralGaugeFields' fused encoder")
         if should_use_hash_function:
             if hashed_indices.dim() != 3:
                 raise ValueError("hash mode expects indices of shape (P, L, 4)")
@@ -179,7 +186,8 @@ class GeneralNeuralGaugeFields(nn.Module):
     def __init__(self, input_dim, hash_table_size: int, num_levels: int, n_min: int, n_max: int,
                  MLP_hidden_layers_widths: list, HPD_hidden_layers_widths: list, HPD_out_features: int = 1,
                  feature_dim: int = 2, topk_k: int = 4, should_keep_topk_only: bool = False, should_bw: bool = False,
-                 should_log: bool = False, HPD_weights_path: str = None, encoding_weights_path: str = None):
+                 should_log: bool = False, HPD_weights_path: str = None, encoding_weights_path: str = None,
+                 table_dtype: torch.dtype = torch.float32):
         super().__init__()
         if input_dim != 2:
             raise ValueError("the gfx950 path implements the reference's 2-D image case (input_dim == 2)")
@@ -211,7 +219,7 @@ class GeneralNeuralGaugeFields(nn.Module):
                 self.HPD.load_state_dict(torch.load(HPD_weights_path))
                 for _name, param in self.HPD.named_parameters():
                     param.requires_grad = False
-        self.encoding = MultiResHashEncoding(hash_table_size, num_levels, feature_dim, topk_k, should_log)
+        self.encoding = MultiResHashEncoding(hash_table_size, num_levels, feature_dim, topk_k, should_log, table_dtype)
         widths = [num_levels * feature_dim, *MLP_hidden_layers_widths, (3 if not should_bw else 1)]
         self._MLP_hidden_layers_widths = widths
         self.mlp = nn.ModuleList([

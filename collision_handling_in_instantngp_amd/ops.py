@@ -15,6 +15,27 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+_f16 = torch.float16
+
+
+def _tab(tables):
+    """(device pointer, GNGF_FEAT_* code) of the level tables: fp32 (the reference) or fp16 storage."""
+    if tables.dtype == _f32:
+        return ptr(tables, _f32, "tables"), 0
+    if tables.dtype == _f16:
+        return ptr(tables, _f16, "tables"), 1
+    raise TypeError(f"hash tables must be float32 or float16, got {tables.dtype}")
+
+
+def _grad_buffer(tables):
+    """table gradients are always accumulated in fp32 (fp16 atomics would round on every add)"""
+    return torch.zeros(tables.shape, dtype=_f32, device=tables.device)
+
+
+def _grad_out(dtables, tables):
+    return dtables if tables.dtype == _f32 else dtables.to(tables.dtype)
+
+
 def hash_indices(xy, n_ls, T):
     """_scale_to_grid + _fast_hash (reference models.py:486-528) -> (P, L, 4) int64."""
     xy = _c(xy)
@@ -93,7 +114,7 @@ class EncodeDirectFunction(torch.autograd.Function):
         K = 0 if vert_idx is None else vert_idx.shape[1]
         NV = 0 if vert_idx is None else vert_idx.shape[0]
         enc = torch.empty((P, L * F), dtype=_f32, device=tables.device)
-        call("gngf_encode_fwd", ptr(xy, _f32, "xy"), ptr(tables, _f32, "tables"), ptr(vert_idx, _i32, "vert_idx"),
+        call("gngf_encode_fwd", ptr(xy, _f32, "xy"), *_tab(tables), ptr(vert_idx, _i32, "vert_idx"),
              ptr(vert_w, _f32, "vert_w"), ptr(n_ls, _i32, "n_ls"), ptr(enc), P, L, F, T, K, mode, vstride, NV, 0, L,
              stream_ptr())
         ctx.save_for_backward(xy, n_ls, tables, vert_idx, vert_w)
@@ -105,11 +126,11 @@ class EncodeDirectFunction(torch.autograd.Function):
         xy, n_ls, tables, vert_idx, vert_w = ctx.saved_tensors
         P, L, F, T, K, mode, vstride, NV = ctx.cfg
         genc = _c(genc)
-        dtables = torch.zeros_like(tables)
+        dtables = _grad_buffer(tables)
         dvw = torch.zeros_like(vert_w) if (vert_w is not None and ctx.needs_input_grad[4]) else None
-        call("gngf_encode_bwd", ptr(xy), ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc, _f32, "grad"),
+        call("gngf_encode_bwd", ptr(xy), *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc, _f32, "grad"),
              ptr(dtables), ptr(dvw), P, L, F, T, K, mode, vstride, NV, 0, L, stream_ptr())
-        return None, None, dtables, None, dvw, None
+        return None, None, _grad_out(dtables, tables), None, dvw, None
 
 
 # ------------------------------------------------------------------------------------------------ dense layers
@@ -470,7 +491,7 @@ class TiledWorkspace:
 def _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G):
     L, T, F = tables.shape
     mode = MODE_HASH if vert_idx is None else MODE_VERTEX_TABLE
-    call("gngf_vertex_grid_fwd", ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), plan.n_ls_c, ptr(G), plan.Ls, F, T,
+    call("gngf_vertex_grid_fwd", *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), plan.n_ls_c, ptr(G), plan.Ls, F, T,
          0 if vert_idx is None else vert_idx.shape[1], mode, vstride, 0 if vert_idx is None else vert_idx.shape[0], stream_ptr())
 
 
@@ -512,11 +533,11 @@ def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None):
 def _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw, order=None):
     L, T, F = tables.shape
     if vert_idx is not None and order is not None:
-        call("gngf_vertex_grid_bwd_sorted", ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(order, _i32, "order"), ptr(n_ls), ptr(dG),
+        call("gngf_vertex_grid_bwd_sorted", *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(order, _i32, "order"), ptr(n_ls), ptr(dG),
              ptr(dtables), ptr(dvw), plan.Ls, F, T, vert_idx.shape[1], vstride, vert_idx.shape[0], stream_ptr())
         return
     mode = MODE_HASH if vert_idx is None else MODE_VERTEX_TABLE
-    call("gngf_vertex_grid_bwd", ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), plan.n_ls_c, ptr(dG), ptr(dtables), ptr(dvw),
+    call("gngf_vertex_grid_bwd", *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), plan.n_ls_c, ptr(dG), ptr(dtables), ptr(dvw),
          plan.Ls, F, T, 0 if vert_idx is None else vert_idx.shape[1], mode, vstride,
          0 if vert_idx is None else vert_idx.shape[0], stream_ptr())
 
@@ -545,7 +566,7 @@ class EncodeFunction(torch.autograd.Function):
             call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), ptr(G),
                  ptr(enc), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, stream_ptr())
         if plan.Ls < L:
-            call("gngf_encode_fwd", ptr(xy, _f32, "xy"), ptr(tables, _f32, "tables"), ptr(vert_idx, _i32, "vert_idx"),
+            call("gngf_encode_fwd", ptr(xy, _f32, "xy"), *_tab(tables), ptr(vert_idx, _i32, "vert_idx"),
                  ptr(vert_w, _f32, "vert_w"), ptr(n_ls, _i32, "n_ls"), ptr(enc), P, L, F, T, K, mode, vstride, NV, plan.Ls, L,
                  stream_ptr())
         ctx.save_for_backward(xy, n_ls, tables, vert_idx, vert_w, order)
@@ -558,7 +579,7 @@ class EncodeFunction(torch.autograd.Function):
         P, L, F, T, K, mode, vstride, NV, plan, ws = ctx.cfg
         genc = _c(genc)
         absmax = _take_absmax_hint(genc)
-        dtables = torch.zeros_like(tables)
+        dtables = _grad_buffer(tables)
         dvw = torch.zeros_like(vert_w) if (vert_w is not None and ctx.needs_input_grad[5]) else None
         if plan.Ls > 0 and P > 0:
             dG = torch.zeros((plan.vtot, F), dtype=_f32, device=tables.device)
@@ -576,11 +597,11 @@ class EncodeFunction(torch.autograd.Function):
         else:
             dvw_t = None
         if plan.Ls < L:
-            call("gngf_encode_bwd", ptr(xy), ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc, _f32, "grad"),
+            call("gngf_encode_bwd", ptr(xy), *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc, _f32, "grad"),
                  ptr(dtables), ptr(dvw), P, L, F, T, K, mode, vstride, NV, plan.Ls, L, stream_ptr())
         if dvw_t is not None:
             dvw = dvw + dvw_t
-        return None, None, None, dtables, None, dvw, None, None
+        return None, None, None, _grad_out(dtables, tables), None, dvw, None, None
 
 
 def encode_apply(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, path=None, order=None):
@@ -651,7 +672,7 @@ def encode_kernels(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, genc,
     K = 0 if vert_idx is None else vert_idx.shape[1]
     NV = 0 if vert_idx is None else vert_idx.shape[0]
     enc = torch.empty((P, L * F), dtype=_f32, device=xy.device)
-    dtables = torch.zeros_like(tables)
+    dtables = _grad_buffer(tables)
     plan = EncodePlan(P, n_ls_host, F, path)
     s = stream_ptr
     out = {}
@@ -669,9 +690,9 @@ def encode_kernels(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, genc,
         out["encode_bwd:tiled"] = lambda: _pixel_bwd(plan, ws, n_ls, genc, dG, L, F)
         out["vertex_bwd"] = lambda: _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, None, order)
     if plan.Ls < L:
-        out["encode_fwd:direct"] = lambda: call("gngf_encode_fwd", ptr(xy), ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls),
+        out["encode_fwd:direct"] = lambda: call("gngf_encode_fwd", ptr(xy), *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls),
                                                 ptr(enc), P, L, F, T, K, mode, vstride, NV, plan.Ls, L, s())
-        out["encode_bwd:direct"] = lambda: call("gngf_encode_bwd", ptr(xy), ptr(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls),
+        out["encode_bwd:direct"] = lambda: call("gngf_encode_bwd", ptr(xy), *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls),
                                                 ptr(genc), ptr(dtables), ptr(None), P, L, F, T, K, mode, vstride, NV, plan.Ls,
                                                 L, s())
     return out

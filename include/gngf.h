@@ -12,7 +12,8 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); launches are asynchronous;
  *   - the return value is a hipError_t as int (0 = hipSuccess); nothing throws;
  *     hipErrorInvalidValue (1) = rejected arguments (null pointer, unsupported F/K, negative size);
- *   - fp32 everywhere unless stated; indices handed to / from the reference-shaped API are int64,
+ *   - fp32 everywhere unless stated (`tables` of the fused encoder may be fp16 storage: feat_dtype; table GRADIENTS are
+ *     always accumulated in fp32); indices handed to / from the reference-shaped API are int64,
  *     internal per-vertex tables use int32;
  *   - layouts:  xy (P,2) = (row, col) in [0,1];  tables (L,T,F) contiguous, level-major;
  *               enc (P, L*F) level-major / feature-minor (models.py:651);
@@ -34,6 +35,9 @@ extern "C" {
 
 /* blend of the K looked-up rows — models.py:212-217 (global should_softmax_topk_features) */
 enum { GNGF_BLEND_SOFTMAX = 0 /* True */, GNGF_BLEND_RAW = 1 /* None */, GNGF_BLEND_NORM = 2 /* False */ };
+
+/* storage type of the level tables: fp32 (the reference) or fp16 (BASELINE.json config 5); arithmetic and gradients are fp32 */
+enum { GNGF_FEAT_F32 = 0, GNGF_FEAT_F16 = 1 };
 
 /* index source of the fused encoder */
 enum { GNGF_MODE_HASH = 0 /* models.py:412-414 */, GNGF_MODE_VERTEX_TABLE = 1 /* models.py:416-418, de-duplicated */ };
@@ -62,12 +66,12 @@ int gngf_bilinear_bwd(const float* xy, const int32_t* n_ls, const float* genc, f
  * mode HASH: vert_idx/vert_w NULL, K ignored.
  * mode VERTEX_TABLE: vert_idx (NV,K) int32 slots and vert_w (NV,K) blend weights per grid vertex
  *   (vid = gy*vstride + gx), i.e. HPD(top-K) evaluated once per DISTINCT vertex instead of per instance. */
-int gngf_encode_fwd(const float* xy, const float* tables, const int32_t* vert_idx, const float* vert_w,
+int gngf_encode_fwd(const float* xy, const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w,
                     const int32_t* n_ls, float* enc, int64_t P, int L, int F, int64_t T, int K,
                     int mode, int vstride, int64_t NV, int l0, int l1, void* stream);
 /* backward: dtables (L,T,F) accumulated (caller zero-fills); dvert_w (NV,K) accumulated (caller zero-fills),
  * = sum over instances of c_v * <g, E_l[idx_k]>  (gradient w.r.t. the blend WEIGHT, before the blend's own backward). */
-int gngf_encode_bwd(const float* xy, const float* tables, const int32_t* vert_idx, const float* vert_w,
+int gngf_encode_bwd(const float* xy, const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w,
                     const int32_t* n_ls, const float* genc, float* dtables, float* dvert_w,
                     int64_t P, int L, int F, int64_t T, int K, int mode, int vstride, int64_t NV, int l0, int l1,
                     void* stream);
@@ -82,11 +86,11 @@ int gngf_bin_pixels(const float* xy, int64_t P, int tile_shift, int NB, int chun
                     int32_t* tile_item_base, int32_t* items, int32_t* n_items, float* sorted, void* stream);
 /* vertex stage: G[(goff_l + gy*(N_l+2) + gx)*F + f] for levels [0, Ls), goff_l = sum_{j<l} (N_j+2)^2.
  * n_ls_host mirrors n_ls on the host (grid sizing only). */
-int gngf_vertex_grid_fwd(const float* tables, const int32_t* vert_idx, const float* vert_w, const int32_t* n_ls,
+int gngf_vertex_grid_fwd(const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w, const int32_t* n_ls,
                          const int32_t* n_ls_host, float* G, int Ls, int F, int64_t T, int K, int mode, int vstride,
                          int64_t NV, void* stream);
 /* dG -> dtables (L,T,F) accumulated (caller zero-fills) and dvert_w (NV,K) accumulated (NULL when not needed). */
-int gngf_vertex_grid_bwd(const float* tables, const int32_t* vert_idx, const float* vert_w, const int32_t* n_ls,
+int gngf_vertex_grid_bwd(const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w, const int32_t* n_ls,
                          const int32_t* n_ls_host, const float* dG, float* dtables, float* dvert_w, int Ls, int F, int64_t T,
                          int K, int mode, int vstride, int64_t NV, void* stream);
 /* pixel stage over the work items of gngf_bin_pixels: enc / genc rows are (P, L*F); levels [0, Ls) handled here.
@@ -107,7 +111,7 @@ int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32
 /* vertex stage backward for the vertex-table source in SLOT order (order (NV*K) int32 = argsort of vert_idx, flat):
  * contention-free for any slot distribution (wave-level segmented reduction, one atomic per (wave, slot run));
  * dtables accumulated, dvert_w (NV,K) written without atomics (NULL when not needed). */
-int gngf_vertex_grid_bwd_sorted(const float* tables, const int32_t* vert_idx, const float* vert_w, const int32_t* order,
+int gngf_vertex_grid_bwd_sorted(const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w, const int32_t* order,
                                 const int32_t* n_ls, const float* dG, float* dtables, float* dvert_w, int Ls, int F, int64_t T,
                                 int K, int vstride, int64_t NV, void* stream);
 

@@ -217,3 +217,38 @@ def test_binning_is_a_permutation_grouped_by_tile(ops):
         assert np.all(tile[s_:s_ + c_] == t_)
     off = ws.tile_off.cpu().numpy()
     assert off[-1] == P and np.array_equal(np.bincount(tile, minlength=TS * TS), np.diff(off))
+
+
+@pytest.mark.parametrize("mode", ["hash", "vt"])
+@pytest.mark.parametrize("path", ["tiled", "direct"])
+def test_fp16_tables_vs_oracle_on_rounded_tables(ops, mode, path):
+    """BASELINE config 5 flavour: fp16 table storage, F = 4.  No reference counterpart: the oracle is the fp32 restatement
+    on the fp16-ROUNDED tables; interpolation and gradient accumulation are fp32, so forward agrees to fp32 round-off and
+    the gradient (returned in fp16) to fp16 rounding (tolerance 1e-3, stated in SURVEY §8d)."""
+    rng = np.random.default_rng(77)
+    n_min, n_max, L, F, T, K, P = 16, 256, 8, 4, 2 ** 12, 3, 30000
+    x = _coords(P, rng)
+    tables16 = ((rng.random((L, T, F), dtype=np.float32) - 0.5) * 2e-2).astype(np.float16)
+    tables = tables16.astype(np.float32)
+    n_ls = orc.level_resolutions(n_min, n_max, L)
+    g = rng.standard_normal((P, L * F)).astype(np.float32)
+    _, grid = orc.scale_to_grid(x, n_ls)
+    if mode == "hash":
+        idx, w, vi, vw, vs = orc.spatial_hash(grid.astype(np.int32), T), None, None, None, 0
+    else:
+        vs = n_max + 2
+        vi_np = rng.integers(0, T, (vs * vs, K)).astype(np.int32)
+        vw_np = rng.random((vs * vs, K), dtype=np.float32)
+        gi = grid.astype(np.int64)
+        vid = gi[:, 1] * vs + gi[:, 0]
+        idx, w = vi_np[vid].astype(np.int64), vw_np[vid]
+        vi, vw = t(vi_np), t(vw_np)
+    want = orc.bilinear_forward(x, n_ls, orc.encoding_forward(tables, idx, w, None))
+    dt, _ = orc.encoding_backward(tables, idx, w, None, orc.bilinear_backward(x, n_ls, g, F))
+    tt = t(tables16).requires_grad_()
+    enc = ops.encode_apply(t(x), t(n_ls, torch.int32), [int(n) for n in n_ls], tt, vi, vw, vs, path=path)
+    assert enc.dtype == torch.float32
+    close(enc, want, 2e-6, 1e-9)
+    enc.backward(t(g))
+    assert tt.grad.dtype == torch.float16
+    close(tt.grad.float(), dt, 1e-3, 1e-3 * float(np.abs(dt).max()))

@@ -6,7 +6,8 @@ from collision_handling_in_instantngp_amd import models, ops
 dev = torch.device("cuda")
 models.should_use_hash_function = True
 net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=2**24, num_levels=16, n_min=16, n_max=8192, MLP_hidden_layers_widths=[64, 64],
-                                      HPD_hidden_layers_widths=[32, 64, 128], HPD_out_features=2**24, feature_dim=4, topk_k=4).to(dev)
+                                      HPD_hidden_layers_widths=[32, 64, 128], HPD_out_features=2**24, feature_dim=4, topk_k=4,
+                                      table_dtype=(torch.float16 if "fp16" in sys.argv else torch.float32)).to(dev)
 net.return_indices = False
 P = 2**20
 g = torch.Generator(device=dev).manual_seed(65535)
@@ -26,7 +27,7 @@ e0.record()
 for _ in range(5): step()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
-print(f"cfg5-shape (fp32 tables) hash fwd+bwd: {ms:.3f} ms/step  {P/ms/1e3:.1f} Mpixel/s")
+print(f"cfg5-shape ({net.encoding._base.dtype} tables) hash fwd+bwd: {ms:.3f} ms/step  {P/ms/1e3:.1f} Mpixel/s")
 # direct-vs-tiled forward agreement at this size
 e1_ = ops.encode_apply(xy, net._n_ls_flat(dev), net._n_ls_host, net.encoding.packed_tables(), None, None, 0, path="direct")
 e2_ = ops.encode_apply(xy, net._n_ls_flat(dev), net._n_ls_host, net.encoding.packed_tables(), None, None, 0, path="tiled")
