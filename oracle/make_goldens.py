@@ -341,7 +341,48 @@ def g10(F_, U_, M, P_):
     save("G10_diagnostics", **out)
 
 
-GROUPS = {"G10": g10, "G1": g1, "G2": g2_g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
+def seeded_tables(L, T, Fd, seed=SEED + 11):
+    """Level tables too large for a fixture (64 MiB at T=2^19) are regenerated from a seeded CPU generator on both sides."""
+    gen = torch.Generator().manual_seed(seed)
+    return (torch.rand((L, T, Fd), generator=gen) * 2 - 1) * 1e-4
+
+
+def g11(F_, U_, M, P_):
+    """Headline shape in hash mode (BASELINE configs[2] flavour on strawberry): L=16, F=2, T=2^19, N 16->512, two epochs
+    of three 1/3-image batches through the reference's own train_step; MSE / PSNR trajectory."""
+    mods = (F_, U_, M)
+    rh.set_flag(mods, "should_use_hash_function", True)
+    img, X, Y, h, w = load_strawberry()
+    L, T, Fd = 16, 2 ** 19, 2
+    net = make_net(M, mods, hash_mode=True, T=T, L=L, n_min=16, n_max=512, F=Fd)
+    tabs = seeded_tables(L, T, Fd)
+    with torch.no_grad():
+        for l in range(L):
+            net.encoding._hash_tables[l].weight.copy_(tabs[l])
+    out = {}
+    for k_, v_ in net.mlp.state_dict().items():
+        out["init_mlp_" + k_.replace(".", "_")] = np32(v_)
+    torch.manual_seed(SEED)
+    shape = h * w
+    shuffled = torch.randperm(shape).int()
+    reordered = torch.zeros((shape,)).int()
+    reordered[shuffled] = torch.arange(shape).int()
+    loss_fn = U_.Loss(delta=1, gamma=-2, epsilon=1)
+    opt = F_.get_optimizer(net, 1e-4, 1e-3, 1e-3, 0, 1e-6, 1e-6)
+    mses, psnrs = [], []
+    for e in range(2):
+        r = F_.train_step(net, loss_fn, opt, X.clone(), Y.clone(), w, h, T, 4, 1, 1, 1e-3, batch_percentage=P_.batch_size,
+                          num_levels=L, should_shuffle=True, shuffled_indices=shuffled, reordered_indices=reordered)
+        loss_item, show, _c, _m, _cnt, mse, _kl, _cl, _ipl = r
+        psnr = F_.calc_psnr(show, img)
+        print(e, mse, psnr)
+        mses.append(mse); psnrs.append(psnr)
+    out.update(mse=np.array(mses), psnr=np.array(psnrs), shuffled=shuffled.numpy())
+    rh.set_flag(mods, "should_use_hash_function", False)
+    save("G11_hash_L16_T19_curve", **out)
+
+
+GROUPS = {"G11": g11, "G10": g10, "G1": g1, "G2": g2_g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
