@@ -340,6 +340,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(a.mode, a.cpu_sample)
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -542,6 +542,18 @@ def _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw,
          0 if vert_idx is None else vert_idx.shape[0], stream_ptr())
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One helper stream per device: work that does not depend on the binned pixels (vertex stage, zero-filling the
+    gradient buffers the backward will need) runs beside the binning kernels; joins are explicit (capturable)."""
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 class EncodeFunction(torch.autograd.Function):
     """Fused coords -> (P, L*F) encoder.  Levels [0, plan.Ls) run through the tiled form (vertex stage + binned,
     LDS-privatised pixel stage), levels [plan.Ls, L) through the direct form.  Same inputs / gradients as
@@ -559,10 +571,20 @@ class EncodeFunction(torch.autograd.Function):
         ws = None
         if vert_idx is not None and order is None and plan.Ls > 0 and P > 0 and ctx.needs_input_grad[3]:
             order = slot_order(vert_idx, plan.n_ls_host[:plan.Ls], vstride)
+        pre = None
         if plan.Ls > 0 and P > 0:
+            cur = torch.cuda.current_stream()
+            side = _side_stream(tables.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):                      # beside the binning: vertex stage + gradient buffers
+                G = torch.empty((plan.vtot, F), dtype=_f32, device=tables.device)
+                _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G)
+                if ctx.needs_input_grad[3]:
+                    pre = [_grad_buffer(tables), torch.zeros((plan.vtot, F), dtype=_f32, device=tables.device)]
             ws = TiledWorkspace(plan, xy)
-            G = torch.empty((plan.vtot, F), dtype=_f32, device=tables.device)
-            _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G)
+            cur.wait_stream(side)
+            for buf in [G] + (pre or []):
+                buf.record_stream(cur)
             call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), ptr(G),
                  ptr(enc), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, stream_ptr())
         if plan.Ls < L:
@@ -571,6 +593,7 @@ class EncodeFunction(torch.autograd.Function):
                  stream_ptr())
         ctx.save_for_backward(xy, n_ls, tables, vert_idx, vert_w, order)
         ctx.cfg = (P, L, F, T, K, mode, vstride, NV, plan, ws)
+        ctx.pre = pre                                           # zero-filled (dtables, dG), consumed by the first backward
         return enc
 
     @staticmethod
@@ -579,10 +602,11 @@ class EncodeFunction(torch.autograd.Function):
         P, L, F, T, K, mode, vstride, NV, plan, ws = ctx.cfg
         genc = _c(genc)
         absmax = _take_absmax_hint(genc)
-        dtables = _grad_buffer(tables)
+        pre, ctx.pre = ctx.pre, None                            # a second backward (retain_graph) allocates fresh buffers
+        dtables = pre[0] if pre else _grad_buffer(tables)
         dvw = torch.zeros_like(vert_w) if (vert_w is not None and ctx.needs_input_grad[5]) else None
         if plan.Ls > 0 and P > 0:
-            dG = torch.zeros((plan.vtot, F), dtype=_f32, device=tables.device)
+            dG = pre[1] if pre else torch.zeros((plan.vtot, F), dtype=_f32, device=tables.device)
             _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax)
             if DP_EXCHANGE is not None and plan.Ls == L:
                 DP_EXCHANGE(dG)                     # one small all-reduce instead of the (L,T,F) table gradient
