@@ -11,12 +11,18 @@ groups = {
     "vertex_fwd": ["gngf::vertex_fwd_kernel<2, true>"],
     "vertex_bwd": ["gngf::vertex_bwd_sorted_kernel<2>"],
 }
+# FETCH_SIZE correction, calibrated per kernel on a known byte count as the guide asks (the 128 MiB enc / d-enc rows):
+# kernels whose dominant reads are 16 B per lane report exactly half (factor 2: decoder_fwd reads 128 MiB of enc and
+# FETCH_SIZE says 64.2 MiB); tiled_bwd reads its 128 MiB of d-enc rows as 8 B per lane and FETCH_SIZE already says
+# 154 MiB = rows + binned pixels (factor 1).
+fetch_factor = {"encode_bwd:tiled": 1.0}
 out = {}
 for name, ks in groups.items():
     f = sum(summ.get(k, {}).get("FETCH_SIZE", 0.0) for k in ks)
     w = sum(summ.get(k, {}).get("WRITE_SIZE", 0.0) for k in ks)
     if f or w:
-        out[name] = {"hbm_bytes_per_launch": (2 * f + w) * 1024, "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB": w,
-                     "note": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; gfx950 FETCH_SIZE counts 128-B requests at 64 B"}
+        ff = fetch_factor.get(name, 2.0)
+        out[name] = {"hbm_bytes_per_launch": (ff * f + w) * 1024, "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB": w, "fetch_factor": ff,
+                     "note": "bytes = (fetch_factor*FETCH_SIZE + WRITE_SIZE)*1024; gfx950 FETCH_SIZE counts wide (16 B/lane) reads at half"}
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
