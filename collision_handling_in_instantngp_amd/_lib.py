@@ -43,6 +43,7 @@ SIGNATURES = {
     "gngf_gemm_acc": [_P, _P, _P, _L, _L, _L, _I, _I, _P],
     "gngf_softmax_topk": [_P, _P, _P, _P, _L, _L, _I, _P],
     "gngf_softmax_bwd_lowrank": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _L, _I, _P],
+    "gngf_logits_topk_pbar": [_P, _P, _P, _P, _P, _I, _P, _L, _L, _I, _P],
     "gngf_topk": [_P, _P, _P, _L, _L, _I, _P],
     "gngf_softmax_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _L, _L, _I, _P],
     "gngf_vertex_coords": [_P, _L, _L, _I, _P],

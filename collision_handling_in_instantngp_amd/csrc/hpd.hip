@@ -153,6 +153,120 @@ softmax_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dq, co
   if (tid < K && dq) dz[topi[row * K + tid]] += pk[tid] * dq[row * K + tid];
 }
 
+// ---------------------------------------------------------------------------------------------- streaming forward
+// One read of the logits per row: online (max, sum-exp) and top-K selection on the LOGITS (softmax is monotone, so the
+// K winners are the same; exactly tied probabilities between distinct logits are ordered by logit, equal logits by the
+// lower index — torch.topk leaves tie order unspecified).  The K probabilities are exp(z_k - max) / sum, the same
+// expression the dense softmax evaluates.  Nothing is written back: the (rows, T) distribution never exists.
+__global__ void __launch_bounds__(kRowBlock)
+logits_stats_topk_kernel(const float* __restrict__ z, float* __restrict__ topv, int32_t* __restrict__ topi,
+                         float* __restrict__ rowstat, int64_t T, int K) {
+  extern __shared__ float smem[];
+  float* lv = smem;
+  int* li = reinterpret_cast<int*>(smem + (size_t)K * kRowBlock);
+  float* red = smem + (size_t)2 * K * kRowBlock;
+  int* redi = reinterpret_cast<int*>(red + 8);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* p = z + (int64_t)blockIdx.x * T;
+  for (int k = 0; k < K; ++k) { lv[k * kRowBlock + tid] = -INFINITY; li[k * kRowBlock + tid] = INT_MAX; }
+  float m = -INFINITY, s = 0.f, thr = -INFINITY;
+  bool has_nan = false;
+  for (int64_t t = tid; t < T; t += kRowBlock) {
+    const float v = p[t];
+    has_nan |= (v != v);
+    if (v > m) { s = s * expf(m - v) + 1.f; m = v; }            // first element: s = 0 * exp(-inf) + 1
+    else s += expf(v - m);
+    if (v > thr) {
+      int k = K - 1;
+      while (k > 0 && lv[(k - 1) * kRowBlock + tid] < v) {
+        lv[k * kRowBlock + tid] = lv[(k - 1) * kRowBlock + tid];
+        li[k * kRowBlock + tid] = li[(k - 1) * kRowBlock + tid];
+        --k;
+      }
+      lv[k * kRowBlock + tid] = v;
+      li[k * kRowBlock + tid] = (int)t;
+      thr = lv[(K - 1) * kRowBlock + tid];
+    }
+  }
+  // block combine of the online statistics: M = max m_t, S = sum s_t exp(m_t - M)
+  const float wm = wave_max(m);
+  const unsigned long long nanmask = __ballot(has_nan);
+  if (lane == 0) { red[wave] = wm; redi[wave] = nanmask != 0ull; }
+  __syncthreads();
+  const float M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const bool row_nan = (redi[0] | redi[1] | redi[2] | redi[3]) != 0;
+  __syncthreads();
+  float sc = (m == -INFINITY) ? 0.f : s * expf(m - M);
+  sc = wave_sum(sc);
+  if (lane == 0) red[wave] = sc;
+  __syncthreads();
+  const float S = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
+  if (tid == 0) {
+    rowstat[2 * (int64_t)blockIdx.x] = M;
+    rowstat[2 * (int64_t)blockIdx.x + 1] = row_nan ? __int_as_float(0x7fc00000) : S;
+  }
+  int head = 0;
+  for (int r = 0; r < K; ++r) {
+    float cv = head < K ? lv[head * kRowBlock + tid] : -INFINITY;
+    int ci = head < K ? li[head * kRowBlock + tid] : INT_MAX;
+    int owner = tid;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(cv, o, 64);
+      const int oi = __shfl_xor(ci, o, 64);
+      const int oo = __shfl_xor(owner, o, 64);
+      if (beats(ov, oi, cv, ci)) { cv = ov; ci = oi; owner = oo; }
+    }
+    if (lane == 0) { red[wave] = cv; redi[wave] = ci; redi[4 + wave] = owner; }
+    __syncthreads();
+    float bv = red[0]; int bi = redi[0], bo = redi[4];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (beats(red[w], redi[w], bv, bi)) { bv = red[w]; bi = redi[w]; bo = redi[4 + w]; }
+    if (tid == bo) ++head;
+    if (tid == 0) {
+      float q = expf(bv - M) / S;
+      if (row_nan || q != q) q = 0.f;                           // nan_to_num (models.py:111)
+      else if (q > 3.4028234663852886e38f) q = 3.4028234663852886e38f;
+      topv[(int64_t)blockIdx.x * K + r] = q;
+      topi[(int64_t)blockIdx.x * K + r] = row_nan ? r : bi;     // a NaN row is all zeros after nan_to_num: slots 0..K-1
+    }
+    __syncthreads();
+  }
+}
+
+// pbar[l][t] += sum_r mw[r][l] * exp(z[r][t] - m_r) / s_r  over the rows of one chunk.  A block owns 256 columns for the
+// whole chunk (plain read-modify-write, no atomics: launches of successive chunks are stream-ordered); row statistics
+// and multiplicity weights are wave-uniform scalar loads.
+__device__ __forceinline__ float prob_of_fwd(float z, float m, float s) {
+  const float q = expf(z - m) / s;
+  return (q != q) ? 0.f : (q > 3.4028234663852886e38f ? 3.4028234663852886e38f : q);
+}
+
+template <int LMAX>
+__global__ void __launch_bounds__(256)
+pbar_accum_kernel(const float* __restrict__ Z, const float* __restrict__ rowstat, const float* __restrict__ mw, int L,
+                  float* __restrict__ pbar, int64_t U, int64_t T) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool ok = t < T;
+  const int64_t ts = ok ? t : T - 1;
+  float acc[LMAX];
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l) acc[l] = 0.f;
+  for (int64_t r = 0; r < U; ++r) {
+    const float m = rowstat[2 * r], sden = rowstat[2 * r + 1];       // uniform -> scalar loads
+    const float pv = prob_of_fwd(Z[r * T + ts], m, sden);
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) acc[l] += ((l < L) ? mw[r * L + l] : 0.f) * pv;
+  }
+  if (ok) {
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l)
+      if (l < L) pbar[(int64_t)l * T + t] += acc[l];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- low-rank softmax backward
 // Backward of softmax + top-K + batch-mean loss from RECOMPUTED LOGITS, for the chunked per-vertex path:
 //   p = exp(z - m) / s (row stats saved by the forward),  g[r,t] = sum_l mw[r,l] G[l,t]  (+ dq_k at the top-K slots)
@@ -387,6 +501,30 @@ extern "C" int gngf_softmax_topk(float* logits_probs, float* topk_val, int32_t* 
   }
   softmax_topk_kernel<<<dim3((unsigned)U), dim3(kRowBlock), smem, as_stream(stream)>>>(logits_probs, topk_val, topk_idx, T, K, 1,
                                                                                        rowstat);
+  GNGF_RETURN_LAUNCH();
+}
+
+// Streaming forward of the per-vertex HPD tail: logits (U,T) are only READ.  topk_val/topk_idx (U,K), rowstat (U,2);
+// when mw (U,L) is given, pbar (L,T) += mw^T * softmax(logits).
+extern "C" int gngf_logits_topk_pbar(const float* logits, float* topk_val, int32_t* topk_idx, float* rowstat, const float* mw,
+                                     int L, float* pbar, int64_t U, int64_t T, int K, void* stream) {
+  GNGF_CHECK_ARG(U >= 0 && T > 0 && K > 0 && K <= GNGF_MAX_TOPK && K <= T && T < INT_MAX && L >= 0 && L <= GNGF_MAX_LEVELS);
+  if (U == 0) return 0;
+  GNGF_CHECK_ARG(logits && topk_val && topk_idx && rowstat && (L == 0 || (mw && pbar)));
+  hipStream_t s = as_stream(stream);
+  const size_t smem = ((size_t)2 * K * kRowBlock + 16) * sizeof(float);
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(logits_stats_topk_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  logits_stats_topk_kernel<<<dim3((unsigned)U), dim3(kRowBlock), smem, s>>>(logits, topk_val, topk_idx, rowstat, T, K);
+  if (L > 0) {
+    const dim3 grid((unsigned)ceil_div(T, 256));
+    if (L <= 4) pbar_accum_kernel<4><<<grid, dim3(256), 0, s>>>(logits, rowstat, mw, L, pbar, U, T);
+    else if (L <= 16) pbar_accum_kernel<16><<<grid, dim3(256), 0, s>>>(logits, rowstat, mw, L, pbar, U, T);
+    else pbar_accum_kernel<32><<<grid, dim3(256), 0, s>>>(logits, rowstat, mw, L, pbar, U, T);
+  }
   GNGF_RETURN_LAUNCH();
 }
 

@@ -269,9 +269,13 @@ class HpdVertexFunction(torch.autograd.Function):
             hs = HpdVertexFunction._hidden(vertex_coords(u0, n, vstride, dev), params, n_layers)
             z = probs[u0:u0 + n] if keep_probs else scratch[:n]
             call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(z), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
-            call("gngf_softmax_topk", ptr(z), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), ptr(rowstat[u0:u0 + n]), n, T, K, stream_ptr())
-            if pbar is not None:
-                gemm_acc(mw[u0:u0 + n], z, pbar, L, T, n, ta=True, tb=False)
+            if keep_probs:      # dense distribution requested (small shapes): softmax in place, p-bar by GEMM
+                call("gngf_softmax_topk", ptr(z), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), ptr(rowstat[u0:u0 + n]), n, T, K, stream_ptr())
+                if pbar is not None:
+                    gemm_acc(mw[u0:u0 + n], z, pbar, L, T, n, ta=True, tb=False)
+            else:               # streaming: the logits are only read (stats + top-K in one pass, p-bar in a second)
+                call("gngf_logits_topk_pbar", ptr(z), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), ptr(rowstat[u0:u0 + n]),
+                     ptr(mw[u0:u0 + n] if pbar is not None else None), L if pbar is not None else 0, ptr(pbar), n, T, K, stream_ptr())
         if pbar is not None and DP_MEAN is not None:
             DP_MEAN(pbar)      # the loss is a nonlinear function of the batch mean: average BEFORE the log (SURVEY §8e ii)
         ctx.cfg = (NV, vstride, K, rows, n_layers, T, keep_probs)

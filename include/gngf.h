@@ -147,6 +147,11 @@ int gngf_decoder_slab_floats(int in_dim, int out_dim);
  * exp(z - max); NaN marks a NaN-poisoned row), optional (NULL): lets the backward rebuild p from recomputed logits. */
 int gngf_softmax_topk(float* logits_probs, float* topk_val, int32_t* topk_idx, float* rowstat, int64_t U, int64_t T, int K,
                       void* stream);
+/* streaming form for the chunked per-vertex path: logits are only READ (the (rows,T) distribution is never written):
+ * one pass gives the online row statistics and the top-K (selected on the logits; probabilities = exp(z_k - max)/sum),
+ * a second pass accumulates pbar (L,T) += mw (U,L)^T softmax(logits) when mw is given (L = 0: skipped). */
+int gngf_logits_topk_pbar(const float* logits, float* topk_val, int32_t* topk_idx, float* rowstat, const float* mw, int L,
+                          float* pbar, int64_t U, int64_t T, int K, void* stream);
 /* DifferentiableTopk.forward alone (models.py:11) on arbitrary rows x (U,T); same ordering rules. */
 int gngf_topk(const float* x, float* topk_val, int32_t* topk_idx, int64_t U, int64_t T, int K, void* stream);
 /* backward of the above without the dense zero-filled scatter of models.py:27-35:

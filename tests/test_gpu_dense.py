@@ -236,3 +236,36 @@ def test_softmax_bwd_lowrank_from_logits_vs_numpy(ops, U, T, K, Lv):
     scale = np.abs(want).max()
     close(logits, want, 2e-4, 2e-6 * scale)
     close(db, want.sum(0), 2e-4, 2e-5 * scale)
+
+
+@pytest.mark.parametrize("U,T,K,Lv", [(70, 500, 4, 5), (33, 9000, 8, 16), (40, 257, 1, 0), (5, 100000, 32, 3)])
+def test_streaming_logits_topk_pbar_vs_numpy(ops, U, T, K, Lv):
+    """one-read online statistics + top-K on the logits, and the p-bar accumulation from logits"""
+    from collision_handling_in_instantngp_amd._lib import call, ptr, stream_ptr
+    rng = np.random.default_rng(U * 3 + K)
+    z = (rng.standard_normal((U, T)) * 3).astype(np.float32)
+    z[0, : T // 3] = z[0, 0]                                  # ties: lower index wins
+    if U > 2:
+        z[2, 9] = np.nan                                       # NaN row -> probabilities all zero, slots 0..K-1
+    zt = t(z)
+    tv = torch.empty((U, K), device=DEV)
+    ti = torch.empty((U, K), dtype=torch.int32, device=DEV)
+    rowstat = torch.empty((U, 2), device=DEV)
+    mw_t = t(rng.random((U, max(Lv, 1))).astype(np.float32))
+    pbar = torch.zeros((max(Lv, 1), T), device=DEV)
+    call("gngf_logits_topk_pbar", ptr(zt), ptr(tv), ptr(ti), ptr(rowstat), ptr(mw_t if Lv else None), Lv, ptr(pbar if Lv else None),
+         U, T, K, stream_ptr())
+    assert torch.equal(zt, t(z)) or np.isnan(z).any()           # logits are not modified
+    zz = z.astype(np.float64)
+    zm = zz - np.nanmax(zz, -1, keepdims=True)
+    e = np.exp(zm)
+    sm = e / e.sum(-1, keepdims=True)
+    nan_rows = np.isnan(z).any(-1)
+    sm[nan_rows] = 0.0
+    order = np.argsort(-np.where(nan_rows[:, None], -np.arange(T)[None, :].astype(np.float64), zz), axis=-1, kind="stable")[:, :K]
+    order[nan_rows] = np.arange(K)[None, :]
+    assert np.array_equal(ti.cpu().numpy().astype(np.int64), order)
+    close(tv, np.take_along_axis(sm, order, -1), 3e-5, 1e-12)
+    if Lv:
+        want = mw_t.cpu().numpy().astype(np.float64).T @ sm
+        close(pbar, want, 1e-4, 1e-9)
