@@ -254,11 +254,20 @@ pbar_accum_kernel(const float* __restrict__ Z, const float* __restrict__ rowstat
   float acc[LMAX];
 #pragma unroll
   for (int l = 0; l < LMAX; ++l) acc[l] = 0.f;
-  for (int64_t r = 0; r < U; ++r) {
-    const float m = rowstat[2 * r], sden = rowstat[2 * r + 1];       // uniform -> scalar loads
-    const float pv = prob_of_fwd(Z[r * T + ts], m, sden);
+  constexpr int RU = 8;                                            // rows per trip: their loads are issued together
+  for (int64_t r0 = 0; r0 < U; r0 += RU) {
+    float zv[RU];
 #pragma unroll
-    for (int l = 0; l < LMAX; ++l) acc[l] += ((l < L) ? mw[r * L + l] : 0.f) * pv;
+    for (int q = 0; q < RU; ++q) { const int64_t r = r0 + q < U ? r0 + q : U - 1; zv[q] = Z[r * T + ts]; }
+#pragma unroll
+    for (int q = 0; q < RU; ++q) {
+      if (r0 + q >= U) break;
+      const int64_t r = r0 + q;
+      const float m = rowstat[2 * r], sden = rowstat[2 * r + 1];     // uniform -> scalar loads
+      const float pv = prob_of_fwd(zv[q], m, sden);
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) acc[l] += ((l < L) ? mw[r * L + l] : 0.f) * pv;
+    }
   }
   if (ok) {
 #pragma unroll
