@@ -300,3 +300,38 @@ def test_headline_shape_hash_training_curve_matches_reference(golden):
             np.testing.assert_allclose(mse, float(g["mse"][e]), rtol=2e-3)
     finally:
         models.should_use_hash_function = False
+
+
+@pytest.mark.parametrize("mode", ["hash", "gngf_frozen"])
+def test_hipgraph_replay_of_a_step_equals_eager(golden, mode):
+    """bench.py replays one captured forward+backward (helper stream, hint hand-off, per-call workspaces included):
+    the replayed gradients must equal the eager ones."""
+    import bench
+    from collision_handling_in_instantngp_amd import models
+    models.should_use_hash_function = (mode == "hash")
+    try:
+        torch.manual_seed(1)
+        net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=2 ** 15, num_levels=8, n_min=16, n_max=128,
+                                              MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
+                                              HPD_out_features=2 ** 15, feature_dim=2, topk_k=4)
+        net.return_indices = False
+        net.dense_probs = False
+        if mode != "hash":
+            for p in net.HPD.parameters():
+                p.requires_grad = False
+            net.compute_pbar = False
+        X, Y, h, w = strawberry(golden)
+        xy, tgt = X[:60000].contiguous(), Y[:60000].contiguous()
+        step = bench.make_step(net, models, mode, xy, tgt, 1)
+        step()
+        eager = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+        replay = bench.graphed(step)
+        for _ in range(2):
+            replay()
+        torch.cuda.synchronize()
+        for k, p in net.named_parameters():
+            if k in eager:
+                scale = float(eager[k].abs().max()) + 1e-30
+                assert float((p.grad - eager[k]).abs().max()) <= 2e-5 * scale, k
+    finally:
+        models.should_use_hash_function = False
