@@ -312,15 +312,15 @@ tiled_fwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
   }
 }
 
-// fp32 term -> 64-bit fixed point with 2^S fractional scaling, by integer arithmetic on the float's bits
-// (truncation toward zero: error < 2^-S per term).  S is chosen per work item so that no sum can overflow.
+// fp32 term -> 64-bit fixed point with 2^S fractional scaling, exactly, in six VALU operations: scale by the power of
+// two 2^(S-32) (exact), split into floor and fraction (both exact in fp32), convert each half with the hardware
+// converters.  |t * 2^(S-32)| < 2^31 by the choice of S (the whole SUM must stay below 2^62); floor semantics.
 __device__ __forceinline__ long long to_fixed(float t, int S) {
-  const unsigned bits = __float_as_uint(t);
-  const int e = (int)((bits >> 23) & 0xffu);
-  const long long m = (long long)((bits & 0x7fffffu) | (e ? 0x800000u : 0u));
-  const int sh = (e ? e : 1) - 150 + S;
-  long long q = sh >= 0 ? (m << sh) : (sh > -64 ? (m >> (-sh)) : 0ll);
-  return (bits >> 31) ? -q : q;
+  const float u = ldexpf(t, S - 32);
+  const float fl = floorf(u);
+  const int hi = (int)fl;
+  const unsigned lo = (unsigned)ldexpf(u - fl, 32);
+  return ((long long)hi << 32) + (long long)(unsigned long long)lo;
 }
 
 // Backward pixel stage.  gfx950's LDS float atomic (ds_add_f32) retires ~3 cycles PER LANE (193 cycles per
