@@ -261,7 +261,8 @@ __device__ unsigned long long g_stamps[16];
 constexpr int kImgStride = 34;   // 8-byte aligned rows: ds_read_b64 of two consecutive pixels, conflict-free (34*i mod 64)
 constexpr int kImgFloats = 64 * kImgStride;
 
-template <int KIN, bool LEAKY>
+// EXACT: in_dim == KIN (no per-feature predicates anywhere in the loop)
+template <int KIN, bool LEAKY, bool EXACT>
 __global__ void __launch_bounds__(kDecThreads, 1)
 decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, const float* __restrict__ dY,
                    const float* __restrict__ W0, const float* __restrict__ b0, const float* __restrict__ W1,
@@ -270,6 +271,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   using FF = FwdFrags<KIN>;
   constexpr int S0 = KIN / 2;
   constexpr int TX = (KIN + 31) / 32;                    // 32-row tiles of the input width
+  if (EXACT) in_dim = KIN;
   extern __shared__ float smem[];
   float* A0 = smem;                                      // forward fragments (recompute)
   float* A1 = A0 + FF::kA0;
@@ -305,12 +307,12 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   float* imgA = img + wave * 2 * kImgFloats;
   float* imgB = imgA + kImgFloats;
 
-  f32x16 dW1acc[2][2], dW0acc[2][TX], dW2acc[2];
-  f32x16 db0acc[2], db1acc[2];
+  f32x16 dW1acc[2][2], dW0acc[2][TX];
+  f32x4 dW2acc = {0.f, 0.f, 0.f, 0.f};                   // lane j: dW2[c][j], c = 0..3
+  float db0acc[2] = {0.f, 0.f}, db1acc[2] = {0.f, 0.f};  // lane (i,h): partial of db[32a + i] over the half's 16 pixels
   float db2acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
-    dW2acc[a] = 0; db0acc[a] = 0; db1acc[a] = 0;
 #pragma unroll
     for (int b = 0; b < 2; ++b) dW1acc[a][b] = 0;
 #pragma unroll
@@ -339,7 +341,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     const int64_t q = t * 128 + wave * 32 + i;
     const bool ok = t < ntiles && q < P;
 #pragma unroll
-    for (int s = 0; s < S0; ++s) { xr[s] = (ok && (in_dim == KIN || h * S0 + s < in_dim)) ? xn[s] : 0.f; asm volatile("" : "+v"(xr[s])); }
+    for (int s = 0; s < S0; ++s) { xr[s] = (ok && (EXACT || h * S0 + s < in_dim)) ? xn[s] : 0.f; asm volatile("" : "+v"(xr[s])); }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       // dz3 = dY * y (1 - y)   (Sigmoid backward), zero for padding pixels: they then contribute nothing anywhere
@@ -352,7 +354,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   consume(blockIdx.x);
   __builtin_amdgcn_sched_barrier(0);
   fetch((int64_t)blockIdx.x + gridDim.x < ntiles ? (int64_t)blockIdx.x + gridDim.x : blockIdx.x);
-  float dxmax = 0.f;                                     // largest |d enc| this lane produced (hint for the encoder backward)
+  unsigned dxmax = 0u;                                   // bits of the largest |d enc| this lane produced (hint for the encoder backward)
 #if defined(GNGF_STAMPS)
   unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
@@ -374,23 +376,20 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) imgB[(32 * t + crow(r, h)) * kImgStride + i] = acc2[t][r];
-    {   // operands for all 16 k-steps first (pixel k = 16h + s, two per ds_read_b64), THEN the MFMAs: issued one by one
-        // behind each MFMA the reads expose the full LDS latency 32 times per phase (measured: ~50 % MFMA idle)
-      float2 av[8], b0p[8], b1p[8];
+    {   // 3-4 x 64 outputs: v_mfma_f32_4x4x1_16b (16 blocks of 4x4, one pixel per instruction, 8 cycles) instead of two
+        // 32x32 tiles that would be 90 % zeros.  Lane j: B = h2[j][px] (its own image row), A = dz3[j & 3][px];
+        // d[c] accumulates dW2[c][j].  Operands are read first (two pixels per ds_read_b64), then the MFMA run.
+      float2 av[16], bv[16];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        av[q] = *reinterpret_cast<const float2*>(imgA + (i & 3) * kImgStride + 16 * h + 2 * q);
-        b0p[q] = *reinterpret_cast<const float2*>(imgB + i * kImgStride + 16 * h + 2 * q);
-        b1p[q] = *reinterpret_cast<const float2*>(imgB + (32 + i) * kImgStride + 16 * h + 2 * q);
+      for (int q = 0; q < 16; ++q) {
+        av[q] = *reinterpret_cast<const float2*>(imgA + (lane & 3) * kImgStride + 2 * q);
+        bv[q] = *reinterpret_cast<const float2*>(imgB + lane * kImgStride + 2 * q);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float a0 = i < 4 ? av[q].x : 0.f, a1 = i < 4 ? av[q].y : 0.f;
-        dW2acc[0] = MFMA(a0, b0p[q].x, dW2acc[0]);
-        dW2acc[1] = MFMA(a0, b1p[q].x, dW2acc[1]);
-        dW2acc[0] = MFMA(a1, b0p[q].y, dW2acc[0]);
-        dW2acc[1] = MFMA(a1, b1p[q].y, dW2acc[1]);
+      for (int q = 0; q < 16; ++q) {
+        dW2acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].x, bv[q].x, dW2acc, 0, 0, 0);
+        dW2acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].y, bv[q].y, dW2acc, 0, 0, 0);
       }
     }
     STAMP(2);
@@ -406,7 +405,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { d2[t][r] *= hidden_dact<LEAKY>(acc2[t][r]); db1acc[t][r] += d2[t][r]; }
+      for (int r = 0; r < 16; ++r) d2[t][r] *= hidden_dact<LEAKY>(acc2[t][r]);
     STAMP(3);
     // ---- dW1 += dz2^T h1 : dz2T -> imgA, h1T -> imgB
 #pragma unroll
@@ -437,6 +436,11 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
         dW1acc[1][0] = MFMA(a1p[q].y, b0p[q].y, dW1acc[1][0]);
         dW1acc[1][1] = MFMA(a1p[q].y, b1p[q].y, dW1acc[1][1]);
       }
+      // db1[32a + i] += sum over this half's 16 pixels of dz2 (the A operands ARE dz2^T): 2 registers instead of 32
+      float2 s0 = a0p[0], s1 = a1p[0];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) { s0.x += a0p[q].x; s0.y += a0p[q].y; s1.x += a1p[q].x; s1.y += a1p[q].y; }
+      db1acc[0] += s0.x + s0.y; db1acc[1] += s1.x + s1.y;
     }
     STAMP(4);
     // ---- dh1^T = W1^T dz2^T
@@ -457,7 +461,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { d1[t][r] *= hidden_dact<LEAKY>(acc1[t][r]); db0acc[t][r] += d1[t][r]; }
+      for (int r = 0; r < 16; ++r) d1[t][r] *= hidden_dact<LEAKY>(acc1[t][r]);
     STAMP(5);
     // ---- dW0 += dz1^T x : dz1T -> imgA, xT -> imgB (rows = input features)
 #pragma unroll
@@ -488,6 +492,10 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
           dW0acc[0][tx] = MFMA(a0p[q].y, bp[tx][q].y, dW0acc[0][tx]);
           dW0acc[1][tx] = MFMA(a1p[q].y, bp[tx][q].y, dW0acc[1][tx]);
         }
+      float2 s0 = a0p[0], s1 = a1p[0];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) { s0.x += a0p[q].x; s0.y += a0p[q].y; s1.x += a1p[q].x; s1.y += a1p[q].y; }
+      db0acc[0] += s0.x + s0.y; db0acc[1] += s1.x + s1.y;
     }
     STAMP(6);
     // ---- d enc^T = W0^T dz1^T ; regs 4g..4g+3 are 4 consecutive input features.  Two accumulator chains per tile.
@@ -507,7 +515,10 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
       }
       dxv[tx] = dxa + dxb;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { const float a = fabsf(dxv[tx][r]); dxmax = (a > dxmax || a != a) ? a : dxmax; }   // NaN sticks
+      for (int r = 0; r < 16; ++r) {      // |x| bit patterns order like the values, NaN above inf: it sticks
+        const unsigned a = __float_as_uint(dxv[tx][r]) & 0x7fffffffu;
+        dxmax = a > dxmax ? a : dxmax;
+      }
     }
     // end of tile: consume tile t+1's rows (their loads were issued a whole tile ago), THEN store, THEN prefetch t+2
     consume(tile + gridDim.x);
@@ -518,7 +529,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int col = 32 * tx + 8 * g + 4 * h;
-          if (in_dim == KIN) {
+          if (EXACT) {
             if (32 * tx + 8 * g + 8 <= KIN)            // KIN = 16: only g = 0, 1 are real input features
               *reinterpret_cast<float4*>(dX + pix * KIN + col) =
                   make_float4(dxv[tx][4 * g], dxv[tx][4 * g + 1], dxv[tx][4 * g + 2], dxv[tx][4 * g + 3]);
@@ -543,8 +554,8 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
 #endif
   if (absmax) {                                          // non-negative floats (and NaN > inf) order like their bit patterns
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const float ov = __shfl_xor(dxmax, o, 64); dxmax = (ov > dxmax || ov != ov) ? ov : dxmax; }
-    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(dxmax));
+    for (int o = 32; o > 0; o >>= 1) { const unsigned ov = (unsigned)__shfl_xor((int)dxmax, o, 64); dxmax = ov > dxmax ? ov : dxmax; }
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(absmax), dxmax);
   }
   // ---- wave accumulators -> workgroup slab.  No LDS float atomics (ds_add_f32 costs ~190 cycles per wave-instruction
   // on gfx950): every wave stores its tiles into its own LDS region, bias partials are reduced over the 32 pixel lanes
@@ -567,18 +578,15 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
 #pragma unroll
       for (int tx = 0; tx < TX; ++tx)
         if (32 * tx + i < in_dim) sW0[row * in_dim + 32 * tx + i] = dW0acc[ti][tx][r];
-      float v0 = db0acc[ti][r], v1 = db1acc[ti][r];       // every lane of a half holds one pixel's share
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o, 64); v1 += __shfl_xor(v1, o, 64); }
-      if (i == 0) { sb0[row] = v0; sb1[row] = v1; }
     }
 #pragma unroll
-  for (int tj = 0; tj < 2; ++tj)
+  for (int ti = 0; ti < 2; ++ti) {                       // the two lane halves hold the two 16-pixel halves of every tile
+    const float v0 = db0acc[ti] + __shfl_xor(db0acc[ti], 32, 64), v1 = db1acc[ti] + __shfl_xor(db1acc[ti], 32, 64);
+    if (h == 0) { sb0[32 * ti + i] = v0; sb1[32 * ti + i] = v1; }
+  }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = crow(r, h);
-      if (row < out_dim) sW2[row * kH + 32 * tj + i] = dW2acc[tj][r];
-    }
+  for (int c = 0; c < 4; ++c)
+    if (c < out_dim) sW2[c * kH + lane] = dW2acc[c];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     float v = h == 0 ? db2acc[c] : 0.f;
@@ -682,12 +690,14 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
     GNGF_CHECK_ARG(enc && rgb && drgb && W0 && b0 && W1 && b1 && W2 && denc);
     DISPATCH_KIN(in_dim, {
       const size_t smem = bwd_smem_bytes<kKIN>(in_dim, out_dim);
-      const void* fn = leaky ? reinterpret_cast<const void*>(decoder_bwd_kernel<kKIN, true>)
-                             : reinterpret_cast<const void*>(decoder_bwd_kernel<kKIN, false>);
-      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      using Kern = void (*)(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                            const float*, float*, float*, float*, int64_t, int, int);
+      const bool exact = in_dim == kKIN;
+      const Kern fn = leaky ? (exact ? decoder_bwd_kernel<kKIN, true, true> : decoder_bwd_kernel<kKIN, true, false>)
+                            : (exact ? decoder_bwd_kernel<kKIN, false, true> : decoder_bwd_kernel<kKIN, false, false>);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
-      if (leaky) decoder_bwd_kernel<kKIN, true><<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, denc_absmax, P, in_dim, out_dim);
-      else decoder_bwd_kernel<kKIN, false><<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, denc_absmax, P, in_dim, out_dim);
+      fn<<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, denc_absmax, P, in_dim, out_dim);
     });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
