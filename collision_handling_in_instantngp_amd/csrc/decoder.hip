@@ -27,10 +27,22 @@ __device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2
 // k index (feature of a 64-wide activation held as two accumulator tiles) consumed at chained k-step s2 by lane half h
 __device__ __forceinline__ int kmapC(int s2, int h) { return 32 * (s2 >> 4) + crow(s2 & 15, h); }
 
-template <bool LEAKY> __device__ __forceinline__ float hidden_act(float z) { return LEAKY ? (z > 0.f ? z : 0.01f * z) : fmaxf(z, 0.f); }
+// One VALU instruction for ReLU (fmaxf compiles to a canonicalising v_max pair), two for LeakyReLU (max(z, 0.01 z)).
+// On gfx950 a wave's VALU instructions do NOT overlap its MFMAs (measured: 64 + 10 + 4n cycles for an MFMA followed by
+// n VALU instructions, tools/micro/gen_mfma_mix.py), so every VALU instruction in the tile loop costs 4 cycles flat.
+__device__ __forceinline__ float vmax0(float z) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(z)); return r; }
+template <bool LEAKY> __device__ __forceinline__ float hidden_act(float z) {
+  if (LEAKY) { float r; const float t = 0.01f * z; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(z), "v"(t)); return r; }
+  return vmax0(z);
+}
 template <bool LEAKY> __device__ __forceinline__ float hidden_dact(float y) { return y > 0.f ? 1.f : (LEAKY ? 0.01f : 0.f); }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// scheduling groups (LLVM SchedGroupMask): the next N instructions of that class, in the order the groups are written
+#define SG_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, (n), 0)
+#define SG_VALU(n) __builtin_amdgcn_sched_group_barrier(0x002, (n), 0)
+#define SG_DSR(n) __builtin_amdgcn_sched_group_barrier(0x100, (n), 0)
+#define SG_DSW(n) __builtin_amdgcn_sched_group_barrier(0x200, (n), 0)
 
 // Coalesced copy of the raw weights into LDS with a +1 padded row stride (conflict-free strided reads afterwards):
 //   W0s [64][in_dim+1] | W1s [64][65] | W2s [4][65] | b0 [64] | b1 [64] | b2 [4]
@@ -148,13 +160,25 @@ __device__ __forceinline__ void hidden_layers(const float* A0, const float* A1, 
 // the lane's own accumulator register is the B operand, the lane's (channel = lane%4) weight the A operand; the two
 // lane halves hold different features of the same pixel and are combined with one cross-half shuffle).
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-template <int KIN, bool LEAKY>
+#if defined(GNGF_STAMPS)   // diagnostic build only (tools/perf_decoder.py --stamps): per-phase cycle shares of the backward loop
+__device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_fstamps[16];
+#define STAMP(k) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    ph[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
+template <int KIN, bool LEAKY, bool EXACT>
 __global__ void __launch_bounds__(kDecThreads, 1)
 decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, const float* __restrict__ b0,
                    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
                    const float* __restrict__ b2, float* __restrict__ Y, int64_t P, int in_dim, int out_dim) {
   constexpr int S0 = KIN / 2;
+  if (EXACT) in_dim = KIN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
   const int64_t ntiles = (P + 127) / 128;
   // register-resident operands, gathered from a coalesced LDS copy of the raw weights
@@ -178,48 +202,75 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
   float b2v[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) b2v[c] = raw[o.b2 + c];
-
-  float xn[S0];
-  {
-    const int64_t pix0 = (int64_t)blockIdx.x * 128 + wave * 32 + i;
-    load_x<KIN>(X, pix0, pix0 < P && (int64_t)blockIdx.x < ntiles, in_dim, h, xn, P);
+  // The weight fragments are only ever MFMA operands: park them in the accumulation half of the register file so that
+  // the activations (touched by VALU between the layers) get the architectural VGPRs and need no v_accvgpr moves.
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int s = 0; s < S0; ++s) asm volatile("" : "+a"(a0r[t][s]));
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) asm volatile("" : "+a"(a1r[t][s2]));
   }
-  // Stores are software-pipelined one tile late: CDNA4's vmcnt counts stores too and hipcc waits vmcnt(0) at the first
-  // use of the prefetched row, so a store issued at the END of a tile would put its full write latency on the critical
-  // path of the next tile.  Issued right after that wait instead, it retires under the next tile's MFMAs.
-  float yprev[4] = {0.f, 0.f, 0.f, 0.f};
-  int64_t pixprev = -1;
+#pragma unroll
+  for (int s2 = 0; s2 < 32; ++s2) asm volatile("" : "+a"(w2a[s2]));
+
+  // Rows are fetched and results stored through per-tile buffer descriptors: out-of-range lanes (the ragged last tile,
+  // tiles past the end, the idle lane half of a store, channels >= out_dim) read zeros / are dropped by the hardware
+  // range check, so the loop body has no branches and stays ONE scheduling region per phase.
+  const unsigned xoff = (unsigned)(((wave * 32 + i) * in_dim + (EXACT ? h * S0 : 0)) * 4);
+  auto fetch = [&](int64_t t, float* dst) {
+    const int64_t tt = t < ntiles ? t : ntiles;          // past the end: an empty window, every lane reads zeros
+    int64_t rem = (P - tt * 128) * in_dim * 4;
+    rem = rem < 0 ? 0 : (rem > 128 * in_dim * 4 ? 128 * in_dim * 4 : rem);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X) + tt * 128 * in_dim, 0, (int)rem, 0x00020000);
+    if (EXACT) {
+#pragma unroll
+      for (int k = 0; k < S0 / 4; ++k) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff + 16 * k, 0, 0);
+        dst[4 * k] = __uint_as_float(v.x); dst[4 * k + 1] = __uint_as_float(v.y);
+        dst[4 * k + 2] = __uint_as_float(v.z); dst[4 * k + 3] = __uint_as_float(v.w);
+      }
+    } else {
+#pragma unroll
+      for (int sx = 0; sx < S0; ++sx) {
+        const int k = h * S0 + sx;
+        dst[sx] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, k < in_dim ? xoff + 4 * k : 0x40000000u, 0, 0));
+      }
+    }
+  };
+  const unsigned yoff = (unsigned)(((wave * 32 + i) * out_dim) * 4);
+  float xn[S0];
+  fetch(blockIdx.x, xn);
+#if defined(GNGF_STAMPS)
+  unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
+#endif
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t pix = tile * 128 + wave * 32 + i;
-    const bool valid = pix < P;
+    STAMP(0);
     float xr[S0];
 #pragma unroll
-    for (int s = 0; s < S0; ++s) { xr[s] = valid ? xn[s] : 0.f; asm volatile("" : "+v"(xr[s])); }
+    for (int sx = 0; sx < S0; ++sx) { xr[sx] = xn[sx]; asm volatile("" : "+v"(xr[sx])); }
     // hipcc waits vmcnt(0) at the first use of a value loaded in the previous iteration; pin that use ABOVE the
-    // next tile's loads so the wait retires only the old loads and the new ones fly under this tile's MFMAs.
+    // next tile's loads so the wait retires only the old loads (and the old stores) and the new ones fly under the MFMAs.
     __builtin_amdgcn_sched_barrier(0);
-    if (pixprev >= 0 && h == 0) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (c < out_dim) Y[pixprev * out_dim + c] = yprev[c];
-    }
-    {
-      const int64_t npix = (tile + gridDim.x) * 128 + wave * 32 + i;
-      load_x<KIN>(X, npix, npix < P && tile + gridDim.x < ntiles, in_dim, h, xn, P);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    fetch(tile + gridDim.x, xn);
+    STAMP(1);
+    // MFMA runs and VALU bursts strictly alternate (every switch costs ~10 cycles on top of 4 per VALU instruction)
     f32x16 acc1[2], acc2[2];
     acc1[0] = MFMA(a0r[0][0], xr[0], b0v[0]);
     acc1[1] = MFMA(a0r[1][0], xr[0], b0v[1]);
 #pragma unroll
-    for (int s = 1; s < S0; ++s) {
-      acc1[0] = MFMA(a0r[0][s], xr[s], acc1[0]);
-      acc1[1] = MFMA(a0r[1][s], xr[s], acc1[1]);
+    for (int sx = 1; sx < S0; ++sx) {
+      acc1[0] = MFMA(a0r[0][sx], xr[sx], acc1[0]);
+      acc1[1] = MFMA(a0r[1][sx], xr[sx], acc1[1]);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[t][r] = hidden_act<LEAKY>(acc1[t][r]);
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(2);
     acc2[0] = MFMA(a1r[0][0], acc1[0][0], b1v[0]);
     acc2[1] = MFMA(a1r[1][0], acc1[0][0], b1v[1]);
 #pragma unroll
@@ -228,36 +279,46 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
       acc2[0] = MFMA(a1r[0][s2], b, acc2[0]);
       acc2[1] = MFMA(a1r[1][s2], b, acc2[1]);
     }
-    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s2 = 0; s2 < 32; ++s2)
-      d = __builtin_amdgcn_mfma_f32_4x4x1f32(w2a[s2], hidden_act<LEAKY>(acc2[s2 >> 4][s2 & 15]), d, 0, 0, 0);
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float z = d[c] + __shfl_xor(d[c], 32, 64) + b2v[c];
-      yprev[c] = 1.0f / (1.0f + expf(-z));
+      for (int r = 0; r < 16; ++r) acc2[t][r] = hidden_act<LEAKY>(acc2[t][r]);
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(3);
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < 32; s2 += 2) {
+      d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2a[s2], acc2[s2 >> 4][s2 & 15], d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2a[s2 + 1], acc2[(s2 + 1) >> 4][(s2 + 1) & 15], d1, 0, 0, 0);
     }
-    pixprev = valid ? pix : -1;
-  }
-  if (pixprev >= 0 && h == 0) {
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      int64_t rem = (P - tile * 128) * out_dim * 4;
+      rem = rem > 128 * out_dim * 4 ? 128 * out_dim * 4 : rem;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Y + tile * 128 * out_dim, 0, (int)rem, 0x00020000);
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (c < out_dim) Y[pixprev * out_dim + c] = yprev[c];
+      for (int c = 0; c < 4; ++c) {
+        const float dc = d0[c] + d1[c];
+        const float z = dc + __shfl_xor(dc, 32, 64) + b2v[c];
+        // Sigmoid on the hardware exp2 / rcp units (1 ulp each; |error| < 3e-7 absolute, tests hold 1e-6)
+        const float y = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
+        const unsigned off = (h == 0 && c < out_dim) ? yoff + 4u * c : 0x40000000u;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs, off, 0, 0);
+      }
+    }
+    STAMP(4);
   }
+#if defined(GNGF_STAMPS)
+  if (blockIdx.x == 7 && threadIdx.x == 0)
+    for (int k = 0; k < 10; ++k) g_fstamps[k] = ph[k];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ backward
 // slab layout (floats): dW0 [64*in_dim] | dW1 [64*64] | dW2 [out_dim*64] | db0 [64] | db1 [64] | db2 [out_dim]
 __host__ __device__ inline int slab_size(int in_dim, int out_dim) { return kH * in_dim + kH * kH + out_dim * kH + 2 * kH + out_dim; }
 
-#if defined(GNGF_STAMPS)   // diagnostic build only (tools/perf_decoder.py --stamps): per-phase cycle shares of the backward loop
-__device__ unsigned long long g_stamps[16];
-#define STAMP(k) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
-    ph[k] += t_ - tlast; tlast = t_; } while (0)
-#else
-#define STAMP(k) do {} while (0)
-#endif
 constexpr int kImgStride = 34;   // 8-byte aligned rows: ds_read_b64 of two consecutive pixels, conflict-free (34*i mod 64)
 constexpr int kImgFloats = 64 * kImgStride;
 
@@ -662,8 +723,12 @@ extern "C" int gngf_decoder_fwd(const float* enc, const float* W0, const float* 
   const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);       // one persistent workgroup per CU
   const size_t smem = sizeof(float) * (size_t)raw_offsets(in_dim).total;
   DISPATCH_KIN(in_dim, {
-    if (leaky) decoder_fwd_kernel<kKIN, true><<<dim3(grid), dim3(kDecThreads), smem, as_stream(stream)>>>(enc, W0, b0, W1, b1, W2, b2, rgb, P, in_dim, out_dim);
-    else decoder_fwd_kernel<kKIN, false><<<dim3(grid), dim3(kDecThreads), smem, as_stream(stream)>>>(enc, W0, b0, W1, b1, W2, b2, rgb, P, in_dim, out_dim);
+    using Kern = void (*)(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
+                          int64_t, int, int);
+    const bool exact = in_dim == kKIN;
+    const Kern fn = leaky ? (exact ? decoder_fwd_kernel<kKIN, true, true> : decoder_fwd_kernel<kKIN, true, false>)
+                          : (exact ? decoder_fwd_kernel<kKIN, false, true> : decoder_fwd_kernel<kKIN, false, false>);
+    fn<<<dim3(grid), dim3(kDecThreads), smem, as_stream(stream)>>>(enc, W0, b0, W1, b1, W2, b2, rgb, P, in_dim, out_dim);
   });
   GNGF_RETURN_LAUNCH();
 }
@@ -708,6 +773,9 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
 }
 
 #if defined(GNGF_STAMPS)
+extern "C" int gngf_debug_read_fwd_stamps(unsigned long long* host16) {
+  return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(gngf::g_fstamps), 16 * sizeof(unsigned long long));
+}
 extern "C" int gngf_debug_read_stamps(unsigned long long* host16) {
   return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(gngf::g_stamps), 16 * sizeof(unsigned long long));
 }

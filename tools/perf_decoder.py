@@ -35,3 +35,10 @@ if os.environ.get("GNGF_LIB_PATH", "").endswith("stamps.so"):
     for n, v in zip(names, buf[:8]):
         print(f"  {n:18s} {v/32:9.0f} cycles/tile  {100*v/max(tot,1):5.1f}%")
     print("  total per tile", tot / 32)
+    _lib.load().gngf_debug_read_fwd_stamps.argtypes = [ctypes.c_void_p]
+    print("fwd rc", _lib.load().gngf_debug_read_fwd_stamps(buf))
+    names = ["loop top", "consume/store/prefetch", "L1 (+act tile 0)", "L2 k<32 (+act tile 1)", "L2 k>=32 (+out tile 0)", "out tile 1 + sigmoid"]
+    tot = sum(buf[:6])
+    for n, v in zip(names, buf[:6]):
+        print(f"  {n:26s} {v/32:9.0f} cycles/tile  {100*v/max(tot,1):5.1f}%")
+    print("  total per tile", tot / 32)
