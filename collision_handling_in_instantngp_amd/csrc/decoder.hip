@@ -15,6 +15,8 @@
 //   Hidden activations are recomputed in backward (96 of 324 MFMAs per 32 pixels) instead of being stored
 //   (512 B/pixel of HBM traffic each way).
 #include "gngf_common.h"
+#include <type_traits>
+#include <utility>
 
 namespace gngf {
 
@@ -36,6 +38,39 @@ template <bool LEAKY> __device__ __forceinline__ float hidden_act(float z) {
   return vmax0(z);
 }
 template <bool LEAKY> __device__ __forceinline__ float hidden_dact(float y) { return y > 0.f ? 1.f : (LEAKY ? 0.01f : 0.f); }
+// d * act'(y) as a select (two VALU instructions; the multiply by a 0/1 mask would be a third)
+template <bool LEAKY> __device__ __forceinline__ float hidden_dsel(float y, float d) { return y > 0.f ? d : (LEAKY ? 0.01f * d : 0.f); }
+
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+// LDS access with an immediate byte offset from a per-lane base address (see decoder_bwd_kernel)
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const float*)p;
+}
+template <int OFF> __device__ __forceinline__ void lds_store(unsigned addr, float v) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset is 16 bits");
+  asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ f32x2 lds_load2(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset is 16 bits");
+  f32x2 r;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+template <int OFF> __device__ __forceinline__ float lds_load1(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset is 16 bits");
+  float r;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+// The consumers of lds_load* results depend on the loads, not on this wait: the scheduling barrier keeps them below it.
+__device__ __forceinline__ void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <typename F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 // scheduling groups (LLVM SchedGroupMask): the next N instructions of that class, in the order the groups are written
@@ -321,6 +356,12 @@ __host__ __device__ inline int slab_size(int in_dim, int out_dim) { return kH * 
 
 constexpr int kImgStride = 34;   // 8-byte aligned rows: ds_read_b64 of two consecutive pixels, conflict-free (34*i mod 64)
 constexpr int kImgFloats = 64 * kImgStride;
+// per-wave transposition images of the backward kernel: imgA | imgB | imgZ (dz3, 4 rows) | imgX (input rows; aliased to
+// imgB when the input is 64 wide — the four dedicated images would not fit next to the 64-wide fragments in 160 KB)
+template <int KIN> struct BwdLds {
+  static constexpr bool kDedicatedX = KIN <= 32;
+  static constexpr int kWaveFloats = 2 * kImgFloats + 4 * kImgStride + (kDedicatedX ? KIN * kImgStride : 0);
+};
 
 // EXACT: in_dim == KIN (no per-feature predicates anywhere in the loop)
 template <int KIN, bool LEAKY, bool EXACT>
@@ -340,7 +381,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   float* A1T = A2T + 2 * 2 * 64;                         // [t(2)][s2(32)][64] : W1[kmapC(s2,h)][32t+i]
   float* A0T = A1T + 2 * 32 * 64;                        // [t(TX)][s2(32)][64]: W0[kmapC(s2,h)][32t+i]
   float* bs = A0T + TX * 32 * 64;                        // b0 | b1
-  float* img = bs + 2 * kH;                              // per wave: imgA [64][33], imgB [64][33]
+  float* img = bs + 2 * kH;                              // per wave: imgA [64][34] | imgB [64][34] | imgZ [4][34] | imgX [KIN][34]
   const int nslab = slab_size(in_dim, out_dim);
 
   float* raw = img;                                      // the image area is free until the main loop starts
@@ -365,13 +406,48 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
-  float* imgA = img + wave * 2 * kImgFloats;
-  float* imgB = imgA + kImgFloats;
+  using BL = BwdLds<KIN>;
+  float* imgA = img + wave * BL::kWaveFloats;
+  // Per-lane LDS byte addresses of the transposition images.  All image traffic goes through ds ops with IMMEDIATE
+  // offsets from these few bases (inline asm): left to itself hipcc pairs the stores into ds_write2_b32, whose 8-bit
+  // offsets force a v_add per pair — and a VALU instruction costs 4 issue cycles that nothing overlaps (see above).
+  const unsigned aImg = lds_addr(imgA);
+  const unsigned wTile = aImg + (unsigned)(4 * h * kImgStride + i) * 4u;        // accumulator tile -> rows crow(r, h), column i
+  constexpr int kImgB = kImgFloats * 4;                                         // byte offsets of images B, Z (dz3), X (input rows)
+  constexpr int kImgZ = 2 * kImgFloats * 4;
+  constexpr int kImgX = BL::kDedicatedX ? (2 * kImgFloats + 4 * kImgStride) * 4 : kImgB;
+  const unsigned wDz3 = aImg + (unsigned)i * 4u;                                // dz3 -> rows c of imgZ
+  const unsigned wX = aImg + (unsigned)(h * S0 * kImgStride + i) * 4u;          // x slice -> rows h*S0 + s of imgX
+  const unsigned rOp = aImg + (unsigned)(i * kImgStride + 16 * h) * 4u;         // operand rows i (+32), pixels 16h + 2q, 2q+1
+  const unsigned rZ2 = aImg + (unsigned)((lane & 3) * kImgStride) * 4u;         // dW2: A rows lane & 3 of imgZ, all 32 pixels
+  const unsigned rH2 = aImg + (unsigned)(lane * kImgStride) * 4u;               //      B rows lane of imgA
+  auto put_tile = [&](auto IMG, const f32x16 (&v)[2]) {
+    static_for<32>([&](auto E) {
+      constexpr int t = E.value >> 4, r = E.value & 15;
+      lds_store<decltype(IMG)::value * kImgB + (32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile, v[t][r]);
+    });
+  };
+  // the lane's own elements of a tile pair back from image IMG (same addresses as put_tile)
+  auto get_tile = [&](auto IMG, float (&v)[2][16]) {
+    static_for<32>([&](auto E) {
+      constexpr int t = E.value >> 4, r = E.value & 15;
+      v[t][r] = lds_load1<decltype(IMG)::value * kImgB + (32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile);
+    });
+  };
+  // operand rows i (a = 0) / 32 + i (a = 1) of the image at byte offset OFF: 8 x two pixels
+  auto get_rows = [&](auto OFF, auto A, f32x2 (&dst)[8]) {
+    static_for<8>([&](auto Q) { dst[Q.value] = lds_load2<decltype(OFF)::value + (32 * decltype(A)::value * kImgStride + 2 * Q.value) * 4>(rOp); });
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using OA = std::integral_constant<int, 0>;
+  using OB = std::integral_constant<int, kImgB>;
+  using OX = std::integral_constant<int, kImgX>;
 
   f32x16 dW1acc[2][2], dW0acc[2][TX];
   f32x4 dW2acc = {0.f, 0.f, 0.f, 0.f};                   // lane j: dW2[c][j], c = 0..3
   float db0acc[2] = {0.f, 0.f}, db1acc[2] = {0.f, 0.f};  // lane (i,h): partial of db[32a + i] over the half's 16 pixels
-  float db2acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float db2acc[4] = {0.f, 0.f, 0.f, 0.f};                // both lane halves accumulate the same pixel; half 0 is used
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -380,112 +456,179 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     for (int b = 0; b < TX; ++b) dW0acc[a][b] = 0;
   }
 
+  // The loop-carried weight-gradient tiles must STAY in accumulation registers: left alone hipcc assigns them to VGPRs
+  // and copies 100 registers into AGPRs and back around the MFMA runs of every tile.  Pinned at every phase boundary.
+  auto pin_acc = [&]() {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) asm volatile("" : "+a"(dW1acc[a][b]));
+#pragma unroll
+      for (int b = 0; b < TX; ++b) asm volatile("" : "+a"(dW0acc[a][b]));
+    }
+    asm volatile("" : "+a"(dW2acc));
+  };
   const int64_t ntiles = (P + 127) / 128;
-  // next-tile prefetch of the input row, the forward output and its gradient (raw values; masked when consumed)
-  float xn[S0], yn[4], dyn[4];
-  auto fetch = [&](int64_t t) {
-    int64_t q = t * 128 + wave * 32 + i;
-    q = q < P ? q : P - 1;
-    load_x<KIN>(X, q, true, in_dim, h, xn, P);
+  // Rows are fetched / stored through per-tile buffer descriptors (as in the forward kernel): lanes past the end of
+  // the batch read zeros (so dz3 = 0 and they contribute nothing anywhere) and their stores are dropped — no masks.
+  const unsigned xoff = (unsigned)(((wave * 32 + i) * in_dim + (EXACT ? h * S0 : 0)) * 4);
+  const unsigned yoff = (unsigned)(((wave * 32 + i) * out_dim) * 4);
+  // Pipeline: x of tile t+1 is loaded straight into xr as soon as tile t has consumed it (after layer 1 / after the x
+  // image is written), y and dy of tile t+1 once dz3 of tile t is dead; both land long before the next tile starts, and
+  // the d-enc stores at the end of a tile are issued after them, so no wait ever covers a store (vmcnt counts in order).
+  float xr[S0], yn[4], dyn[4], dz3[4];
+  auto tile_window = [&](int64_t t, int64_t& tt, int& rows) {
+    tt = t < ntiles ? t : ntiles;                        // past the end: an empty window, every lane reads zeros
+    int64_t rem = P - tt * 128;
+    rows = (int)(rem < 0 ? 0 : (rem > 128 ? 128 : rem));
+  };
+  auto fetch_x = [&](int64_t t) {
+    int64_t tt; int rows;
+    tile_window(t, tt, rows);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X) + tt * 128 * in_dim, 0, rows * in_dim * 4, 0x00020000);
+    if (EXACT) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int cc = c < out_dim ? c : 0;
-      yn[c] = Yout[q * out_dim + cc];
-      dyn[c] = dY[q * out_dim + cc];
+      for (int k = 0; k < S0 / 4; ++k) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + 16 * k, 0, 0);
+        xr[4 * k] = __uint_as_float(v.x); xr[4 * k + 1] = __uint_as_float(v.y);
+        xr[4 * k + 2] = __uint_as_float(v.z); xr[4 * k + 3] = __uint_as_float(v.w);
+      }
+    } else {
+#pragma unroll
+      for (int sx = 0; sx < S0; ++sx) {
+        const int k = h * S0 + sx;
+        xr[sx] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, k < in_dim ? xoff + 4 * k : 0x40000000u, 0, 0));
+      }
     }
   };
-  // Software pipeline: the rows of tile t+1 are CONSUMED (vmcnt wait) at the END of tile t, before tile t's d-enc stores
-  // are issued and before the loads of tile t+2 — so neither the store latency nor the load latency is ever waited for
-  // at the top of a tile (CDNA4's vmcnt counts stores; hipcc waits vmcnt(0) at the first use of a prefetched value).
-  float xr[S0], dz3[4];
-  auto consume = [&](int64_t t) {
-    const int64_t q = t * 128 + wave * 32 + i;
-    const bool ok = t < ntiles && q < P;
-#pragma unroll
-    for (int s = 0; s < S0; ++s) { xr[s] = (ok && (EXACT || h * S0 + s < in_dim)) ? xn[s] : 0.f; asm volatile("" : "+v"(xr[s])); }
+  auto fetch_y = [&](int64_t t) {
+    int64_t tt; int rows;
+    tile_window(t, tt, rows);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Yout) + tt * 128 * out_dim, 0, rows * out_dim * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dY) + tt * 128 * out_dim, 0, rows * out_dim * 4, 0x00020000);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      // dz3 = dY * y (1 - y)   (Sigmoid backward), zero for padding pixels: they then contribute nothing anywhere
-      dz3[c] = (ok && c < out_dim) ? dyn[c] * (yn[c] * (1.f - yn[c])) : 0.f;
-      asm volatile("" : "+v"(dz3[c]));
-      if (h == 0) db2acc[c] += dz3[c];
+      const unsigned off = c < out_dim ? yoff + 4u * c : 0x40000000u;
+      yn[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0));
+      dyn[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0));
     }
   };
-  fetch(blockIdx.x);
-  consume(blockIdx.x);
-  __builtin_amdgcn_sched_barrier(0);
-  fetch((int64_t)blockIdx.x + gridDim.x < ntiles ? (int64_t)blockIdx.x + gridDim.x : blockIdx.x);
+  auto make_dz3 = [&]() {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      dz3[c] = dyn[c] * (yn[c] * (1.f - yn[c]));          // Sigmoid backward; 0 for padding pixels and channels
+      asm volatile("" : "+v"(dz3[c]));                   // (keeps dz3 in registers: it is selected by lane half below)
+      db2acc[c] += dz3[c];
+    }
+  };
+  fetch_x(blockIdx.x);
+  fetch_y(blockIdx.x);
+  make_dz3();
+  // biases: accumulator-file residents, the C operand of the first MFMA of each recompute chain
+  f32x16 b0v[2], b1v[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { b0v[t][r] = bs[32 * t + crow(r, h)]; b1v[t][r] = bs[kH + 32 * t + crow(r, h)]; }
+    asm volatile("" : "+a"(b0v[t]), "+a"(b1v[t]));
+  }
   unsigned dxmax = 0u;                                   // bits of the largest |d enc| this lane produced (hint for the encoder backward)
 #if defined(GNGF_STAMPS)
   unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
 #endif
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t pix = tile * 128 + wave * 32 + i;
-    const bool valid = pix < P;
+    pin_acc();
     STAMP(0);
+    // Register lifetimes are kept short on purpose (hipcc parks long-lived VGPR values in AGPRs and every move is a
+    // 4-cycle VALU instruction): x goes to its own image right away, h1 to imgB as soon as it exists (it is read back
+    // for the activation mask of dh1), h2 / dz2 / dz1 take turns in imgA.
+    if (BL::kDedicatedX) static_for<S0>([&](auto SX) { lds_store<kImgX + SX.value * kImgStride * 4>(wX, xr[SX.value]); });
     f32x16 acc1[2], acc2[2];
-    hidden_layers<KIN, LEAKY>(A0, A1, bs, bs + kH, xr, lane, h, acc1, acc2);
-    STAMP(1);
-
-    // ---- dW2 += dz3^T h2 : images  dz3T -> imgA rows 0..3,  h2T -> imgB
-    if (h == 0) {
+    {
+      float f0[2][S0];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) imgA[c * kImgStride + i] = dz3[c];
+      for (int sx = 0; sx < S0; ++sx) { f0[0][sx] = A0[(0 * S0 + sx) * 64 + lane]; f0[1][sx] = A0[(1 * S0 + sx) * 64 + lane]; }
+      __builtin_amdgcn_sched_barrier(0);
+      acc1[0] = MFMA(f0[0][0], xr[0], b0v[0]);
+      acc1[1] = MFMA(f0[1][0], xr[0], b0v[1]);
+#pragma unroll
+      for (int sx = 1; sx < S0; ++sx) {
+        acc1[0] = MFMA(f0[0][sx], xr[sx], acc1[0]);
+        acc1[1] = MFMA(f0[1][sx], xr[sx], acc1[1]);
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (BL::kDedicatedX) fetch_x(tile + gridDim.x);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) imgB[(32 * t + crow(r, h)) * kImgStride + i] = acc2[t][r];
+      for (int r = 0; r < 16; ++r) acc1[t][r] = hidden_act<LEAKY>(acc1[t][r]);
+    put_tile(I1{}, acc1);
+    {
+      float f1[2][32];
+#pragma unroll
+      for (int s2 = 0; s2 < 32; ++s2) { f1[0][s2] = A1[(0 * 32 + s2) * 64 + lane]; f1[1][s2] = A1[(1 * 32 + s2) * 64 + lane]; }
+      __builtin_amdgcn_sched_barrier(0);
+      acc2[0] = MFMA(f1[0][0], acc1[0][0], b1v[0]);
+      acc2[1] = MFMA(f1[1][0], acc1[0][0], b1v[1]);
+#pragma unroll
+      for (int s2 = 1; s2 < 32; ++s2) {
+        const float b = acc1[s2 >> 4][s2 & 15];
+        acc2[0] = MFMA(f1[0][s2], b, acc2[0]);
+        acc2[1] = MFMA(f1[1][s2], b, acc2[1]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[t][r] = hidden_act<LEAKY>(acc2[t][r]);
+    pin_acc();
+    STAMP(1);
+
+    // ---- dW2 += dz3^T h2 : images  dz3T -> imgZ,  h2T -> imgA
+    static_for<4>([&](auto C) { lds_store<kImgZ + C.value * kImgStride * 4>(wDz3, dz3[C.value]); });
+    put_tile(I0{}, acc2);
     {   // 3-4 x 64 outputs: v_mfma_f32_4x4x1_16b (16 blocks of 4x4, one pixel per instruction, 8 cycles) instead of two
         // 32x32 tiles that would be 90 % zeros.  Lane j: B = h2[j][px] (its own image row), A = dz3[j & 3][px];
         // d[c] accumulates dW2[c][j].  Operands are read first (two pixels per ds_read_b64), then the MFMA run.
-      float2 av[16], bv[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        av[q] = *reinterpret_cast<const float2*>(imgA + (lane & 3) * kImgStride + 2 * q);
-        bv[q] = *reinterpret_cast<const float2*>(imgB + lane * kImgStride + 2 * q);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      f32x2 av[16], bv[16];
+      static_for<16>([&](auto Q) { av[Q.value] = lds_load2<kImgZ + 8 * Q.value>(rZ2); bv[Q.value] = lds_load2<8 * Q.value>(rH2); });
+      lds_wait();
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         dW2acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].x, bv[q].x, dW2acc, 0, 0, 0);
         dW2acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].y, bv[q].y, dW2acc, 0, 0, 0);
       }
     }
+    pin_acc();
     STAMP(2);
     // ---- dh2^T = W2^T dz3^T  (k = output channel, padded to 4)
     f32x16 d2[2];
     d2[0] = 0; d2[1] = 0;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const float b = h == 0 ? dz3[2 * s] : dz3[2 * s + 1];
+      float lo = dz3[2 * s], hi = dz3[2 * s + 1];
+      asm volatile("" : "+v"(lo), "+v"(hi));             // a select of two registers, not a load from a private array
+      const float b = h == 0 ? lo : hi;
       d2[0] = MFMA(A2T[(0 * 2 + s) * 64 + lane], b, d2[0]);
       d2[1] = MFMA(A2T[(1 * 2 + s) * 64 + lane], b, d2[1]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_y(tile + gridDim.x);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) d2[t][r] *= hidden_dact<LEAKY>(acc2[t][r]);
+      for (int r = 0; r < 16; ++r) d2[t][r] = hidden_dsel<LEAKY>(acc2[t][r], d2[t][r]);
+    pin_acc();
     STAMP(3);
-    // ---- dW1 += dz2^T h1 : dz2T -> imgA, h1T -> imgB
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        imgA[(32 * t + crow(r, h)) * kImgStride + i] = d2[t][r];
-        imgB[(32 * t + crow(r, h)) * kImgStride + i] = acc1[t][r];
-      }
+    // ---- dW1 += dz2^T h1 : dz2T -> imgA (h2 is dead), h1T already in imgB
+    put_tile(I0{}, d2);
     {
-      float2 a0p[8], a1p[8], b0p[8], b1p[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        a0p[q] = *reinterpret_cast<const float2*>(imgA + i * kImgStride + 16 * h + 2 * q);
-        a1p[q] = *reinterpret_cast<const float2*>(imgA + (32 + i) * kImgStride + 16 * h + 2 * q);
-        b0p[q] = *reinterpret_cast<const float2*>(imgB + i * kImgStride + 16 * h + 2 * q);
-        b1p[q] = *reinterpret_cast<const float2*>(imgB + (32 + i) * kImgStride + 16 * h + 2 * q);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      f32x2 a0p[8], a1p[8], b0p[8], b1p[8];
+      get_rows(OA{}, I0{}, a0p); get_rows(OA{}, I1{}, a1p); get_rows(OB{}, I0{}, b0p); get_rows(OB{}, I1{}, b1p);
+      lds_wait();
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         dW1acc[0][0] = MFMA(a0p[q].x, b0p[q].x, dW1acc[0][0]);
@@ -497,14 +640,16 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
         dW1acc[1][0] = MFMA(a1p[q].y, b0p[q].y, dW1acc[1][0]);
         dW1acc[1][1] = MFMA(a1p[q].y, b1p[q].y, dW1acc[1][1]);
       }
+      __builtin_amdgcn_sched_barrier(0);
       // db1[32a + i] += sum over this half's 16 pixels of dz2 (the A operands ARE dz2^T): 2 registers instead of 32
-      float2 s0 = a0p[0], s1 = a1p[0];
+      f32x2 s0 = a0p[0], s1 = a1p[0];
 #pragma unroll
-      for (int q = 1; q < 8; ++q) { s0.x += a0p[q].x; s0.y += a0p[q].y; s1.x += a1p[q].x; s1.y += a1p[q].y; }
+      for (int q = 1; q < 8; ++q) { s0 += a0p[q]; s1 += a1p[q]; }
       db1acc[0] += s0.x + s0.y; db1acc[1] += s1.x + s1.y;
     }
+    pin_acc();
     STAMP(4);
-    // ---- dh1^T = W1^T dz2^T
+    // ---- dh1^T = W1^T dz2^T, masked with h1 read back from imgB
     f32x16 d1[2];
     d1[0] = 0; d1[1] = 0;
     {
@@ -519,31 +664,30 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
         d1[1] = MFMA(ft[1][s2], b, d1[1]);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      float h1v[2][16];
+      get_tile(I1{}, h1v);
+      lds_wait();
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) d1[t][r] *= hidden_dact<LEAKY>(acc1[t][r]);
+        for (int r = 0; r < 16; ++r) d1[t][r] = hidden_dsel<LEAKY>(h1v[t][r], d1[t][r]);
+    }
+    pin_acc();
     STAMP(5);
-    // ---- dW0 += dz1^T x : dz1T -> imgA, xT -> imgB (rows = input features)
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) imgA[(32 * t + crow(r, h)) * kImgStride + i] = d1[t][r];
-#pragma unroll
-    for (int s = 0; s < S0; ++s) imgB[(h * S0 + s) * kImgStride + i] = xr[s];
-    if (KIN < 32) {
-      for (int rr = KIN + h; rr < 32; rr += 2) imgB[rr * kImgStride + i] = 0.f;
+    // ---- dW0 += dz1^T x : dz1T -> imgA, xT in imgX (rows = input features)
+    put_tile(I0{}, d1);
+    if (!BL::kDedicatedX) {
+      static_for<S0>([&](auto SX) { lds_store<kImgX + SX.value * kImgStride * 4>(wX, xr[SX.value]); });
+      fetch_x(tile + gridDim.x);
     }
     {
-      float2 a0p[8], a1p[8], bp[TX][8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        a0p[q] = *reinterpret_cast<const float2*>(imgA + i * kImgStride + 16 * h + 2 * q);
-        a1p[q] = *reinterpret_cast<const float2*>(imgA + (32 + i) * kImgStride + 16 * h + 2 * q);
-#pragma unroll
-        for (int tx = 0; tx < TX; ++tx) bp[tx][q] = *reinterpret_cast<const float2*>(imgB + (32 * tx + i) * kImgStride + 16 * h + 2 * q);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      f32x2 a0p[8], a1p[8], bp[TX][8];
+      get_rows(OA{}, I0{}, a0p); get_rows(OA{}, I1{}, a1p);
+      get_rows(OX{}, I0{}, bp[0]);
+      if (TX > 1) get_rows(OX{}, I1{}, bp[TX - 1]);
+      lds_wait();
 #pragma unroll
       for (int q = 0; q < 8; ++q)
 #pragma unroll
@@ -553,58 +697,60 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
           dW0acc[0][tx] = MFMA(a0p[q].y, bp[tx][q].y, dW0acc[0][tx]);
           dW0acc[1][tx] = MFMA(a1p[q].y, bp[tx][q].y, dW0acc[1][tx]);
         }
-      float2 s0 = a0p[0], s1 = a1p[0];
+      __builtin_amdgcn_sched_barrier(0);
+      f32x2 s0 = a0p[0], s1 = a1p[0];
 #pragma unroll
-      for (int q = 1; q < 8; ++q) { s0.x += a0p[q].x; s0.y += a0p[q].y; s1.x += a1p[q].x; s1.y += a1p[q].y; }
+      for (int q = 1; q < 8; ++q) { s0 += a0p[q]; s1 += a1p[q]; }
       db0acc[0] += s0.x + s0.y; db0acc[1] += s1.x + s1.y;
     }
+    pin_acc();
     STAMP(6);
-    // ---- d enc^T = W0^T dz1^T ; regs 4g..4g+3 are 4 consecutive input features.  Two accumulator chains per tile.
+    // ---- d enc^T = W0^T dz1^T ; regs 4g..4g+3 are 4 consecutive input features
     f32x16 dxv[TX];
 #pragma unroll
     for (int tx = 0; tx < TX; ++tx) {
-      f32x16 dxa, dxb;
-      dxa = 0; dxb = 0;
       float ft[32];
 #pragma unroll
       for (int s2 = 0; s2 < 32; ++s2) ft[s2] = A0T[(tx * 32 + s2) * 64 + lane];
       __builtin_amdgcn_sched_barrier(0);
+      dxv[tx] = 0;
 #pragma unroll
-      for (int s2 = 0; s2 < 32; s2 += 2) {
-        dxa = MFMA(ft[s2], d1[s2 >> 4][s2 & 15], dxa);
-        dxb = MFMA(ft[s2 + 1], d1[(s2 + 1) >> 4][(s2 + 1) & 15], dxb);
-      }
-      dxv[tx] = dxa + dxb;
+      for (int s2 = 0; s2 < 32; ++s2) dxv[tx] = MFMA(ft[s2], d1[s2 >> 4][s2 & 15], dxv[tx]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tx = 0; tx < TX; ++tx)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {      // |x| bit patterns order like the values, NaN above inf: it sticks
         const unsigned a = __float_as_uint(dxv[tx][r]) & 0x7fffffffu;
         dxmax = a > dxmax ? a : dxmax;
       }
-    }
-    // end of tile: consume tile t+1's rows (their loads were issued a whole tile ago), THEN store, THEN prefetch t+2
-    consume(tile + gridDim.x);
+    make_dz3();                                          // of tile t+1 (y, dy were requested half a tile ago)
     __builtin_amdgcn_sched_barrier(0);
-    if (valid) {
+    {
+      int64_t rem = P - tile * 128;
+      rem = rem > 128 ? 128 : rem;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dX + tile * 128 * in_dim, 0, (int)rem * in_dim * 4, 0x00020000);
+      const unsigned base = (unsigned)((wave * 32 + i) * in_dim) * 4u;
 #pragma unroll
       for (int tx = 0; tx < TX; ++tx)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int col = 32 * tx + 8 * g + 4 * h;
           if (EXACT) {
-            if (32 * tx + 8 * g + 8 <= KIN)            // KIN = 16: only g = 0, 1 are real input features
-              *reinterpret_cast<float4*>(dX + pix * KIN + col) =
-                  make_float4(dxv[tx][4 * g], dxv[tx][4 * g + 1], dxv[tx][4 * g + 2], dxv[tx][4 * g + 3]);
+            if (32 * tx + 8 * g + 8 <= KIN) {          // KIN = 16: only g = 0, 1 are real input features
+              u32x4 v = {__float_as_uint(dxv[tx][4 * g]), __float_as_uint(dxv[tx][4 * g + 1]), __float_as_uint(dxv[tx][4 * g + 2]),
+                         __float_as_uint(dxv[tx][4 * g + 3])};
+              __builtin_amdgcn_raw_buffer_store_b128(v, rs, base + 4u * col, 0, 0);
+            }
           } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              if (col + q < in_dim) dX[pix * in_dim + col + q] = dxv[tx][4 * g + q];
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dxv[tx][4 * g + q]), rs, col + q < in_dim ? base + 4u * (col + q) : 0x40000000u, 0, 0);
           }
         }
     }
-    {
-      const int64_t t2 = tile + 2 * (int64_t)gridDim.x;
-      fetch(t2 < ntiles ? t2 : tile);
-    }
+    pin_acc();
     __builtin_amdgcn_sched_barrier(0);
     STAMP(7);
   }
@@ -690,7 +836,7 @@ template <int KIN>
 static size_t bwd_smem_bytes(int in_dim, int out_dim) {
   using FF = FwdFrags<KIN>;
   constexpr int TX = (KIN + 31) / 32;
-  const int img = 4 * 2 * kImgFloats, slab = slab_size(in_dim, out_dim);
+  const int img = 4 * BwdLds<KIN>::kWaveFloats, slab = slab_size(in_dim, out_dim);
   const size_t main_loop = (size_t)(FF::kA0 + FF::kA1 + 2 * 2 * 64 + 2 * 32 * 64 + TX * 32 * 64 + 2 * kH + img);
   const size_t epilogue = (size_t)4 * slab;            // four per-wave regions over the dead fragment/image areas
   return sizeof(float) * (main_loop > epilogue ? main_loop : epilogue);
