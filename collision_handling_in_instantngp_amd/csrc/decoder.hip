@@ -537,187 +537,222 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
 #endif
+  // first tile's layer-1 fragments; later tiles load theirs under the dW0 run of the tile before
+  float f0[2][S0];
+#pragma unroll
+  for (int sx = 0; sx < S0; ++sx) { f0[0][sx] = A0[(0 * S0 + sx) * 64 + lane]; f0[1][sx] = A0[(1 * S0 + sx) * 64 + lane]; }
+  // Schedule of one 32-pixel tile.  A lone wave per SIMD issues in order: VALU instructions never overlap its MFMAs
+  // (4 cycles each, flat), but LDS / VMEM / scalar instructions issued between two MFMAs disappear under the 64-cycle
+  // matrix pass.  So every MFMA run CARRIES the LDS traffic of the steps that follow it (image stores, operand and
+  // fragment loads; a scheduling barrier per k-step pins the interleave), and the VALU work is gathered in five bursts:
+  //   R1  [x image, W1 frags]  | relu | R2 [h1 image, dz3 image, W1^T frags] + dh2 | relu, mask |
+  //   dh1 [h2 image, dW2 operands -> 32 4x4 MFMAs; dz2 image; dW1 operands; h1 read-back] | mask, db1 |
+  //   dW1 [dz1 image, dW0 operands, W0^T frags] | dW0 [next tile's W0 frags] | dX | |d enc| max, db0, next dz3 | stores
+#define STEP_END() __builtin_amdgcn_sched_barrier(0)
+  const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     pin_acc();
     STAMP(0);
-    // Register lifetimes are kept short on purpose (hipcc parks long-lived VGPR values in AGPRs and every move is a
-    // 4-cycle VALU instruction): x goes to its own image right away, h1 to imgB as soon as it exists (it is read back
-    // for the activation mask of dh1), h2 / dz2 / dz1 take turns in imgA.
-    if (BL::kDedicatedX) static_for<S0>([&](auto SX) { lds_store<kImgX + SX.value * kImgStride * 4>(wX, xr[SX.value]); });
     f32x16 acc1[2], acc2[2];
-    {
-      float f0[2][S0];
+    float f1[2][32], ft[2][32];
+    // ---- R1: h1^T = W0 x^T + b0
+    static_for<S0>([&](auto SX) {
+      constexpr int sx = SX.value;
+      if constexpr (sx == 0) { acc1[0] = MFMA(f0[0][0], xr[0], b0v[0]); acc1[1] = MFMA(f0[1][0], xr[0], b0v[1]); }
+      else { acc1[0] = MFMA(f0[0][sx], xr[sx], acc1[0]); acc1[1] = MFMA(f0[1][sx], xr[sx], acc1[1]); }
+      if (BL::kDedicatedX) lds_store<kImgX + sx * kImgStride * 4>(wX, xr[sx]);
 #pragma unroll
-      for (int sx = 0; sx < S0; ++sx) { f0[0][sx] = A0[(0 * S0 + sx) * 64 + lane]; f0[1][sx] = A0[(1 * S0 + sx) * 64 + lane]; }
-      __builtin_amdgcn_sched_barrier(0);
-      acc1[0] = MFMA(f0[0][0], xr[0], b0v[0]);
-      acc1[1] = MFMA(f0[1][0], xr[0], b0v[1]);
-#pragma unroll
-      for (int sx = 1; sx < S0; ++sx) {
-        acc1[0] = MFMA(f0[0][sx], xr[sx], acc1[0]);
-        acc1[1] = MFMA(f0[1][sx], xr[sx], acc1[1]);
+      for (int j = 0; j < 64 / S0; ++j) {                // W1 fragments of R2
+        const int e = sx * (64 / S0) + j;
+        f1[e >> 5][e & 31] = A1[e * 64 + lane];
       }
-    }
-    __builtin_amdgcn_sched_barrier(0);
+      STEP_END();
+    });
     if (BL::kDedicatedX) fetch_x(tile + gridDim.x);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[t][r] = hidden_act<LEAKY>(acc1[t][r]);
-    put_tile(I1{}, acc1);
+    STEP_END();
+    // ---- R2: h2^T = W1 h1^T + b1
+    static_for<32>([&](auto S2) {
+      constexpr int s2 = S2.value, t = s2 >> 4, r = s2 & 15;
+      if constexpr (s2 == 0) { acc2[0] = MFMA(f1[0][0], acc1[0][0], b1v[0]); acc2[1] = MFMA(f1[1][0], acc1[0][0], b1v[1]); }
+      else { acc2[0] = MFMA(f1[0][s2], acc1[t][r], acc2[0]); acc2[1] = MFMA(f1[1][s2], acc1[t][r], acc2[1]); }
+      lds_store<kImgB + (32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile, acc1[t][r]);          // h1 image
+      if constexpr (s2 < 4) lds_store<kImgZ + s2 * kImgStride * 4>(wDz3, dz3[s2]);                           // dz3 image
+      ft[0][s2] = A1T[(0 * 32 + s2) * 64 + lane];         // W1^T fragments of dh1
+      ft[1][s2] = A1T[(1 * 32 + s2) * 64 + lane];
+      STEP_END();
+    });
+    pin_acc();
+    STAMP(1);
+    // ---- dh2^T = W2^T dz3^T  (k = output channel, padded to 4): needs no activation, so it runs straight behind R2 and
+    //      the ReLU of h2 and the mask of dh2 share one VALU burst
+    f32x16 d2[2];
     {
-      float f1[2][32];
+      float fa[2][2], bsel[2];
 #pragma unroll
-      for (int s2 = 0; s2 < 32; ++s2) { f1[0][s2] = A1[(0 * 32 + s2) * 64 + lane]; f1[1][s2] = A1[(1 * 32 + s2) * 64 + lane]; }
-      __builtin_amdgcn_sched_barrier(0);
-      acc2[0] = MFMA(f1[0][0], acc1[0][0], b1v[0]);
-      acc2[1] = MFMA(f1[1][0], acc1[0][0], b1v[1]);
-#pragma unroll
-      for (int s2 = 1; s2 < 32; ++s2) {
-        const float b = acc1[s2 >> 4][s2 & 15];
-        acc2[0] = MFMA(f1[0][s2], b, acc2[0]);
-        acc2[1] = MFMA(f1[1][s2], b, acc2[1]);
+      for (int sk = 0; sk < 2; ++sk) {
+        fa[0][sk] = A2T[(0 * 2 + sk) * 64 + lane]; fa[1][sk] = A2T[(1 * 2 + sk) * 64 + lane];
+        float lo = dz3[2 * sk], hi = dz3[2 * sk + 1];
+        asm volatile("" : "+v"(lo), "+v"(hi));             // a select of two registers, not a load from a private array
+        bsel[sk] = h == 0 ? lo : hi;
       }
+      STEP_END();
+      d2[0] = MFMA(fa[0][0], bsel[0], kZero16); d2[1] = MFMA(fa[1][0], bsel[0], kZero16);
+      d2[0] = MFMA(fa[0][1], bsel[1], d2[0]); d2[1] = MFMA(fa[1][1], bsel[1], d2[1]);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    fetch_y(tile + gridDim.x);
+    STEP_END();
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[t][r] = hidden_act<LEAKY>(acc2[t][r]);
+      for (int r = 0; r < 16; ++r) {
+        acc2[t][r] = hidden_act<LEAKY>(acc2[t][r]);
+        d2[t][r] = hidden_dsel<LEAKY>(acc2[t][r], d2[t][r]);
+      }
     pin_acc();
-    STAMP(1);
-
-    // ---- dW2 += dz3^T h2 : images  dz3T -> imgZ,  h2T -> imgA
-    static_for<4>([&](auto C) { lds_store<kImgZ + C.value * kImgStride * 4>(wDz3, dz3[C.value]); });
-    put_tile(I0{}, acc2);
-    {   // 3-4 x 64 outputs: v_mfma_f32_4x4x1_16b (16 blocks of 4x4, one pixel per instruction, 8 cycles) instead of two
-        // 32x32 tiles that would be 90 % zeros.  Lane j: B = h2[j][px] (its own image row), A = dz3[j & 3][px];
-        // d[c] accumulates dW2[c][j].  Operands are read first (two pixels per ds_read_b64), then the MFMA run.
+    STEP_END();
+    STAMP(3);
+    // ---- dh1^T = W1^T dz2^T.  Underneath: the h2 image and the dW2 operands (then the 32 4x4 MFMAs of dW2 in mid-run),
+    //      the dz2 image (over h2, whose reads were issued first), the dW1 operands and h1 for the mask.
+    f32x16 d1[2];
+    f32x2 a0p[8], a1p[8], b0p[8], b1p[8];
+    float h1v[2][16];
+    {
       f32x2 av[16], bv[16];
-      static_for<16>([&](auto Q) { av[Q.value] = lds_load2<kImgZ + 8 * Q.value>(rZ2); bv[Q.value] = lds_load2<8 * Q.value>(rH2); });
+      static_for<16>([&](auto S2) {
+        constexpr int s2 = S2.value;
+        if constexpr (s2 == 0) { d1[0] = MFMA(ft[0][0], d2[0][0], kZero16); d1[1] = MFMA(ft[1][0], d2[0][0], kZero16); }
+        else { d1[0] = MFMA(ft[0][s2], d2[0][s2], d1[0]); d1[1] = MFMA(ft[1][s2], d2[0][s2], d1[1]); }
+        if constexpr (s2 < 8) {                           // h2 image (imgA), 4 stores per step
+          static_for<4>([&](auto E) {
+            constexpr int e = 4 * s2 + E.value, t = e >> 4, r = e & 15;
+            lds_store<(32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile, acc2[t][r]);
+          });
+        } else {                                          // then the dW2 operands
+          static_for<2>([&](auto E) {
+            constexpr int q = 2 * (s2 - 8) + E.value;
+            av[q] = lds_load2<kImgZ + 8 * q>(rZ2);
+            bv[q] = lds_load2<8 * q>(rH2);
+          });
+        }
+        STEP_END();
+      });
       lds_wait();
+      // dW2 (3-4 x 64 outputs) on v_mfma_f32_4x4x1_16b: 16 blocks of 4x4, one pixel per instruction, 8 cycles — instead
+      // of two 32x32 tiles that would be 90 % zeros.  Lane j: B = h2[j][px] (its own image row), A = dz3[j & 3][px].
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         dW2acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].x, bv[q].x, dW2acc, 0, 0, 0);
         dW2acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].y, bv[q].y, dW2acc, 0, 0, 0);
       }
+      STEP_END();
     }
-    pin_acc();
-    STAMP(2);
-    // ---- dh2^T = W2^T dz3^T  (k = output channel, padded to 4)
-    f32x16 d2[2];
-    d2[0] = 0; d2[1] = 0;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      float lo = dz3[2 * s], hi = dz3[2 * s + 1];
-      asm volatile("" : "+v"(lo), "+v"(hi));             // a select of two registers, not a load from a private array
-      const float b = h == 0 ? lo : hi;
-      d2[0] = MFMA(A2T[(0 * 2 + s) * 64 + lane], b, d2[0]);
-      d2[1] = MFMA(A2T[(1 * 2 + s) * 64 + lane], b, d2[1]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    fetch_y(tile + gridDim.x);
+    static_for<16>([&](auto S2) {
+      constexpr int s2 = 16 + S2.value, k = S2.value;
+      d1[0] = MFMA(ft[0][s2], d2[1][k], d1[0]);
+      d1[1] = MFMA(ft[1][s2], d2[1][k], d1[1]);
+      if constexpr (k < 8) {                              // dz2 image: 4 stores per step
+        static_for<4>([&](auto E) {
+          constexpr int e = 4 * k + E.value, t = e >> 4, r = e & 15;
+          lds_store<(32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile, d2[t][r]);
+        });
+      } else {                                            // dW1 operands (after ALL dz2 stores) and h1 read-back
+        constexpr int q = k - 8;
+        a0p[q] = lds_load2<(2 * q) * 4>(rOp);
+        a1p[q] = lds_load2<(32 * kImgStride + 2 * q) * 4>(rOp);
+        b0p[q] = lds_load2<kImgB + (2 * q) * 4>(rOp);
+        b1p[q] = lds_load2<kImgB + (32 * kImgStride + 2 * q) * 4>(rOp);
+        static_for<4>([&](auto E) {
+          constexpr int e = 4 * q + E.value, t = e >> 4, r = e & 15;
+          h1v[t][r] = lds_load1<kImgB + (32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile);
+        });
+      }
+      STEP_END();
+    });
+    lds_wait();
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) d2[t][r] = hidden_dsel<LEAKY>(acc2[t][r], d2[t][r]);
-    pin_acc();
-    STAMP(3);
-    // ---- dW1 += dz2^T h1 : dz2T -> imgA (h2 is dead), h1T already in imgB
-    put_tile(I0{}, d2);
-    {
-      f32x2 a0p[8], a1p[8], b0p[8], b1p[8];
-      get_rows(OA{}, I0{}, a0p); get_rows(OA{}, I1{}, a1p); get_rows(OB{}, I0{}, b0p); get_rows(OB{}, I1{}, b1p);
-      lds_wait();
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        dW1acc[0][0] = MFMA(a0p[q].x, b0p[q].x, dW1acc[0][0]);
-        dW1acc[0][1] = MFMA(a0p[q].x, b1p[q].x, dW1acc[0][1]);
-        dW1acc[1][0] = MFMA(a1p[q].x, b0p[q].x, dW1acc[1][0]);
-        dW1acc[1][1] = MFMA(a1p[q].x, b1p[q].x, dW1acc[1][1]);
-        dW1acc[0][0] = MFMA(a0p[q].y, b0p[q].y, dW1acc[0][0]);
-        dW1acc[0][1] = MFMA(a0p[q].y, b1p[q].y, dW1acc[0][1]);
-        dW1acc[1][0] = MFMA(a1p[q].y, b0p[q].y, dW1acc[1][0]);
-        dW1acc[1][1] = MFMA(a1p[q].y, b1p[q].y, dW1acc[1][1]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // db1[32a + i] += sum over this half's 16 pixels of dz2 (the A operands ARE dz2^T): 2 registers instead of 32
+      for (int r = 0; r < 16; ++r) d1[t][r] = hidden_dsel<LEAKY>(h1v[t][r], d1[t][r]);
+    {   // db1[32a + i] += sum over this half's 16 pixels of dz2 (the A operands ARE dz2^T): 2 registers instead of 32
       f32x2 s0 = a0p[0], s1 = a1p[0];
 #pragma unroll
       for (int q = 1; q < 8; ++q) { s0 += a0p[q]; s1 += a1p[q]; }
       db1acc[0] += s0.x + s0.y; db1acc[1] += s1.x + s1.y;
     }
     pin_acc();
-    STAMP(4);
-    // ---- dh1^T = W1^T dz2^T, masked with h1 read back from imgB
-    f32x16 d1[2];
-    d1[0] = 0; d1[1] = 0;
-    {
-      float ft[2][32];
-#pragma unroll
-      for (int s2 = 0; s2 < 32; ++s2) { ft[0][s2] = A1T[(0 * 32 + s2) * 64 + lane]; ft[1][s2] = A1T[(1 * 32 + s2) * 64 + lane]; }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s2 = 0; s2 < 32; ++s2) {
-        const float b = d2[s2 >> 4][s2 & 15];
-        d1[0] = MFMA(ft[0][s2], b, d1[0]);
-        d1[1] = MFMA(ft[1][s2], b, d1[1]);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      float h1v[2][16];
-      get_tile(I1{}, h1v);
-      lds_wait();
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d1[t][r] = hidden_dsel<LEAKY>(h1v[t][r], d1[t][r]);
-    }
-    pin_acc();
+    STEP_END();
     STAMP(5);
-    // ---- dW0 += dz1^T x : dz1T -> imgA, xT in imgX (rows = input features)
-    put_tile(I0{}, d1);
-    if (!BL::kDedicatedX) {
-      static_for<S0>([&](auto SX) { lds_store<kImgX + SX.value * kImgStride * 4>(wX, xr[SX.value]); });
-      fetch_x(tile + gridDim.x);
-    }
-    {
-      f32x2 a0p[8], a1p[8], bp[TX][8];
-      get_rows(OA{}, I0{}, a0p); get_rows(OA{}, I1{}, a1p);
-      get_rows(OX{}, I0{}, bp[0]);
-      if (TX > 1) get_rows(OX{}, I1{}, bp[TX - 1]);
-      lds_wait();
+    // ---- dW1 += dz2^T h1.  Underneath: the dz1 image (over dz2, already in registers), dW0 operands, W0^T fragments
+    f32x2 c0p[8], c1p[8], xp[TX][8];
+    float fx[TX][32];
+    static_for<8>([&](auto Q) {
+      constexpr int q = Q.value;
+      dW1acc[0][0] = MFMA(a0p[q].x, b0p[q].x, dW1acc[0][0]);
+      dW1acc[0][1] = MFMA(a0p[q].x, b1p[q].x, dW1acc[0][1]);
+      dW1acc[1][0] = MFMA(a1p[q].x, b0p[q].x, dW1acc[1][0]);
+      dW1acc[1][1] = MFMA(a1p[q].x, b1p[q].x, dW1acc[1][1]);
+      dW1acc[0][0] = MFMA(a0p[q].y, b0p[q].y, dW1acc[0][0]);
+      dW1acc[0][1] = MFMA(a0p[q].y, b1p[q].y, dW1acc[0][1]);
+      dW1acc[1][0] = MFMA(a1p[q].y, b0p[q].y, dW1acc[1][0]);
+      dW1acc[1][1] = MFMA(a1p[q].y, b1p[q].y, dW1acc[1][1]);
+      if constexpr (q < 4) {
+        static_for<8>([&](auto E) {
+          constexpr int e = 8 * q + E.value, t = e >> 4, r = e & 15;
+          lds_store<(32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile, d1[t][r]);                 // dz1 image (imgA)
+        });
+        if constexpr (!BL::kDedicatedX)                    // 64-wide input: its image shares imgB (h1 is dead by now)
+          static_for<S0 / 4>([&](auto E) { constexpr int sx = q * (S0 / 4) + E.value; lds_store<kImgX + sx * kImgStride * 4>(wX, xr[sx]); });
+      } else {
+        static_for<2>([&](auto E) {
+          constexpr int qq = 2 * (q - 4) + E.value;
+          c0p[qq] = lds_load2<(2 * qq) * 4>(rOp);
+          c1p[qq] = lds_load2<(32 * kImgStride + 2 * qq) * 4>(rOp);
+          xp[0][qq] = lds_load2<kImgX + (2 * qq) * 4>(rOp);
+          if constexpr (TX > 1) xp[TX - 1][qq] = lds_load2<kImgX + (32 * kImgStride + 2 * qq) * 4>(rOp);
+        });
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
+        for (int tx = 0; tx < TX; ++tx)
 #pragma unroll
-        for (int tx = 0; tx < TX; ++tx) {
-          dW0acc[0][tx] = MFMA(a0p[q].x, bp[tx][q].x, dW0acc[0][tx]);
-          dW0acc[1][tx] = MFMA(a1p[q].x, bp[tx][q].x, dW0acc[1][tx]);
-          dW0acc[0][tx] = MFMA(a0p[q].y, bp[tx][q].y, dW0acc[0][tx]);
-          dW0acc[1][tx] = MFMA(a1p[q].y, bp[tx][q].y, dW0acc[1][tx]);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-      f32x2 s0 = a0p[0], s1 = a1p[0];
+          for (int j = 0; j < 8; ++j) fx[tx][8 * (q - 4) + j] = A0T[(tx * 32 + 8 * (q - 4) + j) * 64 + lane];
+      }
+      STEP_END();
+    });
+    if (!BL::kDedicatedX) fetch_x(tile + gridDim.x);
+    lds_wait();
+    pin_acc();
+    STAMP(4);
+    // ---- dW0 += dz1^T x, with the next tile's W0 fragments underneath
+    static_for<8>([&](auto Q) {
+      constexpr int q = Q.value;
 #pragma unroll
-      for (int q = 1; q < 8; ++q) { s0 += a0p[q]; s1 += a1p[q]; }
-      db0acc[0] += s0.x + s0.y; db0acc[1] += s1.x + s1.y;
-    }
+      for (int tx = 0; tx < TX; ++tx) {
+        dW0acc[0][tx] = MFMA(c0p[q].x, xp[tx][q].x, dW0acc[0][tx]);
+        dW0acc[1][tx] = MFMA(c1p[q].x, xp[tx][q].x, dW0acc[1][tx]);
+        dW0acc[0][tx] = MFMA(c0p[q].y, xp[tx][q].y, dW0acc[0][tx]);
+        dW0acc[1][tx] = MFMA(c1p[q].y, xp[tx][q].y, dW0acc[1][tx]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2 * S0 / 8; ++j) {
+        const int e = q * (2 * S0 / 8) + j;
+        f0[e / S0][e % S0] = A0[e * 64 + lane];
+      }
+      STEP_END();
+    });
     pin_acc();
     STAMP(6);
     // ---- d enc^T = W0^T dz1^T ; regs 4g..4g+3 are 4 consecutive input features
     f32x16 dxv[TX];
 #pragma unroll
     for (int tx = 0; tx < TX; ++tx) {
-      float ft[32];
+      dxv[tx] = MFMA(fx[tx][0], d1[0][0], kZero16);
 #pragma unroll
-      for (int s2 = 0; s2 < 32; ++s2) ft[s2] = A0T[(tx * 32 + s2) * 64 + lane];
-      __builtin_amdgcn_sched_barrier(0);
-      dxv[tx] = 0;
-#pragma unroll
-      for (int s2 = 0; s2 < 32; ++s2) dxv[tx] = MFMA(ft[s2], d1[s2 >> 4][s2 & 15], dxv[tx]);
+      for (int s2 = 1; s2 < 32; ++s2) dxv[tx] = MFMA(fx[tx][s2], d1[s2 >> 4][s2 & 15], dxv[tx]);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    STEP_END();
 #pragma unroll
     for (int tx = 0; tx < TX; ++tx)
 #pragma unroll
@@ -725,8 +760,14 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
         const unsigned a = __float_as_uint(dxv[tx][r]) & 0x7fffffffu;
         dxmax = a > dxmax ? a : dxmax;
       }
+    {
+      f32x2 s0 = c0p[0], s1 = c1p[0];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) { s0 += c0p[q]; s1 += c1p[q]; }
+      db0acc[0] += s0.x + s0.y; db0acc[1] += s1.x + s1.y;
+    }
     make_dz3();                                          // of tile t+1 (y, dy were requested half a tile ago)
-    __builtin_amdgcn_sched_barrier(0);
+    STEP_END();
     {
       int64_t rem = P - tile * 128;
       rem = rem > 128 ? 128 : rem;
@@ -751,7 +792,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
         }
     }
     pin_acc();
-    __builtin_amdgcn_sched_barrier(0);
+    STEP_END();
     STAMP(7);
   }
 
