@@ -537,10 +537,15 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
 #endif
-  // first tile's layer-1 fragments; later tiles load theirs under the dW0 run of the tile before
+  // first tile's layer-1 fragments; later tiles load theirs under the dW0 run of the tile before.  (64-wide input: the
+  // register file cannot carry them across the tile as well — they are loaded at the top of every tile instead, and the
+  // second half of the W0^T fragments takes their place under dW0.)
+  constexpr bool kCarryF0 = KIN <= 32;
   float f0[2][S0];
+  if (kCarryF0) {
 #pragma unroll
-  for (int sx = 0; sx < S0; ++sx) { f0[0][sx] = A0[(0 * S0 + sx) * 64 + lane]; f0[1][sx] = A0[(1 * S0 + sx) * 64 + lane]; }
+    for (int sx = 0; sx < S0; ++sx) { f0[0][sx] = A0[(0 * S0 + sx) * 64 + lane]; f0[1][sx] = A0[(1 * S0 + sx) * 64 + lane]; }
+  }
   // Schedule of one 32-pixel tile.  A lone wave per SIMD issues in order: VALU instructions never overlap its MFMAs
   // (4 cycles each, flat), but LDS / VMEM / scalar instructions issued between two MFMAs disappear under the 64-cycle
   // matrix pass.  So every MFMA run CARRIES the LDS traffic of the steps that follow it (image stores, operand and
@@ -555,6 +560,11 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     STAMP(0);
     f32x16 acc1[2], acc2[2];
     float f1[2][32], ft[2][32];
+    if (!kCarryF0) {
+#pragma unroll
+      for (int sx = 0; sx < S0; ++sx) { f0[0][sx] = A0[(0 * S0 + sx) * 64 + lane]; f0[1][sx] = A0[(1 * S0 + sx) * 64 + lane]; }
+      STEP_END();
+    }
     // ---- R1: h1^T = W0 x^T + b0
     static_for<S0>([&](auto SX) {
       constexpr int sx = SX.value;
@@ -715,9 +725,11 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
           if constexpr (TX > 1) xp[TX - 1][qq] = lds_load2<kImgX + (32 * kImgStride + 2 * qq) * 4>(rOp);
         });
 #pragma unroll
-        for (int tx = 0; tx < TX; ++tx)
+        for (int j = 0; j < 8; ++j) fx[0][8 * (q - 4) + j] = A0T[(8 * (q - 4) + j) * 64 + lane];
+        if (kCarryF0 && TX > 1) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) fx[tx][8 * (q - 4) + j] = A0T[(tx * 32 + 8 * (q - 4) + j) * 64 + lane];
+          for (int j = 0; j < 8; ++j) fx[TX - 1][8 * (q - 4) + j] = A0T[((TX - 1) * 32 + 8 * (q - 4) + j) * 64 + lane];
+        }
       }
       STEP_END();
     });
@@ -735,10 +747,15 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
         dW0acc[0][tx] = MFMA(c0p[q].y, xp[tx][q].y, dW0acc[0][tx]);
         dW0acc[1][tx] = MFMA(c1p[q].y, xp[tx][q].y, dW0acc[1][tx]);
       }
+      if (kCarryF0) {
 #pragma unroll
-      for (int j = 0; j < 2 * S0 / 8; ++j) {
-        const int e = q * (2 * S0 / 8) + j;
-        f0[e / S0][e % S0] = A0[e * 64 + lane];
+        for (int j = 0; j < 2 * S0 / 8; ++j) {
+          const int e = q * (2 * S0 / 8) + j;
+          f0[e / S0][e % S0] = A0[e * 64 + lane];
+        }
+      } else if (TX > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fx[TX - 1][4 * q + j] = A0T[((TX - 1) * 32 + 4 * q + j) * 64 + lane];
       }
       STEP_END();
     });
