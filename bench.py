@@ -89,7 +89,7 @@ def make_step(net, models, mode, xy, target, world):
             mse, kls, coll = loss_fn(rgb, target, T, probs, empty, empty)
             loss = train.assemble_loss(mse, kls, coll, 1, 1, 1e-3)
         else:
-            loss = torch.nn.functional.mse_loss(rgb, target)
+            loss = loss_fn._mse(rgb, target)      # frozen HPD / hash: the KL-JS and collision terms carry no gradient
         loss.backward()
         if world > 1:
             parallel.allreduce_gradients(net, world)

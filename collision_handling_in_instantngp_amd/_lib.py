@@ -52,6 +52,9 @@ SIGNATURES = {
     "gngf_vertex_multiplicity": [_P, _P, _P, _L, _I, _I, _L, _P],
     "gngf_multiplicity_weights": [_P, _P, _L, _I, _F, _P],
     "gngf_expand_vertex_table": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _L, _P],
+    "gngf_mse_workspace_floats": [],
+    "gngf_mse_fwd": [_P, _P, _P, _P, _L, _P],
+    "gngf_mse_bwd": [_P, _P, _P, _P, _L, _P],
 }
 
 _lib = None

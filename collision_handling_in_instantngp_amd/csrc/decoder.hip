@@ -9,11 +9,22 @@
 //   layer n+1 — no LDS round trip, no lane movement between layers; only the weight (A) fragments come from LDS, stored
 //   in exactly the k-order the accumulator layout dictates.  One wave owns 32 pixels; a 256-thread workgroup 128.
 //   Weight gradients contract over the pixel index, which needs pixel on the k axis: the wave transposes its 32-pixel
-//   tiles through a private, +1-padded LDS image ([feature][33]: conflict-free b32 reads and writes), accumulates
-//   dW tiles in registers across its whole pixel range, and the workgroup emits ONE partial slab; a tiny second
-//   kernel sums the slabs (store pass + sum pass instead of ~10^6 contended float atomics).
-//   Hidden activations are recomputed in backward (96 of 324 MFMAs per 32 pixels) instead of being stored
+//   tiles through private LDS images ([feature][34]: conflict-free b32 stores and two-pixel b64 loads), accumulates dW
+//   tiles in accumulation registers across its whole pixel range, and the workgroup emits ONE partial slab; a tiny second
+//   kernel sums the slabs (store pass + sum pass instead of ~10^6 contended float atomics).  The 3-wide dW2 runs on
+//   v_mfma_f32_4x4x1_16b blocks, bias gradients fall out of the transposed operands (2 registers instead of 32).
+//   Hidden activations are recomputed in backward (96 of 292 MFMAs per 32 pixels) instead of being stored
 //   (512 B/pixel of HBM traffic each way).
+//
+// Issue model the schedules are built on (measured, tools/micro/gen_mfma_mix.py, mfma_2wave.cpp; one wave per SIMD):
+//   * v_mfma_f32_32x32x2_f32 issues back to back at exactly 64 cycles, dependent accumulator chains included;
+//   * a VALU instruction NEVER overlaps the wave's (or a sibling wave's) MFMAs: an MFMA followed by n VALU instructions
+//     costs 64 + ~10 + 4n cycles — v_accvgpr_read/write and address arithmetic included;
+//   * LDS, VMEM and scalar instructions placed between two MFMAs are free (up to ~15 per MFMA).
+//   Hence: as few VALU instructions as possible (one-instruction ReLU, selects instead of mask multiplies, immediate
+//   LDS offsets instead of address adds, buffer loads/stores whose range check replaces the tail masks, loop-carried
+//   tiles pinned to AGPRs so hipcc does not shuttle them), gathered in a few bursts, and all LDS traffic of a phase
+//   issued underneath the MFMA run of the phase before (a scheduling barrier per k-step pins the interleave).
 #include "gngf_common.h"
 #include <type_traits>
 #include <utility>
@@ -37,7 +48,6 @@ template <bool LEAKY> __device__ __forceinline__ float hidden_act(float z) {
   if (LEAKY) { float r; const float t = 0.01f * z; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(z), "v"(t)); return r; }
   return vmax0(z);
 }
-template <bool LEAKY> __device__ __forceinline__ float hidden_dact(float y) { return y > 0.f ? 1.f : (LEAKY ? 0.01f : 0.f); }
 // d * act'(y) as a select (two VALU instructions; the multiply by a 0/1 mask would be a third)
 template <bool LEAKY> __device__ __forceinline__ float hidden_dsel(float y, float d) { return y > 0.f ? d : (LEAKY ? 0.01f * d : 0.f); }
 
@@ -121,71 +131,6 @@ __device__ __forceinline__ void fill_fwd_frags(float* A0, float* A1, const float
     const int i = lane & 31, h = lane >> 5;
     A1[e] = raw[o.w1 + (32 * t + i) * 65 + kmapC(s2, h)];
   }
-}
-
-// Loads the lane's slice of its pixel's input row: xr[s] = X[pix][h*KIN/2 + s].  Branch-free on the fast path (the pixel
-// index is clamped into range and the result masked) so that the loads can stay in flight across the loop back-edge.
-template <int KIN>
-__device__ __forceinline__ void load_x(const float* __restrict__ X, int64_t pix, bool valid, int in_dim, int h, float* xr,
-                                       int64_t P) {
-  constexpr int S0 = KIN / 2;
-  if (in_dim == KIN) {
-    const int64_t q = pix < P ? pix : P - 1;
-    const float4* src = reinterpret_cast<const float4*>(X + q * KIN + h * S0);
-#pragma unroll
-    for (int k = 0; k < S0 / 4; ++k) {      // raw values: the caller masks padding pixels when it CONSUMES them
-      const float4 v = src[k];
-      xr[4 * k] = v.x; xr[4 * k + 1] = v.y; xr[4 * k + 2] = v.z; xr[4 * k + 3] = v.w;
-    }
-  } else {
-#pragma unroll
-    for (int s = 0; s < S0; ++s) {
-      const int k = h * S0 + s;
-      xr[s] = (valid && k < in_dim) ? X[pix * in_dim + k] : 0.f;
-    }
-  }
-}
-
-// Layers 1 and 2 for one 32-pixel tile of this wave: acc1 = h1^T, acc2 = h2^T (both activated).
-template <int KIN, bool LEAKY>
-__device__ __forceinline__ void hidden_layers(const float* A0, const float* A1, const float* b0s, const float* b1s,
-                                              const float* xr, int lane, int h, f32x16 (&acc1)[2], f32x16 (&acc2)[2]) {
-  constexpr int S0 = KIN / 2;
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc1[t][r] = b0s[32 * t + crow(r, h)]; acc2[t][r] = b1s[32 * t + crow(r, h)]; }
-  // Fragments are burst-loaded into registers BEFORE each MFMA run (one exposed LDS latency per run): left to itself
-  // hipcc issues each ds_read one or two MFMAs ahead of its use and stalls the matrix pipe on lgkmcnt every step.
-  {
-    float f0[2][S0];
-#pragma unroll
-    for (int s = 0; s < S0; ++s) { f0[0][s] = A0[(0 * S0 + s) * 64 + lane]; f0[1][s] = A0[(1 * S0 + s) * 64 + lane]; }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < S0; ++s) {
-      acc1[0] = MFMA(f0[0][s], xr[s], acc1[0]);
-      acc1[1] = MFMA(f0[1][s], xr[s], acc1[1]);
-    }
-  }
-  float f1[2][32];
-#pragma unroll
-  for (int s2 = 0; s2 < 32; ++s2) { f1[0][s2] = A1[(0 * 32 + s2) * 64 + lane]; f1[1][s2] = A1[(1 * 32 + s2) * 64 + lane]; }
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[t][r] = hidden_act<LEAKY>(acc1[t][r]);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int s2 = 0; s2 < 32; ++s2) {
-    const float b = acc1[s2 >> 4][s2 & 15];
-    acc2[0] = MFMA(f1[0][s2], b, acc2[0]);
-    acc2[1] = MFMA(f1[1][s2], b, acc2[1]);
-  }
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[t][r] = hidden_act<LEAKY>(acc2[t][r]);
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -274,21 +219,15 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
     }
   };
   const unsigned yoff = (unsigned)(((wave * 32 + i) * out_dim) * 4);
-  float xn[S0];
-  fetch(blockIdx.x, xn);
+  // x of the next tile is loaded straight into xr as soon as layer 1 has consumed it: it lands under layer 2
+  float xr[S0];
+  fetch(blockIdx.x, xr);
 #if defined(GNGF_STAMPS)
   unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
 #endif
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     STAMP(0);
-    float xr[S0];
-#pragma unroll
-    for (int sx = 0; sx < S0; ++sx) { xr[sx] = xn[sx]; asm volatile("" : "+v"(xr[sx])); }
-    // hipcc waits vmcnt(0) at the first use of a value loaded in the previous iteration; pin that use ABOVE the
-    // next tile's loads so the wait retires only the old loads (and the old stores) and the new ones fly under the MFMAs.
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(tile + gridDim.x, xn);
     STAMP(1);
     // MFMA runs and VALU bursts strictly alternate (every switch costs ~10 cycles on top of 4 per VALU instruction)
     f32x16 acc1[2], acc2[2];
@@ -299,6 +238,8 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
       acc1[0] = MFMA(a0r[0][sx], xr[sx], acc1[0]);
       acc1[1] = MFMA(a0r[1][sx], xr[sx], acc1[1]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(tile + gridDim.x, xr);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -421,29 +362,6 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   const unsigned rOp = aImg + (unsigned)(i * kImgStride + 16 * h) * 4u;         // operand rows i (+32), pixels 16h + 2q, 2q+1
   const unsigned rZ2 = aImg + (unsigned)((lane & 3) * kImgStride) * 4u;         // dW2: A rows lane & 3 of imgZ, all 32 pixels
   const unsigned rH2 = aImg + (unsigned)(lane * kImgStride) * 4u;               //      B rows lane of imgA
-  auto put_tile = [&](auto IMG, const f32x16 (&v)[2]) {
-    static_for<32>([&](auto E) {
-      constexpr int t = E.value >> 4, r = E.value & 15;
-      lds_store<decltype(IMG)::value * kImgB + (32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile, v[t][r]);
-    });
-  };
-  // the lane's own elements of a tile pair back from image IMG (same addresses as put_tile)
-  auto get_tile = [&](auto IMG, float (&v)[2][16]) {
-    static_for<32>([&](auto E) {
-      constexpr int t = E.value >> 4, r = E.value & 15;
-      v[t][r] = lds_load1<decltype(IMG)::value * kImgB + (32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile);
-    });
-  };
-  // operand rows i (a = 0) / 32 + i (a = 1) of the image at byte offset OFF: 8 x two pixels
-  auto get_rows = [&](auto OFF, auto A, f32x2 (&dst)[8]) {
-    static_for<8>([&](auto Q) { dst[Q.value] = lds_load2<decltype(OFF)::value + (32 * decltype(A)::value * kImgStride + 2 * Q.value) * 4>(rOp); });
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using OA = std::integral_constant<int, 0>;
-  using OB = std::integral_constant<int, kImgB>;
-  using OX = std::integral_constant<int, kImgX>;
-
   f32x16 dW1acc[2][2], dW0acc[2][TX];
   f32x4 dW2acc = {0.f, 0.f, 0.f, 0.f};                   // lane j: dW2[c][j], c = 0..3
   float db0acc[2] = {0.f, 0.f}, db1acc[2] = {0.f, 0.f};  // lane (i,h): partial of db[32a + i] over the half's 16 pixels

@@ -3,7 +3,7 @@ all arithmetic happens in the HIP kernels.  CPU tensors raise (no fallback)."""
 import torch
 
 from . import _lib
-from ._lib import call, ptr, stream_ptr
+from ._lib import call, ptr, query, stream_ptr
 
 BLEND_CODES = {True: 0, None: 1, False: 2}   # should_softmax_topk_features -> GNGF_BLEND_*
 MODE_HASH, MODE_VERTEX_TABLE = 0, 1
@@ -637,6 +637,42 @@ def encode_apply(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, path=No
     order: optional cached slot_order(vert_idx) (frozen tables)."""
     plan = EncodePlan(xy.shape[0], n_ls_host, tables.shape[2], path)
     return EncodeFunction.apply(xy, n_ls, plan, tables, vert_idx, vert_w, vstride, order)
+
+
+_MSE_WORKSPACE = {}
+
+
+class MseFunction(torch.autograd.Function):
+    """torch.nn.MSELoss() (reference utils.py:99) on device tensors: one launch for the value, one for the gradient
+    (csrc/loss.hip) instead of three framework kernels.  apply(pred, label) -> 0-dim loss."""
+
+    @staticmethod
+    def forward(ctx, pred, label):
+        pred, label = _c(pred), _c(label)
+        if pred.shape != label.shape:
+            raise ValueError(f"pred {tuple(pred.shape)} and label {tuple(label.shape)} differ")
+        if pred.numel() == 0:
+            raise ValueError("MSE of an empty batch")
+        dev = pred.device
+        ws = _MSE_WORKSPACE.get(dev)
+        if ws is None:
+            ws = _MSE_WORKSPACE[dev] = torch.zeros(query("gngf_mse_workspace_floats"), dtype=_f32, device=dev)
+        loss = torch.empty((), dtype=_f32, device=dev)
+        call("gngf_mse_fwd", ptr(pred, _f32, "pred"), ptr(label, _f32, "label"), ptr(loss), ptr(ws), pred.numel(), stream_ptr())
+        ctx.save_for_backward(pred, label)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, label = ctx.saved_tensors
+        gout = _c(gout.to(_f32))
+        dpred = torch.empty_like(pred)
+        call("gngf_mse_bwd", ptr(pred), ptr(label), ptr(gout), ptr(dpred), pred.numel(), stream_ptr())
+        return dpred, None
+
+
+def mse_loss(pred, label):
+    return MseFunction.apply(pred, label)
 
 
 class DecoderFunction(torch.autograd.Function):

@@ -182,6 +182,15 @@ int gngf_expand_vertex_table(const float* xy, const int32_t* n_ls, const int32_t
                              int64_t* vid_out, int64_t* out_idx, float* out_val, int64_t P, int L, int K, int vstride,
                              int64_t NV, void* stream);
 
+/* ---- pixel loss (row f1 of the scope table: the caller of the path) -------------------------------------------------
+ * torch.nn.MSELoss() of utils.py:99 on the (P,out_dim) outputs: loss[0] = mean((pred - label)^2) over n elements.
+ * workspace: gngf_mse_workspace_floats() floats, zero-filled once before the first call (the last word is a counter the
+ * kernel resets itself).  Deterministic (fixed summation order). */
+int gngf_mse_workspace_floats(void);
+int gngf_mse_fwd(const float* pred, const float* label, float* loss, float* workspace, int64_t n, void* stream);
+/* its backward: dpred (n) = gout[0] * 2 (pred - label) / n   (gout: device scalar, the gradient of the loss value) */
+int gngf_mse_bwd(const float* pred, const float* label, const float* gout, float* dpred, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

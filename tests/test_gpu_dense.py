@@ -269,3 +269,18 @@ def test_streaming_logits_topk_pbar_vs_numpy(ops, U, T, K, Lv):
     if Lv:
         want = mw_t.cpu().numpy().astype(np.float64).T @ sm
         close(pbar, want, 1e-4, 1e-9)
+
+
+@pytest.mark.parametrize("n", [(1, 3), (7, 3), (1000, 3), (4099, 4), (2 ** 18 + 5, 3)])
+def test_mse_kernels_vs_numpy(ops, n):
+    """csrc/loss.hip: value and gradient of torch.nn.MSELoss (reference utils.py:99), incl. a non-unit upstream gradient,
+    repeated launches (the kernel's self-resetting counter) and sizes that are not multiples of the vector width."""
+    rng = np.random.default_rng(n[0])
+    a, b = rng.random(n, dtype=np.float32), rng.random(n, dtype=np.float32)
+    want = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    for rep in range(3):
+        x = t(a).requires_grad_()
+        loss = ops.mse_loss(x, t(b))
+        (loss * 3.0).backward()
+        close(loss.detach().cpu().numpy(), want, 2e-6, 0)
+        close(x.grad.cpu().numpy(), 3.0 * 2.0 * (a.astype(np.float64) - b) / a.size, 1e-6, 1e-12)
