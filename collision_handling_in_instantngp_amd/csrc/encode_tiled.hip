@@ -51,22 +51,24 @@ bin_count_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, in
   for (int i = threadIdx.x; i < ntiles; i += kBinThreads) blockhist[(int64_t)i * NB + blockIdx.x] = hist[i];
 }
 
-// K2a: one WAVE per tile row of blockhist [tile][NB] (NB <= 128: 2 entries per lane): exclusive scan inside the row,
-// row total to tot[tile].  grid = ceil(ntiles / 4) blocks of 4 waves.
+// K2a: one WAVE per tile row of blockhist [tile][NB] (NB <= 512: 8 consecutive entries per lane): exclusive scan inside the
+// row, row total to tot[tile].  grid = ceil(ntiles / 4) blocks of 4 waves.
+constexpr int kBinMaxBlocks = 512;
 __global__ void __launch_bounds__(256)
 bin_rowscan_kernel(int32_t* __restrict__ blockhist, int NB, int ntiles, int32_t* __restrict__ tot) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= ntiles) return;
   int32_t* row = blockhist + (int64_t)t * NB;
-  const int b0 = 2 * lane, b1 = 2 * lane + 1;
-  const int v0 = b0 < NB ? row[b0] : 0, v1 = b1 < NB ? row[b1] : 0;
-  int incl = v0 + v1;
+  int v[8], mine = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { const int b = 8 * lane + q; v[q] = b < NB ? row[b] : 0; mine += v[q]; }
+  int incl = mine;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
-  const int ex = incl - (v0 + v1);
-  if (b0 < NB) row[b0] = ex;
-  if (b1 < NB) row[b1] = ex + v0;
+  int ex = incl - mine;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { const int b = 8 * lane + q; if (b < NB) row[b] = ex; ex += v[q]; }
   if (lane == 63) tot[t] = incl;
 }
 
@@ -587,14 +589,14 @@ using namespace gngf;
     default: return (int)hipErrorInvalidValue;      \
   }
 
-// Bins P pixels into 4^tile_shift spatial tiles.  NB = number of binning blocks (<= 128), chunk = max pixels per
+// Bins P pixels into 4^tile_shift spatial tiles.  NB = number of binning blocks (<= 512), chunk = max pixels per
 // work item.  Outputs: sorted (P float4 = x, y, bits(original index), 0), items (max_items int4 = start, count,
 // tile, items of that tile; max_items >= ceil(P/chunk) + 4^tile_shift), n_items (1), tile_off and tile_item_base
 // (4^tile_shift + 1 each: exclusive prefixes of pixels / items per tile), blockhist (4^tile_shift * (NB + 1) scratch).
 extern "C" int gngf_bin_pixels(const float* xy, int64_t P, int tile_shift, int NB, int chunk, int32_t* blockhist,
                                int32_t* tile_off, int32_t* tile_item_base, int32_t* items, int32_t* n_items, float* sorted,
                                void* stream) {
-  GNGF_CHECK_ARG(P >= 0 && P < (1ll << 31) && tile_shift >= 0 && tile_shift <= 6 && NB > 0 && NB <= 128 && chunk > 0);
+  GNGF_CHECK_ARG(P >= 0 && P < (1ll << 31) && tile_shift >= 0 && tile_shift <= 6 && NB > 0 && NB <= kBinMaxBlocks && chunk > 0);
   GNGF_CHECK_ARG(xy && blockhist && tile_off && tile_item_base && items && n_items && sorted);
   const int ntiles = 1 << (2 * tile_shift);
   const int64_t per_block = ceil_div(ceil_div(P, NB), kBinThreads) * kBinThreads;

@@ -470,7 +470,7 @@ class EncodePlan:
         self.ntiles = 1 << (2 * shift)
         self.lds_bytes = int(lds)
         self.chunk = TILED_CHUNK
-        self.NB = max(1, min(128, -(-P // 8192)))
+        self.NB = max(1, min(128, -(-P // 8192)))        # more binning workgroups do not help (measured: tools/perf_bin.py)
         self.max_items = -(-P // self.chunk) + self.ntiles
         self.vtot = sum((n + 2) ** 2 for n in self.n_ls_host[:Ls])
         self.n_ls_c = (_ct.c_int32 * L)(*self.n_ls_host)

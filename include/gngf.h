@@ -77,11 +77,11 @@ int gngf_encode_bwd(const float* xy, const void* tables, int feat_dtype, const i
                     void* stream);
 
 /* ---- a5..a12 fused, "tiled" form: vertex stage + spatially binned, LDS-privatised pixel stage.
- * gngf_bin_pixels: bins P pixels into 4^tile_shift tiles of [0,1]^2.  NB binning blocks (<= 1024); `chunk` = max pixels
+ * gngf_bin_pixels: bins P pixels into 4^tile_shift tiles of [0,1]^2.  NB binning blocks (<= 512); `chunk` = max pixels
  *   per work item.  Outputs: sorted (P,4) fp32 = x, y, bits(original index), 0;  items (max_items,4) int32 = start, count,
  *   tile, items-of-tile with max_items >= ceil(P/chunk) + 4^tile_shift;  n_items (1);  tile_off and tile_item_base
  *   (4^tile_shift + 1 each: exclusive prefixes of pixels / items per tile);  blockhist: scratch of 4^tile_shift * (NB + 1)
- *   int32, NB <= 128. */
+ *   int32. */
 int gngf_bin_pixels(const float* xy, int64_t P, int tile_shift, int NB, int chunk, int32_t* blockhist, int32_t* tile_off,
                     int32_t* tile_item_base, int32_t* items, int32_t* n_items, float* sorted, void* stream);
 /* vertex stage: G[(goff_l + gy*(N_l+2) + gx)*F + f] for levels [0, Ls), goff_l = sum_{j<l} (N_j+2)^2.
