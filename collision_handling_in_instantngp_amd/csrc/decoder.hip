@@ -293,7 +293,10 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
 
 // ------------------------------------------------------------------------------------------------ backward
 // slab layout (floats): dW0 [64*in_dim] | dW1 [64*64] | dW2 [out_dim*64] | db0 [64] | db1 [64] | db2 [out_dim]
-__host__ __device__ inline int slab_size(int in_dim, int out_dim) { return kH * in_dim + kH * kH + out_dim * kH + 2 * kH + out_dim; }
+// ... | max |d enc| of the workgroup (bit pattern; the slab reduction takes the maximum of this slot instead of the sum —
+// no atomics and no memset for the encoder's fixed-point bound)
+__host__ __device__ inline int slab_sums(int in_dim, int out_dim) { return kH * in_dim + kH * kH + out_dim * kH + 2 * kH + out_dim; }
+__host__ __device__ inline int slab_size(int in_dim, int out_dim) { return slab_sums(in_dim, out_dim) + 1; }
 
 constexpr int kImgStride = 34;   // 8-byte aligned rows: ds_read_b64 of two consecutive pixels, conflict-free (34*i mod 64)
 constexpr int kImgFloats = 64 * kImgStride;
@@ -735,11 +738,9 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   if (blockIdx.x == 7 && threadIdx.x == 0)
     for (int k = 0; k < 10; ++k) g_stamps[k] = ph[k];
 #endif
-  if (absmax) {                                          // non-negative floats (and NaN > inf) order like their bit patterns
+  // non-negative floats (and NaN > inf) order like their bit patterns
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const unsigned ov = (unsigned)__shfl_xor((int)dxmax, o, 64); dxmax = ov > dxmax ? ov : dxmax; }
-    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(absmax), dxmax);
-  }
+  for (int o = 32; o > 0; o >>= 1) { const unsigned ov = (unsigned)__shfl_xor((int)dxmax, o, 64); dxmax = ov > dxmax ? ov : dxmax; }
   // ---- wave accumulators -> workgroup slab.  No LDS float atomics (ds_add_f32 costs ~190 cycles per wave-instruction
   // on gfx950): every wave stores its tiles into its own LDS region, bias partials are reduced over the 32 pixel lanes
   // with shuffles, then the four regions are summed into ONE plain-store slab per workgroup.
@@ -777,26 +778,43 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if (lane == 0 && c < out_dim) sb2[c] = v;
   }
+  if (lane == 0) region[nslab - 1] = __uint_as_float(dxmax);
   __syncthreads();
   float* out = slabs + (int64_t)blockIdx.x * nslab;
-  for (int e = threadIdx.x; e < nslab; e += kDecThreads)
+  for (int e = threadIdx.x; e < nslab - 1; e += kDecThreads)
     out[e] = (smem[e] + smem[nslab + e]) + (smem[2 * nslab + e] + smem[3 * nslab + e]);
+  if (threadIdx.x == 0) {
+    unsigned mx = 0u;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const unsigned v = __float_as_uint(smem[w * nslab + nslab - 1]); mx = v > mx ? v : mx; }
+    out[nslab - 1] = __uint_as_float(mx);
+  }
 }
 
 // sums the per-workgroup slabs and writes the six gradient tensors.  64 elements x 16 slab-groups per block.
 __global__ void __launch_bounds__(1024)
 decoder_reduce_kernel(const float* __restrict__ slabs, int nslabs, int nslab, int in_dim, int out_dim,
                       float* __restrict__ dW0, float* __restrict__ db0, float* __restrict__ dW1, float* __restrict__ db1,
-                      float* __restrict__ dW2, float* __restrict__ db2) {
+                      float* __restrict__ dW2, float* __restrict__ db2, float* __restrict__ absmax) {
   __shared__ float red[16][64];
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + c;
+  const bool is_max = e == nslab - 1;                    // last slot: max of bit patterns, not a sum
   float s = 0.f;
   if (e < nslab)
-    for (int b = q; b < nslabs; b += 16) s += slabs[(int64_t)b * nslab + e];
+    for (int b = q; b < nslabs; b += 16) {
+      const float v = slabs[(int64_t)b * nslab + e];
+      s = is_max ? (__float_as_uint(v) > __float_as_uint(s) ? v : s) : s + v;
+    }
   red[q][c] = s;
   __syncthreads();
   if (q != 0 || e >= nslab) return;
+  if (is_max) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s = __float_as_uint(red[k][c]) > __float_as_uint(s) ? red[k][c] : s;
+    if (absmax) *absmax = s;
+    return;
+  }
 #pragma unroll
   for (int k = 1; k < 16; ++k) s += red[k][c];
   const int o0 = kH * in_dim, o1 = o0 + kH * kH, o2 = o1 + out_dim * kH, o3 = o2 + kH, o4 = o3 + kH;
@@ -866,10 +884,6 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
   const int nslab = slab_size(in_dim, out_dim);
   hipStream_t s = as_stream(stream);
   const int nslabs = gngf_decoder_bwd_slabs(P);
-  if (denc_absmax) {
-    hipError_t e = hipMemsetAsync(denc_absmax, 0, sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
-  }
   if (P == 0) {
     hipError_t e = hipMemsetAsync(slabs, 0, sizeof(float) * (size_t)nslab, s);
     if (e != hipSuccess) return (int)e;
@@ -890,7 +904,7 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
     if (e != hipSuccess) return (int)e;
   }
   decoder_reduce_kernel<<<dim3((unsigned)((nslab + 63) / 64)), dim3(1024), 0, s>>>(slabs, nslabs, nslab, in_dim, out_dim, dW0,
-                                                                                   db0, dW1, db1, dW2, db2);
+                                                                                   db0, dW1, db1, dW2, db2, denc_absmax);
   GNGF_RETURN_LAUNCH();
 }
 

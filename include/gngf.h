@@ -184,8 +184,8 @@ int gngf_expand_vertex_table(const float* xy, const int32_t* n_ls, const int32_t
 
 /* ---- pixel loss (row f1 of the scope table: the caller of the path) -------------------------------------------------
  * torch.nn.MSELoss() of utils.py:99 on the (P,out_dim) outputs: loss[0] = mean((pred - label)^2) over n elements.
- * workspace: gngf_mse_workspace_floats() floats, zero-filled once before the first call (the last word is a counter the
- * kernel resets itself).  Deterministic (fixed summation order). */
+ * workspace: gngf_mse_workspace_floats() floats, 8-byte aligned, zero-filled once before the first call (the kernel
+ * resets it).  One launch; workgroup partials meet in a double-precision atomic. */
 int gngf_mse_workspace_floats(void);
 int gngf_mse_fwd(const float* pred, const float* label, float* loss, float* workspace, int64_t n, void* stream);
 /* its backward: dpred (n) = gout[0] * 2 (pred - label) / n   (gout: device scalar, the gradient of the loss value) */
