@@ -314,14 +314,14 @@ tiled_fwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
   }
 }
 
-// fp32 term -> 64-bit fixed point with 2^S fractional scaling, exactly, in six VALU operations: scale by the power of
-// two 2^(S-32) (exact), split into floor and fraction (both exact in fp32), convert each half with the hardware
-// converters.  |t * 2^(S-32)| < 2^31 by the choice of S (the whole SUM must stay below 2^62); floor semantics.
-__device__ __forceinline__ long long to_fixed(float t, int S) {
-  const float u = ldexpf(t, S - 32);
-  const float fl = floorf(u);
-  const int hi = (int)fl;
-  const unsigned lo = (unsigned)ldexpf(u - fl, 32);
+// fp32 term -> 64-bit fixed point, exactly, in four VALU operations.  The term arrives PRE-SCALED by 2^(S-32) (the
+// gradient is scaled once per item; scaling by a power of two commutes with the rounding of the product g*c, so the
+// term is bit-identical to ldexp(g*c, S-32)): floor-convert gives the high word, the fraction (exact in fp32) times 2^32
+// the low word.  |u| < 2^31 by the choice of S (the whole SUM must stay below 2^62); floor semantics.
+__device__ __forceinline__ long long to_fixed_scaled(float u) {
+  int hi;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(hi) : "v"(u));
+  const unsigned lo = (unsigned)ldexpf(__builtin_amdgcn_fractf(u), 32);
   return ((long long)hi << 32) + (long long)(unsigned long long)lo;
 }
 
@@ -409,10 +409,11 @@ tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
           unsigned long long* b = a + wx * F;
 #pragma unroll
           for (int f = 0; f < F; ++f) {
-            atomicAdd(a + f, (unsigned long long)to_fixed(g[f] * c.c[0], S));
-            atomicAdd(a + F + f, (unsigned long long)to_fixed(g[f] * c.c[1], S));
-            atomicAdd(b + f, (unsigned long long)to_fixed(g[f] * c.c[2], S));
-            atomicAdd(b + F + f, (unsigned long long)to_fixed(g[f] * c.c[3], S));
+            const float gs = ldexpf(g[f], S - 32);
+            atomicAdd(a + f, (unsigned long long)to_fixed_scaled(gs * c.c[0]));
+            atomicAdd(a + F + f, (unsigned long long)to_fixed_scaled(gs * c.c[1]));
+            atomicAdd(b + f, (unsigned long long)to_fixed_scaled(gs * c.c[2]));
+            atomicAdd(b + F + f, (unsigned long long)to_fixed_scaled(gs * c.c[3]));
           }
         } else {
 #pragma unroll
