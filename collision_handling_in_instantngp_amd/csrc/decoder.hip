@@ -83,6 +83,17 @@ template <typename F, int... I> __device__ __forceinline__ void static_for_impl(
 template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// The same MFMA with its accumulator tile in ARCHITECTURAL VGPRs (hipcc's builtin always selects the AGPR form in a
+// 512-register kernel, and every VALU touch of an AGPR result costs a v_accvgpr_read): used for the tiles whose results
+// go straight through VALU (activations, masks).  Inline asm is invisible to the hazard recogniser, so the one hazard
+// these chains have is handled by hand: MFMA_DRAIN (18 wait states, ISA "XDL write VGPR -> VALU / memory read" for a
+// 16-pass MFMA) sits between the last MFMA of a chain and the first consumer of its result.  Dependent accumulation
+// into the same registers issues back to back (measured: tools/micro/gen_mfma_regs.py), operands are read at issue.
+#define MFMA_V(acc, a, b) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b))
+#define MFMA_V_INIT(acc, a, b, c) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %3" : "=&v"(acc) : "a"(a), "v"(b), "v"(c))
+#define MFMA_VV(acc, a, b) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define MFMA_VV_ZERO(acc, a, b) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b))
+#define MFMA_DRAIN(x, y) asm volatile("s_nop 15\n\ts_nop 2" : "+v"(x), "+v"(y))
 // scheduling groups (LLVM SchedGroupMask): the next N instructions of that class, in the order the groups are written
 #define SG_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, (n), 0)
 #define SG_VALU(n) __builtin_amdgcn_sched_group_barrier(0x002, (n), 0)
@@ -231,13 +242,14 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
     STAMP(1);
     // MFMA runs and VALU bursts strictly alternate (every switch costs ~10 cycles on top of 4 per VALU instruction)
     f32x16 acc1[2], acc2[2];
-    acc1[0] = MFMA(a0r[0][0], xr[0], b0v[0]);
-    acc1[1] = MFMA(a0r[1][0], xr[0], b0v[1]);
+    MFMA_V_INIT(acc1[0], a0r[0][0], xr[0], b0v[0]);
+    MFMA_V_INIT(acc1[1], a0r[1][0], xr[0], b0v[1]);
 #pragma unroll
     for (int sx = 1; sx < S0; ++sx) {
-      acc1[0] = MFMA(a0r[0][sx], xr[sx], acc1[0]);
-      acc1[1] = MFMA(a0r[1][sx], xr[sx], acc1[1]);
+      MFMA_V(acc1[0], a0r[0][sx], xr[sx]);
+      MFMA_V(acc1[1], a0r[1][sx], xr[sx]);
     }
+    MFMA_DRAIN(acc1[0], acc1[1]);
     __builtin_amdgcn_sched_barrier(0);
     fetch(tile + gridDim.x, xr);
     __builtin_amdgcn_sched_barrier(0);
@@ -247,14 +259,15 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
       for (int r = 0; r < 16; ++r) acc1[t][r] = hidden_act<LEAKY>(acc1[t][r]);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(2);
-    acc2[0] = MFMA(a1r[0][0], acc1[0][0], b1v[0]);
-    acc2[1] = MFMA(a1r[1][0], acc1[0][0], b1v[1]);
+    MFMA_V_INIT(acc2[0], a1r[0][0], acc1[0][0], b1v[0]);
+    MFMA_V_INIT(acc2[1], a1r[1][0], acc1[0][0], b1v[1]);
 #pragma unroll
     for (int s2 = 1; s2 < 32; ++s2) {
       const float b = acc1[s2 >> 4][s2 & 15];
-      acc2[0] = MFMA(a1r[0][s2], b, acc2[0]);
-      acc2[1] = MFMA(a1r[1][s2], b, acc2[1]);
+      MFMA_V(acc2[0], a1r[0][s2], b);
+      MFMA_V(acc2[1], a1r[1][s2], b);
     }
+    MFMA_DRAIN(acc2[0], acc2[1]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -475,7 +488,6 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   //   dh1 [h2 image, dW2 operands -> 32 4x4 MFMAs; dz2 image; dW1 operands; h1 read-back] | mask, db1 |
   //   dW1 [dz1 image, dW0 operands, W0^T frags] | dW0 [next tile's W0 frags] | dX | |d enc| max, db0, next dz3 | stores
 #define STEP_END() __builtin_amdgcn_sched_barrier(0)
-  const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     pin_acc();
     STAMP(0);
@@ -531,10 +543,11 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
         bsel[sk] = h == 0 ? lo : hi;
       }
       STEP_END();
-      d2[0] = MFMA(fa[0][0], bsel[0], kZero16); d2[1] = MFMA(fa[1][0], bsel[0], kZero16);
-      d2[0] = MFMA(fa[0][1], bsel[1], d2[0]); d2[1] = MFMA(fa[1][1], bsel[1], d2[1]);
+      MFMA_VV_ZERO(d2[0], fa[0][0], bsel[0]); MFMA_VV_ZERO(d2[1], fa[1][0], bsel[0]);
+      MFMA_VV(d2[0], fa[0][1], bsel[1]); MFMA_VV(d2[1], fa[1][1], bsel[1]);
     }
     fetch_y(tile + gridDim.x);
+    MFMA_DRAIN(d2[0], d2[1]);
     STEP_END();
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -555,8 +568,8 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
       f32x2 av[16], bv[16];
       static_for<16>([&](auto S2) {
         constexpr int s2 = S2.value;
-        if constexpr (s2 == 0) { d1[0] = MFMA(ft[0][0], d2[0][0], kZero16); d1[1] = MFMA(ft[1][0], d2[0][0], kZero16); }
-        else { d1[0] = MFMA(ft[0][s2], d2[0][s2], d1[0]); d1[1] = MFMA(ft[1][s2], d2[0][s2], d1[1]); }
+        if constexpr (s2 == 0) { MFMA_VV_ZERO(d1[0], ft[0][0], d2[0][0]); MFMA_VV_ZERO(d1[1], ft[1][0], d2[0][0]); }
+        else { MFMA_VV(d1[0], ft[0][s2], d2[0][s2]); MFMA_VV(d1[1], ft[1][s2], d2[0][s2]); }
         if constexpr (s2 < 8) {                           // h2 image (imgA), 4 stores per step
           static_for<4>([&](auto E) {
             constexpr int e = 4 * s2 + E.value, t = e >> 4, r = e & 15;
@@ -583,8 +596,8 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     }
     static_for<16>([&](auto S2) {
       constexpr int s2 = 16 + S2.value, k = S2.value;
-      d1[0] = MFMA(ft[0][s2], d2[1][k], d1[0]);
-      d1[1] = MFMA(ft[1][s2], d2[1][k], d1[1]);
+      MFMA_VV(d1[0], ft[0][s2], d2[1][k]);
+      MFMA_VV(d1[1], ft[1][s2], d2[1][k]);
       if constexpr (k < 8) {                              // dz2 image: 4 stores per step
         static_for<4>([&](auto E) {
           constexpr int e = 4 * k + E.value, t = e >> 4, r = e & 15;
@@ -603,6 +616,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
       }
       STEP_END();
     });
+    MFMA_DRAIN(d1[0], d1[1]);
     lds_wait();
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -686,10 +700,11 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     f32x16 dxv[TX];
 #pragma unroll
     for (int tx = 0; tx < TX; ++tx) {
-      dxv[tx] = MFMA(fx[tx][0], d1[0][0], kZero16);
+      MFMA_VV_ZERO(dxv[tx], fx[tx][0], d1[0][0]);
 #pragma unroll
-      for (int s2 = 1; s2 < 32; ++s2) dxv[tx] = MFMA(fx[tx][s2], d1[s2 >> 4][s2 & 15], dxv[tx]);
+      for (int s2 = 1; s2 < 32; ++s2) MFMA_VV(dxv[tx], fx[tx][s2], d1[s2 >> 4][s2 & 15]);
     }
+    MFMA_DRAIN(dxv[0], dxv[TX - 1]);
     STEP_END();
 #pragma unroll
     for (int tx = 0; tx < TX; ++tx)
