@@ -6,11 +6,13 @@ summ = json.loads(subprocess.check_output([sys.executable, "tools/pmc_summary.py
 groups = {
     "encode_fwd:tiled": ["gngf::tiled_fwd_kernel<2>"],
     "encode_bwd:tiled": ["gngf::tiled_bwd_kernel<2>", "gngf::gather_partials_kernel<2>"],
-    "decoder_fwd": ["gngf::decoder_fwd_kernel<32>"],
-    "decoder_bwd": ["gngf::decoder_bwd_kernel<32>", "gngf::decoder_reduce_kernel"],
-    "vertex_fwd": ["gngf::vertex_fwd_kernel<2, true>"],
-    "vertex_bwd": ["gngf::vertex_bwd_sorted_kernel<2>"],
+    "decoder_fwd": ["gngf::decoder_fwd_kernel<32"],
+    "decoder_bwd": ["gngf::decoder_bwd_kernel<32", "gngf::decoder_reduce_kernel"],
+    "vertex_fwd": ["gngf::vertex_fwd_kernel<2, true"],
+    "vertex_bwd": ["gngf::vertex_bwd_sorted_kernel<2"],
 }
+def pick(prefix, counter):          # kernel names carry their full template argument lists: match by prefix
+    return sum(v.get(counter, 0.0) for k, v in summ.items() if k.startswith(prefix))
 # FETCH_SIZE correction, calibrated per kernel on a known byte count as the guide asks (the 128 MiB enc / d-enc rows):
 # kernels whose dominant reads are 16 B per lane report exactly half (factor 2: decoder_fwd reads 128 MiB of enc and
 # FETCH_SIZE says 64.2 MiB); tiled_bwd reads its 128 MiB of d-enc rows as 8 B per lane and FETCH_SIZE already says
@@ -18,8 +20,8 @@ groups = {
 fetch_factor = {"encode_bwd:tiled": 1.0}
 out = {}
 for name, ks in groups.items():
-    f = sum(summ.get(k, {}).get("FETCH_SIZE", 0.0) for k in ks)
-    w = sum(summ.get(k, {}).get("WRITE_SIZE", 0.0) for k in ks)
+    f = sum(pick(k, "FETCH_SIZE") for k in ks)
+    w = sum(pick(k, "WRITE_SIZE") for k in ks)
     if f or w:
         ff = fetch_factor.get(name, 2.0)
         out[name] = {"hbm_bytes_per_launch": (ff * f + w) * 1024, "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB": w, "fetch_factor": ff,
