@@ -494,43 +494,72 @@ gather_partials_kernel(const float* __restrict__ partials, const int32_t* __rest
   for (int f = 0; f < F; ++f) d[f] += acc[f];      // += : the out-of-sub-grid fallback may already have added (atomically, earlier kernel)
 }
 
+// DPP lane movement (row_shr:n = 0x110+n inside 16-lane rows, row_bcast:15 = 0x142, row_bcast:31 = 0x143); lanes without a
+// source keep `old` (0 for values, -1 for slot numbers)
+template <int CTRL, int ROWMASK> __device__ __forceinline__ float dppf(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROWMASK, 0xF, false));
+}
+template <int CTRL, int ROWMASK> __device__ __forceinline__ int dppi(int x) {
+  return __builtin_amdgcn_update_dpp(-1, x, CTRL, ROWMASK, 0xF, false);
+}
+
 // Vertex stage backward for the vertex-table index source, contention-free for ANY slot distribution (a freshly
 // initialised HPD maps most vertices to a handful of slots): the (vertex,k) entries are visited in SLOT order
 // (`order` = argsort of vert_idx), each lane takes one entry and walks the levels it belongs to, and equal slots —
 // adjacent lanes — are combined with a wave-level segmented scan before the one atomic per (wave, run).
 // dvert_w needs no atomics at all: every entry is owned by exactly one lane.
+constexpr int kVB = 1024;          // vertex_bwd_sorted workgroup: 16 waves share one atomic per (run, level)
 template <int F, typename TT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kVB)
 vertex_bwd_sorted_kernel(const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
                          const int32_t* __restrict__ order, const int32_t* __restrict__ n_ls, const float* __restrict__ dG,
                          float* __restrict__ dtables, float* __restrict__ dvert_w, int Ls, int64_t T, int K, int vstride,
                          int64_t NE) {
+  constexpr int NW = kVB / 64;
   __shared__ int s_n[GNGF_MAX_LEVELS];
   __shared__ int64_t s_goff[GNGF_MAX_LEVELS];
+  __shared__ int s_first[NW], s_last[NW], s_lstart[NW];
+  __shared__ float s_tail[2][NW][F];
   if (threadIdx.x < Ls) s_n[threadIdx.x] = n_ls[threadIdx.x];
   __syncthreads();
   if (threadIdx.x == 0) { int64_t o = 0; for (int l = 0; l < Ls; ++l) { s_goff[l] = o; o += (int64_t)(s_n[l] + 2) * (s_n[l] + 2); } }
-  __syncthreads();
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * kVB + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool live = j < NE;
   const int e = live ? order[j] : 0;
   const int slot = live ? vert_idx[e] : -1 - lane;          // dead lanes never merge with anything
   const float w = live ? vert_w[e] : 0.f;
   const int vid = e / K;
   const int gy = vid / vstride, gx = vid - gy * vstride;
-  const int slot_up = __shfl_up(slot, 1, 64), slot_dn = __shfl_down(slot, 1, 64);
-  const bool run_tail = (lane == 63) || (slot_dn != slot);
-  (void)slot_up;
+  const int slot_dn = __shfl_down(slot, 1, 64);
+  // segment predicates of the DPP scan: does the lane 1/2/4/8 below in the 16-lane row, the last lane of the previous
+  // row (rows 1, 3), lane 31 (rows 2, 3) hold the same slot?  (out-of-row sources read as -1: never equal)
+  const bool p1 = dppi<0x111, 0xF>(slot) == slot, p2 = dppi<0x112, 0xF>(slot) == slot, p4 = dppi<0x114, 0xF>(slot) == slot,
+             p8 = dppi<0x118, 0xF>(slot) == slot, pA = dppi<0x142, 0xA>(slot) == slot, pB = dppi<0x143, 0xC>(slot) == slot;
   float dw_acc = 0.f;
-  // first level this lane's vertex belongs to (levels ascend, so it belongs to every later one); the wave starts at
-  // the smallest such level among its lanes — with the (first level, slot) visiting order that is the lanes' own.
+  // first level this lane's vertex belongs to (levels ascend, so it belongs to every later one); the workgroup starts at
+  // the smallest such level among its lanes — with the (first level, slot) visiting order that is mostly the lanes' own.
+  __syncthreads();                                          // s_n, s_goff
   int lmin = Ls;
   if (live) { const int mg = gx > gy ? gx : gy; lmin = 0; while (lmin < Ls && mg > s_n[lmin] + 1) ++lmin; }
   int lstart = lmin;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { const int ov = __shfl_xor(lstart, o, 64); lstart = ov < lstart ? ov : lstart; }
-  for (int l = lstart; l < Ls; ++l) {
+  // A freshly initialised HPD sends a million (vertex,k) entries to a few dozen slots: one atomic per (wave, run, level)
+  // would still pile ~300 same-address float atomics on each table row.  The 16 waves of the workgroup chain their runs
+  // through LDS instead: a run that continues into the next wave hands its partial sum over, and only the wave in which the
+  // run ENDS (or the last wave of the workgroup) issues the atomic.  The chaining depends on the slots only, not the level.
+  const int first_slot = __shfl(slot, 0, 64), last_slot = __shfl(slot, 63, 64);
+  if (lane == 0) { s_first[wave] = first_slot; s_last[wave] = last_slot; s_lstart[wave] = lstart; }
+  __syncthreads();
+  int lblock = Ls;
+#pragma unroll
+  for (int q = 0; q < NW; ++q) lblock = s_lstart[q] < lblock ? s_lstart[q] : lblock;
+  const bool continues = wave + 1 < NW && s_first[wave + 1] == last_slot;    // my last run goes on in the next wave
+  // lanes that emit the atomic of their run: its last lane, unless the run is handed to the next wave
+  const bool emit = live && ((lane == 63) ? !continues : (slot_dn != slot));
+  const bool in_first_run = slot == first_slot;             // (slots are sorted: equal means the same run)
+  for (int l = lblock; l < Ls; ++l) {
     const int n = s_n[l];
     const bool in = live && l >= lmin;
     float v[F];
@@ -550,23 +579,44 @@ vertex_bwd_sorted_kernel(const TT* __restrict__ tables, const int32_t* __restric
       for (int f = 0; f < F; ++f) v[f] = 0.f;
     }
     dw_acc += dot;
-    // the whole wave skips a level none of its lanes belongs to
-    if (__ballot(in) == 0ull) continue;
-    // segmented inclusive scan over equal-slot runs
+    // segmented inclusive scan over equal-slot runs, entirely on DPP (no ds_bpermute): 16-lane rows first, then lane
+    // 15 / 47 into the next row and lane 31 into the upper half.
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int os = __shfl_up(slot, o, 64);
-#pragma unroll
-      for (int f = 0; f < F; ++f) {
-        const float ov = __shfl_up(v[f], o, 64);
-        if (lane >= o && os == slot) v[f] += ov;
-      }
+    for (int f = 0; f < F; ++f) {
+      float x = v[f], y;
+      // the lane movement must run with the FULL exec mask (a DPP source lane that is masked off reads as invalid):
+      // the empty asm keeps hipcc from sinking it under the predicate
+      y = dppf<0x111, 0xF>(x); asm volatile("" : "+v"(y)); x += p1 ? y : 0.f;
+      y = dppf<0x112, 0xF>(x); asm volatile("" : "+v"(y)); x += p2 ? y : 0.f;
+      y = dppf<0x114, 0xF>(x); asm volatile("" : "+v"(y)); x += p4 ? y : 0.f;
+      y = dppf<0x118, 0xF>(x); asm volatile("" : "+v"(y)); x += p8 ? y : 0.f;
+      y = dppf<0x142, 0xA>(x); asm volatile("" : "+v"(y)); x += pA ? y : 0.f;
+      y = dppf<0x143, 0xC>(x); asm volatile("" : "+v"(y)); x += pB ? y : 0.f;
+      v[f] = x;
     }
-    if (run_tail && live) {
+    // hand-over between waves (double-buffered by level parity: one barrier per level)
+    float (*tail)[F] = s_tail[l & 1];
+    if (lane == 63) {
+#pragma unroll
+      for (int f = 0; f < F; ++f) tail[wave][f] = v[f];
+    }
+    __syncthreads();
+    float carry[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) carry[f] = 0.f;
+    for (int q = wave - 1; q >= 0; --q) {                   // wave-uniform walk down the chain that ends in my first run
+      if (s_last[q] != first_slot) break;
+#pragma unroll
+      for (int f = 0; f < F; ++f) carry[f] += tail[q][f];
+      if (s_first[q] != s_last[q]) break;                   // that wave's last run began inside it: the chain starts there
+    }
+    if (emit) {
       float* d = dtables + ((int64_t)l * T + slot) * F;
 #pragma unroll
-      for (int f = 0; f < F; ++f)
-        if (v[f] != 0.f) atomicAdd(d + f, v[f]);
+      for (int f = 0; f < F; ++f) {
+        const float tot = v[f] + (in_first_run ? carry[f] : 0.f);
+        if (tot != 0.f) atomicAdd(d + f, tot);
+      }
     }
   }
   if (live && dvert_w) dvert_w[e] = dw_acc;
@@ -716,7 +766,7 @@ extern "C" int gngf_vertex_grid_bwd_sorted(const void* tables, int feat_dtype, c
   GNGF_CHECK_ARG(Ls > 0 && Ls <= GNGF_MAX_LEVELS && T > 0 && K > 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0);
   GNGF_CHECK_ARG(tables && vert_idx && vert_w && order && n_ls && dG && dtables && NV * K < (1ll << 31));
   const int64_t NE = NV * K;
-  DISPATCH_TT(feat_dtype, DISPATCH_F(F, (vertex_bwd_sorted_kernel<kF, TT><<<dim3((unsigned)ceil_div(NE, 256)), dim3(256), 0,
+  DISPATCH_TT(feat_dtype, DISPATCH_F(F, (vertex_bwd_sorted_kernel<kF, TT><<<dim3((unsigned)ceil_div(NE, kVB)), dim3(kVB), 0,
                                                                           as_stream(stream)>>>(
                               static_cast<const TT*>(tables), vert_idx, vert_w, order, n_ls, dG, dtables, dvert_w, Ls, T, K,
                               vstride, NE))));
