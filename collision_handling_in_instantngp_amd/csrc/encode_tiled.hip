@@ -508,7 +508,7 @@ template <int CTRL, int ROWMASK> __device__ __forceinline__ int dppi(int x) {
 // (`order` = argsort of vert_idx), each lane takes one entry and walks the levels it belongs to, and equal slots —
 // adjacent lanes — are combined with a wave-level segmented scan before the one atomic per (wave, run).
 // dvert_w needs no atomics at all: every entry is owned by exactly one lane.
-constexpr int kVB = 1024;          // vertex_bwd_sorted workgroup: 16 waves share one atomic per (run, level)
+constexpr int kVB = 512;           // vertex_bwd_sorted workgroup: 8 waves share one atomic per (run, level); measured 1024: 35 us, 512: 26, 256: 27
 template <int F, typename TT>
 __global__ void __launch_bounds__(kVB)
 vertex_bwd_sorted_kernel(const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
@@ -546,7 +546,7 @@ vertex_bwd_sorted_kernel(const TT* __restrict__ tables, const int32_t* __restric
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { const int ov = __shfl_xor(lstart, o, 64); lstart = ov < lstart ? ov : lstart; }
   // A freshly initialised HPD sends a million (vertex,k) entries to a few dozen slots: one atomic per (wave, run, level)
-  // would still pile ~300 same-address float atomics on each table row.  The 16 waves of the workgroup chain their runs
+  // would still pile ~300 same-address float atomics on each table row.  The waves of the workgroup chain their runs
   // through LDS instead: a run that continues into the next wave hands its partial sum over, and only the wave in which the
   // run ENDS (or the last wave of the workgroup) issues the atomic.  The chaining depends on the slots only, not the level.
   const int first_slot = __shfl(slot, 0, 64), last_slot = __shfl(slot, 63, 64);

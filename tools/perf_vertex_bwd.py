@@ -8,7 +8,7 @@ dev = torch.device("cuda")
 xy, target, _ = bench.strawberry_batch(2**20, 0, dev)
 net, models = bench.build_model("gngf_frozen", dev)
 kt = bench.kernel_times(net, models, "gngf_frozen", xy, n=20)
-print({k: round(v * 1e3, 1) for k, v in kt.items()}, "us")
+print({k: round(v * 1e6, 1) for k, v in kt.items()}, "us")
 with torch.no_grad():
     _tv, ti, w, vstride, NV, order = net._frozen_vertex_table(0)
 flat = ti.reshape(-1)[order.long()]
