@@ -132,8 +132,39 @@ def timed(step, steps, warmup, world):
     return dt
 
 
+ENTRY_NAMES = {"gngf_bin_pixels": "bin_pixels", "gngf_vertex_grid_fwd": "vertex_fwd", "gngf_encode_tiled_fwd": "encode_fwd:tiled",
+               "gngf_encode_tiled_bwd": "encode_bwd:tiled", "gngf_vertex_grid_bwd_sorted": "vertex_bwd", "gngf_vertex_grid_bwd": "vertex_bwd",
+               "gngf_decoder_fwd": "decoder_fwd", "gngf_decoder_bwd": "decoder_bwd", "gngf_mse_fwd": "mse_fwd", "gngf_mse_bwd": "mse_bwd",
+               "gngf_encode_fwd": "encode_fwd:direct", "gngf_encode_bwd": "encode_bwd:direct"}
+
+
+def kernel_times_in_step(eager_step, n=20, warm=3):
+    """Average launch duration of every C-ABI entry point INSIDE the training step: HIP events recorded on the stream
+    each kernel is launched on (torch's current stream at the call; the helper stream for the vertex stage), bracketing
+    every call of n eagerly launched steps.  `decoder_bwd` = decoder_bwd_kernel + decoder_reduce_kernel,
+    `encode_bwd:tiled` = tiled_bwd_kernel + gather_partials_kernel (one entry point each)."""
+    from collision_handling_in_instantngp_amd import _lib
+    for _ in range(warm):
+        eager_step()
+    torch.cuda.synchronize()
+    _lib.PROFILE = {}
+    try:
+        for _ in range(n):
+            eager_step()
+        torch.cuda.synchronize()
+        prof = _lib.PROFILE
+    finally:
+        _lib.PROFILE = None
+    out = {}
+    for name, pairs in prof.items():
+        key = ENTRY_NAMES.get(name, name)
+        ms = [a.elapsed_time(b) for a, b in pairs]
+        out[key] = out.get(key, 0.0) + sum(ms) / n * 1e-3          # seconds per step (entry points called once per step)
+    return out
+
+
 def kernel_times(net, models, mode, xy, n=20):
-    """HIP-event timing (on the launch stream = torch's current stream) of each hot kernel launched alone."""
+    """Fallback: HIP-event timing (on the launch stream = torch's current stream) of each hot kernel launched alone."""
     from collision_handling_in_instantngp_amd import ops
     dev = xy.device
     n_ls = net._n_ls_flat(dev)
@@ -283,7 +314,13 @@ def main():
         dt = timed(step, steps, warmup, world)
         results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                          "launch": launch}
-        if head and rank == 0:
+        if head and rank == 0 and world == 1:
+            try:
+                kt = kernel_times_in_step(make_step(net, models, mode, xy, target, world), n=(3 if mode == "gngf_learning" else 20),
+                                          warm=(0 if mode == "gngf_learning" else 3))
+            except Exception as e:  # pragma: no cover
+                kt = {"error": repr(e)}
+        elif head and rank == 0:
             try:
                 kt = kernel_times(net, models, mode, xy)
             except Exception as e:  # pragma: no cover

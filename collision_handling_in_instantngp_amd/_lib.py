@@ -110,8 +110,20 @@ def query(name, *args):
     return getattr(load(), name)(*args)
 
 
+# Optional in-step profiling (bench.py): when PROFILE is a dict, every entry point is bracketed by HIP events recorded
+# on torch's current stream — the stream the kernels are launched on — and the pairs are collected per entry point.
+PROFILE = None
+
+
 def call(name, *args):
-    rc = getattr(load(), name)(*args)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(load(), name)(*args)
+        e1.record()
+        PROFILE.setdefault(name, []).append((e0, e1))
+    else:
+        rc = getattr(load(), name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed with hipError_t {rc}"
                            + (" (hipErrorInvalidValue: rejected arguments)" if rc == 1 else ""))
