@@ -5,7 +5,7 @@
 namespace gngf {
 
 constexpr int kLossThreads = 1024;                      // 16 waves per CU: the value kernel is a latency-bound stream
-constexpr int kLossBlocks = 256;
+constexpr int kLossBlocks = 64;                       // few workgroups: their two same-address atomics each are the serial part
 
 // loss = sum((pred - label)^2) / n in ONE launch (a launch costs ~6 us inside a replayed step; a last-block-reduces
 // scheme built on an agent-scope release FENCE is worse: on this chip the fence writes the whole L2 back, 15 us
