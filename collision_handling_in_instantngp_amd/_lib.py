@@ -33,8 +33,9 @@ SIGNATURES = {
     "gngf_encode_tiled_fwd": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gngf_encode_tiled_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gngf_vertex_grid_bwd_sorted": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _L, _P],
-    "gngf_decoder_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
-    "gngf_decoder_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "gngf_decoder_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "gngf_decoder_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "gngf_decoder_hidden_floats": [_L],
     "gngf_decoder_bwd_slabs": [_L],
     "gngf_decoder_slab_floats": [_I, _I],
     "gngf_linear_fwd": [_P, _P, _P, _P, _L, _I, _I, _I, _P],
@@ -57,6 +58,7 @@ SIGNATURES = {
     "gngf_mse_bwd": [_P, _P, _P, _P, _L, _P],
 }
 
+_RETURNS_INT64 = {"gngf_decoder_hidden_floats"}
 _lib = None
 
 
@@ -80,10 +82,10 @@ def load():
         except AttributeError as e:
             raise GngfLibraryError(f"{LIB_PATH} does not export {name}: stale build?") from e
         fn.argtypes = argtypes
-        fn.restype = _I
+        fn.restype = _L if name in _RETURNS_INT64 else _I
     ver = lib.gngf_abi_version()
-    if ver != 1:
-        raise GngfLibraryError(f"ABI version mismatch: library {ver}, binding 1")
+    if ver != 2:
+        raise GngfLibraryError(f"ABI version mismatch: library {ver}, binding 2")
     _lib = lib
     return lib
 

@@ -94,6 +94,7 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 #define MFMA_VV(acc, a, b) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define MFMA_VV_ZERO(acc, a, b) asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b))
 #define MFMA_DRAIN(x, y) asm volatile("s_nop 15\n\ts_nop 2" : "+v"(x), "+v"(y))
+#define MFMA_DRAIN1(x) asm volatile("s_nop 15\n\ts_nop 2" : "+v"(x))
 // scheduling groups (LLVM SchedGroupMask): the next N instructions of that class, in the order the groups are written
 #define SG_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, (n), 0)
 #define SG_VALU(n) __builtin_amdgcn_sched_group_barrier(0x002, (n), 0)
@@ -156,6 +157,7 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 #if defined(GNGF_STAMPS)   // diagnostic build only (tools/perf_decoder.py --stamps): per-phase cycle shares of the backward loop
 __device__ unsigned long long g_stamps[16];
 __device__ unsigned long long g_fstamps[16];
+__device__ unsigned long long g_blocktime[2][256][2];   // [fwd/bwd][workgroup][start, end] (s_memtime)
 #define STAMP(k) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
     ph[k] += t_ - tlast; tlast = t_; } while (0)
@@ -163,13 +165,47 @@ __device__ unsigned long long g_fstamps[16];
 #define STAMP(k) do {} while (0)
 #endif
 
-template <int KIN, bool LEAKY, bool EXACT>
+// Saved hidden activations: per 128-pixel tile 64 KB = [layer 2][wave 4][register group 8][lane 64][4 floats]; a lane's
+// 16-byte pieces are the register quadruples 4g..4g+3 of its accumulator tile pair, so that every store / load instruction
+// of a wave moves 1 KB of consecutive memory and the backward kernel gets the tiles back in the register layout it needs.
+constexpr int kHiddenTileFloats = 2 * 4 * 8 * 64 * 4;
+__device__ __forceinline__ void hidden_store(float* hidden, int64_t tile, int which, unsigned hoff, const f32x16 (&v)[2]) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hidden + tile * kHiddenTileFloats, 0, kHiddenTileFloats * 4, 0x00020000);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x4 q = {__float_as_uint(v[t][4 * g]), __float_as_uint(v[t][4 * g + 1]), __float_as_uint(v[t][4 * g + 2]),
+                       __float_as_uint(v[t][4 * g + 3])};
+      __builtin_amdgcn_raw_buffer_store_b128(q, rs, hoff, which * 32768 + (t * 4 + g) * 1024, 0);
+    }
+}
+__device__ __forceinline__ void hidden_load(const float* hidden, int64_t tile, int64_t ntiles, int which, unsigned hoff, f32x16 (&v)[2]) {
+  const int64_t tt = tile < ntiles ? tile : ntiles - 1;   // past the end: any valid tile (the values are never used)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hidden) + tt * kHiddenTileFloats, 0, kHiddenTileFloats * 4, 0x00020000);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, hoff, which * 32768 + (t * 4 + g) * 1024, 0);
+      v[t][4 * g] = __uint_as_float(q.x); v[t][4 * g + 1] = __uint_as_float(q.y);
+      v[t][4 * g + 2] = __uint_as_float(q.z); v[t][4 * g + 3] = __uint_as_float(q.w);
+    }
+}
+
+// SAVE: the activated hidden tiles are also written to `hidden` for the backward kernel (layout: hidden_offset below).
+// Stores are issued between MFMAs and cost no issue time; the 512 B/pixel ride on HBM bandwidth the kernel does not use.
+template <int KIN, bool LEAKY, bool EXACT, bool SAVE>
 __global__ void __launch_bounds__(kDecThreads, 1)
 decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, const float* __restrict__ b0,
                    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
-                   const float* __restrict__ b2, float* __restrict__ Y, int64_t P, int in_dim, int out_dim) {
+                   const float* __restrict__ b2, float* __restrict__ Y, float* __restrict__ hidden, int64_t P, int in_dim,
+                   int out_dim) {
   constexpr int S0 = KIN / 2;
   if (EXACT) in_dim = KIN;
+#if defined(GNGF_STAMPS)
+  if (threadIdx.x == 0) g_blocktime[0][blockIdx.x & 255][0] = __builtin_readcyclecounter();
+#endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
   const int64_t ntiles = (P + 127) / 128;
   // register-resident operands, gathered from a coalesced LDS copy of the raw weights
@@ -214,13 +250,12 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
     int64_t rem = (P - tt * 128) * in_dim * 4;
     rem = rem < 0 ? 0 : (rem > 128 * in_dim * 4 ? 128 * in_dim * 4 : rem);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X) + tt * 128 * in_dim, 0, (int)rem, 0x00020000);
-    if (EXACT) {
-#pragma unroll
-      for (int k = 0; k < S0 / 4; ++k) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff + 16 * k, 0, 0);
-        dst[4 * k] = __uint_as_float(v.x); dst[4 * k + 1] = __uint_as_float(v.y);
-        dst[4 * k + 2] = __uint_as_float(v.z); dst[4 * k + 3] = __uint_as_float(v.w);
-      }
+    if (EXACT) {                                          // asm loads: see the vmcnt note below
+      static_for<S0 / 4>([&](auto K) {
+        f32x4 v;
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(v) : "v"(xoff), "s"(rs), "n"(16 * K.value) : "memory");
+        dst[4 * K.value] = v.x; dst[4 * K.value + 1] = v.y; dst[4 * K.value + 2] = v.z; dst[4 * K.value + 3] = v.w;
+      });
     } else {
 #pragma unroll
       for (int sx = 0; sx < S0; ++sx) {
@@ -230,15 +265,28 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
     }
   };
   const unsigned yoff = (unsigned)(((wave * 32 + i) * out_dim) * 4);
+  const unsigned hoff = (unsigned)(wave * 8192 + lane * 16);
   // x of the next tile is loaded straight into xr as soon as layer 1 has consumed it: it lands under layer 2
   float xr[S0];
   fetch(blockIdx.x, xr);
+  // hipcc sizes the vmcnt wait in front of the first use of a prefetched register for the WORST predecessor of the loop
+  // header: coming from the prologue nothing follows the loads, so it waits for "all but 3" memory operations on every
+  // iteration — including the 12-20 stores the previous tile issued after its loads, i.e. for the full write latency at
+  // the top of every tile (+2.8 k cycles per tile with the hidden-layer stores).  The exact-width path therefore issues
+  // the row loads through inline asm and waits for them itself: kStoresPerTile memory operations follow them in a tile.
+  constexpr int kStoresPerTile = (SAVE ? 16 : 0) + 4;
+  if (EXACT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if defined(GNGF_STAMPS)
   unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory");
 #endif
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     STAMP(0);
+    if (EXACT) {                                           // the row loads of this tile (issued a tile ago) have landed
+      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kStoresPerTile) : "memory");
+#pragma unroll
+      for (int sx = 0; sx < S0; ++sx) asm volatile("" : "+v"(xr[sx]));
+    }
     STAMP(1);
     // MFMA runs and VALU bursts strictly alternate (every switch costs ~10 cycles on top of 4 per VALU instruction)
     f32x16 acc1[2], acc2[2];
@@ -259,6 +307,7 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
       for (int r = 0; r < 16; ++r) acc1[t][r] = hidden_act<LEAKY>(acc1[t][r]);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(2);
+    if (SAVE) hidden_store(hidden, tile, 0, hoff, acc1);
     MFMA_V_INIT(acc2[0], a1r[0][0], acc1[0][0], b1v[0]);
     MFMA_V_INIT(acc2[1], a1r[1][0], acc1[0][0], b1v[1]);
 #pragma unroll
@@ -275,6 +324,7 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
       for (int r = 0; r < 16; ++r) acc2[t][r] = hidden_act<LEAKY>(acc2[t][r]);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(3);
+    if (SAVE) hidden_store(hidden, tile, 1, hoff, acc2);
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s2 = 0; s2 < 32; s2 += 2) {
@@ -301,6 +351,7 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
 #if defined(GNGF_STAMPS)
   if (blockIdx.x == 7 && threadIdx.x == 0)
     for (int k = 0; k < 10; ++k) g_fstamps[k] = ph[k];
+  if (threadIdx.x == 0) g_blocktime[0][blockIdx.x & 255][1] = __builtin_readcyclecounter();
 #endif
 }
 
@@ -321,16 +372,21 @@ template <int KIN> struct BwdLds {
 };
 
 // EXACT: in_dim == KIN (no per-feature predicates anywhere in the loop)
-template <int KIN, bool LEAKY, bool EXACT>
+// RECOMPUTE: the hidden activations are recomputed from enc (96 more MFMAs per tile); otherwise they are read back from
+// the buffer the forward kernel saved them to (loads are free between MFMAs: 22.0 k -> ~14 k cycles per tile).
+template <int KIN, bool LEAKY, bool EXACT, bool RECOMPUTE>
 __global__ void __launch_bounds__(kDecThreads, 1)
 decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, const float* __restrict__ dY,
                    const float* __restrict__ W0, const float* __restrict__ b0, const float* __restrict__ W1,
                    const float* __restrict__ b1, const float* __restrict__ W2, float* __restrict__ dX,
-                   float* __restrict__ slabs, float* __restrict__ absmax, int64_t P, int in_dim, int out_dim) {
+                   float* __restrict__ slabs, const float* __restrict__ hidden, int64_t P, int in_dim, int out_dim) {
   using FF = FwdFrags<KIN>;
   constexpr int S0 = KIN / 2;
   constexpr int TX = (KIN + 31) / 32;                    // 32-row tiles of the input width
   if (EXACT) in_dim = KIN;
+#if defined(GNGF_STAMPS)
+  if (threadIdx.x == 0) g_blocktime[1][blockIdx.x & 255][0] = __builtin_readcyclecounter();
+#endif
   extern __shared__ float smem[];
   float* A0 = smem;                                      // forward fragments (recompute)
   float* A1 = A0 + FF::kA0;
@@ -460,11 +516,13 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   make_dz3();
   // biases: accumulator-file residents, the C operand of the first MFMA of each recompute chain
   f32x16 b0v[2], b1v[2];
+  if (RECOMPUTE) {
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 2; ++t) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { b0v[t][r] = bs[32 * t + crow(r, h)]; b1v[t][r] = bs[kH + 32 * t + crow(r, h)]; }
-    asm volatile("" : "+a"(b0v[t]), "+a"(b1v[t]));
+      for (int r = 0; r < 16; ++r) { b0v[t][r] = bs[32 * t + crow(r, h)]; b1v[t][r] = bs[kH + 32 * t + crow(r, h)]; }
+      asm volatile("" : "+a"(b0v[t]), "+a"(b1v[t]));
+    }
   }
   unsigned dxmax = 0u;                                   // bits of the largest |d enc| this lane produced (hint for the encoder backward)
 #if defined(GNGF_STAMPS)
@@ -476,7 +534,18 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   // second half of the W0^T fragments takes their place under dW0.)
   constexpr bool kCarryF0 = KIN <= 32;
   float f0[2][S0];
-  if (kCarryF0) {
+  // hidden tiles (h1 = acc1, h2 = acc2, activated) and the W1^T fragments of dh1: recomputed / loaded inside the tile when
+  // RECOMPUTE, else carried across the loop — read from the forward kernel's buffer one tile ahead
+  f32x16 acc1[2], acc2[2];
+  float ft[2][32];
+  const unsigned hoff = (unsigned)(wave * 8192 + lane * 16);
+  if (!RECOMPUTE) {
+    hidden_load(hidden, blockIdx.x, ntiles, 0, hoff, acc1);
+    hidden_load(hidden, blockIdx.x, ntiles, 1, hoff, acc2);
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) { ft[0][s2] = A1T[(0 * 32 + s2) * 64 + lane]; ft[1][s2] = A1T[(1 * 32 + s2) * 64 + lane]; }
+  }
+  if (RECOMPUTE && kCarryF0) {
 #pragma unroll
     for (int sx = 0; sx < S0; ++sx) { f0[0][sx] = A0[(0 * S0 + sx) * 64 + lane]; f0[1][sx] = A0[(1 * S0 + sx) * 64 + lane]; }
   }
@@ -491,8 +560,8 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     pin_acc();
     STAMP(0);
-    f32x16 acc1[2], acc2[2];
-    float f1[2][32], ft[2][32];
+    float f1[2][32];
+    if constexpr (RECOMPUTE) {
     if (!kCarryF0) {
 #pragma unroll
       for (int sx = 0; sx < S0; ++sx) { f0[0][sx] = A0[(0 * S0 + sx) * 64 + lane]; f0[1][sx] = A0[(1 * S0 + sx) * 64 + lane]; }
@@ -528,6 +597,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
       ft[1][s2] = A1T[(1 * 32 + s2) * 64 + lane];
       STEP_END();
     });
+    }   // RECOMPUTE
     pin_acc();
     STAMP(1);
     // ---- dh2^T = W2^T dz3^T  (k = output channel, padded to 4): needs no activation, so it runs straight behind R2 and
@@ -545,7 +615,12 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
       STEP_END();
       MFMA_VV_ZERO(d2[0], fa[0][0], bsel[0]); MFMA_VV_ZERO(d2[1], fa[1][0], bsel[0]);
       MFMA_VV(d2[0], fa[0][1], bsel[1]); MFMA_VV(d2[1], fa[1][1], bsel[1]);
+      if constexpr (!RECOMPUTE) {                          // the images R1 / R2 would have carried
+        if (BL::kDedicatedX) static_for<S0>([&](auto SX) { lds_store<kImgX + SX.value * kImgStride * 4>(wX, xr[SX.value]); });
+        static_for<4>([&](auto C) { lds_store<kImgZ + C.value * kImgStride * 4>(wDz3, dz3[C.value]); });
+      }
     }
+    if (!RECOMPUTE && BL::kDedicatedX) fetch_x(tile + gridDim.x);
     fetch_y(tile + gridDim.x);
     MFMA_DRAIN(d2[0], d2[1]);
     STEP_END();
@@ -553,7 +628,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        acc2[t][r] = hidden_act<LEAKY>(acc2[t][r]);
+        if (RECOMPUTE) acc2[t][r] = hidden_act<LEAKY>(acc2[t][r]);
         d2[t][r] = hidden_dsel<LEAKY>(acc2[t][r], d2[t][r]);
       }
     pin_acc();
@@ -574,6 +649,8 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
           static_for<4>([&](auto E) {
             constexpr int e = 4 * s2 + E.value, t = e >> 4, r = e & 15;
             lds_store<(32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile, acc2[t][r]);
+            if constexpr (!RECOMPUTE)                       // and the h1 image (imgB) that R2 would have carried
+              lds_store<kImgB + (32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile, acc1[t][r]);
           });
         } else {                                          // then the dW2 operands
           static_for<2>([&](auto E) {
@@ -609,10 +686,11 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
         a1p[q] = lds_load2<(32 * kImgStride + 2 * q) * 4>(rOp);
         b0p[q] = lds_load2<kImgB + (2 * q) * 4>(rOp);
         b1p[q] = lds_load2<kImgB + (32 * kImgStride + 2 * q) * 4>(rOp);
-        static_for<4>([&](auto E) {
-          constexpr int e = 4 * q + E.value, t = e >> 4, r = e & 15;
-          h1v[t][r] = lds_load1<kImgB + (32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile);
-        });
+        if constexpr (RECOMPUTE)
+          static_for<4>([&](auto E) {
+            constexpr int e = 4 * q + E.value, t = e >> 4, r = e & 15;
+            h1v[t][r] = lds_load1<kImgB + (32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile);
+          });
       }
       STEP_END();
     });
@@ -621,12 +699,16 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) d1[t][r] = hidden_dsel<LEAKY>(h1v[t][r], d1[t][r]);
+      for (int r = 0; r < 16; ++r) d1[t][r] = hidden_dsel<LEAKY>(RECOMPUTE ? h1v[t][r] : acc1[t][r], d1[t][r]);
     {   // db1[32a + i] += sum over this half's 16 pixels of dz2 (the A operands ARE dz2^T): 2 registers instead of 32
       f32x2 s0 = a0p[0], s1 = a1p[0];
 #pragma unroll
       for (int q = 1; q < 8; ++q) { s0 += a0p[q]; s1 += a1p[q]; }
       db1acc[0] += s0.x + s0.y; db1acc[1] += s1.x + s1.y;
+    }
+    if (!RECOMPUTE) {                                      // h2 is dead: fetch the next tile's (needed first, at its mask)
+      STEP_END();
+      hidden_load(hidden, tile + gridDim.x, ntiles, 1, hoff, acc2);
     }
     pin_acc();
     STEP_END();
@@ -682,13 +764,14 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
         dW0acc[0][tx] = MFMA(c0p[q].y, xp[tx][q].y, dW0acc[0][tx]);
         dW0acc[1][tx] = MFMA(c1p[q].y, xp[tx][q].y, dW0acc[1][tx]);
       }
-      if (kCarryF0) {
+      if constexpr (!RECOMPUTE && q == 0) hidden_load(hidden, tile + gridDim.x, ntiles, 0, hoff, acc1);   // next tile's h1
+      if (RECOMPUTE && kCarryF0) {
 #pragma unroll
         for (int j = 0; j < 2 * S0 / 8; ++j) {
           const int e = q * (2 * S0 / 8) + j;
           f0[e / S0][e % S0] = A0[e * 64 + lane];
         }
-      } else if (TX > 1) {
+      } else if (!kCarryF0 && TX > 1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) fx[TX - 1][4 * q + j] = A0T[((TX - 1) * 32 + 4 * q + j) * 64 + lane];
       }
@@ -702,9 +785,17 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     for (int tx = 0; tx < TX; ++tx) {
       MFMA_VV_ZERO(dxv[tx], fx[tx][0], d1[0][0]);
 #pragma unroll
-      for (int s2 = 1; s2 < 32; ++s2) MFMA_VV(dxv[tx], fx[tx][s2], d1[s2 >> 4][s2 & 15]);
+      for (int s2 = 1; s2 < 32; ++s2) {
+        MFMA_VV(dxv[tx], fx[tx][s2], d1[s2 >> 4][s2 & 15]);
+        if (!RECOMPUTE && tx == TX - 1) {                  // the next tile's W1^T fragments ride under the last dX chain
+          ft[0][s2] = A1T[(0 * 32 + s2) * 64 + lane];
+          ft[1][s2] = A1T[(1 * 32 + s2) * 64 + lane];
+          if (s2 == 1) { ft[0][0] = A1T[lane]; ft[1][0] = A1T[32 * 64 + lane]; }
+        }
+      }
     }
-    MFMA_DRAIN(dxv[0], dxv[TX - 1]);
+    if constexpr (TX > 1) MFMA_DRAIN(dxv[0], dxv[TX - 1]);
+    else MFMA_DRAIN1(dxv[0]);
     STEP_END();
 #pragma unroll
     for (int tx = 0; tx < TX; ++tx)
@@ -752,6 +843,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
 #if defined(GNGF_STAMPS)
   if (blockIdx.x == 7 && threadIdx.x == 0)
     for (int k = 0; k < 10; ++k) g_stamps[k] = ph[k];
+  if (threadIdx.x == 0) g_blocktime[1][blockIdx.x & 255][1] = __builtin_readcyclecounter();
 #endif
   // non-negative floats (and NaN > inf) order like their bit patterns
 #pragma unroll
@@ -867,10 +959,14 @@ extern "C" int gngf_decoder_bwd_slabs(int64_t P) {
 }
 extern "C" int gngf_decoder_slab_floats(int in_dim, int out_dim) { return slab_size(in_dim, out_dim); }
 
+// floats of the saved-activation buffer for P pixels (whole 128-pixel tiles)
+extern "C" int64_t gngf_decoder_hidden_floats(int64_t P) { return ((P + 127) / 128) * (int64_t)kHiddenTileFloats; }
+
 // rgb (P,out_dim) = decoder(enc (P,in_dim)); hidden widths fixed at 64/64, in_dim <= 64, out_dim <= 4.
+// hidden (optional): gngf_decoder_hidden_floats(P) floats that receive the activated hidden layers for gngf_decoder_bwd.
 extern "C" int gngf_decoder_fwd(const float* enc, const float* W0, const float* b0, const float* W1, const float* b1,
-                                const float* W2, const float* b2, float* rgb, int64_t P, int in_dim, int out_dim, int leaky,
-                                void* stream) {
+                                const float* W2, const float* b2, float* rgb, float* hidden, int64_t P, int in_dim, int out_dim,
+                                int leaky, void* stream) {
   GNGF_CHECK_ARG(P >= 0 && in_dim > 0 && in_dim <= 64 && out_dim > 0 && out_dim <= 4);
   if (P == 0) return 0;
   GNGF_CHECK_ARG(enc && W0 && b0 && W1 && b1 && W2 && b2 && rgb);
@@ -879,21 +975,27 @@ extern "C" int gngf_decoder_fwd(const float* enc, const float* W0, const float* 
   const size_t smem = sizeof(float) * (size_t)raw_offsets(in_dim).total;
   DISPATCH_KIN(in_dim, {
     using Kern = void (*)(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
-                          int64_t, int, int);
+                          float*, int64_t, int, int);
     const bool exact = in_dim == kKIN;
-    const Kern fn = leaky ? (exact ? decoder_fwd_kernel<kKIN, true, true> : decoder_fwd_kernel<kKIN, true, false>)
-                          : (exact ? decoder_fwd_kernel<kKIN, false, true> : decoder_fwd_kernel<kKIN, false, false>);
-    fn<<<dim3(grid), dim3(kDecThreads), smem, as_stream(stream)>>>(enc, W0, b0, W1, b1, W2, b2, rgb, P, in_dim, out_dim);
+    Kern fn;
+    if (hidden)
+      fn = leaky ? (exact ? decoder_fwd_kernel<kKIN, true, true, true> : decoder_fwd_kernel<kKIN, true, false, true>)
+                 : (exact ? decoder_fwd_kernel<kKIN, false, true, true> : decoder_fwd_kernel<kKIN, false, false, true>);
+    else
+      fn = leaky ? (exact ? decoder_fwd_kernel<kKIN, true, true, false> : decoder_fwd_kernel<kKIN, true, false, false>)
+                 : (exact ? decoder_fwd_kernel<kKIN, false, true, false> : decoder_fwd_kernel<kKIN, false, false, false>);
+    fn<<<dim3(grid), dim3(kDecThreads), smem, as_stream(stream)>>>(enc, W0, b0, W1, b1, W2, b2, rgb, hidden, P, in_dim, out_dim);
   });
   GNGF_RETURN_LAUNCH();
 }
 
 // d enc (P,in_dim) and the six parameter gradients (each WRITTEN, not accumulated).  rgb = the forward output.
 // slabs: workspace of gngf_decoder_bwd_slabs(P) * gngf_decoder_slab_floats(in_dim, out_dim) floats.
+// hidden (optional): the buffer gngf_decoder_fwd filled for the SAME enc / weights; NULL: the hidden layers are recomputed.
 extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float* drgb, const float* W0, const float* b0,
                                 const float* W1, const float* b1, const float* W2, float* denc, float* dW0, float* db0,
-                                float* dW1, float* db1, float* dW2, float* db2, float* slabs, float* denc_absmax, int64_t P,
-                                int in_dim, int out_dim, int leaky, void* stream) {
+                                float* dW1, float* db1, float* dW2, float* db2, float* slabs, float* denc_absmax,
+                                const float* hidden, int64_t P, int in_dim, int out_dim, int leaky, void* stream) {
   GNGF_CHECK_ARG(P >= 0 && in_dim > 0 && in_dim <= 64 && out_dim > 0 && out_dim <= 4);
   GNGF_CHECK_ARG(dW0 && db0 && dW1 && db1 && dW2 && db2 && slabs);
   const int nslab = slab_size(in_dim, out_dim);
@@ -907,13 +1009,18 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
     DISPATCH_KIN(in_dim, {
       const size_t smem = bwd_smem_bytes<kKIN>(in_dim, out_dim);
       using Kern = void (*)(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
-                            const float*, float*, float*, float*, int64_t, int, int);
+                            const float*, float*, float*, const float*, int64_t, int, int);
       const bool exact = in_dim == kKIN;
-      const Kern fn = leaky ? (exact ? decoder_bwd_kernel<kKIN, true, true> : decoder_bwd_kernel<kKIN, true, false>)
-                            : (exact ? decoder_bwd_kernel<kKIN, false, true> : decoder_bwd_kernel<kKIN, false, false>);
+      Kern fn;
+      if (hidden)
+        fn = leaky ? (exact ? decoder_bwd_kernel<kKIN, true, true, false> : decoder_bwd_kernel<kKIN, true, false, false>)
+                   : (exact ? decoder_bwd_kernel<kKIN, false, true, false> : decoder_bwd_kernel<kKIN, false, false, false>);
+      else
+        fn = leaky ? (exact ? decoder_bwd_kernel<kKIN, true, true, true> : decoder_bwd_kernel<kKIN, true, false, true>)
+                   : (exact ? decoder_bwd_kernel<kKIN, false, true, true> : decoder_bwd_kernel<kKIN, false, false, true>);
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
-      fn<<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, denc_absmax, P, in_dim, out_dim);
+      fn<<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, hidden, P, in_dim, out_dim);
     });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -926,6 +1033,9 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
 #if defined(GNGF_STAMPS)
 extern "C" int gngf_debug_read_fwd_stamps(unsigned long long* host16) {
   return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(gngf::g_fstamps), 16 * sizeof(unsigned long long));
+}
+extern "C" int gngf_debug_read_blocktime(unsigned long long* host1024) {
+  return (int)hipMemcpyFromSymbol(host1024, HIP_SYMBOL(gngf::g_blocktime), 2 * 256 * 2 * sizeof(unsigned long long));
 }
 extern "C" int gngf_debug_read_stamps(unsigned long long* host16) {
   return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(gngf::g_stamps), 16 * sizeof(unsigned long long));

@@ -675,6 +675,12 @@ def mse_loss(pred, label):
     return MseFunction.apply(pred, label)
 
 
+# Keep the decoder's activated hidden layers (512 B / pixel) from forward to backward instead of recomputing them: the
+# stores and loads ride under the MFMAs of kernels that leave most of the HBM bandwidth unused (decoder backward 345 -> ~230 us
+# at 2^20 px).  False: recompute (no extra memory).
+DECODER_SAVE_HIDDEN = True
+
+
 class DecoderFunction(torch.autograd.Function):
     """The reference's default decoder (in -> 64 -> 64 -> out, ReLU|LeakyReLU, Sigmoid; models.py:382-392) as ONE fused
     MFMA kernel per direction (csrc/decoder.hip).  apply(enc, leaky, W0, b0, W1, b1, W2, b2) -> rgb."""
@@ -686,9 +692,13 @@ class DecoderFunction(torch.autograd.Function):
         P, in_dim = enc.shape
         out_dim = ws[4].shape[0]
         rgb = torch.empty((P, out_dim), dtype=_f32, device=enc.device)
-        call("gngf_decoder_fwd", ptr(enc, _f32, "enc"), *[ptr(w, _f32) for w in ws], ptr(rgb), P, in_dim, out_dim, int(leaky),
-             stream_ptr())
+        hidden = None
+        if DECODER_SAVE_HIDDEN and P > 0 and any(ctx.needs_input_grad):
+            hidden = torch.empty((_lib.query("gngf_decoder_hidden_floats", P),), dtype=_f32, device=enc.device)
+        call("gngf_decoder_fwd", ptr(enc, _f32, "enc"), *[ptr(w, _f32) for w in ws], ptr(rgb), ptr(hidden), P, in_dim, out_dim,
+             int(leaky), stream_ptr())
         ctx.save_for_backward(enc, rgb, *ws)
+        ctx.hidden = hidden
         ctx.cfg = (P, in_dim, out_dim, int(leaky))
         return rgb
 
@@ -704,7 +714,9 @@ class DecoderFunction(torch.autograd.Function):
                             dtype=_f32, device=dev)
         absmax = torch.empty((1,), dtype=_f32, device=dev)
         call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb, _f32, "grad"), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2),
-             ptr(denc), *[ptr(g) for g in grads], ptr(slabs), ptr(absmax), P, in_dim, out_dim, leaky, stream_ptr())
+             ptr(denc), *[ptr(g) for g in grads], ptr(slabs), ptr(absmax), ptr(ctx.hidden), P, in_dim, out_dim, leaky,
+             stream_ptr())
+        ctx.hidden = None
         _ABSMAX_HINTS[denc.data_ptr()] = (absmax, denc._version)
         return (denc, None, *grads)
 
@@ -773,13 +785,15 @@ def decoder_kernels(enc, params, leaky, drgb):
     slabs = torch.empty((_lib.query("gngf_decoder_bwd_slabs", P) * _lib.query("gngf_decoder_slab_floats", in_dim, out_dim),),
                         dtype=_f32, device=enc.device)
 
+    hidden = torch.empty((_lib.query("gngf_decoder_hidden_floats", P),), dtype=_f32, device=enc.device) if DECODER_SAVE_HIDDEN else None
+
     def fwd():
-        call("gngf_decoder_fwd", ptr(enc), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(rgb), P, in_dim, out_dim,
-             int(leaky), stream_ptr())
+        call("gngf_decoder_fwd", ptr(enc), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(rgb), ptr(hidden), P, in_dim,
+             out_dim, int(leaky), stream_ptr())
 
     def bwd():
         call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(denc),
-             *[ptr(g) for g in grads], ptr(slabs), ptr(None), P, in_dim, out_dim, int(leaky), stream_ptr())
+             *[ptr(g) for g in grads], ptr(slabs), ptr(None), ptr(hidden), P, in_dim, out_dim, int(leaky), stream_ptr())
 
     fwd()
     return {"decoder_fwd": fwd, "decoder_bwd": bwd}

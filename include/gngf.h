@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNGF_ABI_VERSION 1
+#define GNGF_ABI_VERSION 2
 #define GNGF_MAX_LEVELS 32
 #define GNGF_MAX_TOPK 32
 
@@ -129,15 +129,21 @@ int gngf_gemm_acc(const float* A, const float* B, float* C, int64_t M, int64_t N
 
 /* ---- a13: the decoder MLP fused (models.py:382-392,469-470): Linear(in,64)+act, Linear(64,64)+act, Linear(64,out)+Sigmoid,
  * act = ReLU (leaky = 0) or LeakyReLU(0.01) (leaky = 1); in_dim <= 64, out_dim <= 4.  W* are (out,in) like nn.Linear. */
+/* hidden (optional): gngf_decoder_hidden_floats(P) floats that receive the two activated hidden layers (512 B / pixel) for
+ * gngf_decoder_bwd — the stores ride under the forward kernel's MFMAs, and the backward kernel then reads them back
+ * instead of recomputing them (96 of its 292 MFMAs per 32 pixels). */
 int gngf_decoder_fwd(const float* enc, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
-                     const float* b2, float* rgb, int64_t P, int in_dim, int out_dim, int leaky, void* stream);
+                     const float* b2, float* rgb, float* hidden, int64_t P, int in_dim, int out_dim, int leaky, void* stream);
+int64_t gngf_decoder_hidden_floats(int64_t P);
 /* backward: denc (P,in_dim) and the six parameter gradients, each WRITTEN (not accumulated); rgb = the forward output.
  * slabs: workspace of gngf_decoder_bwd_slabs(P) * gngf_decoder_slab_floats(in_dim, out_dim) floats.
  * denc_absmax (1 float, optional): receives max |denc| (NaN if any element is NaN) — a bound the tiled encoder backward
- * can take instead of scanning its input once more. */
+ * can take instead of scanning its input once more.
+ * hidden (optional): the buffer gngf_decoder_fwd filled for the same enc and weights; NULL: recompute. */
 int gngf_decoder_bwd(const float* enc, const float* rgb, const float* drgb, const float* W0, const float* b0, const float* W1,
                      const float* b1, const float* W2, float* denc, float* dW0, float* db0, float* dW1, float* db1, float* dW2,
-                     float* db2, float* slabs, float* denc_absmax, int64_t P, int in_dim, int out_dim, int leaky, void* stream);
+                     float* db2, float* slabs, float* denc_absmax, const float* hidden, int64_t P, int in_dim, int out_dim,
+                     int leaky, void* stream);
 int gngf_decoder_bwd_slabs(int64_t P);
 int gngf_decoder_slab_floats(int in_dim, int out_dim);
 

@@ -11,7 +11,7 @@ def header_functions():
     src = open(os.path.join(ROOT, "include", "gngf.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\bint\s+(gngf_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"\b(?:int|int64_t)\s+(gngf_\w+)\s*\(([^)]*)\)\s*;", src):
         args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
         out[m.group(1)] = args
     return out
@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert len(decl) >= 8
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in include/gngf.h but not exported"
-    assert lib.gngf_abi_version() == 1
+    assert lib.gngf_abi_version() == 2
 
 
 def test_bindings_mirror_header_arity_and_kinds():

@@ -271,6 +271,34 @@ def test_streaming_logits_topk_pbar_vs_numpy(ops, U, T, K, Lv):
         close(pbar, want, 1e-4, 1e-9)
 
 
+@pytest.mark.parametrize("P,in_dim,leaky", [(1000, 32, False), (4500, 16, True), (777, 64, False), (300, 24, True), (128 * 257 + 5, 32, False)])
+def test_decoder_saved_hidden_equals_recompute(ops, P, in_dim, leaky):
+    """The two backward variants of the fused decoder (hidden layers read back from the forward kernel's buffer /
+    recomputed) are the same arithmetic: bit-identical d enc and parameter gradients."""
+    rng = np.random.default_rng(P)
+    x = rng.standard_normal((P, in_dim)).astype(np.float32)
+    dims = [in_dim, 64, 64, 3]
+    ws = []
+    for i in range(3):
+        ws += [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32), (0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32)]
+    dy = rng.standard_normal((P, 3)).astype(np.float32)
+    acts = (ops.ACT_LEAKY if leaky else ops.ACT_RELU,) * 2 + (ops.ACT_SIGMOID,)
+    res = []
+    old = ops.DECODER_SAVE_HIDDEN
+    try:
+        for save in (True, False):
+            ops.DECODER_SAVE_HIDDEN = save
+            xt = t(x).requires_grad_()
+            params = [t(w).requires_grad_() for w in ws]
+            y = ops.decoder_apply(xt, acts, params, fused=True)
+            y.backward(t(dy))
+            res.append([y.detach().cpu().numpy(), xt.grad.cpu().numpy()] + [p.grad.cpu().numpy() for p in params])
+    finally:
+        ops.DECODER_SAVE_HIDDEN = old
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("n", [(1, 3), (7, 3), (1000, 3), (4099, 4), (2 ** 18 + 5, 3)])
 def test_mse_kernels_vs_numpy(ops, n):
     """csrc/loss.hip: value and gradient of torch.nn.MSELoss (reference utils.py:99), incl. a non-unit upstream gradient,

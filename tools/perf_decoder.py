@@ -13,8 +13,9 @@ drgb = torch.randn((P, out_dim), device=dev)
 denc = torch.empty_like(enc)
 grads = [torch.empty_like(w) for w in Ws]
 slabs = torch.empty((_lib.query("gngf_decoder_bwd_slabs", P) * _lib.query("gngf_decoder_slab_floats", in_dim, out_dim),), device=dev)
-def fwd(): call("gngf_decoder_fwd", ptr(enc), *[ptr(w) for w in Ws], ptr(rgb), P, in_dim, out_dim, 0, stream_ptr())
-def bwd(): call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(Ws[3]), ptr(Ws[4]), ptr(denc), *[ptr(g) for g in grads], ptr(slabs), ptr(None), P, in_dim, out_dim, 0, stream_ptr())
+hidden = torch.empty((_lib.query("gngf_decoder_hidden_floats", P),), device=dev) if os.environ.get("GNGF_RECOMPUTE", "0") != "1" else None
+def fwd(): call("gngf_decoder_fwd", ptr(enc), *[ptr(w) for w in Ws], ptr(rgb), ptr(hidden), P, in_dim, out_dim, 0, stream_ptr())
+def bwd(): call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(Ws[3]), ptr(Ws[4]), ptr(denc), *[ptr(g) for g in grads], ptr(slabs), ptr(None), ptr(hidden), P, in_dim, out_dim, 0, stream_ptr())
 for name, fn in (("decoder_fwd", fwd), ("decoder_bwd", bwd)):
     for _ in range(3): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -42,3 +43,14 @@ if os.environ.get("GNGF_LIB_PATH", "").endswith("stamps.so"):
     for n, v in zip(names, buf[:6]):
         print(f"  {n:26s} {v/32:9.0f} cycles/tile  {100*v/max(tot,1):5.1f}%")
     print("  total per tile", tot / 32)
+
+    import numpy as np
+    bt = (ctypes.c_uint64 * 1024)()
+    _lib.load().gngf_debug_read_blocktime.argtypes = [ctypes.c_void_p]
+    _lib.load().gngf_debug_read_blocktime(bt)
+    a = np.array(bt[:], dtype=np.float64).reshape(2, 256, 2)
+    for k, nm in enumerate(("fwd", "bwd")):
+        t0, t1 = a[k, :, 0], a[k, :, 1]
+        dur = t1 - t0
+        print(f"{nm}: workgroup durations (s_memtime ticks) min {dur.min():.0f} mean {dur.mean():.0f} max {dur.max():.0f};  first start -> last end {t1.max() - t0.min():.0f};"
+              f"  start spread {t0.max() - t0.min():.0f}")
