@@ -13,8 +13,11 @@
 //   tiles in accumulation registers across its whole pixel range, and the workgroup emits ONE partial slab; a tiny second
 //   kernel sums the slabs (store pass + sum pass instead of ~10^6 contended float atomics).  The 3-wide dW2 runs on
 //   v_mfma_f32_4x4x1_16b blocks, bias gradients fall out of the transposed operands (2 registers instead of 32).
-//   Hidden activations are recomputed in backward (96 of 292 MFMAs per 32 pixels) instead of being stored
-//   (512 B/pixel of HBM traffic each way).
+//   Hidden activations travel from forward to backward through HBM (512 B/pixel each way, register-layout tiles of
+//   1 KB per instruction): the stores and loads are issued between MFMAs and cost no issue time, whereas recomputing
+//   the two layers cost 96 of 292 MFMAs per 32 pixels (the recompute variant is kept for callers without the buffer).
+//   The extra traffic is not free either — the chip is power-limited and clocks the cores ~10 % lower under it
+//   (tools/perf_decoder.py: same cycle counts, longer wall time) — but the trade wins 40 us per step.
 //
 // Issue model the schedules are built on (measured, tools/micro/gen_mfma_mix.py, mfma_2wave.cpp; one wave per SIMD):
 //   * v_mfma_f32_32x32x2_f32 issues back to back at exactly 64 cycles, dependent accumulator chains included;
