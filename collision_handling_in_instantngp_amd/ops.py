@@ -420,7 +420,7 @@ import math as _math
 
 ENCODE_PATH = "auto"        # "auto" | "direct" | "tiled"  (tests force a path; auto = tiled when it pays)
 DP_EXCHANGE = None          # data parallel: callable that sum-all-reduces + averages the vertex-grid gradient in place
-DP_TABLES_REDUCED = False   # set when the table gradient of the last backward came out of an exchanged dG
+DP_TABLES_REDUCED = 0       # number of leading levels whose table gradient of the last backward came out of an exchanged dG
 DP_MEAN = None              # data parallel: callable averaging a tensor over ranks in place (batch-mean distribution p-bar)
 DP_MAX = None               # data parallel: callable max-reducing a small tensor over ranks in place (coordinate bounds)
 TILED_CHUNK = 1024          # max pixels per (tile, chunk) work item
@@ -612,9 +612,9 @@ class EncodeFunction(torch.autograd.Function):
         if plan.Ls > 0 and P > 0:
             dG = pre[1] if pre else torch.zeros((plan.vtot, F), dtype=_f32, device=tables.device)
             _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax)
-            if DP_EXCHANGE is not None and plan.Ls == L:
-                DP_EXCHANGE(dG)                     # one small all-reduce instead of the (L,T,F) table gradient
-                globals()["DP_TABLES_REDUCED"] = True
+            if DP_EXCHANGE is not None:
+                DP_EXCHANGE(dG)                     # one small all-reduce instead of the staged levels' table gradient
+                globals()["DP_TABLES_REDUCED"] = plan.Ls
             if order is not None and dvw is not None and plan.Ls < L:
                 # the sorted kernel WRITES dvert_w; the direct levels below accumulate into the same buffer
                 dvw_t = torch.empty_like(dvw)

@@ -27,8 +27,8 @@ def enable_vertex_grid_exchange(world: int, group=None):
     """Exchange the dense per-level VERTEX-GRID gradient (sum_l (N_l+2)^2 * F floats: 5.7 MB at N 16->512) inside the
     encoder backward instead of the (L,T,F) table gradient (64 MiB at T = 2^19) afterwards: the vertex stage
     dG -> dE is linear and identical on every rank, so reducing dG first gives the same table gradient with ~11x
-    fewer bytes on the xGMI links.  Applies when the tiled form covers every level; otherwise the table buffer is
-    all-reduced as before."""
+    fewer bytes on the xGMI links.  Levels that run in the direct form (the finest levels of very fine grids) keep the
+    table-gradient all-reduce, restricted to their own contiguous slice of the (L,T,F) buffer."""
     if world <= 1:
         ops.DP_EXCHANGE = ops.DP_MEAN = ops.DP_MAX = None
         return
@@ -64,14 +64,13 @@ def allreduce_gradients(net, world: int, group=None):
     enc = getattr(net, "encoding", None)
     base = getattr(enc, "_grad_base", None) if enc is not None else None
     work = []
-    tables_done = ops.DP_TABLES_REDUCED          # set by the encoder backward when it exchanged dG (see above)
-    ops.DP_TABLES_REDUCED = False
-    if base is not None and tables_done:
+    tables_done = int(ops.DP_TABLES_REDUCED)     # leading levels already reduced through dG by the encoder backward
+    ops.DP_TABLES_REDUCED = 0
+    if base is not None:
         handled = {id(m.weight) for m in enc._hash_tables}
-        base = None
-    elif base is not None:
-        work.append(dist.all_reduce(base, op=dist.ReduceOp.SUM, group=group, async_op=True))
-        handled = {id(m.weight) for m in enc._hash_tables}
+        base = base[tables_done:] if tables_done < base.shape[0] else None      # (L,T,F): the direct-form levels only
+        if base is not None:
+            work.append(dist.all_reduce(base, op=dist.ReduceOp.SUM, group=group, async_op=True))
     rest = [p for p in net.parameters() if p.requires_grad and p.grad is not None and id(p) not in handled]
     flat = None
     if rest:

@@ -25,9 +25,12 @@ def _grads(net):
 
 
 def _make(models, mode):
-    models.should_use_hash_function = (mode == "hash")
+    models.should_use_hash_function = (mode.startswith("hash"))
     torch.manual_seed(7)
-    net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=2 ** 14, num_levels=8, n_min=16, n_max=128,
+    # "hash_partial": n_max = 1024 at 2^15 pixels leaves the finest levels to the direct form (N_l^2 > 4 P): the exchange
+    # then covers the staged levels through dG and the direct levels through their slice of the table gradient
+    net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=2 ** 14, num_levels=8, n_min=16,
+                                          n_max=(1024 if mode == "hash_partial" else 128),
                                           MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
                                           HPD_out_features=2 ** 14, feature_dim=2, topk_k=4)
     net.return_indices = False
@@ -79,17 +82,21 @@ def _worker(rank, world, port, mode, ret):
         for k in ref:
             scale = np.abs(ref[k]).max() + 1e-30
             ok &= bool(np.abs(got[k] - ref[k]).max() <= 2e-4 * scale)
-    ret[rank] = (ok, bool(reduced_flag))
+    ret[rank] = (ok, int(reduced_flag))
     parallel.enable_vertex_grid_exchange(1)
     models.should_use_hash_function = False
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("mode", ["hash", "gngf_frozen", "gngf_learning"])
+@pytest.mark.parametrize("mode", ["hash", "gngf_frozen", "gngf_learning", "hash_partial"])
 def test_two_rank_sharded_step_equals_single_rank(mode):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), mode, ret), nprocs=2, join=True)
     assert ret[0][0], "sharded gradients differ from the single-rank step"
     assert ret[0][1] and ret[1][1], "the vertex-grid exchange did not engage"
+    if mode == "hash_partial":
+        assert 0 < ret[0][1] < 8, f"expected a partially staged plan, got {ret[0][1]} staged levels"
+    else:
+        assert ret[0][1] == 8
