@@ -709,7 +709,14 @@ class DecoderFunction(torch.autograd.Function):
         drgb = _c(drgb)
         dev = enc.device
         denc = torch.empty_like(enc)
-        grads = [torch.empty_like(w) for w in (W0, b0, W1, b1, W2, b2)]
+        # the six parameter gradients are consecutive views of ONE buffer: the data-parallel exchange all-reduces that
+        # buffer in place (parallel.allreduce_gradients) instead of packing and unpacking a bucket
+        ws = (W0, b0, W1, b1, W2, b2)
+        flat = torch.empty((sum(w.numel() for w in ws),), dtype=_f32, device=dev)
+        grads, off = [], 0
+        for w in ws:
+            grads.append(flat[off:off + w.numel()].view(w.shape))
+            off += w.numel()
         slabs = torch.empty((_lib.query("gngf_decoder_bwd_slabs", P) * _lib.query("gngf_decoder_slab_floats", in_dim, out_dim),),
                             dtype=_f32, device=dev)
         absmax = torch.empty((1,), dtype=_f32, device=dev)

@@ -56,6 +56,20 @@ def shard_batch(n_items: int, rank: int, world: int):
     return lo, hi
 
 
+def _flat_alias(grads):
+    """One flat tensor aliasing `grads` when they are consecutive contiguous slices of a single storage (the fused
+    decoder backward lays its six gradients out that way), else None."""
+    if not grads:
+        return None
+    g0 = grads[0]
+    base, off = g0.untyped_storage().data_ptr(), g0.storage_offset()
+    for g in grads:
+        if g.untyped_storage().data_ptr() != base or g.storage_offset() != off or not g.is_contiguous() or g.dtype != g0.dtype:
+            return None
+        off += g.numel()
+    return torch.as_strided(g0, (off - g0.storage_offset(),), (1,), g0.storage_offset())
+
+
 def allreduce_gradients(net, world: int, group=None):
     if world <= 1:
         return
@@ -73,8 +87,12 @@ def allreduce_gradients(net, world: int, group=None):
             work.append(dist.all_reduce(base, op=dist.ReduceOp.SUM, group=group, async_op=True))
     rest = [p for p in net.parameters() if p.requires_grad and p.grad is not None and id(p) not in handled]
     flat = None
+    in_place = False
     if rest:
-        flat = torch.cat([p.grad.reshape(-1) for p in rest])
+        flat = _flat_alias([p.grad for p in rest])
+        in_place = flat is not None
+        if not in_place:
+            flat = torch.cat([p.grad.reshape(-1) for p in rest])
         work.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
     for w in work:
         w.wait()
@@ -83,7 +101,7 @@ def allreduce_gradients(net, world: int, group=None):
     if flat is not None:
         flat.mul_(inv)
         off = 0
-        for p in rest:
+        for p in ([] if in_place else rest):
             n = p.grad.numel()
             p.grad.copy_(flat[off:off + n].view_as(p.grad))
             off += n
