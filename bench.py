@@ -75,7 +75,8 @@ def build_model(mode, dev):
     return net, models
 
 
-def make_step(net, models, mode, xy, target, world):
+def make_step(net, models, mode, xy, target, world, exchange=True):
+    """One training step: forward, loss, backward (+ the gradient exchange when world > 1 and `exchange`)."""
     from collision_handling_in_instantngp_amd import train, parallel
     loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
     params = [p for p in net.parameters() if p.requires_grad]
@@ -91,7 +92,7 @@ def make_step(net, models, mode, xy, target, world):
         else:
             loss = loss_fn._mse(rgb, target)      # frozen HPD / hash: the KL-JS and collision terms carry no gradient
         loss.backward()
-        if world > 1:
+        if world > 1 and exchange:
             parallel.allreduce_gradients(net, world)
     return step
 
@@ -107,7 +108,8 @@ def graphed(step, warm=3):
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    # thread_local: other threads of the process (the RCCL watchdog at world > 1) may query events while we capture
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
         step()
     return g.replay
 
@@ -304,12 +306,26 @@ def main():
         net, models = build_model(mode, dev)
         step = make_step(net, models, mode, xy, target, world)
         launch = "eager"
-        if a.graph and world == 1 and mode != "gngf_learning":
+        if a.graph and mode != "gngf_learning":
+            # world > 1: the vertex stage of the encoder backward is deferred behind the dG exchange, so forward + backward
+            # hold no collective and replay from one hipGraph; the exchange (RCCL) and the vertex stage follow eagerly.
             try:
-                step = graphed(step)
-                launch = "hipGraph"
+                if world > 1:
+                    from collision_handling_in_instantngp_amd import parallel
+                    parallel.defer_vertex_stage(True)
+                    replay = graphed(make_step(net, models, mode, xy, target, world, exchange=False))
+
+                    def step(replay=replay, net=net):
+                        replay()
+                        parallel.allreduce_gradients(net, world, keep_tables_flag=True)
+                    launch = "hipGraph + eager exchange"
+                else:
+                    step = graphed(step)
+                    launch = "hipGraph"
             except Exception as e:  # pragma: no cover
                 print(f"[bench] graph capture failed ({e!r}); running eagerly", file=sys.stderr)
+                if world > 1:
+                    parallel.defer_vertex_stage(False)
                 step = make_step(net, models, mode, xy, target, world)
         dt = timed(step, steps, warmup, world)
         results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
@@ -326,6 +342,9 @@ def main():
             except Exception as e:  # pragma: no cover
                 kt = {"error": repr(e)}
         models.should_use_hash_function = False
+        if world > 1:
+            from collision_handling_in_instantngp_amd import parallel as _par
+            _par.defer_vertex_stage(False)
         del net, step
         torch.cuda.empty_cache()
 

@@ -421,6 +421,12 @@ import math as _math
 ENCODE_PATH = "auto"        # "auto" | "direct" | "tiled"  (tests force a path; auto = tiled when it pays)
 DP_EXCHANGE = None          # data parallel: callable that sum-all-reduces + averages the vertex-grid gradient in place
 DP_TABLES_REDUCED = 0       # number of leading levels whose table gradient of the last backward came out of an exchanged dG
+# Deferred vertex stage (data parallel, index sources without a trainable weight): when True, the encoder backward stops
+# after the pixel stage and leaves (arguments of the vertex stage) in DP_DEFERRED; parallel.finish_backward() all-reduces
+# dG and runs the vertex stage.  The backward pass then contains no collective, so the whole forward+backward can be
+# replayed from ONE hipGraph on every rank (bench.py does; eager launch gaps cost ~15 % of a step).
+DP_DEFER_VERTEX = False
+DP_DEFERRED = None
 DP_MEAN = None              # data parallel: callable averaging a tensor over ranks in place (batch-mean distribution p-bar)
 DP_MAX = None               # data parallel: callable max-reducing a small tensor over ranks in place (coordinate bounds)
 TILED_CHUNK = 1024          # max pixels per (tile, chunk) work item
@@ -534,6 +540,18 @@ def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None):
          plan.lds_bytes, plan.chunk, stream_ptr())
 
 
+def run_deferred_vertex_stage():
+    """Second half of a deferred encoder backward (see DP_DEFER_VERTEX): dG -> table gradient.  The arguments stay
+    registered (a replayed hipGraph refills the same buffers), so this can be called after every replay."""
+    if DP_DEFERRED is None:
+        return False
+    plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, order = DP_DEFERRED
+    if DP_EXCHANGE is not None:
+        DP_EXCHANGE(dG)
+    _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, None, order)
+    return True
+
+
 def _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw, order=None):
     L, T, F = tables.shape
     if vert_idx is not None and order is not None:
@@ -612,6 +630,14 @@ class EncodeFunction(torch.autograd.Function):
         if plan.Ls > 0 and P > 0:
             dG = pre[1] if pre else torch.zeros((plan.vtot, F), dtype=_f32, device=tables.device)
             _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax)
+            if DP_EXCHANGE is not None and DP_DEFER_VERTEX and dvw is None:
+                # the caller exchanges dG and runs the vertex stage after backward (parallel.finish_backward)
+                globals()["DP_DEFERRED"] = (plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, order)
+                globals()["DP_TABLES_REDUCED"] = plan.Ls
+                if plan.Ls < L:
+                    call("gngf_encode_bwd", ptr(xy), *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc, _f32, "grad"),
+                         ptr(dtables), ptr(dvw), P, L, F, T, K, mode, vstride, NV, plan.Ls, L, stream_ptr())
+                return None, None, None, _grad_out(dtables, tables), None, dvw, None, None
             if DP_EXCHANGE is not None:
                 DP_EXCHANGE(dG)                     # one small all-reduce instead of the staged levels' table gradient
                 globals()["DP_TABLES_REDUCED"] = plan.Ls

@@ -70,16 +70,30 @@ def _flat_alias(grads):
     return torch.as_strided(g0, (off - g0.storage_offset(),), (1,), g0.storage_offset())
 
 
-def allreduce_gradients(net, world: int, group=None):
+def defer_vertex_stage(on: bool = True):
+    """Keep collectives OUT of the backward pass: the encoder backward stops after the pixel stage, and
+    allreduce_gradients() / finish_backward() exchange dG and run the vertex stage afterwards.  With it the whole
+    forward + backward is collective-free and can be replayed from one hipGraph on every rank.  Applies to index sources
+    without trainable per-vertex weights (hash, frozen HPD); a trainable HPD keeps the in-backward exchange."""
+    ops.DP_DEFER_VERTEX = bool(on)
+    if not on:
+        ops.DP_DEFERRED = None
+
+
+def allreduce_gradients(net, world: int, group=None, keep_tables_flag: bool = False):
+    """All gradient traffic of one step.  keep_tables_flag: the step is replayed from a hipGraph, so the staged-level
+    count recorded at capture time stays valid for every replay."""
     if world <= 1:
         return
+    ops.run_deferred_vertex_stage()
     inv = 1.0 / world
     handled = set()
     enc = getattr(net, "encoding", None)
     base = getattr(enc, "_grad_base", None) if enc is not None else None
     work = []
     tables_done = int(ops.DP_TABLES_REDUCED)     # leading levels already reduced through dG by the encoder backward
-    ops.DP_TABLES_REDUCED = 0
+    if not keep_tables_flag:
+        ops.DP_TABLES_REDUCED = 0
     if base is not None:
         handled = {id(m.weight) for m in enc._hash_tables}
         base = base[tables_done:] if tables_done < base.shape[0] else None      # (L,T,F): the direct-form levels only

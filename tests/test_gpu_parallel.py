@@ -25,6 +25,7 @@ def _grads(net):
 
 
 def _make(models, mode):
+    mode = mode.replace("_deferred", "")
     models.should_use_hash_function = (mode.startswith("hash"))
     torch.manual_seed(7)
     # "hash_partial": n_max = 1024 at 2^15 pixels leaves the finest levels to the direct form (N_l^2 > 4 P): the exchange
@@ -60,7 +61,7 @@ def _worker(rank, world, port, mode, ret):
 
     def loss_of(bx, by):
         rgb, probs, _i, _c = net(bx, 1.0)
-        if mode == "gngf_learning":      # MSE + KL/JS of the batch-mean distribution (functions.py:243-245)
+        if mode.startswith("gngf_learning"):      # MSE + KL/JS of the batch-mean distribution (functions.py:243-245)
             mse, kls, coll = loss_fn(rgb, by, probs.shape[-1], probs, empty, empty)
             return train.assemble_loss(mse, kls, coll, 1, 1, 1e-3)
         return torch.nn.functional.mse_loss(rgb, by)
@@ -72,10 +73,15 @@ def _worker(rank, world, port, mode, ret):
         ref = _grads(net)
         net.zero_grad()
     parallel.enable_vertex_grid_exchange(world)
+    defer = mode.endswith("_deferred")
+    parallel.defer_vertex_stage(defer)
     lo, hi = parallel.shard_batch(P, rank, world)
     loss_of(xy[lo:hi], tgt[lo:hi]).backward()
     reduced_flag = ops.DP_TABLES_REDUCED
+    if defer:
+        assert ops.DP_DEFERRED is not None, "the vertex stage was not deferred"
     parallel.allreduce_gradients(net, world)
+    parallel.defer_vertex_stage(False)
     got = _grads(net)
     ok = True
     if rank == 0:
@@ -89,14 +95,15 @@ def _worker(rank, world, port, mode, ret):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("mode", ["hash", "gngf_frozen", "gngf_learning", "hash_partial"])
+@pytest.mark.parametrize("mode", ["hash", "gngf_frozen", "gngf_learning", "hash_partial", "hash_deferred", "gngf_frozen_deferred",
+                                  "hash_partial_deferred"])
 def test_two_rank_sharded_step_equals_single_rank(mode):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), mode, ret), nprocs=2, join=True)
     assert ret[0][0], "sharded gradients differ from the single-rank step"
     assert ret[0][1] and ret[1][1], "the vertex-grid exchange did not engage"
-    if mode == "hash_partial":
+    if mode.startswith("hash_partial"):
         assert 0 < ret[0][1] < 8, f"expected a partially staged plan, got {ret[0][1]} staged levels"
     else:
         assert ret[0][1] == 8
