@@ -429,7 +429,7 @@ DP_DEFER_VERTEX = False
 DP_DEFERRED = None
 DP_MEAN = None              # data parallel: callable averaging a tensor over ranks in place (batch-mean distribution p-bar)
 DP_MAX = None               # data parallel: callable max-reducing a small tensor over ranks in place (coordinate bounds)
-TILED_CHUNK = 1024          # max pixels per (tile, chunk) work item
+TILED_CHUNK = None          # max pixels per (tile, chunk) work item; None: about two average tiles' worth (see EncodePlan)
 TILED_MIN_PIXELS = 1 << 14  # below this the binning overhead is not worth it
 TILED_CELLS_PER_PIXEL = 4.0 # a level is staged while N_l^2 <= this * P (sparser levels: direct form)
 TILED_LDS_LIMIT = 48 * 1024    # forward image; the backward image (64-bit accumulators) is twice this
@@ -475,7 +475,14 @@ class EncodePlan:
         self.tile_shift = shift
         self.ntiles = 1 << (2 * shift)
         self.lds_bytes = int(lds)
-        self.chunk = TILED_CHUNK
+        # one work item per tile for the typical tile (an item that is a sliver of a split tile still stages every
+        # sub-grid): twice the mean pixels per tile, as a power of two in [1024, 4096].  Measured at 2^20 px / 1024 tiles:
+        # chunk 1024 -> 0.70 ms per step, 2048..4096 -> 0.67 ms (tools/ab_chunk.py).
+        if TILED_CHUNK is not None:
+            self.chunk = int(TILED_CHUNK)
+        else:
+            want = 2 * max(1, -(-P // self.ntiles))
+            self.chunk = min(4096, max(1024, 1 << (want - 1).bit_length()))
         self.NB = max(1, min(128, -(-P // 8192)))        # more binning workgroups do not help (measured: tools/perf_bin.py)
         self.max_items = -(-P // self.chunk) + self.ntiles
         self.vtot = sum((n + 2) ** 2 for n in self.n_ls_host[:Ls])
