@@ -259,15 +259,26 @@ tiled_fwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
   const int tid = threadIdx.x;
   const int TSm = (1 << tile_shift) - 1;
   setup_tile(m, n_ls, Ls, it.z & TSm, it.z >> tile_shift, tile_shift, F, lds_floats);
-  for (int l = 0; l < Ls; ++l) {
-    const int wx = m.wx[l], sz = wx * m.wy[l];
-    const float* src = G + (m.goff[l] + (int64_t)m.cy[l] * m.gw[l] + m.cx[l]) * F;
-    float* dst = lds + m.loff[l];
-    for (int i = tid; i < sz; i += kTB) {
+  // Staging, flattened over (level, vertex): a loop per level would expose one L2 round trip per level (16 x ~1.5 us per
+  // work item — the fixed cost that made many small items slow); here every thread's few loads are in flight together.
+  // Staged sub-grids are back to back in LDS (loff ascending), so element e of the image belongs to the last staged
+  // level whose offset is <= e.
+  {
+    int used = 0;
+    for (int l = 0; l < Ls; ++l) used += m.wx[l] * m.wy[l];            // vertices (levels that did not fit have wx = 0)
+    for (int e = tid; e < used; e += kTB) {
+      int l = 0, base = 0;
+      for (int q = 0, acc = 0; q < Ls; ++q) {
+        const int sz = m.wx[q] * m.wy[q];
+        if (sz > 0 && e >= acc) { l = q; base = acc; }
+        acc += sz;
+      }
+      const int i = e - base, wx = m.wx[l];
       const int iy = i / wx, ix = i - iy * wx;
-      const float* s = src + ((int64_t)iy * m.gw[l] + ix) * F;
+      const float* sp = G + (m.goff[l] + (int64_t)(m.cy[l] + iy) * m.gw[l] + m.cx[l] + ix) * F;
+      float* dst = lds + m.loff[l] + i * F;
 #pragma unroll
-      for (int f = 0; f < F; ++f) dst[i * F + f] = s[f];
+      for (int f = 0; f < F; ++f) dst[f] = sp[f];
     }
   }
   __syncthreads();
@@ -278,18 +289,48 @@ tiled_fwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
   const float* sub = lds + m.loff[l];
   const float* Gl = G + m.goff[l] * F;
   const int LF = L * F;
-  // 4 pixels per lane per trip, their (dependent) loads issued together: the loop is latency-bound otherwise
+  // 4 pixels per lane per trip, their loads issued together.  The kernel is VALU-bound (~26 M wave-instructions), so the
+  // common case — every pixel of the trip inside its staged sub-grid, true for all in-domain coordinates — runs without
+  // per-lane branches; a wave-uniform vote sends trips with an outlier to the general path.
   constexpr int U = 4;
+  float* enc_l = enc + l * F;
   for (int j0 = lp; j0 < it.y; j0 += U * ppp) {
     float4 sv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) { const int j = j0 + u * ppp; sv[u] = sorted[it.x + (j < it.y ? j : it.y - 1)]; }
+    Cell cs[U];
+    int off[U];
+    bool inside = true;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      cs[u] = make_cell(sv[u].x, sv[u].y, n);
+      const int lx = cs[u].gx - cx, ly = cs[u].gy - cy;
+      inside = inside && ((unsigned)lx < (unsigned)(wx - 1)) && ((unsigned)ly < (unsigned)(wy - 1));
+      off[u] = (ly * wx + lx) * F;
+    }
+    if (__ballot(!inside) == 0ull) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float* a = sub + off[u];
+        const float* b = a + wx * F;
+        float r[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+          r[f] = ((a[f] * cs[u].c[0] + a[F + f] * cs[u].c[1]) + b[f] * cs[u].c[2]) + b[F + f] * cs[u].c[3];
+        if (j0 + u * ppp < it.y) {
+          float* o = enc_l + (int64_t)__float_as_int(sv[u].z) * LF;
+#pragma unroll
+          for (int f = 0; f < F; ++f) o[f] = r[f];
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (j0 + u * ppp >= it.y) break;
       const float4 s = sv[u];
       const int64_t p = (int64_t)__float_as_int(s.z);
-      const Cell c = make_cell(s.x, s.y, n);
+      const Cell c = cs[u];
       const int lx = c.gx - cx, ly = c.gy - cy;
       float v[4][F];
       if (lx >= 0 && ly >= 0 && lx + 1 < wx && ly + 1 < wy) {
