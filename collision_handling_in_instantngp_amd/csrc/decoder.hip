@@ -172,6 +172,9 @@ __device__ unsigned long long g_blocktime[2][256][2];   // [fwd/bwd][workgroup][
 // 16-byte pieces are the register quadruples 4g..4g+3 of its accumulator tile pair, so that every store / load instruction
 // of a wave moves 1 KB of consecutive memory and the backward kernel gets the tiles back in the register layout it needs.
 constexpr int kHiddenTileFloats = 2 * 4 * 8 * 64 * 4;
+#ifndef GNGF_BWD_X_AUX
+#define GNGF_BWD_X_AUX 0       // cache policy of the backward kernel's (last) read of enc
+#endif
 #ifndef GNGF_HIDDEN_AUX
 #define GNGF_HIDDEN_AUX 2      // cache policy of the hidden-layer traffic: nt (streaming: written once, read once ~0.3 ms later; -15 us per step vs default)
 #endif
@@ -485,7 +488,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     if (EXACT) {
 #pragma unroll
       for (int k = 0; k < S0 / 4; ++k) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + 16 * k, 0, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + 16 * k, 0, GNGF_BWD_X_AUX);
         xr[4 * k] = __uint_as_float(v.x); xr[4 * k + 1] = __uint_as_float(v.y);
         xr[4 * k + 2] = __uint_as_float(v.z); xr[4 * k + 3] = __uint_as_float(v.w);
       }
