@@ -43,3 +43,20 @@ def test_plan_small_batches_use_direct_form():
     assert ops.EncodePlan(2000, [8, 12, 20, 32], 2, "tiled").Ls == 4
     assert ops.EncodePlan(100, [8, 12, 20, 32], 2, "tiled").Ls < 4           # too sparse at the finest level
     assert ops.EncodePlan(2 ** 20, [8, 12, 20, 32], 2, "direct").Ls == 0
+
+
+def test_work_item_size_follows_mean_tile_population():
+    """ops.EncodePlan: chunk = twice the mean pixels per tile as a power of two in [1024, 4096] (an item that is a sliver of
+    a split tile still stages every sub-grid), overridable through ops.TILED_CHUNK."""
+    n = [int(v) for v in models.level_resolutions(16, 512, 16)]
+    assert ops.EncodePlan(2 ** 20, n, 2, "tiled").chunk == 2048         # 1024 tiles of ~1024 px
+    assert ops.EncodePlan(2 ** 16, n, 2, "tiled").chunk == 1024         # floor
+    assert ops.EncodePlan(2 ** 23, n, 2, "tiled").chunk == 4096         # cap
+    p = ops.EncodePlan(2 ** 20, n, 2, "tiled")
+    assert p.max_items >= -(-p.P // p.chunk) + p.ntiles
+    old = ops.TILED_CHUNK
+    try:
+        ops.TILED_CHUNK = 512
+        assert ops.EncodePlan(2 ** 20, n, 2, "tiled").chunk == 512
+    finally:
+        ops.TILED_CHUNK = old
