@@ -210,6 +210,98 @@ gemm128_kernel(const float* __restrict__ A, const float* __restrict__ B, float* 
   }
 }
 
+// Fast path of the 128x128 kernel for full, aligned tiles without an activation mask (every large HPD GEMM but the ragged
+// last row chunk).  A lone VALU instruction costs as much as 1/16 of an MFMA and never overlaps one (decoder.hip, "issue
+// model"), and the general staging above spends ~270 of them per K-block on 64-bit address arithmetic, bounds and
+// alignment tests: 43 % MFMA utilisation.  Here every thread keeps two running source pointers per operand, the next
+// K-block's 16-byte loads are in flight while the current one is multiplied (register double buffer), LDS addresses are
+// immediates, and the K loop is MFMAs, LDS traffic and two barriers.
+template <bool TRANS> __device__ __forceinline__ void stash128(float* S, const float4 (&v)[2], int tid) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int li = tid + e * 256;
+    if (TRANS) {
+      const int kk = li >> 5, rq = (li & 31) * 4;
+      *reinterpret_cast<float4*>(S + kk * LDS2 + rq) = v[e];
+    } else {
+      const int rr = li >> 2, kq = (li & 3) * 4;
+      S[(kq + 0) * LDS2 + rr] = v[e].x; S[(kq + 1) * LDS2 + rr] = v[e].y;
+      S[(kq + 2) * LDS2 + rr] = v[e].z; S[(kq + 3) * LDS2 + rr] = v[e].w;
+    }
+  }
+}
+
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256)
+gemm128_fast_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                    int64_t lda, int64_t ldb, int64_t ldc, const float* __restrict__ bias, int act, int64_t K,
+                    int64_t kchunk, int atomic_out) {
+  __shared__ float As[BK * LDS2];
+  __shared__ float Bs[BK * LDS2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.y * BM2, n0 = (int64_t)blockIdx.x * BN2;
+  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+  const int nkb = (int)((kend - kbeg) / BK);
+  // running pointers of this thread's two float4 per operand and their advance per K-block
+  const float* pa[2];
+  const float* pb[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int li = tid + e * 256;
+    pa[e] = TA ? A + (kbeg + (li >> 5)) * lda + m0 + (li & 31) * 4 : A + (m0 + (li >> 2)) * lda + kbeg + (li & 3) * 4;
+    pb[e] = !TB ? B + (kbeg + (li >> 5)) * ldb + n0 + (li & 31) * 4 : B + (n0 + (li >> 2)) * ldb + kbeg + (li & 3) * 4;
+  }
+  const int64_t sa = TA ? (int64_t)BK * lda : BK, sb = !TB ? (int64_t)BK * ldb : BK;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = 0;
+  float4 va[2], vb[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) { va[e] = *reinterpret_cast<const float4*>(pa[e]); vb[e] = *reinterpret_cast<const float4*>(pb[e]); }
+  const float* ap = As + h * LDS2 + wm * 64 + i;
+  const float* bp = Bs + h * LDS2 + wn * 64 + i;
+  for (int kb = 0; kb < nkb; ++kb) {
+    stash128<TA>(As, va, tid);
+    stash128<!TB>(Bs, vb, tid);
+    __syncthreads();
+    if (kb + 1 < nkb) {                                   // next block's loads fly under this block's MFMAs
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        pa[e] += sa; pb[e] += sb;
+        va[e] = *reinterpret_cast<const float4*>(pa[e]); vb[e] = *reinterpret_cast<const float4*>(pb[e]);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = ap[kk * LDS2], a1 = ap[kk * LDS2 + 32];
+      const float b0 = bp[kk * LDS2], b1 = bp[kk * LDS2 + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int64_t col = n0 + wn * 64 + tn * 32 + i;
+    const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = acc[tm][tn][r] + bv;
+        if (atomic_out) atomicAdd(C + row * ldc + col, v);
+        else C[row * ldc + col] = act_fwd(v, act);
+      }
+  }
+}
+
 // column sums of dZ = dY * act'(Y):  db[n] = sum_m dZ[m][n].  grid.x = ceil(N/64), grid.y = row slices; atomics.
 __global__ void __launch_bounds__(256)
 colsum_kernel(const float* __restrict__ dY, const float* __restrict__ Ymask, int mask_act, float* __restrict__ db,
@@ -245,6 +337,12 @@ static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int6
   }
   if (M >= BM2 && N >= BN2) {          // large problems: 128x128 tiles, 2x2 accumulators per wave
     dim3 grid2((unsigned)ceil_div(N, BN2), (unsigned)ceil_div(M, BM2), (unsigned)splitk);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0;
+    if (M % BM2 == 0 && N % BN2 == 0 && K % BK == 0 && kchunk % BK == 0 && !amask && aligned) {
+      gemm128_fast_kernel<TA, TB><<<grid2, dim3(256), 0, s>>>(A, B, C, lda, ldb, ldc, bias, act, K, kchunk,
+                                                             (splitk > 1 || force_atomic) ? 1 : 0);
+      return (int)hipGetLastError();
+    }
     gemm128_kernel<TA, TB><<<grid2, dim3(256), 0, s>>>(A, B, C, M, N, K, lda, ldb, ldc, bias, act, amask, mask_act, kchunk,
                                                       (splitk > 1 || force_atomic) ? 1 : 0);
     return (int)hipGetLastError();
