@@ -354,34 +354,46 @@ softmax_bwd_tile_kernel(float* __restrict__ Z, const float* __restrict__ rowstat
       for (int l = 0; l < LMAX; ++l) Gc[q][l] = l < L ? G[(int64_t)l * T + ts] : 0.f;
     }
     float colsum[CPT] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < nr; ++r) {
-      const int64_t row = r0 + r;
-      const float m = rowstat[2 * row], rs = 1.0f / rowstat[2 * row + 1];  // uniform -> scalar loads, one reciprocal per row
-      const float dr = APPLY ? dot[row] : 0.f;
-      float mwr[LMAX];
+    constexpr int RU = 4;                        // rows per trip: their logits are loaded together (the loop is latency-bound otherwise)
+    for (int rb = 0; rb < nr; rb += RU) {
+      float zv[RU][CPT];
 #pragma unroll
-      for (int l = 0; l < LMAX; ++l) mwr[l] = (l < L) ? mw[row * L + l] : 0.f;
-      float part = 0.f;
+      for (int u = 0; u < RU; ++u) {
+        const int64_t row = r0 + (rb + u < nr ? rb + u : nr - 1);
 #pragma unroll
-      for (int q = 0; q < CPT; ++q) {
-        if (!okc[q]) continue;
-        float* zp = Z + row * T + tc[q];
-        const float p = prob_fast(*zp, m, rs);
-        float g = 0.f;
-#pragma unroll
-        for (int l = 0; l < LMAX; ++l) g += mwr[l] * Gc[q][l];
-        if (APPLY) {
-          const float dz = p * (g - dr);
-          *zp = dz;
-          colsum[q] += dz;
-        } else {
-          part += p * g;
-        }
+        for (int q = 0; q < CPT; ++q) zv[u][q] = okc[q] ? Z[row * T + tc[q]] : 0.f;
       }
-      if (!APPLY) {                              // wave-level sum of this trip's 256 columns, kept per (wave, row) in LDS
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-        if (lane == 0) red[wave][r] += part;
+      for (int u = 0; u < RU; ++u) {
+        const int r = rb + u;
+        if (r >= nr) break;
+        const int64_t row = r0 + r;
+        const float m = rowstat[2 * row], rs = 1.0f / rowstat[2 * row + 1];  // uniform -> scalar loads, one reciprocal per row
+        const float dr = APPLY ? dot[row] : 0.f;
+        float mwr[LMAX];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) mwr[l] = (l < L) ? mw[row * L + l] : 0.f;
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+          if (!okc[q]) continue;
+          const float p = prob_fast(zv[u][q], m, rs);
+          float g = 0.f;
+#pragma unroll
+          for (int l = 0; l < LMAX; ++l) g += mwr[l] * Gc[q][l];
+          if (APPLY) {
+            const float dz = p * (g - dr);
+            Z[row * T + tc[q]] = dz;
+            colsum[q] += dz;
+          } else {
+            part += p * g;
+          }
+        }
+        if (!APPLY) {                            // wave-level sum of this trip's 256 columns, kept per (wave, row) in LDS
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+          if (lane == 0) red[wave][r] += part;
+        }
       }
     }
     if (APPLY && db) {
