@@ -171,11 +171,7 @@ logits_stats_topk_kernel(const float* __restrict__ z, float* __restrict__ topv, 
   for (int k = 0; k < K; ++k) { lv[k * kRowBlock + tid] = -INFINITY; li[k * kRowBlock + tid] = INT_MAX; }
   float m = -INFINITY, s = 0.f, thr = -INFINITY;
   bool has_nan = false;
-  for (int64_t t = tid; t < T; t += kRowBlock) {
-    const float v = p[t];
-    has_nan |= (v != v);
-    if (v > m) { s = s * expf(m - v) + 1.f; m = v; }            // first element: s = 0 * exp(-inf) + 1
-    else s += expf(v - m);
+  auto consider = [&](float v, int64_t t) {                      // insertion into the thread's sorted top-K list
     if (v > thr) {
       int k = K - 1;
       while (k > 0 && lv[(k - 1) * kRowBlock + tid] < v) {
@@ -186,6 +182,43 @@ logits_stats_topk_kernel(const float* __restrict__ z, float* __restrict__ topv, 
       lv[k * kRowBlock + tid] = v;
       li[k * kRowBlock + tid] = (int)t;
       thr = lv[(K - 1) * kRowBlock + tid];
+    }
+  };
+  // The pass is VALU-bound, not HBM-bound (an online-softmax update with expf costs ~25 instructions per logit): a thread
+  // takes 8 logits per trip (two 16-byte loads), rescales its running sum ONCE per trip by the new maximum and adds the 8
+  // terms with the hardware exp2 (the row sum only normalises; its ~1e-6 relative error is far inside the parity
+  // tolerance, and the K probabilities below still use expf on the exact maximum).
+  constexpr float kLog2e = 1.4426950408889634f;
+  const bool vec = (T % 4 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+  if (vec) {
+    for (int64_t t0 = (int64_t)tid * 4; t0 < T; t0 += (int64_t)kRowBlock * 8) {
+      const float4 a = *reinterpret_cast<const float4*>(p + t0);
+      const int64_t t1 = t0 + (int64_t)kRowBlock * 4;
+      const bool two = t1 < T;
+      const float4 b = two ? *reinterpret_cast<const float4*>(p + t1) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      float mx = m;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { has_nan |= (v[q] != v[q]); mx = fmaxf(mx, v[q]); }
+      if (mx > m) { s = (m == -INFINITY) ? 0.f : s * __builtin_amdgcn_exp2f((m - mx) * kLog2e); m = mx; }
+      if (m > -INFINITY) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += __builtin_amdgcn_exp2f((v[q] - m) * kLog2e);     // exp2(-inf) = 0 for the padding
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) consider(v[q], t0 + q);
+      if (two) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) consider(v[4 + q], t1 + q);
+      }
+    }
+  } else {
+    for (int64_t t = tid; t < T; t += kRowBlock) {
+      const float v = p[t];
+      has_nan |= (v != v);
+      if (v > m) { s = s * expf(m - v) + 1.f; m = v; }            // first element: s = 0 * exp(-inf) + 1
+      else s += expf(v - m);
+      consider(v, t);
     }
   }
   // block combine of the online statistics: M = max m_t, S = sum s_t exp(m_t - M)
