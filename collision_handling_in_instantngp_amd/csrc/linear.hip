@@ -7,6 +7,7 @@
 // Tile: 64x64 per 256-thread block, one 32x32 accumulator per wave, BK = 16 staged through LDS with a
 // +1 padded stride (bank = (17*row + k) % 32: conflict-free ds_read_b32 for the one-float A/B operands).
 #include "gngf_common.h"
+#include <utility>
 
 namespace gngf {
 
@@ -216,88 +217,140 @@ gemm128_kernel(const float* __restrict__ A, const float* __restrict__ B, float* 
 // alignment tests: 43 % MFMA utilisation.  Here every thread keeps two running source pointers per operand, the next
 // K-block's 16-byte loads are in flight while the current one is multiplied (register double buffer), LDS addresses are
 // immediates, and the K loop is MFMAs, LDS traffic and two barriers.
-template <bool TRANS> __device__ __forceinline__ void stash128(float* S, const float4 (&v)[2], int tid) {
+#ifndef GNGF_FAST_BK
+#define GNGF_FAST_BK 32
+#endif
+constexpr int kFastBK = GNGF_FAST_BK;
+#ifndef GNGF_FAST_WAVES
+#define GNGF_FAST_WAVES 4
+#endif
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+__device__ __forceinline__ unsigned lds_base(const float* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const float*)p;
+}
+
+template <bool TRANS, int BKF> __device__ __forceinline__ void stash128(float* S, const u32x4 (&v)[BKF / 8], int tid) {
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
+  for (int e = 0; e < BKF / 8; ++e) {
     const int li = tid + e * 256;
     if (TRANS) {
       const int kk = li >> 5, rq = (li & 31) * 4;
-      *reinterpret_cast<float4*>(S + kk * LDS2 + rq) = v[e];
+      *reinterpret_cast<u32x4*>(S + kk * LDS2 + rq) = v[e];
     } else {
-      const int rr = li >> 2, kq = (li & 3) * 4;
-      S[(kq + 0) * LDS2 + rr] = v[e].x; S[(kq + 1) * LDS2 + rr] = v[e].y;
-      S[(kq + 2) * LDS2 + rr] = v[e].z; S[(kq + 3) * LDS2 + rr] = v[e].w;
+      const int rr = li / (BKF / 4), kq = (li % (BKF / 4)) * 4;
+      S[(kq + 0) * LDS2 + rr] = __uint_as_float(v[e].x); S[(kq + 1) * LDS2 + rr] = __uint_as_float(v[e].y);
+      S[(kq + 2) * LDS2 + rr] = __uint_as_float(v[e].z); S[(kq + 3) * LDS2 + rr] = __uint_as_float(v[e].w);
     }
   }
 }
 
-template <bool TA, bool TB>
-__global__ void __launch_bounds__(256)
+// LDS read with an immediate byte offset (no address VALU in the K loop) and the wait that pairs with it: LDS returns
+// data in order, so waiting for "at most PENDING operations outstanding" releases the older reads only.
+template <int OFF> __device__ __forceinline__ float ds_ld(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset is 16 bits");
+  float r;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+template <int PENDING> __device__ __forceinline__ void ds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(PENDING) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <typename F, int... I> __device__ __forceinline__ void unrolled_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void unrolled(F&& f) { unrolled_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <bool TA, bool TB, int BKF>
+__global__ void __launch_bounds__(256, GNGF_FAST_WAVES)
 gemm128_fast_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                     int64_t lda, int64_t ldb, int64_t ldc, const float* __restrict__ bias, int act, int64_t K,
-                    int64_t kchunk, int atomic_out) {
-  __shared__ float As[BK * LDS2];
-  __shared__ float Bs[BK * LDS2];
+                    int64_t kchunk, int atomic_out, int tiles_m, int tiles_n) {
+  constexpr int NV4 = BKF / 8;                            // float4 per thread and operand per K-block
+  __shared__ float As[BKF * LDS2];
+  __shared__ float Bs[BKF * LDS2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
-  const int64_t m0 = (int64_t)blockIdx.y * BM2, n0 = (int64_t)blockIdx.x * BN2;
-  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  // Tile order.  Workgroups are dealt round-robin to the 8 XCDs (one L2 each), so XCD x takes the x-th eighth of the tile
+  // list, and the list runs fastest along the dimension with fewer tiles: the tiles in flight on one XCD then share
+  // their tile of the large operand (read from HBM once, not once per tile row) while the small operand stays in L2.
+  int64_t t = blockIdx.x;
+  const int64_t ntiles = (int64_t)tiles_m * tiles_n;
+  if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);
+  const int64_t m0 = (tiles_m <= tiles_n ? t % tiles_m : t / tiles_n) * BM2;
+  const int64_t n0 = (tiles_m <= tiles_n ? t / tiles_m : t % tiles_n) * BN2;
+  const int64_t kbeg = (int64_t)blockIdx.y * kchunk;
   const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
-  const int nkb = (int)((kend - kbeg) / BK);
-  // running pointers of this thread's two float4 per operand and their advance per K-block
-  const float* pa[2];
-  const float* pb[2];
+  const int nkb = (int)((kend - kbeg) / BKF);
+  // Global operands come through buffer descriptors rebased (scalar ALU) on each K-block's window; the per-thread
+  // byte offsets inside a window are loop invariant.
+  const float* Aw = TA ? A + kbeg * lda + m0 : A + m0 * lda + kbeg;
+  const float* Bw = !TB ? B + kbeg * ldb + n0 : B + n0 * ldb + kbeg;
+  const int64_t sa = TA ? (int64_t)BKF * lda : BKF, sb = !TB ? (int64_t)BKF * ldb : BKF;
+  unsigned oa[NV4], ob[NV4];
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
+  for (int e = 0; e < NV4; ++e) {
     const int li = tid + e * 256;
-    pa[e] = TA ? A + (kbeg + (li >> 5)) * lda + m0 + (li & 31) * 4 : A + (m0 + (li >> 2)) * lda + kbeg + (li & 3) * 4;
-    pb[e] = !TB ? B + (kbeg + (li >> 5)) * ldb + n0 + (li & 31) * 4 : B + (n0 + (li >> 2)) * ldb + kbeg + (li & 3) * 4;
+    oa[e] = 4u * (TA ? (unsigned)(li >> 5) * (unsigned)lda + (li & 31) * 4 : (unsigned)(li / (BKF / 4)) * (unsigned)lda + (li % (BKF / 4)) * 4);
+    ob[e] = 4u * (!TB ? (unsigned)(li >> 5) * (unsigned)ldb + (li & 31) * 4 : (unsigned)(li / (BKF / 4)) * (unsigned)ldb + (li % (BKF / 4)) * 4);
   }
-  const int64_t sa = TA ? (int64_t)BK * lda : BK, sb = !TB ? (int64_t)BK * ldb : BK;
   f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = 0;
-  float4 va[2], vb[2];
+  u32x4 va[NV4], vb[NV4];
+  auto fetch = [&](int kb) {
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Aw + kb * sa), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bw + kb * sb), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-  for (int e = 0; e < 2; ++e) { va[e] = *reinterpret_cast<const float4*>(pa[e]); vb[e] = *reinterpret_cast<const float4*>(pb[e]); }
-  const float* ap = As + h * LDS2 + wm * 64 + i;
-  const float* bp = Bs + h * LDS2 + wn * 64 + i;
-  for (int kb = 0; kb < nkb; ++kb) {
-    stash128<TA>(As, va, tid);
-    stash128<!TB>(Bs, vb, tid);
-    __syncthreads();
-    if (kb + 1 < nkb) {                                   // next block's loads fly under this block's MFMAs
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        pa[e] += sa; pb[e] += sb;
-        va[e] = *reinterpret_cast<const float4*>(pa[e]); vb[e] = *reinterpret_cast<const float4*>(pb[e]);
-      }
+    for (int e = 0; e < NV4; ++e) {
+      va[e] = __builtin_amdgcn_raw_buffer_load_b128(rsa, oa[e], 0, 0);
+      vb[e] = __builtin_amdgcn_raw_buffer_load_b128(rsb, ob[e], 0, 0);
     }
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a0 = ap[kk * LDS2], a1 = ap[kk * LDS2 + 32];
-      const float b0 = bp[kk * LDS2], b1 = bp[kk * LDS2 + 32];
+  };
+  fetch(0);
+  const unsigned ra = lds_base(As + h * LDS2 + wm * 64 + i), rb = lds_base(Bs + h * LDS2 + wn * 64 + i);
+  for (int kb = 0; kb < nkb; ++kb) {
+    stash128<TA, BKF>(As, va, tid);
+    stash128<!TB, BKF>(Bs, vb, tid);
+    __syncthreads();
+    if (kb + 1 < nkb) fetch(kb + 1);                      // next block's loads fly under this block's MFMAs
+    // operands of step s+1 are read from LDS while the four MFMAs of step s run
+    float a0 = ds_ld<0>(ra), a1 = ds_ld<128>(ra), b0 = ds_ld<0>(rb), b1 = ds_ld<128>(rb);
+    unrolled<BKF / 2>([&](auto S) {
+      constexpr int s = S.value;
+      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+      if constexpr (s + 1 < BKF / 2) {
+        constexpr int o = (2 * s + 2) * LDS2 * 4;
+        na0 = ds_ld<o>(ra); na1 = ds_ld<o + 128>(ra); nb0 = ds_ld<o>(rb); nb1 = ds_ld<o + 128>(rb);
+        ds_wait<4>();
+      } else {
+        ds_wait<0>();
+      }
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    });
     __syncthreads();
   }
+  // C tile through one descriptor: lane offset in a VGPR, the (row, column block) offset of each store is scalar
+  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(C + m0 * ldc + n0, 0, 0x7fffffff, 0x00020000);
+  const unsigned oc = 4u * ((unsigned)(wm * 64 + 4 * h) * (unsigned)ldc + wn * 64 + i);
 #pragma unroll
   for (int tn = 0; tn < 2; ++tn) {
-    const int64_t col = n0 + wn * 64 + tn * 32 + i;
-    const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
+    const float bv = (bias && blockIdx.y == 0) ? bias[n0 + wn * 64 + tn * 32 + i] : 0.f;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const unsigned so = 4u * ((unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)ldc + tn * 32);
         const float v = acc[tm][tn][r] + bv;
-        if (atomic_out) atomicAdd(C + row * ldc + col, v);
-        else C[row * ldc + col] = act_fwd(v, act);
+        if (atomic_out) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rsc, oc, so, 0);
+        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(act_fwd(v, act)), rsc, oc, so, 0);
       }
   }
 }
@@ -338,10 +391,19 @@ static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int6
   if (M >= BM2 && N >= BN2) {          // large problems: 128x128 tiles, 2x2 accumulators per wave
     dim3 grid2((unsigned)ceil_div(N, BN2), (unsigned)ceil_div(M, BM2), (unsigned)splitk);
     const bool aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0;
-    if (M % BM2 == 0 && N % BN2 == 0 && K % BK == 0 && kchunk % BK == 0 && !amask && aligned) {
-      gemm128_fast_kernel<TA, TB><<<grid2, dim3(256), 0, s>>>(A, B, C, lda, ldb, ldc, bias, act, K, kchunk,
-                                                             (splitk > 1 || force_atomic) ? 1 : 0);
-      return (int)hipGetLastError();
+    const bool windows32 = lda < (1 << 22) && ldb < (1 << 22) && ldc < (1 << 22);   // 128 rows * ld * 4 B < 2^31
+    if (M % BM2 == 0 && N % BN2 == 0 && !amask && aligned && windows32) {
+      const dim3 gridf(grid2.x * grid2.y, (unsigned)splitk);
+      if (K % kFastBK == 0 && kchunk % kFastBK == 0) {
+        gemm128_fast_kernel<TA, TB, kFastBK><<<gridf, dim3(256), 0, s>>>(A, B, C, lda, ldb, ldc, bias, act, K, kchunk,
+                                                                        (splitk > 1 || force_atomic) ? 1 : 0, (int)grid2.y, (int)grid2.x);
+        return (int)hipGetLastError();
+      }
+      if (K % BK == 0 && kchunk % BK == 0) {
+        gemm128_fast_kernel<TA, TB, BK><<<gridf, dim3(256), 0, s>>>(A, B, C, lda, ldb, ldc, bias, act, K, kchunk,
+                                                                   (splitk > 1 || force_atomic) ? 1 : 0, (int)grid2.y, (int)grid2.x);
+        return (int)hipGetLastError();
+      }
     }
     gemm128_kernel<TA, TB><<<grid2, dim3(256), 0, s>>>(A, B, C, M, N, K, lda, ldb, ldc, bias, act, amask, mask_act, kchunk,
                                                       (splitk > 1 || force_atomic) ? 1 : 0);
