@@ -10,6 +10,7 @@
 #include <limits.h>
 
 namespace gngf {
+using f32x16_t = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kRowBlock = 256;
 
@@ -338,6 +339,66 @@ pbar_accum_kernel(const float* __restrict__ Z, const float* __restrict__ rowstat
     }
 }
 
+// The same accumulation on the matrix cores (T % 32 == 0): pbar (L x T) = mw^T (L x U) * P (U x T) is a GEMM whose B
+// operand is the probability computed on the fly from the logit each lane has just loaded.  One 32x32x2 MFMA consumes two
+// rows x 32 columns: A[m = l][k] = mw[row][l], B[k][n] = p[row][col], with lane (i, h) holding k = h.  A wave keeps a
+// 32 x 32 tile of p-bar in its accumulator for every row of the chunk; the rows' (max, 1 / sum) and weights are staged
+// in LDS per block of 128 rows and read with immediate offsets.  ~6 VALU instructions and one MFMA per logit-lane instead
+// of 19 VALU instructions: the pass follows the HBM stream.
+constexpr int kPbRows = 128;
+
+__global__ void __launch_bounds__(256)
+pbar_mfma_kernel(const float* __restrict__ Z, const float* __restrict__ rowstat, const float* __restrict__ mw, int L,
+                 float* __restrict__ pbar, int64_t U, int64_t T) {
+  __shared__ float2 s_stat[kPbRows];
+  __shared__ float s_mw[kPbRows * 32];
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t c0 = ((int64_t)blockIdx.x * 4 + wave) * 32;          // this wave's 32 columns
+  const bool live = c0 < T;
+  f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const unsigned voff = 4u * ((unsigned)h * (unsigned)T + (unsigned)i);
+  const unsigned step = 8u * (unsigned)T;                             // two rows, in bytes
+  for (int64_t rb = 0; rb < U; rb += kPbRows) {
+    const int vrows = (int)(U - rb < kPbRows ? U - rb : kPbRows);
+    __syncthreads();                                                  // the previous block's LDS reads are done
+    if (tid < kPbRows) {
+      const bool ok = tid < vrows;
+      s_stat[tid] = make_float2(ok ? rowstat[2 * (rb + tid)] : 0.f, ok ? 1.0f / rowstat[2 * (rb + tid) + 1] : 0.f);
+    }
+    for (int e = tid; e < kPbRows * 32; e += 256) {
+      const int row = e >> 5, l = e & 31;
+      s_mw[e] = (row < vrows && l < L) ? mw[(rb + row) * L + l] : 0.f;
+    }
+    __syncthreads();
+    if (!live) continue;
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z) + rb * T + c0, 0, (int)((int64_t)vrows * T * 4), 0x00020000);
+    const int nsteps = (vrows + 1) >> 1;
+    constexpr int NB = 16;                                            // steps per batch: their loads are issued together
+    for (int j0 = 0; j0 < nsteps; j0 += NB) {
+      float zv[NB];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) zv[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rz, voff + (unsigned)(j0 + q) * step, 0, 0));
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        const int row = 2 * (j0 + q) + h;                             // < 128; rows past the chunk: logit 0 (out of range), (0, 0), weight 0
+        const float2 st = s_stat[row];
+        const float a = s_mw[row * 32 + i];
+        const float qv = __builtin_amdgcn_exp2f((zv[q] - st.x) * 1.4426950408889634f) * st.y;
+        const float pv = __builtin_amdgcn_fmed3f(qv, 0.f, 3.4028234663852886e38f);   // nan_to_num
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pv, acc, 0, 0, 0);
+      }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int l = (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (l < L) pbar[(int64_t)l * T + c0 + i] += acc[r];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- low-rank softmax backward
 // Backward of softmax + top-K + batch-mean loss from RECOMPUTED LOGITS, for the chunked per-vertex path:
 //   p = exp(z - m) / s (row stats saved by the forward),  g[r,t] = sum_l mw[r,l] G[l,t]  (+ dq_k at the top-K slots)
@@ -438,6 +499,95 @@ softmax_bwd_tile_kernel(float* __restrict__ Z, const float* __restrict__ rowstat
   if (!APPLY) {
     __syncthreads();
     if (tid < nr) atomicAdd(dot + r0 + tid, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+  }
+}
+
+// The same two passes with the low-rank product on the matrix cores (T % 32 == 0).  g = mw (rows x L) * G (L x T) is a
+// GEMM with a contraction of L <= 32: eight 32x32x2 MFMAs per 32 x 32 tile instead of 16 VALU FMAs per logit, which
+// leaves ~8 VALU instructions per logit (probability, product, sums) and makes both passes streaming-bound.
+// A wave owns 32 rows for a range of columns: its A operand (the rows' weights) and the per-row constants of the MFMA
+// result layout (lane (i, h), register r <-> row (r & 3) + 8 (r >> 2) + 4 h, column i) stay in registers; logits move
+// through buffer descriptors whose record count ends at the last valid row, so rows past U read 0 and are not written.
+constexpr int kLrRows = 128;       // 4 waves x 32 rows
+constexpr int kLrCols = 4096;      // columns per block: 128 tiles of 32
+
+template <bool APPLY, int LP>
+__global__ void __launch_bounds__(256)
+softmax_bwd_mfma_kernel(float* __restrict__ Z, const float* __restrict__ rowstat, const float* __restrict__ mw,
+                        const float* __restrict__ G, int L, float* __restrict__ dot, float* __restrict__ db, int64_t U,
+                        int64_t T) {
+  __shared__ float colsum[APPLY ? kLrCols : 1];
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t r0 = (int64_t)blockIdx.y * kLrRows + wave * 32;
+  const int64_t c0 = (int64_t)blockIdx.x * kLrCols;
+  const int ntile = (int)(((c0 + kLrCols < T) ? kLrCols : (T - c0)) / 32);
+  const bool use_db = APPLY && db != nullptr;
+  if (use_db) {
+    for (int c = tid; c < kLrCols; c += 256) colsum[c] = 0.f;
+    __syncthreads();
+  }
+  const int64_t vrows = U - r0 < 0 ? 0 : (U - r0 < 32 ? U - r0 : 32);       // valid rows of this wave
+  if (vrows > 0 || use_db) {
+    // A operand: A[m = i][k = 2 j + h] = mw[r0 + i][2 j + h]
+    float aop[LP / 2];
+#pragma unroll
+    for (int j = 0; j < LP / 2; ++j) aop[j] = (i < vrows && 2 * j + h < L) ? mw[(r0 + i) * L + 2 * j + h] : 0.f;
+    float rm[16], rrs[16], rdr[16], dacc[16];
+    unsigned voff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int lr = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const bool ok = lr < vrows;
+      rm[r] = ok ? rowstat[2 * (r0 + lr)] : 0.f;
+      rrs[r] = ok ? 1.0f / rowstat[2 * (r0 + lr) + 1] : 0.f;
+      rdr[r] = (APPLY && ok) ? dot[r0 + lr] : 0.f;
+      dacc[r] = 0.f;
+      voff[r] = 4u * ((unsigned)lr * (unsigned)T + (unsigned)i);
+    }
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(Z + r0 * T + c0, 0, (int)(vrows * T * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G) + c0, 0, 0x7fffffff, 0x00020000);
+    const unsigned goff = 4u * ((unsigned)h * (unsigned)T + (unsigned)i);
+    for (int tb = 0; tb < ntile; ++tb) {
+      const unsigned so = 128u * (unsigned)tb;
+      float zv[16], bop[LP / 2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rz, voff[r], so, 0));
+#pragma unroll
+      for (int j = 0; j < LP / 2; ++j)
+        bop[j] = (2 * j + h < L) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, goff + 8u * (unsigned)j * (unsigned)T, so, 0)) : 0.f;
+      f32x16_t g = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < LP / 2; ++j) g = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[j], bop[j], g, 0, 0, 0);
+      float cs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float q = __builtin_amdgcn_exp2f((zv[r] - rm[r]) * 1.4426950408889634f) * rrs[r];
+        const float p = __builtin_amdgcn_fmed3f(q, 0.f, 3.4028234663852886e38f);          // nan_to_num: NaN -> 0, inf -> max
+        if (APPLY) {
+          const float dz = p * (g[r] - rdr[r]);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz), rz, voff[r], so, 0);
+          cs += dz;
+        } else {
+          dacc[r] += p * g[r];
+        }
+      }
+      if (use_db) atomicAdd(&colsum[tb * 32 + i], cs);                 // LDS float add; both row halves and all waves
+    }
+    if (!APPLY) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = dacc[r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        const int lr = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (i == 0 && lr < vrows) atomicAdd(dot + r0 + lr, v);
+      }
+    }
+  }
+  if (use_db) {
+    __syncthreads();
+    for (int c = tid; c < ntile * 32; c += 256) atomicAdd(db + c0 + c, colsum[c]);
   }
 }
 
@@ -604,7 +754,9 @@ extern "C" int gngf_logits_topk_pbar(const float* logits, float* topk_val, int32
   logits_stats_topk_kernel<<<dim3((unsigned)U), dim3(kRowBlock), smem, s>>>(logits, topk_val, topk_idx, rowstat, T, K);
   if (L > 0) {
     const dim3 grid((unsigned)ceil_div(T, 1024));
-    if (L <= 4) pbar_accum_kernel<4><<<grid, dim3(256), 0, s>>>(logits, rowstat, mw, L, pbar, U, T);
+    if (T % 32 == 0 && T < (1 << 22) && L > 4)          // 128 rows * T * 4 B inside 31-bit offsets
+      pbar_mfma_kernel<<<dim3((unsigned)ceil_div(T, 128)), dim3(256), 0, s>>>(logits, rowstat, mw, L, pbar, U, T);
+    else if (L <= 4) pbar_accum_kernel<4><<<grid, dim3(256), 0, s>>>(logits, rowstat, mw, L, pbar, U, T);
     else if (L <= 16) pbar_accum_kernel<16><<<grid, dim3(256), 0, s>>>(logits, rowstat, mw, L, pbar, U, T);
     else pbar_accum_kernel<32><<<grid, dim3(256), 0, s>>>(logits, rowstat, mw, L, pbar, U, T);
   }
@@ -652,17 +804,27 @@ extern "C" int gngf_softmax_bwd_lowrank(float* logits_dz, const float* rowstat, 
   float* pk = scratch + U;
   hipError_t e = hipMemsetAsync(dot, 0, sizeof(float) * (size_t)U, s);
   if (e != hipSuccess) return (int)e;
-  const dim3 grid((unsigned)ceil_div(T, kSbCols), (unsigned)ceil_div(U, kSbRows));
+  const bool mfma = (T % 32 == 0) && T < (1 << 24) && L <= 32;      // 32 rows * T * 4 B and L * T * 4 B inside 32-bit offsets
+  const dim3 grid(mfma ? (unsigned)ceil_div(T, kLrCols) : (unsigned)ceil_div(T, kSbCols),
+                  mfma ? (unsigned)ceil_div(U, kLrRows) : (unsigned)ceil_div(U, kSbRows));
   const bool small = L <= 4;
   if (L > 0) {
-    if (small) softmax_bwd_tile_kernel<false, 4><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, nullptr, U, T);
+    if (mfma) {
+      if (small) softmax_bwd_mfma_kernel<false, 4><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, nullptr, U, T);
+      else if (L <= 16) softmax_bwd_mfma_kernel<false, 16><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, nullptr, U, T);
+      else softmax_bwd_mfma_kernel<false, 32><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, nullptr, U, T);
+    } else if (small) softmax_bwd_tile_kernel<false, 4><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, nullptr, U, T);
     else if (L <= 16) softmax_bwd_tile_kernel<false, 16><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, nullptr, U, T);
     else softmax_bwd_tile_kernel<false, 32><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, nullptr, U, T);
   }
   if (K > 0)
     softmax_bwd_topk_dot_kernel<<<dim3((unsigned)ceil_div(U * K, 256)), dim3(256), 0, s>>>(logits_dz, rowstat, dq, topk_idx, pk,
                                                                                           dot, U, T, K);
-  if (small) softmax_bwd_tile_kernel<true, 4><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, db, U, T);
+  if (mfma) {
+    if (small) softmax_bwd_mfma_kernel<true, 4><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, db, U, T);
+    else if (L <= 16) softmax_bwd_mfma_kernel<true, 16><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, db, U, T);
+    else softmax_bwd_mfma_kernel<true, 32><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, db, U, T);
+  } else if (small) softmax_bwd_tile_kernel<true, 4><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, db, U, T);
   else if (L <= 16) softmax_bwd_tile_kernel<true, 16><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, db, U, T);
   else softmax_bwd_tile_kernel<true, 32><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, db, U, T);
   if (K > 0)

@@ -204,7 +204,10 @@ def test_fused_decoder_vs_numpy(ops, P, in_dim, out_dim, leaky):
         close(params[2 * i + 1].grad, dB[i], 2e-4, 2e-5 * scale)
 
 
-@pytest.mark.parametrize("U,T,K,Lv", [(100, 700, 4, 5), (64, 8192 + 300, 3, 16), (130, 257, 0, 4), (70, 1000, 6, 0)])
+@pytest.mark.parametrize("U,T,K,Lv", [(100, 700, 4, 5), (64, 8192 + 300, 3, 16), (130, 257, 0, 4), (70, 1000, 6, 0),
+                                      # T % 32 == 0: the MFMA form of the two passes (ragged last row block, 1..32 levels)
+                                      (200, 4096 + 64, 4, 16), (130, 8192, 3, 5), (33, 96, 2, 3), (70, 1024, 6, 0),
+                                      (129, 640, 0, 29)])
 def test_softmax_bwd_lowrank_from_logits_vs_numpy(ops, U, T, K, Lv):
     """streamed softmax / top-K / batch-mean backward from recomputed logits (chunked per-vertex path)"""
     from collision_handling_in_instantngp_amd._lib import call, ptr, stream_ptr
@@ -238,7 +241,9 @@ def test_softmax_bwd_lowrank_from_logits_vs_numpy(ops, U, T, K, Lv):
     close(db, want.sum(0), 2e-4, 2e-5 * scale)
 
 
-@pytest.mark.parametrize("U,T,K,Lv", [(70, 500, 4, 5), (33, 9000, 8, 16), (40, 257, 1, 0), (5, 100000, 32, 3)])
+@pytest.mark.parametrize("U,T,K,Lv", [(70, 500, 4, 5), (33, 9000, 8, 16), (40, 257, 1, 0), (5, 100000, 32, 3),
+                                      # T % 32 == 0 and more than 4 levels: the MFMA form of the p-bar accumulation
+                                      (300, 4096 + 96, 4, 16), (129, 8192, 2, 5), (7, 160, 3, 32), (257, 1024, 4, 11)])
 def test_streaming_logits_topk_pbar_vs_numpy(ops, U, T, K, Lv):
     """one-read online statistics + top-K on the logits, and the p-bar accumulation from logits"""
     from collision_handling_in_instantngp_amd._lib import call, ptr, stream_ptr
