@@ -422,7 +422,7 @@ ENCODE_PATH = "auto"        # "auto" | "direct" | "tiled"  (tests force a path; 
 DP_EXCHANGE = None          # data parallel: callable that sum-all-reduces + averages the vertex-grid gradient in place
 DP_TABLES_REDUCED = 0       # number of leading levels whose table gradient of the last backward came out of an exchanged dG
 # Deferred vertex stage (data parallel, index sources without a trainable weight): when True, the encoder backward stops
-# after the pixel stage and leaves (arguments of the vertex stage) in DP_DEFERRED; parallel.finish_backward() all-reduces
+# after the pixel stage and leaves (arguments of the vertex stage) in DP_DEFERRED; parallel.allreduce_gradients() all-reduces
 # dG and runs the vertex stage.  The backward pass then contains no collective, so the whole forward+backward can be
 # replayed from ONE hipGraph on every rank (bench.py does; eager launch gaps cost ~15 % of a step).
 DP_DEFER_VERTEX = False
@@ -547,13 +547,15 @@ def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None):
          plan.lds_bytes, plan.chunk, stream_ptr())
 
 
-def run_deferred_vertex_stage():
+def run_deferred_vertex_stage(exchanged=False):
     """Second half of a deferred encoder backward (see DP_DEFER_VERTEX): dG -> table gradient.  The arguments stay
-    registered (a replayed hipGraph refills the same buffers), so this can be called after every replay."""
+    registered (a replayed hipGraph refills the same buffers), so this can be called after every replay.
+    exchanged: the caller has already averaged dG over the ranks (parallel.allreduce_gradients does, together with the
+    other gradients)."""
     if DP_DEFERRED is None:
         return False
     plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, order = DP_DEFERRED
-    if DP_EXCHANGE is not None:
+    if DP_EXCHANGE is not None and not exchanged:
         DP_EXCHANGE(dG)
     _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, None, order)
     return True
@@ -638,7 +640,7 @@ class EncodeFunction(torch.autograd.Function):
             dG = pre[1] if pre else torch.zeros((plan.vtot, F), dtype=_f32, device=tables.device)
             _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax)
             if DP_EXCHANGE is not None and DP_DEFER_VERTEX and dvw is None:
-                # the caller exchanges dG and runs the vertex stage after backward (parallel.finish_backward)
+                # the caller exchanges dG and runs the vertex stage after backward (parallel.allreduce_gradients)
                 globals()["DP_DEFERRED"] = (plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, order)
                 globals()["DP_TABLES_REDUCED"] = plan.Ls
                 if plan.Ls < L:

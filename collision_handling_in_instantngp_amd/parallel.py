@@ -32,7 +32,7 @@ def enable_vertex_grid_exchange(world: int, group=None):
     if world <= 1:
         ops.DP_EXCHANGE = ops.DP_MEAN = ops.DP_MAX = None
         return
-    ops.DP_EXCHANGE = lambda t: (all_reduce_sum(t, group), t.mul_(1.0 / world))
+    ops.DP_EXCHANGE = lambda t: average_tensors([t], world, group)
     # GNGF with a trainable HPD: the KL/JS loss is a nonlinear function of the batch-mean distribution, so p-bar is
     # averaged over ranks in the forward (exact single-GPU equivalence), and every rank builds its per-vertex table over
     # the same vertex rectangle (max of the shards' coordinate bounds).
@@ -80,25 +80,49 @@ def defer_vertex_stage(on: bool = True):
         ops.DP_DEFERRED = None
 
 
+def average_tensors(tensors, world: int, group=None):
+    """In-place mean over ranks of several device tensors as ONE exchange.  RCCL: the all-reduces are issued inside a
+    coalescing group (one fused launch instead of one per tensor; a small collective costs tens of microseconds of
+    latency whatever its size) with the AVG reduction (no separate scaling kernels).  gloo (CPU rehearsals, ranks
+    sharing a GPU in tests): one sum-all-reduce per tensor, staged through the host, then scaled."""
+    tensors = [t for t in tensors if t is not None and t.numel() > 0]
+    if not tensors or world <= 1:
+        return
+    if dist.get_backend(group) == "nccl" and all(t.is_cuda for t in tensors):
+        if len(tensors) == 1:
+            dist.all_reduce(tensors[0], op=dist.ReduceOp.AVG, group=group)
+            return
+        with dist._coalescing_manager(group=group, device=tensors[0].device, async_ops=True) as cm:
+            for t in tensors:
+                dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+        cm.wait()
+        return
+    for t in tensors:
+        all_reduce_sum(t, group)
+        t.mul_(1.0 / world)
+
+
 def allreduce_gradients(net, world: int, group=None, keep_tables_flag: bool = False):
-    """All gradient traffic of one step.  keep_tables_flag: the step is replayed from a hipGraph, so the staged-level
-    count recorded at capture time stays valid for every replay."""
+    """All gradient traffic of one step, as one coalesced exchange: the deferred vertex-grid gradient (if the encoder
+    backward left one, see defer_vertex_stage), the table-gradient slice of the direct-form levels, and every other
+    gradient as one flat buffer; the deferred vertex stage runs behind it.  keep_tables_flag: the step is replayed from
+    a hipGraph, so the staged-level count recorded at capture time stays valid for every replay."""
     if world <= 1:
         return
-    ops.run_deferred_vertex_stage()
-    inv = 1.0 / world
+    tensors = []
+    deferred = ops.DP_DEFERRED
+    if deferred is not None:
+        tensors.append(deferred[6])              # dG of the staged levels
     handled = set()
     enc = getattr(net, "encoding", None)
     base = getattr(enc, "_grad_base", None) if enc is not None else None
-    work = []
     tables_done = int(ops.DP_TABLES_REDUCED)     # leading levels already reduced through dG by the encoder backward
     if not keep_tables_flag:
         ops.DP_TABLES_REDUCED = 0
     if base is not None:
         handled = {id(m.weight) for m in enc._hash_tables}
-        base = base[tables_done:] if tables_done < base.shape[0] else None      # (L,T,F): the direct-form levels only
-        if base is not None:
-            work.append(dist.all_reduce(base, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        if tables_done < base.shape[0]:
+            tensors.append(base[tables_done:])   # (L,T,F): the direct-form levels only
     rest = [p for p in net.parameters() if p.requires_grad and p.grad is not None and id(p) not in handled]
     flat = None
     in_place = False
@@ -107,15 +131,13 @@ def allreduce_gradients(net, world: int, group=None, keep_tables_flag: bool = Fa
         in_place = flat is not None
         if not in_place:
             flat = torch.cat([p.grad.reshape(-1) for p in rest])
-        work.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
-    for w in work:
-        w.wait()
-    if base is not None:
-        base.mul_(inv)
-    if flat is not None:
-        flat.mul_(inv)
+        tensors.append(flat)
+    average_tensors(tensors, world, group)
+    if deferred is not None:
+        ops.run_deferred_vertex_stage(exchanged=True)
+    if flat is not None and not in_place:
         off = 0
-        for p in ([] if in_place else rest):
+        for p in rest:
             n = p.grad.numel()
             p.grad.copy_(flat[off:off + n].view_as(p.grad))
             off += n

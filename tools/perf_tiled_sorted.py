@@ -15,7 +15,11 @@ genc = torch.randn((2**20, 32), device=dev)
 plan = ops.EncodePlan(2**20, n_host, 2)
 ws = ops.TiledWorkspace(plan, xy)
 xy_sorted = ws.sorted[:, :2].contiguous()
-for name, pts in (("random order", xy), ("tile order", xy_sorted)):
+# third ordering: row-major order of the finest cells (binning keeps it inside each tile up to a block's local shuffle):
+# adjacent lanes then touch adjacent LDS words — what would a within-tile sort buy the LDS-bound pixel stage?
+key = (xy[:, 1] * 512).floor().long() * 512 + (xy[:, 0] * 512).floor().long()
+xy_cell = xy[torch.argsort(key, stable=True)].contiguous()
+for name, pts in (("random order", xy), ("tile order", xy_sorted), ("cell order", xy_cell)):
     ks = ops.encode_kernels(pts, n_ls, n_host, tables, None, None, 0, genc)
     for k in ("encode_fwd:tiled", "encode_bwd:tiled"):
         fn = ks[k]
