@@ -56,6 +56,8 @@ SIGNATURES = {
     "gngf_mse_workspace_floats": [],
     "gngf_mse_fwd": [_P, _P, _P, _P, _L, _P],
     "gngf_mse_bwd": [_P, _P, _P, _P, _L, _P],
+    "gngf_adam_block_elems": [],
+    "gngf_adam_step": [_P, _I, _L, _P, _P, _P, _I, _F, _F, _F, _P],
 }
 
 _RETURNS_INT64 = {"gngf_decoder_hidden_floats"}
@@ -84,8 +86,8 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _L if name in _RETURNS_INT64 else _I
     ver = lib.gngf_abi_version()
-    if ver != 2:
-        raise GngfLibraryError(f"ABI version mismatch: library {ver}, binding 2")
+    if ver != 3:
+        raise GngfLibraryError(f"ABI version mismatch: library {ver}, binding 3")
     _lib = lib
     return lib
 

@@ -53,16 +53,106 @@ class Loss(torch.nn.Module):
         return mse_loss, self.js_kl_rows(pbar), collisions_losses
 
 
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam's update (amsgrad off; the reference's get_optimizer, functions.py:96-127) for every tensor of
+    every parameter group in ONE launch of the HIP kernel behind `gngf_adam_step` (csrc/optim.hip).  State keeps
+    torch.optim.Adam's layout (`step`, `exp_avg`, `exp_avg_sq` per parameter), so optimizer state dicts written by the
+    reference's torch.optim.Adam load here and vice versa.  The step count is a device tensor advanced by the kernel:
+    a step needs no host synchronisation and can be captured in a hipGraph together with forward and backward."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) > 4:
+            raise ValueError("at most 4 parameter groups (GNGF_ADAM_MAX_GROUPS)")
+        if len({(g["betas"], g["eps"]) for g in self.param_groups}) != 1:
+            raise ValueError("betas and eps are shared by all groups (as in the reference's get_optimizer)")
+        self._step = None            # device float: steps taken
+        self._table = None           # device byte tensor: the packed segment list
+        self._table_key = None
+        self._total_blocks = 0
+
+    def _segments(self):
+        segs = []
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse or p.dtype != torch.float32 or not p.is_cuda:
+                    raise RuntimeError("FusedAdam handles dense fp32 device parameters")
+                st = self.state[p]
+                if "exp_avg" not in st:
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                if self._step is None:
+                    prev = st.get("step", 0.0)
+                    self._step = torch.full((), float(prev), dtype=torch.float32, device=p.device)
+                st["step"] = self._step          # one shared counter (torch keeps one equal copy per parameter)
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                for t_ in (p, st["exp_avg"], st["exp_avg_sq"]):
+                    if not t_.is_contiguous():
+                        raise RuntimeError("FusedAdam needs contiguous parameters and moments")
+                segs.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), gi, g))
+        return segs
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        import ctypes
+        from ._lib import call, ptr, query, stream_ptr
+        segs = self._segments()
+        if not segs:
+            return loss
+        key = tuple(s_[:6] for s_ in segs)
+        if key != self._table_key:                 # pointers moved (first step, new gradient buffers, loaded state)
+            blk = query("gngf_adam_block_elems")
+            rec = np.zeros(len(segs), dtype=np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"),
+                                                      ("first", "<i8"), ("group", "<i4"), ("pad", "<i4")]))
+            first = 0
+            for i, (pp, gp, mp, vp, n, gi, _keep) in enumerate(segs):
+                rec[i] = (pp, gp, mp, vp, n, first, gi, 0)
+                first += -(-n // blk)
+            self._total_blocks = first
+            dev = self._step.device
+            self._table = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+            self._table_key = key
+        ng = len(self.param_groups)
+        lr = (ctypes.c_float * ng)(*[float(g["lr"]) for g in self.param_groups])
+        wd = (ctypes.c_float * ng)(*[float(g["weight_decay"]) for g in self.param_groups])
+        b1, b2 = self.param_groups[0]["betas"]
+        call("gngf_adam_step", ptr(self._table), len(segs), self._total_blocks, ptr(self._step), lr, wd, ng, float(b1), float(b2),
+             float(self.param_groups[0]["eps"]), stream_ptr())
+        return loss
+
+    def state_dict(self):
+        # torch.optim.Adam advances every parameter's `step` tensor in place: hand out one copy per parameter, not the
+        # shared counter (a shared tensor would be advanced once per parameter after loading into torch's optimizer)
+        sd = super().state_dict()
+        sd["state"] = {k: {**v, **({"step": v["step"].detach().clone()} if "step" in v else {})} for k, v in sd["state"].items()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._step = None                          # re-read from the loaded per-parameter `step`
+        self._table_key = None
+
+
 def get_optimizer(net, encoding_lr, HPD_lr, MLP_lr, encoding_weight_decay, HPD_weight_decay, MLP_weight_decay,
-                  betas=(0.9, 0.99), eps=1e-15):
-    """reference functions.py:96-127."""
+                  betas=(0.9, 0.99), eps=1e-15, fused_kernel=None):
+    """reference functions.py:96-127.  On the GPU the update runs as one launch of this package's Adam kernel
+    (FusedAdam: same rule and state layout as torch.optim.Adam); host tensors (CPU tests of the training algebra) and
+    fused_kernel=False use torch.optim.Adam itself."""
     groups = [{"params": net.encoding.parameters(), "lr": encoding_lr, "weight_decay": encoding_weight_decay}]
     if not models.should_use_hash_function:
         groups.append({"params": net.HPD.parameters(), "lr": HPD_lr, "weight_decay": HPD_weight_decay})
     groups.append({"params": net.mlp.parameters(), "lr": MLP_lr, "weight_decay": MLP_weight_decay})
-    # same update rule as the reference's torch.optim.Adam; the single-kernel ("fused") implementation moves the
-    # 64 MiB of tables + moments in ~0.1 ms per step at cfg2 instead of ~0.3 ms for the per-op default
-    on_gpu = all(p.is_cuda for p in net.parameters())
+    on_gpu = all(p.is_cuda and p.dtype == torch.float32 for p in net.parameters())
+    if fused_kernel is None:
+        fused_kernel = on_gpu
+    if fused_kernel:
+        return FusedAdam(groups, betas=betas, eps=eps)
     return torch.optim.Adam(groups, betas=betas, eps=eps, **({"fused": True} if on_gpu else {}))
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNGF_ABI_VERSION 2
+#define GNGF_ABI_VERSION 3
 #define GNGF_MAX_LEVELS 32
 #define GNGF_MAX_TOPK 32
 
@@ -196,6 +196,21 @@ int gngf_mse_workspace_floats(void);
 int gngf_mse_fwd(const float* pred, const float* label, float* loss, float* workspace, int64_t n, void* stream);
 /* its backward: dpred (n) = gout[0] * 2 (pred - label) / n   (gout: device scalar, the gradient of the loss value) */
 int gngf_mse_bwd(const float* pred, const float* label, const float* gout, float* dpred, int64_t n, void* stream);
+
+/* ---- optimizer (row f2: the caller of the path) ---------------------------------------------------------------------
+ * torch.optim.Adam as get_optimizer builds it (functions.py:96-127: betas (0.9, 0.99), eps 1e-15, L2-style weight
+ * decay, dense moments, per-group lr), every tensor of every group in ONE launch.
+ * segments: device array of nseg 56-byte records
+ *     { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; int64_t n; int64_t first_block;
+ *       int32_t group; int32_t pad; }
+ * with first_block = running sum of ceil(n / gngf_adam_block_elems()) and total_blocks that sum over all segments.
+ * step: device float holding the number of steps taken so far; the call increments it and uses the new value (bias
+ * corrections in double precision), so a step is capturable in a hipGraph.  lr, weight_decay: HOST arrays of ngroups
+ * (<= GNGF_ADAM_MAX_GROUPS) values, indexed by a segment's `group`. */
+#define GNGF_ADAM_MAX_GROUPS 4
+int gngf_adam_block_elems(void);
+int gngf_adam_step(const void* segments, int nseg, int64_t total_blocks, float* step, const float* lr,
+                   const float* weight_decay, int ngroups, float beta1, float beta2, float eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -317,3 +317,71 @@ def test_mse_kernels_vs_numpy(ops, n):
         (loss * 3.0).backward()
         close(loss.detach().cpu().numpy(), want, 2e-6, 0)
         close(x.grad.cpu().numpy(), 3.0 * 2.0 * (a.astype(np.float64) - b) / a.size, 1e-6, 1e-12)
+
+
+def _adam_params(seed, dev, sizes=((3, 5), (1000,), (2, 2049), (1 << 16, 2), (7,))):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.nn.Parameter(torch.randn(s, generator=g).to(dev)) for s in sizes]
+
+
+def test_fused_adam_matches_torch_adam_over_steps(ops):
+    """csrc/optim.hip vs torch.optim.Adam with get_optimizer's hyper-parameters (functions.py:96-127): three groups with
+    their own lr / weight decay, odd sizes (tails, unaligned segments), 12 steps; then the state dicts are swapped."""
+    from collision_handling_in_instantngp_amd.train import FusedAdam
+    pa, pb = _adam_params(0, DEV), _adam_params(0, DEV)
+
+    def groups(ps):
+        return [{"params": ps[:2], "lr": 1e-2, "weight_decay": 1e-6}, {"params": ps[2:4], "lr": 1e-3, "weight_decay": 0.0},
+                {"params": ps[4:], "lr": 5e-3, "weight_decay": 1e-2}]
+    oa = FusedAdam(groups(pa), betas=(0.9, 0.99), eps=1e-15)
+    ob = torch.optim.Adam(groups(pb), betas=(0.9, 0.99), eps=1e-15)
+    gen = torch.Generator().manual_seed(5)
+    for step in range(12):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=gen).to(DEV) * (10.0 ** (step % 4 - 2))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        close(a.detach(), b.detach().cpu().numpy(), 2e-6, 1e-6)     # 12 roundings of a parameter of magnitude ~1
+        for k in ("exp_avg", "exp_avg_sq"):                                # gradients span 1e-2 .. 10: absolute error follows the largest
+            want = ob.state[b][k].cpu().numpy()
+            close(oa.state[a][k], want, 2e-6, 2e-6 * float(np.abs(want).max()))
+        assert float(oa.state[a]["step"]) == 12.0
+    # a torch.optim.Adam state dict (the reference's whole_opt.pt) continues in the kernel, and the other way round
+    oa2 = FusedAdam(groups(pa), betas=(0.9, 0.99), eps=1e-15)
+    oa2.load_state_dict(ob.state_dict())
+    ob2 = torch.optim.Adam(groups(pb), betas=(0.9, 0.99), eps=1e-15)
+    ob2.load_state_dict(oa.state_dict())
+    for a, b in zip(pa, pb):
+        gr = torch.randn(a.shape, generator=gen).to(DEV)
+        a.grad, b.grad = gr.clone(), gr.clone()
+    oa2.step(); ob2.step()
+    for a, b in zip(pa, pb):
+        close(a.detach(), b.detach().cpu().numpy(), 4e-6, 2e-6)
+    assert float(oa2.state[pa[0]]["step"]) == 13.0
+
+
+def test_fused_adam_step_replays_from_a_graph(ops):
+    """the device-side step counter makes the update capturable: 4 replays == 4 eager torch steps on the same gradient"""
+    from collision_handling_in_instantngp_amd.train import FusedAdam
+    pa, pb = _adam_params(3, DEV), _adam_params(3, DEV)
+    oa = FusedAdam(pa, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    ob = torch.optim.Adam(pb, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    for a, b in zip(pa, pb):
+        a.grad = torch.randn_like(a); b.grad = a.grad.clone()
+    oa.step(); ob.step()                                  # eager first step: state exists, pointers are settled
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+            oa.step()
+    torch.cuda.current_stream().wait_stream(side)
+    ob.step()                                             # capture does not execute: replay below is step 2
+    graph.replay()
+    for _ in range(3):
+        graph.replay(); ob.step()
+    torch.cuda.synchronize()
+    assert float(oa.state[pa[0]]["step"]) == 5.0
+    for a, b in zip(pa, pb):
+        close(a.detach(), b.detach().cpu().numpy(), 3e-6, 1e-6)
