@@ -12,6 +12,9 @@ import torch.distributed as dist
 from . import ops
 
 
+_COALESCED_AVG = True
+
+
 def all_reduce_sum(t, group=None):
     """Sum-all-reduce of a device tensor: RCCL when the backend is nccl; with gloo (CPU rehearsals / single-GPU tests
     of the multi-rank logic) the tensor is staged through host memory."""
@@ -88,15 +91,23 @@ def average_tensors(tensors, world: int, group=None):
     tensors = [t for t in tensors if t is not None and t.numel() > 0]
     if not tensors or world <= 1:
         return
-    if dist.get_backend(group) == "nccl" and all(t.is_cuda for t in tensors):
-        if len(tensors) == 1:
-            dist.all_reduce(tensors[0], op=dist.ReduceOp.AVG, group=group)
+    global _COALESCED_AVG
+    if _COALESCED_AVG and dist.get_backend(group) == "nccl" and all(t.is_cuda for t in tensors):
+        try:
+            if len(tensors) == 1:
+                dist.all_reduce(tensors[0], op=dist.ReduceOp.AVG, group=group)
+                return
+            with dist._coalescing_manager(group=group, device=tensors[0].device, async_ops=True) as cm:
+                for t in tensors:
+                    dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+            cm.wait()
             return
-        with dist._coalescing_manager(group=group, device=tensors[0].device, async_ops=True) as cm:
-            for t in tensors:
-                dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
-        cm.wait()
-        return
+        except (RuntimeError, TypeError, AttributeError, ValueError) as e:
+            # an RCCL / torch build without AVG or the coalescing API rejects the call before anything is enqueued, and
+            # it does so on every rank alike: fall back (for good) to one sum-all-reduce per tensor
+            import sys
+            print(f"[parallel] coalesced AVG exchange unavailable ({e!r}); using per-tensor all-reduce", file=sys.stderr)
+            _COALESCED_AVG = False
     for t in tensors:
         all_reduce_sum(t, group)
         t.mul_(1.0 / world)
