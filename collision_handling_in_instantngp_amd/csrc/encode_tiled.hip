@@ -483,7 +483,8 @@ tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
 template <int F>
 __global__ void __launch_bounds__(256)
 gather_partials_kernel(const float* __restrict__ partials, const int32_t* __restrict__ tile_item_base,
-                       const int32_t* __restrict__ n_ls, float* __restrict__ dG, int Ls, int tile_shift, int lds_floats) {
+                       const int32_t* __restrict__ tile_level_off, const int32_t* __restrict__ n_ls, float* __restrict__ dG,
+                       int Ls, int tile_shift, int lds_floats) {
   __shared__ int s_n[GNGF_MAX_LEVELS];
   if (threadIdx.x < Ls) s_n[threadIdx.x] = n_ls[threadIdx.x];
   __syncthreads();
@@ -505,19 +506,31 @@ gather_partials_kernel(const float* __restrict__ partials, const int32_t* __rest
       const int t = (ty << tile_shift) | tx;
       const int it0 = tile_item_base[t], it1 = tile_item_base[t + 1];
       if (it0 == it1) continue;
-      // layout of this tile's sub-grids up to level l
-      int lo = 0, cx = 0, cy = 0, wx = 0, wy = 0;
+      // offset of this tile's level-l sub-grid in an item image: from the precomputed (tile, level) table (-1: the level
+      // did not fit), else re-derived with setup_tile's rule (16 levels x 4 tiles of integer work per vertex: it was 2/3
+      // of this kernel's time)
+      int lo = 0;
       bool fits = false;
-      for (int j = 0; j <= l; ++j) {
-        const int nj = s_n[j];
-        const int cxj = (tx * nj) >> tile_shift, cyj = (ty * nj) >> tile_shift;
-        int hxj = (((tx + 1) * nj) >> tile_shift) + 1, hyj = (((ty + 1) * nj) >> tile_shift) + 1;
-        hxj = hxj > nj + 1 ? nj + 1 : hxj;
-        hyj = hyj > nj + 1 ? nj + 1 : hyj;
-        const int wxj = hxj - cxj + 1, wyj = hyj - cyj + 1, sz = wxj * wyj * F;
-        const bool fj = lo + sz <= lds_floats;
-        if (j == l) { cx = cxj; cy = cyj; wx = wxj; wy = wyj; fits = fj; }
-        else if (fj) lo += sz;
+      const int cx = (tx * n) >> tile_shift, cy = (ty * n) >> tile_shift;
+      int hx = (((tx + 1) * n) >> tile_shift) + 1, hy = (((ty + 1) * n) >> tile_shift) + 1;
+      hx = hx > n + 1 ? n + 1 : hx;
+      hy = hy > n + 1 ? n + 1 : hy;
+      const int wx = hx - cx + 1, wy = hy - cy + 1;
+      if (tile_level_off) {
+        lo = tile_level_off[t * Ls + l];
+        fits = lo >= 0;
+      } else {
+        for (int j = 0; j <= l; ++j) {
+          const int nj = s_n[j];
+          const int cxj = (tx * nj) >> tile_shift, cyj = (ty * nj) >> tile_shift;
+          int hxj = (((tx + 1) * nj) >> tile_shift) + 1, hyj = (((ty + 1) * nj) >> tile_shift) + 1;
+          hxj = hxj > nj + 1 ? nj + 1 : hxj;
+          hyj = hyj > nj + 1 ? nj + 1 : hyj;
+          const int sz = (hxj - cxj + 1) * (hyj - cyj + 1) * F;
+          const bool fj = lo + sz <= lds_floats;
+          if (j == l) fits = fj;
+          else if (fj) lo += sz;
+        }
       }
       const int lx = gx - cx, ly = gy - cy;
       if (!fits || lx < 0 || ly < 0 || lx >= wx || ly >= wy) continue;
@@ -773,9 +786,10 @@ extern "C" int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, 
 }
 
 extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
-                                     const int32_t* tile_item_base, const int32_t* n_ls, const int32_t* n_ls_host,
-                                     const float* genc, const float* genc_absmax, float* dG, float* partials, int L, int Ls,
-                                     int F, int tile_shift, int lds_bytes, int chunk, void* stream) {
+                                     const int32_t* tile_item_base, const int32_t* tile_level_off, const int32_t* n_ls,
+                                     const int32_t* n_ls_host, const float* genc, const float* genc_absmax, float* dG,
+                                     float* partials, int L, int Ls, int F, int tile_shift, int lds_bytes, int chunk,
+                                     void* stream) {
   GNGF_CHECK_ARG(max_items >= 0 && L > 0 && Ls > 0 && Ls <= L && L <= GNGF_MAX_LEVELS && lds_bytes >= 0 && lds_bytes <= 64 * 1024);
   GNGF_CHECK_ARG(chunk > 0 && chunk <= (1 << 20));
   int log2_chunk = 0;
@@ -793,7 +807,8 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
         reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, n_ls, genc, dG, partials,
         genc_absmax, L, Ls, tile_shift, lds_bytes / 4, log2_chunk);
     gather_partials_kernel<kF><<<dim3((unsigned)ceil_div((int64_t)side * side, 256), (unsigned)Ls), dim3(256), 0,
-                                 as_stream(stream)>>>(partials, tile_item_base, n_ls, dG, Ls, tile_shift, lds_bytes / 4);
+                                 as_stream(stream)>>>(partials, tile_item_base, tile_level_off, n_ls, dG, Ls, tile_shift,
+                                                      lds_bytes / 4);
   });
   GNGF_RETURN_LAUNCH();
 }

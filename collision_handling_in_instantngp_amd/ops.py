@@ -540,10 +540,40 @@ def _take_absmax_hint(genc):
     return h[0] if (h is not None and h[1] == genc._version) else None     # any in-place edit since invalidates the bound
 
 
+_TILE_LEVEL_OFF = {}
+
+
+def tile_level_offsets(plan, device):
+    """(ntiles, Ls) int32: float offset of level l's sub-grid inside tile t's LDS image, -1 where the level does not fit —
+    the layout rule of csrc/encode_tiled.hip::setup_tile, evaluated once per (resolutions, tiling, device) so that the
+    gather pass of the backward does not re-derive it for every vertex."""
+    key = (tuple(plan.n_ls_host[:plan.Ls]), plan.tile_shift, plan.lds_bytes, plan.F, str(device))
+    hit = _TILE_LEVEL_OFF.get(key)
+    if hit is None:
+        import numpy as np
+        s, ts = plan.tile_shift, 1 << plan.tile_shift
+        t = np.arange(ts * ts, dtype=np.int64)
+        tx, ty = t & (ts - 1), t >> s
+        lo = np.zeros(ts * ts, dtype=np.int64)
+        out = np.full((ts * ts, plan.Ls), -1, dtype=np.int32)
+        cap = plan.lds_bytes // 4
+        for l, n in enumerate(plan.n_ls_host[:plan.Ls]):
+            cx, cy = (tx * n) >> s, (ty * n) >> s
+            hx = np.minimum((((tx + 1) * n) >> s) + 1, n + 1)
+            hy = np.minimum((((ty + 1) * n) >> s) + 1, n + 1)
+            sz = (hx - cx + 1) * (hy - cy + 1) * plan.F
+            fits = lo + sz <= cap
+            out[fits, l] = lo[fits]
+            lo = np.where(fits, lo + sz, lo)
+        hit = torch.from_numpy(out).to(device)
+        _TILE_LEVEL_OFF[key] = hit
+    return hit
+
+
 def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None):
     partials = torch.empty((plan.max_items * (plan.lds_bytes // 4),), dtype=_f32, device=genc.device)
     call("gngf_encode_tiled_bwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(ws.tile_item_base),
-         ptr(n_ls), plan.n_ls_c, ptr(genc, _f32, "grad"), ptr(absmax), ptr(dG), ptr(partials), L, plan.Ls, F, plan.tile_shift,
+         ptr(tile_level_offsets(plan, genc.device)), ptr(n_ls), plan.n_ls_c, ptr(genc, _f32, "grad"), ptr(absmax), ptr(dG), ptr(partials), L, plan.Ls, F, plan.tile_shift,
          plan.lds_bytes, plan.chunk, stream_ptr())
 
 
@@ -613,6 +643,8 @@ class EncodeFunction(torch.autograd.Function):
                 if ctx.needs_input_grad[3]:
                     pre = [_grad_buffer(tables), torch.zeros((plan.vtot, F), dtype=_f32, device=tables.device)]
             ws = TiledWorkspace(plan, xy)
+            if ctx.needs_input_grad[3]:
+                tile_level_offsets(plan, tables.device)        # cached; built here so that no backward (or graph capture) uploads it
             cur.wait_stream(side)
             for buf in [G] + (pre or []):
                 buf.record_stream(cur)

@@ -100,14 +100,17 @@ int gngf_vertex_grid_bwd(const void* tables, int feat_dtype, const int32_t* vert
  * images of the items that cover it.  Inside a work item the sub-grids accumulate in 64-bit fixed point (LDS float
  * atomics are ~20x slower than 64-bit integer ones on gfx950); `chunk` = the binning chunk (bounds the term count).
  * genc_absmax (1 float, optional): a bound >= max |genc| that fixes the fixed-point scale; NULL: each work item scans its
- * own rows first. */
+ * own rows first.
+ * tile_level_off (4^tile_shift * Ls int32, optional): float offset of level l's sub-grid inside tile t's image at
+ * [t * Ls + l], -1 when the level does not fit (levels are laid out back to back in ascending order, a level that
+ * would exceed lds_bytes is skipped); NULL: the gather pass re-derives it per vertex. */
 int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
                           const int32_t* n_ls, const float* G, float* enc, int L, int Ls, int F, int tile_shift, int lds_bytes,
                           void* stream);
 int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
-                          const int32_t* tile_item_base, const int32_t* n_ls, const int32_t* n_ls_host, const float* genc,
-                          const float* genc_absmax, float* dG, float* partials, int L, int Ls, int F, int tile_shift,
-                          int lds_bytes, int chunk, void* stream);
+                          const int32_t* tile_item_base, const int32_t* tile_level_off, const int32_t* n_ls,
+                          const int32_t* n_ls_host, const float* genc, const float* genc_absmax, float* dG, float* partials,
+                          int L, int Ls, int F, int tile_shift, int lds_bytes, int chunk, void* stream);
 /* vertex stage backward for the vertex-table source in SLOT order (order (NV*K) int32 = argsort of vert_idx, flat):
  * contention-free for any slot distribution (wave-level segmented reduction, one atomic per (wave, slot run));
  * dtables accumulated, dvert_w (NV,K) written without atomics (NULL when not needed). */
