@@ -495,52 +495,88 @@ gather_partials_kernel(const float* __restrict__ partials, const int32_t* __rest
   const int gy = i / gw, gx = i - gy * gw;
   const int TS = 1 << tile_shift;
   // tiles whose [cx, hx] range can contain gx:  cx(t) = (t*n)>>s <= gx   and   hx(t) = min(((t+1)*n>>s)+1, n+1) >= gx
-  auto lo_of = [&](int g) { int t = (int)((((int64_t)(g - 1) << tile_shift) + n - 1) / n) - 1; return t < 0 ? 0 : t; };
-  auto hi_of = [&](int g) { int t = (int)((((int64_t)(g + 1) << tile_shift) + n - 1) / n) - 1; return t > TS - 1 ? TS - 1 : t; };
+  // (32-bit arithmetic: g << tile_shift < 2^20; a 64-bit division costs ~100 instructions, and there were four per vertex)
+  auto lo_of = [&](int g) { int t = (int)((((unsigned)g_max0(g - 1) << tile_shift) + (unsigned)n - 1u) / (unsigned)n) - 1; return t < 0 ? 0 : t; };
+  auto hi_of = [&](int g) { int t = (int)((((unsigned)(g + 1) << tile_shift) + (unsigned)n - 1u) / (unsigned)n) - 1; return t > TS - 1 ? TS - 1 : t; };
   const int tx0 = g_max0(lo_of(gx)), tx1 = hi_of(gx), ty0 = g_max0(lo_of(gy)), ty1 = hi_of(gy);
   float acc[F];
 #pragma unroll
   for (int f = 0; f < F; ++f) acc[f] = 0.f;
-  for (int ty = ty0; ty <= ty1; ++ty)
-    for (int tx = tx0; tx <= tx1; ++tx) {
-      const int t = (ty << tile_shift) | tx;
-      const int it0 = tile_item_base[t], it1 = tile_item_base[t + 1];
-      if (it0 == it1) continue;
-      // offset of this tile's level-l sub-grid in an item image: from the precomputed (tile, level) table (-1: the level
-      // did not fit), else re-derived with setup_tile's rule (16 levels x 4 tiles of integer work per vertex: it was 2/3
-      // of this kernel's time)
-      int lo = 0;
-      bool fits = false;
-      const int cx = (tx * n) >> tile_shift, cy = (ty * n) >> tile_shift;
-      int hx = (((tx + 1) * n) >> tile_shift) + 1, hy = (((ty + 1) * n) >> tile_shift) + 1;
-      hx = hx > n + 1 ? n + 1 : hx;
-      hy = hy > n + 1 ? n + 1 : hy;
-      const int wx = hx - cx + 1, wy = hy - cy + 1;
-      if (tile_level_off) {
-        lo = tile_level_off[t * Ls + l];
-        fits = lo >= 0;
-      } else {
-        for (int j = 0; j <= l; ++j) {
-          const int nj = s_n[j];
-          const int cxj = (tx * nj) >> tile_shift, cyj = (ty * nj) >> tile_shift;
-          int hxj = (((tx + 1) * nj) >> tile_shift) + 1, hyj = (((ty + 1) * nj) >> tile_shift) + 1;
-          hxj = hxj > nj + 1 ? nj + 1 : hxj;
-          hyj = hyj > nj + 1 ? nj + 1 : hyj;
-          const int sz = (hxj - cxj + 1) * (hyj - cyj + 1) * F;
-          const bool fj = lo + sz <= lds_floats;
-          if (j == l) fits = fj;
-          else if (fj) lo += sz;
-        }
-      }
-      const int lx = gx - cx, ly = gy - cy;
-      if (!fits || lx < 0 || ly < 0 || lx >= wx || ly >= wy) continue;
-      const int64_t o = lo + (ly * wx + lx) * F;
-      for (int it = it0; it < it1; ++it) {
-        const float* p = partials + (int64_t)it * lds_floats + o;
-#pragma unroll
-        for (int f = 0; f < F; ++f) acc[f] += p[f];
+  // (first item, one past the last item, float offset of this vertex in the items' images) of tile (tx, ty); empty when
+  // the tile has no items, its image does not hold level l, or the vertex lies outside its sub-grid
+  auto tile_span = [&](int tx, int ty, int& it0, int& it1, int& o) {
+    const int t = (ty << tile_shift) | tx;
+    it0 = tile_item_base[t];
+    it1 = tile_item_base[t + 1];
+    const int cx = (tx * n) >> tile_shift, cy = (ty * n) >> tile_shift;
+    int hx = (((tx + 1) * n) >> tile_shift) + 1, hy = (((ty + 1) * n) >> tile_shift) + 1;
+    hx = hx > n + 1 ? n + 1 : hx;
+    hy = hy > n + 1 ? n + 1 : hy;
+    const int wx = hx - cx + 1, wy = hy - cy + 1;
+    int lo = 0;
+    bool fits = false;
+    if (tile_level_off) {
+      lo = tile_level_off[t * Ls + l];
+      fits = lo >= 0;
+    } else {                                      // setup_tile's rule, re-derived
+      for (int j = 0; j <= l; ++j) {
+        const int nj = s_n[j];
+        const int cxj = (tx * nj) >> tile_shift, cyj = (ty * nj) >> tile_shift;
+        int hxj = (((tx + 1) * nj) >> tile_shift) + 1, hyj = (((ty + 1) * nj) >> tile_shift) + 1;
+        hxj = hxj > nj + 1 ? nj + 1 : hxj;
+        hyj = hyj > nj + 1 ? nj + 1 : hyj;
+        const int sz = (hxj - cxj + 1) * (hyj - cyj + 1) * F;
+        const bool fj = lo + sz <= lds_floats;
+        if (j == l) fits = fj;
+        else if (fj) lo += sz;
       }
     }
+    const int lx = gx - cx, ly = gy - cy;
+    if (!fits || lx < 0 || ly < 0 || lx >= wx || ly >= wy) it1 = it0;
+    o = lo + (ly * wx + lx) * F;
+  };
+  auto add_item = [&](int it, int o) {
+    const float* p = partials + (int64_t)it * lds_floats + o;
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] += p[f];
+  };
+  if (tx1 - tx0 <= 1 && ty1 - ty0 <= 1) {
+    // The usual case, at most 2 x 2 covering tiles: every table read of the four tiles is issued before the first image
+    // read, and the first two items of each tile are read without a loop (the chain tile -> item list -> image was a
+    // serial walk of ~8 dependent memory round trips per vertex).
+    int it0[4], it1[4], o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int tx = tx0 + (q & 1), ty = ty0 + (q >> 1);
+      if (tx <= tx1 && ty <= ty1) tile_span(tx, ty, it0[q], it1[q], o[q]);
+      else { it0[q] = it1[q] = 0; o[q] = 0; }
+    }
+    float v[4][2][F];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const bool on = it0[q] + e < it1[q];
+        const float* p = partials + (int64_t)(on ? it0[q] + e : 0) * lds_floats + (on ? o[q] : 0);
+#pragma unroll
+        for (int f = 0; f < F; ++f) v[q][e][f] = on ? p[f] : 0.f;
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f] += v[q][e][f];
+      for (int it = it0[q] + 2; it < it1[q]; ++it) add_item(it, o[q]);
+    }
+  } else {
+    for (int ty = ty0; ty <= ty1; ++ty)
+      for (int tx = tx0; tx <= tx1; ++tx) {
+        int it0, it1, o;
+        tile_span(tx, ty, it0, it1, o);
+        for (int it = it0; it < it1; ++it) add_item(it, o);
+      }
+  }
   int64_t goff = 0;
   for (int j = 0; j < l; ++j) goff += (int64_t)(s_n[j] + 2) * (s_n[j] + 2);
   float* d = dG + (goff + i) * F;
