@@ -19,7 +19,14 @@
 
 namespace gngf {
 
-constexpr int kTB = 256;        // pixel-stage workgroup
+#ifndef GNGF_TBF
+#define GNGF_TBF 512
+#endif
+#ifndef GNGF_TBB
+#define GNGF_TBB 1024
+#endif
+constexpr int kTBF = GNGF_TBF;  // pixel-stage workgroup, forward
+constexpr int kTB = GNGF_TBB;   // pixel-stage workgroup, backward
 constexpr int kBinThreads = 1024;
 
 __device__ __forceinline__ int g_max0(int v) { return v < 0 ? 0 : v; }
@@ -248,7 +255,7 @@ __device__ __forceinline__ void setup_tile(TileMeta& m, const int32_t* n_ls, int
 }
 
 template <int F>
-__global__ void __launch_bounds__(kTB)
+__global__ void __launch_bounds__(kTBF)
 tiled_fwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ items, const int32_t* __restrict__ n_items,
                  const int32_t* __restrict__ n_ls, const float* __restrict__ G, float* __restrict__ enc, int L, int Ls,
                  int tile_shift, int lds_floats) {
@@ -266,7 +273,7 @@ tiled_fwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
   {
     int used = 0;
     for (int l = 0; l < Ls; ++l) used += m.wx[l] * m.wy[l];            // vertices (levels that did not fit have wx = 0)
-    for (int e = tid; e < used; e += kTB) {
+    for (int e = tid; e < used; e += kTBF) {
       int l = 0, base = 0;
       for (int q = 0, acc = 0; q < Ls; ++q) {
         const int sz = m.wx[q] * m.wy[q];
@@ -282,7 +289,7 @@ tiled_fwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
     }
   }
   __syncthreads();
-  const int ppp = kTB / Ls;                     // pixels per pass: one lane per (pixel, level)
+  const int ppp = kTBF / Ls;                     // pixels per pass: one lane per (pixel, level)
   const int lp = tid / Ls, l = tid - lp * Ls;
   if (lp >= ppp) return;
   const int n = m.n[l], cx = m.cx[l], cy = m.cy[l], wx = m.wx[l], wy = m.wy[l], gw = m.gw[l];
@@ -814,7 +821,7 @@ extern "C" int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, 
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
       if (e != hipSuccess) return (int)e;
     }
-    tiled_fwd_kernel<kF><<<dim3((unsigned)max_items), dim3(kTB), (size_t)lds_bytes, as_stream(stream)>>>(
+    tiled_fwd_kernel<kF><<<dim3((unsigned)max_items), dim3(kTBF), (size_t)lds_bytes, as_stream(stream)>>>(
         reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, n_ls, G, enc, L, Ls, tile_shift,
         lds_bytes / 4);
   });
