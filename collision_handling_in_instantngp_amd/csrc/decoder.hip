@@ -189,8 +189,16 @@ __device__ __forceinline__ void hidden_store(float* hidden, int64_t tile, int wh
       __builtin_amdgcn_raw_buffer_store_b128(q, rs, hoff, which * 32768 + (t * 4 + g) * 1024, GNGF_HIDDEN_AUX);
     }
 }
+#ifndef GNGF_BWD_REVERSE
+#define GNGF_BWD_REVERSE 0
+#endif
+// The backward kernel can walk the tiles in the opposite order to the forward kernel, so that it starts on the hidden
+// layers written last (the part of the 512 MiB buffer that may still sit in the 256 MiB Infinity Cache).  Measured: no
+// effect with any cache policy of the hidden-layer traffic (249 us either way: its reads are prefetched a tile ahead and
+// the kernel is bound by MFMA issue), so the default keeps the forward order.
+__device__ __forceinline__ int64_t bwd_tile(int64_t t, int64_t ntiles) { return GNGF_BWD_REVERSE ? ntiles - 1 - t : t; }
 __device__ __forceinline__ void hidden_load(const float* hidden, int64_t tile, int64_t ntiles, int which, unsigned hoff, f32x16 (&v)[2]) {
-  const int64_t tt = tile < ntiles ? tile : ntiles - 1;   // past the end: any valid tile (the values are never used)
+  const int64_t tt = tile < ntiles ? bwd_tile(tile, ntiles) : ntiles - 1;   // past the end: any valid tile (the values are never used)
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hidden) + tt * kHiddenTileFloats, 0, kHiddenTileFloats * 4, 0x00020000);
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -477,7 +485,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   // the d-enc stores at the end of a tile are issued after them, so no wait ever covers a store (vmcnt counts in order).
   float xr[S0], yn[4], dyn[4], dz3[4];
   auto tile_window = [&](int64_t t, int64_t& tt, int& rows) {
-    tt = t < ntiles ? t : ntiles;                        // past the end: an empty window, every lane reads zeros
+    tt = t < ntiles ? bwd_tile(t, ntiles) : ntiles;      // past the end: an empty window, every lane reads zeros
     int64_t rem = P - tt * 128;
     rows = (int)(rem < 0 ? 0 : (rem > 128 ? 128 : rem));
   };
@@ -822,9 +830,10 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     make_dz3();                                          // of tile t+1 (y, dy were requested half a tile ago)
     STEP_END();
     {
-      int64_t rem = P - tile * 128;
+      const int64_t pt = bwd_tile(tile, ntiles);
+      int64_t rem = P - pt * 128;
       rem = rem > 128 ? 128 : rem;
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dX + tile * 128 * in_dim, 0, (int)rem * in_dim * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dX + pt * 128 * in_dim, 0, (int)rem * in_dim * 4, 0x00020000);
       const unsigned base = (unsigned)((wave * 32 + i) * in_dim) * 4u;
 #pragma unroll
       for (int tx = 0; tx < TX; ++tx)
