@@ -56,6 +56,9 @@ SIGNATURES = {
     "gngf_mse_workspace_floats": [],
     "gngf_mse_fwd": [_P, _P, _P, _P, _L, _P],
     "gngf_mse_bwd": [_P, _P, _P, _P, _L, _P],
+    "gngf_js_kl_workspace_doubles": [_I],
+    "gngf_js_kl_fwd": [_P, _P, _P, _I, _L, _F, _F, _P],
+    "gngf_js_kl_bwd": [_P, _P, _P, _I, _L, _F, _F, _P],
     "gngf_adam_block_elems": [],
     "gngf_adam_step": [_P, _I, _L, _P, _P, _P, _I, _F, _F, _F, _P],
 }

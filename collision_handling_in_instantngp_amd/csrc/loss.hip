@@ -101,3 +101,98 @@ extern "C" int gngf_mse_bwd(const float* pred, const float* label, const float* 
   mse_bwd_kernel<<<dim3(grid), dim3(kLossThreads), 0, as_stream(stream)>>>(pred, label, gout, dpred, n);
   GNGF_RETURN_LAUNCH();
 }
+
+// ---------------------------------------------------------------------------------------------- JS / KL term on p-bar
+// Loss.forward's distribution term (utils.py:122-174) per level l on the batch-mean distribution p = pbar[l,:] (T slots),
+// against the uniform q = 1/T, with torch.nn.KLDivLoss(reduction='batchmean') applied to 1-D rows (so "batch" = T):
+//   kl  = (1/T) sum_t (q log q - q log p_t)
+//   js  = ( (1/T) sum_t (m log m - m log p_t) + (1/T) sum_t (m log m - m log q) ) / 2,    m = (p_t + q) / 2
+//   out = -(gamma + eps) js + eps kl
+// Every per-slot expression is evaluated in fp32 as torch's elementwise ops do; the sums over 2^19 slots run in double
+// (torch: fp32 tree sums), one partial triple per workgroup, finished by a second small launch — no fences, no atomics.
+constexpr int kJsThreads = 256;
+constexpr int kJsSlices = 64;       // workgroups per level
+
+__device__ __forceinline__ float xlogx(float v) { return v == 0.f ? 0.f : v * logf(v); }      // torch.xlogy(v, v)
+
+__global__ void __launch_bounds__(kJsThreads)
+js_kl_partial_kernel(const float* __restrict__ pbar, double* __restrict__ partial, int64_t T) {
+  __shared__ double red[3][kJsThreads / 64];
+  const int l = blockIdx.y;
+  const float* p = pbar + (int64_t)l * T;
+  const float q = 1.0f / (float)T, lq = logf(q), qlq = xlogx(q);
+  double s_kl = 0.0, s_1 = 0.0, s_2 = 0.0;
+  for (int64_t t = (int64_t)blockIdx.x * kJsThreads + threadIdx.x; t < T; t += (int64_t)gridDim.x * kJsThreads) {
+    const float pv = p[t], lp = logf(pv);
+    const float m = (pv + q) / 2.f, mlm = xlogx(m);
+    s_kl += (double)(qlq - q * lp);
+    s_1 += (double)(mlm - m * lp);
+    s_2 += (double)(mlm - m * lq);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s_kl += __shfl_xor(s_kl, o, 64); s_1 += __shfl_xor(s_1, o, 64); s_2 += __shfl_xor(s_2, o, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = s_kl; red[1][wave] = s_1; red[2][wave] = s_2; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double s = 0.0;
+    for (int w = 0; w < kJsThreads / 64; ++w) s += red[threadIdx.x][w];
+    partial[((int64_t)l * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = s;
+  }
+}
+
+__global__ void js_kl_finish_kernel(const double* __restrict__ partial, float* __restrict__ out, int L, int slices, int64_t T,
+                                    float gamma, float eps) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int b = 0; b < slices; ++b)
+    for (int k = 0; k < 3; ++k) s[k] += partial[((int64_t)l * slices + b) * 3 + k];
+  const float kl = (float)(s[0] / (double)T);
+  const float js = ((float)(s[1] / (double)T) + (float)(s[2] / (double)T)) / 2.f;
+  out[l] = -(gamma + eps) * js + eps * kl;
+}
+
+// d out_l / d p_t, times the incoming gradient of out_l
+__global__ void __launch_bounds__(kJsThreads)
+js_kl_bwd_kernel(const float* __restrict__ pbar, const float* __restrict__ gout, float* __restrict__ dpbar, int64_t T,
+                 float gamma, float eps) {
+  const int l = blockIdx.y;
+  const float* p = pbar + (int64_t)l * T;
+  float* d = dpbar + (int64_t)l * T;
+  const float q = 1.0f / (float)T, lq = logf(q), invT = 1.0f / (float)T;
+  const float g = gout[l];
+  const float cj = -(gamma + eps) * 0.5f * invT, ck = eps * invT;
+  for (int64_t t = (int64_t)blockIdx.x * kJsThreads + threadIdx.x; t < T; t += (int64_t)gridDim.x * kJsThreads) {
+    const float pv = p[t], lp = logf(pv);
+    const float m = (pv + q) / 2.f, lm1 = logf(m) + 1.0f;
+    // js1' = (log m + 1)/2 - (log p)/2 - m/p,   js2' = (log m + 1)/2 - (log q)/2,   kl' = -q/p       (each times 1/T)
+    const float djs = (0.5f * lm1 - 0.5f * lp - m / pv) + (0.5f * lm1 - 0.5f * lq);
+    d[t] = g * (cj * djs + ck * (-q / pv));
+  }
+}
+
+extern "C" int gngf_js_kl_workspace_doubles(int L) { return L * kJsSlices * 3; }
+
+// out (L) = -(gamma + eps) JS(p_l, uniform) + eps KL(uniform || p_l) for the L rows of pbar (L,T); workspace:
+// gngf_js_kl_workspace_doubles(L) doubles, 8-byte aligned.
+extern "C" int gngf_js_kl_fwd(const float* pbar, float* out, double* workspace, int L, int64_t T, float gamma, float eps,
+                              void* stream) {
+  GNGF_CHECK_ARG(L > 0 && T > 0 && pbar && out && workspace && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0);
+  hipStream_t s = as_stream(stream);
+  js_kl_partial_kernel<<<dim3(kJsSlices, (unsigned)L), dim3(kJsThreads), 0, s>>>(pbar, workspace, T);
+  js_kl_finish_kernel<<<dim3((unsigned)((L + 63) / 64)), dim3(64), 0, s>>>(workspace, out, L, kJsSlices, T, gamma, eps);
+  GNGF_RETURN_LAUNCH();
+}
+
+// dpbar (L,T) = gout[l] * d out_l / d pbar[l,t]
+extern "C" int gngf_js_kl_bwd(const float* pbar, const float* gout, float* dpbar, int L, int64_t T, float gamma, float eps,
+                              void* stream) {
+  GNGF_CHECK_ARG(L > 0 && T > 0 && pbar && gout && dpbar);
+  const int64_t want = (T + kJsThreads - 1) / kJsThreads;
+  const unsigned gx = (unsigned)(want > 256 ? 256 : want);
+  js_kl_bwd_kernel<<<dim3(gx, (unsigned)L), dim3(kJsThreads), 0, as_stream(stream)>>>(pbar, gout, dpbar, T, gamma, eps);
+  GNGF_RETURN_LAUNCH();
+}

@@ -742,6 +742,37 @@ def mse_loss(pred, label):
     return MseFunction.apply(pred, label)
 
 
+class JsKlFunction(torch.autograd.Function):
+    """The distribution term of the reference's Loss (utils.py:122-174) on the batch-mean distribution:
+    apply(pbar (L,T), gamma, eps) -> (L,) = -(gamma + eps) JS(pbar_l, uniform) + eps KL(uniform || pbar_l).
+    Two launches forward (per-workgroup partial sums in double, then one thread per level), one backward
+    (csrc/loss.hip) instead of ~30 framework kernels over the 32 MiB of p-bar."""
+
+    @staticmethod
+    def forward(ctx, pbar, gamma, eps):
+        pbar = _c(pbar)
+        L, T = pbar.shape
+        out = torch.empty((L,), dtype=_f32, device=pbar.device)
+        ws = torch.empty((query("gngf_js_kl_workspace_doubles", L),), dtype=torch.float64, device=pbar.device)
+        call("gngf_js_kl_fwd", ptr(pbar, _f32, "pbar"), ptr(out), ptr(ws), L, T, float(gamma), float(eps), stream_ptr())
+        ctx.save_for_backward(pbar)
+        ctx.cfg = (float(gamma), float(eps))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (pbar,) = ctx.saved_tensors
+        gamma, eps = ctx.cfg
+        gout = _c(gout.to(_f32))
+        dpbar = torch.empty_like(pbar)
+        call("gngf_js_kl_bwd", ptr(pbar), ptr(gout), ptr(dpbar), pbar.shape[0], pbar.shape[1], gamma, eps, stream_ptr())
+        return dpbar, None, None
+
+
+def js_kl_rows(pbar, gamma, eps):
+    return JsKlFunction.apply(pbar, gamma, eps)
+
+
 # Keep the decoder's activated hidden layers (512 B / pixel) from forward to backward instead of recomputing them: the
 # stores and loads ride under the MFMAs of kernels that leave most of the HBM bandwidth unused (decoder backward 345 -> ~230 us
 # at 2^20 px).  False: recompute (no extra memory).

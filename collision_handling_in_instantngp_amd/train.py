@@ -26,7 +26,13 @@ class Loss(torch.nn.Module):
         return torch.xlogy(target, target).sub(target * log_input).sum(-1) / log_input.shape[-1]
 
     def js_kl_rows(self, pbar):
-        """pbar (L,N) -> (L,) : -(gamma+eps)*JS + eps*KL per level (utils.py:122-174)."""
+        """pbar (L,N) -> (L,) : -(gamma+eps)*JS + eps*KL per level (utils.py:122-174).  Device fp32 distributions run
+        on the HIP kernels (ops.JsKlFunction); the torch expression below is the same formula for host tensors."""
+        if pbar.is_cuda and pbar.dtype == torch.float32 and pbar.dim() == 2:
+            return ops.js_kl_rows(pbar, self._gamma, self._epsilon)
+        return self.js_kl_rows_torch(pbar)
+
+    def js_kl_rows_torch(self, pbar):
         N = pbar.shape[-1]
         q = torch.full_like(pbar, 1.0 / N)
         lp = pbar.log()

@@ -200,6 +200,15 @@ int gngf_mse_fwd(const float* pred, const float* label, float* loss, float* work
 /* its backward: dpred (n) = gout[0] * 2 (pred - label) / n   (gout: device scalar, the gradient of the loss value) */
 int gngf_mse_bwd(const float* pred, const float* label, const float* gout, float* dpred, int64_t n, void* stream);
 
+/* the distribution term of the same Loss (utils.py:122-174) on the batch-mean distribution pbar (L,T):
+ *   out[l] = -(gamma + eps) * JS(pbar_l, uniform) + eps * KL(uniform || pbar_l),
+ * both built from torch.nn.KLDivLoss(reduction='batchmean') on 1-D rows, i.e. divided by T.
+ * workspace: gngf_js_kl_workspace_doubles(L) doubles (8-byte aligned, no initialisation needed). */
+int gngf_js_kl_workspace_doubles(int L);
+int gngf_js_kl_fwd(const float* pbar, float* out, double* workspace, int L, int64_t T, float gamma, float eps, void* stream);
+/* its backward: dpbar (L,T) = gout[l] * d out[l] / d pbar[l,t] */
+int gngf_js_kl_bwd(const float* pbar, const float* gout, float* dpbar, int L, int64_t T, float gamma, float eps, void* stream);
+
 /* ---- optimizer (row f2: the caller of the path) ---------------------------------------------------------------------
  * torch.optim.Adam as get_optimizer builds it (functions.py:96-127: betas (0.9, 0.99), eps 1e-15, L2-style weight
  * decay, dense moments, per-group lr), every tensor of every group in ONE launch.

@@ -385,3 +385,30 @@ def test_fused_adam_step_replays_from_a_graph(ops):
     assert float(oa.state[pa[0]]["step"]) == 5.0
     for a, b in zip(pa, pb):
         close(a.detach(), b.detach().cpu().numpy(), 3e-6, 1e-6)
+
+
+@pytest.mark.parametrize("L,T", [(3, 1000), (16, 1 << 15), (1, 77)])
+def test_js_kl_kernels_vs_float64_and_torch_expression(ops, L, T):
+    """Loss.js_kl_rows (utils.py:122-174) on the HIP kernels: value and gradient vs a float64 evaluation of the same
+    formula, and vs the torch expression the CPU tests pin to the reference's goldens"""
+    from collision_handling_in_instantngp_amd.train import Loss
+    rng = np.random.default_rng(L * 7 + T)
+    z = rng.standard_normal((L, T)) * 2.0
+    p = np.exp(z - z.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+    p = p.astype(np.float32)
+    gamma, eps = 1.0, 0.5
+    loss = Loss(gamma=gamma, epsilon=eps)
+    pt = t(p).requires_grad_()
+    out = loss.js_kl_rows(pt)
+    w = rng.standard_normal(L).astype(np.float32)
+    (out * t(w)).sum().backward()
+    pd = torch.tensor(p, dtype=torch.float64, requires_grad=True)
+    want = loss.js_kl_rows_torch(pd)
+    (want * torch.tensor(w, dtype=torch.float64)).sum().backward()
+    close(out, want.detach().numpy(), 2e-6, 1e-9)
+    scale = float(pd.grad.abs().max())
+    close(pt.grad, pd.grad.numpy(), 2e-5, 1e-6 * scale)
+    # the fp32 torch expression (what ran before) agrees to its own rounding
+    pt2 = t(p).requires_grad_()
+    ref = loss.js_kl_rows_torch(pt2)
+    close(out, ref.detach().cpu().numpy(), 2e-4, 1e-8)
