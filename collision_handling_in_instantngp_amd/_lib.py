@@ -59,11 +59,13 @@ SIGNATURES = {
     "gngf_js_kl_workspace_doubles": [_I],
     "gngf_js_kl_fwd": [_P, _P, _P, _I, _L, _F, _F, _P],
     "gngf_js_kl_bwd": [_P, _P, _P, _I, _L, _F, _F, _P],
+    "gngf_slot_bitmap_words": [_I, _I, _L],
+    "gngf_distinct_slot_counts": [_P, _L, _I, _I, _I, _L, _P, _P, _P],
     "gngf_adam_block_elems": [],
     "gngf_adam_step": [_P, _I, _L, _P, _P, _P, _I, _F, _F, _F, _P],
 }
 
-_RETURNS_INT64 = {"gngf_decoder_hidden_floats"}
+_RETURNS_INT64 = {"gngf_decoder_hidden_floats", "gngf_slot_bitmap_words"}
 _lib = None
 
 

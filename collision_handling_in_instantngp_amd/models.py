@@ -355,21 +355,43 @@ class GeneralNeuralGaugeFields(nn.Module):
             out.append(dict(Counter(per_level[l][first].tolist())))
         return out
 
+    @staticmethod
+    def _distinct_slot_counts(indices, L, T):
+        """(K,L) int32 on the device: distinct slots per (top-K rank, level) of a (P,L,4[,K]) int64 index tensor — one
+        bit-map pass of csrc/stats.hip instead of one torch.unique (sort + host synchronisation) per level and rank."""
+        from ._lib import call, ptr, query, stream_ptr
+        idx = indices.contiguous()
+        K = idx.shape[3] if idx.dim() == 4 else 1
+        bitmap = torch.empty((query("gngf_slot_bitmap_words", L, K, T),), dtype=torch.int32, device=idx.device)
+        counts = torch.empty((K, L), dtype=torch.int32, device=idx.device)
+        call("gngf_distinct_slot_counts", ptr(idx, torch.int64, "indices"), idx.shape[0], L, idx.shape[2], K, T, ptr(bitmap),
+             ptr(counts), stream_ptr())
+        return counts
+
     @torch.no_grad()
     def calc_hash_collisions(self, indices: torch.Tensor):
         """reference models.py:568-619: (#vertices of the level) - (#distinct slots used), per level."""
         n = self._n_ls.reshape(-1).cpu().numpy().astype(np.int64)
         nverts = 4 + (n + 1 - 2) * 4 + (n + 1 - 2) ** 2                      # = (N_l + 1)^2
         L = self._num_levels
+        on_gpu = indices.is_cuda and indices.dtype == torch.int64 and indices.shape[1] == L
         if self._hash_mode:
-            per_level = indices.permute(1, 0, 2).reshape(L, -1)
-            coll = torch.tensor([int(nverts[i]) - int(torch.unique(per_level[i]).numel()) for i in range(L)])
+            if on_gpu:
+                used = self._distinct_slot_counts(indices, L, self._hash_table_size)[0].cpu().numpy().astype(np.int64)
+                coll = torch.from_numpy(nverts - used)
+            else:
+                per_level = indices.permute(1, 0, 2).reshape(L, -1)
+                coll = torch.tensor([int(nverts[i]) - int(torch.unique(per_level[i]).numel()) for i in range(L)])
         else:
             Kk = indices.shape[-1]
-            coll = torch.empty((Kk, L), device=indices.device)
-            for k in range(Kk):
-                per_level = indices[..., k].permute(1, 0, 2).reshape(L, -1)
-                coll[k] = torch.tensor([float(int(nverts[i]) - int(torch.unique(per_level[i]).numel())) for i in range(L)])
+            if on_gpu:
+                used = self._distinct_slot_counts(indices, L, self._hash_table_size).to(torch.float32)     # (K,L)
+                coll = torch.from_numpy(nverts.astype(np.float32)).to(indices.device)[None, :] - used
+            else:
+                coll = torch.empty((Kk, L), device=indices.device)
+                for k in range(Kk):
+                    per_level = indices[..., k].permute(1, 0, 2).reshape(L, -1)
+                    coll[k] = torch.tensor([float(int(nverts[i]) - int(torch.unique(per_level[i]).numel())) for i in range(L)])
             coll = coll.mean(0)
             coll[coll < 0] = 0
         min_possible = torch.tensor(nverts - self._hash_table_size).to(indices.device)

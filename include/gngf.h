@@ -209,6 +209,14 @@ int gngf_js_kl_fwd(const float* pbar, float* out, double* workspace, int L, int6
 /* its backward: dpbar (L,T) = gout[l] * d out[l] / d pbar[l,t] */
 int gngf_js_kl_bwd(const float* pbar, const float* gout, float* dpbar, int L, int64_t T, float gamma, float eps, void* stream);
 
+/* ---- collision statistics (row f3) ----------------------------------------------------------------------------------
+ * counts (K,L) int32 = number of distinct slots in [0,T) among indices[:, l, :, k], indices (P,L,V,K) int64 contiguous
+ * (K = 1: the hash source's (P,L,V)) — the torch.unique(...).numel() of calc_hash_collisions, models.py:568-619.
+ * bitmap: gngf_slot_bitmap_words(L, K, T) uint32 words of workspace (cleared by the call). */
+int64_t gngf_slot_bitmap_words(int L, int K, int64_t T);
+int gngf_distinct_slot_counts(const int64_t* indices, int64_t P, int L, int V, int K, int64_t T, uint32_t* bitmap,
+                              int32_t* counts, void* stream);
+
 /* ---- optimizer (row f2: the caller of the path) ---------------------------------------------------------------------
  * torch.optim.Adam as get_optimizer builds it (functions.py:96-127: betas (0.9, 0.99), eps 1e-15, L2-style weight
  * decay, dense moments, per-group lr), every tensor of every group in ONE launch.

@@ -335,3 +335,23 @@ def test_hipgraph_replay_of_a_step_equals_eager(golden, mode):
                 assert float((p.grad - eager[k]).abs().max()) <= 2e-5 * scale, k
     finally:
         models.should_use_hash_function = False
+
+
+@pytest.mark.parametrize("K", [0, 3])
+def test_distinct_slot_counts_kernel_vs_torch_unique(K):
+    """csrc/stats.hip (bit-map pass) == torch.unique(...).numel() per level and top-K rank, T not a multiple of 32"""
+    from collision_handling_in_instantngp_amd import models
+    L, T, P = 5, 1000 + 7, 20000
+    g = torch.Generator().manual_seed(11 + K)
+    shape = (P, L, 4) if K == 0 else (P, L, 4, K)
+    idx = torch.randint(0, T, shape, generator=g)
+    idx[:, 1] = idx[:, 1] % 3                                  # a level that uses three slots only
+    idx[:, 2] = torch.arange(P).reshape((P, 1) if K == 0 else (P, 1, 1)) % T   # every slot used
+    got = models.GeneralNeuralGaugeFields._distinct_slot_counts(idx.to(DEV), L, T).cpu()
+    Kk = max(K, 1)
+    assert got.shape == (Kk, L)
+    for k in range(Kk):
+        for l in range(L):
+            sl = idx[:, l] if K == 0 else idx[:, l, :, k]
+            assert int(got[k, l]) == int(torch.unique(sl).numel()), (k, l)
+    assert int(got[0, 1]) == 3 and int(got[0, 2]) == T
