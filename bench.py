@@ -81,6 +81,7 @@ def make_step(net, models, mode, xy, target, world, exchange=True):
     loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
     params = [p for p in net.parameters() if p.requires_grad]
     empty = torch.tensor([], device=xy.device)
+    one = torch.ones((), device=xy.device)          # the seed of backward(): loss.backward() would fill a fresh one per step
 
     def step():
         for p in params:
@@ -91,7 +92,7 @@ def make_step(net, models, mode, xy, target, world, exchange=True):
             loss = train.assemble_loss(mse, kls, coll, 1, 1, 1e-3)
         else:
             loss = loss_fn._mse(rgb, target)      # frozen HPD / hash: the KL-JS and collision terms carry no gradient
-        loss.backward()
+        loss.backward(gradient=one)
         if world > 1 and exchange:
             parallel.allreduce_gradients(net, world)
     return step

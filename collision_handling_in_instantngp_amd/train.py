@@ -184,6 +184,7 @@ def train_step(net, loss_fn, optimizer, x, target, w, h, l_mse, l_js_kl, l_colli
     previous_min_possible_collisions = empty if previous_min_possible_collisions is None else previous_min_possible_collisions
     outputs = torch.empty((shape, target.shape[1]), device=dev)
     losses, mses = [], []
+    one = torch.ones((), device=dev)                 # seed of backward(): the same d loss / d loss = 1, without a fill per batch
     for b in range(num_batches):
         lo, hi = b * step, (b + 1) * step
         sel = shuffled_indices[lo:hi].long() if should_shuffle else slice(lo, hi)
@@ -194,7 +195,7 @@ def train_step(net, loss_fn, optimizer, x, target, w, h, l_mse, l_js_kl, l_colli
         mse, kls, colls = loss_fn(out, by, None if probs is None else probs.shape[-1], probs,
                                   previous_collisions, previous_min_possible_collisions)
         loss = assemble_loss(mse, kls, colls, l_mse, l_js_kl, l_collisions)
-        loss.backward()
+        loss.backward(gradient=one.to(loss.dtype))
         optimizer.step()
         losses.append(loss.detach())
         mses.append(mse.detach())
