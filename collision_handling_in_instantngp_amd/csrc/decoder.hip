@@ -1015,7 +1015,8 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
                                 float* dW1, float* db1, float* dW2, float* db2, float* slabs, float* denc_absmax,
                                 const float* hidden, int64_t P, int in_dim, int out_dim, int leaky, void* stream) {
   GNGF_CHECK_ARG(P >= 0 && in_dim > 0 && in_dim <= 64 && out_dim > 0 && out_dim <= 4);
-  GNGF_CHECK_ARG(dW0 && db0 && dW1 && db1 && dW2 && db2 && slabs);
+  const bool reduce_here = dW0 || db0 || dW1 || db1 || dW2 || db2;       // all NULL: the caller runs gngf_decoder_reduce
+  GNGF_CHECK_ARG(slabs && (!reduce_here || (dW0 && db0 && dW1 && db1 && dW2 && db2)));
   const int nslab = slab_size(in_dim, out_dim);
   hipStream_t s = as_stream(stream);
   const int nslabs = gngf_decoder_bwd_slabs(P);
@@ -1043,8 +1044,22 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
-  decoder_reduce_kernel<<<dim3((unsigned)((nslab + 63) / 64)), dim3(1024), 0, s>>>(slabs, nslabs, nslab, in_dim, out_dim, dW0,
-                                                                                   db0, dW1, db1, dW2, db2, denc_absmax);
+  if (reduce_here)
+    decoder_reduce_kernel<<<dim3((unsigned)((nslab + 63) / 64)), dim3(1024), 0, s>>>(slabs, nslabs, nslab, in_dim, out_dim, dW0,
+                                                                                     db0, dW1, db1, dW2, db2, denc_absmax);
+  GNGF_RETURN_LAUNCH();
+}
+
+// Second half of gngf_decoder_bwd when it was called without gradient pointers: slabs -> the six gradients (+ max |denc|).
+// Separate so that it can run on another stream beside the encoder backward, which only needs the per-slab maxima
+// (the last word of every slab: slabs[s * gngf_decoder_slab_floats() + gngf_decoder_slab_floats() - 1]).
+extern "C" int gngf_decoder_reduce(const float* slabs, float* dW0, float* db0, float* dW1, float* db1, float* dW2, float* db2,
+                                   float* denc_absmax, int64_t P, int in_dim, int out_dim, void* stream) {
+  GNGF_CHECK_ARG(P >= 0 && in_dim > 0 && in_dim <= 64 && out_dim > 0 && out_dim <= 4);
+  GNGF_CHECK_ARG(slabs && dW0 && db0 && dW1 && db1 && dW2 && db2);
+  const int nslab = slab_size(in_dim, out_dim);
+  decoder_reduce_kernel<<<dim3((unsigned)((nslab + 63) / 64)), dim3(1024), 0, as_stream(stream)>>>(
+      slabs, gngf_decoder_bwd_slabs(P), nslab, in_dim, out_dim, dW0, db0, dW1, db1, dW2, db2, denc_absmax);
   GNGF_RETURN_LAUNCH();
 }
 

@@ -383,8 +383,8 @@ template <int F>
 __global__ void __launch_bounds__(kTB)
 tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ items, const int32_t* __restrict__ n_items,
                  const int32_t* __restrict__ n_ls, const float* __restrict__ genc, float* __restrict__ dG,
-                 float* __restrict__ partials, const float* __restrict__ gmax_hint, int L, int Ls, int tile_shift,
-                 int lds_floats, int log2_chunk) {
+                 float* __restrict__ partials, const float* __restrict__ gmax_hint, int hint_count, int hint_stride, int L,
+                 int Ls, int tile_shift, int lds_floats, int log2_chunk) {
   extern __shared__ unsigned long long acc64[];
   __shared__ TileMeta m;
   __shared__ float wmax[kTB / 64];
@@ -403,7 +403,8 @@ tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
   // max |genc| (the fused decoder backward does): any bound >= the item's own maximum keeps the sums overflow-free.
   float gmax = 0.f;
   constexpr int U = 4;                                     // 4 pixels per lane per trip: loads issued together
-  if (gmax_hint) gmax = *gmax_hint;
+  if (gmax_hint)                                            // the bound is the largest of hint_count values (one per decoder slab)
+    for (int q = tid; q < hint_count; q += kTB) { const float a = gmax_hint[(int64_t)q * hint_stride]; gmax = (a > gmax || a != a) ? a : gmax; }
   if (lp < ppp && !gmax_hint)
     for (int j0 = lp; j0 < it.y; j0 += U * ppp) {
       int64_t pp[U];
@@ -830,11 +831,11 @@ extern "C" int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, 
 
 extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
                                      const int32_t* tile_item_base, const int32_t* tile_level_off, const int32_t* n_ls,
-                                     const int32_t* n_ls_host, const float* genc, const float* genc_absmax, float* dG,
-                                     float* partials, int L, int Ls, int F, int tile_shift, int lds_bytes, int chunk,
-                                     void* stream) {
+                                     const int32_t* n_ls_host, const float* genc, const float* genc_absmax, int absmax_count,
+                                     int absmax_stride, float* dG, float* partials, int L, int Ls, int F, int tile_shift,
+                                     int lds_bytes, int chunk, void* stream) {
   GNGF_CHECK_ARG(max_items >= 0 && L > 0 && Ls > 0 && Ls <= L && L <= GNGF_MAX_LEVELS && lds_bytes >= 0 && lds_bytes <= 64 * 1024);
-  GNGF_CHECK_ARG(chunk > 0 && chunk <= (1 << 20));
+  GNGF_CHECK_ARG(chunk > 0 && chunk <= (1 << 20) && (!genc_absmax || (absmax_count > 0 && absmax_stride >= 0)));
   int log2_chunk = 0;
   while ((1 << log2_chunk) < chunk) ++log2_chunk;
   if (max_items == 0) return 0;
@@ -848,7 +849,7 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
     }
     tiled_bwd_kernel<kF><<<dim3((unsigned)max_items), dim3(kTB), (size_t)2 * lds_bytes, as_stream(stream)>>>(
         reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, n_ls, genc, dG, partials,
-        genc_absmax, L, Ls, tile_shift, lds_bytes / 4, log2_chunk);
+        genc_absmax, absmax_count, absmax_stride, L, Ls, tile_shift, lds_bytes / 4, log2_chunk);
     gather_partials_kernel<kF><<<dim3((unsigned)ceil_div((int64_t)side * side, 256), (unsigned)Ls), dim3(256), 0,
                                  as_stream(stream)>>>(partials, tile_item_base, tile_level_off, n_ls, dG, Ls, tile_shift,
                                                       lds_bytes / 4);

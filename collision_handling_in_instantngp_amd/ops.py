@@ -571,10 +571,12 @@ def tile_level_offsets(plan, device):
 
 
 def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None):
+    """absmax: None or (tensor, count, stride) — `count` floats `stride` apart whose maximum bounds |genc|."""
     partials = torch.empty((plan.max_items * (plan.lds_bytes // 4),), dtype=_f32, device=genc.device)
+    am, am_count, am_stride = absmax if absmax is not None else (None, 0, 0)
     call("gngf_encode_tiled_bwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(ws.tile_item_base),
-         ptr(tile_level_offsets(plan, genc.device)), ptr(n_ls), plan.n_ls_c, ptr(genc, _f32, "grad"), ptr(absmax), ptr(dG), ptr(partials), L, plan.Ls, F, plan.tile_shift,
-         plan.lds_bytes, plan.chunk, stream_ptr())
+         ptr(tile_level_offsets(plan, genc.device)), ptr(n_ls), plan.n_ls_c, ptr(genc, _f32, "grad"), ptr(am),
+         int(am_count), int(am_stride), ptr(dG), ptr(partials), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, plan.chunk, stream_ptr())
 
 
 def run_deferred_vertex_stage(exchanged=False):
@@ -777,6 +779,19 @@ def js_kl_rows(pbar, gamma, eps):
 # stores and loads ride under the MFMAs of kernels that leave most of the HBM bandwidth unused (decoder backward 345 -> ~230 us
 # at 2^20 px).  False: recompute (no extra memory).
 DECODER_SAVE_HIDDEN = True
+# Reduce the decoder backward's gradient slabs on the helper stream, beside the encoder backward (see DecoderFunction.backward).
+# Measured: a loss — the 8 us reduction takes 47 us next to the pixel stage, which fills every CU, and slows it by 5 us
+# (step 0.65 -> 0.67 ms).  Off; the split entry points stay for callers with idle CUs at that point.
+DECODER_REDUCE_ASIDE = False
+
+
+def _join_at_end_of_backward(cur, side):
+    """Makes `cur` wait for `side` when the running backward pass ends (autograd engine callback); outside a backward pass
+    (a Function's backward called by hand) the join happens at once."""
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: cur.wait_stream(side))
+    except RuntimeError:
+        cur.wait_stream(side)
 
 
 class DecoderFunction(torch.autograd.Function):
@@ -818,11 +833,28 @@ class DecoderFunction(torch.autograd.Function):
         slabs = torch.empty((_lib.query("gngf_decoder_bwd_slabs", P) * _lib.query("gngf_decoder_slab_floats", in_dim, out_dim),),
                             dtype=_f32, device=dev)
         absmax = torch.empty((1,), dtype=_f32, device=dev)
-        call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb, _f32, "grad"), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2),
-             ptr(denc), *[ptr(g) for g in grads], ptr(slabs), ptr(absmax), ptr(ctx.hidden), P, in_dim, out_dim, leaky,
-             stream_ptr())
+        nslab = _lib.query("gngf_decoder_slab_floats", in_dim, out_dim)
+        if DECODER_REDUCE_ASIDE and P > 0:
+            # The slab reduction (8 us + a launch gap) leaves the critical path: the encoder backward, which comes next,
+            # only needs max |d enc| and takes it from the slabs' last words; the six gradients are not read before the
+            # backward pass ends, where the helper stream is joined again.
+            call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb, _f32, "grad"), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2),
+                 ptr(denc), *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(ctx.hidden), P, in_dim, out_dim, leaky, stream_ptr())
+            cur, side = torch.cuda.current_stream(), _side_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                call("gngf_decoder_reduce", ptr(slabs), *[ptr(g) for g in grads], ptr(absmax), P, in_dim, out_dim, stream_ptr())
+            for buf in (slabs, flat, absmax):
+                buf.record_stream(side)
+            _join_at_end_of_backward(cur, side)
+            hint = (slabs[nslab - 1:], _lib.query("gngf_decoder_bwd_slabs", P), nslab)
+        else:
+            call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb, _f32, "grad"), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2),
+                 ptr(denc), *[ptr(g) for g in grads], ptr(slabs), ptr(absmax), ptr(ctx.hidden), P, in_dim, out_dim, leaky,
+                 stream_ptr())
+            hint = (absmax, 1, 0)
         ctx.hidden = None
-        _ABSMAX_HINTS[denc.data_ptr()] = (absmax, denc._version)
+        _ABSMAX_HINTS[denc.data_ptr()] = (hint, denc._version)
         return (denc, None, *grads)
 
 

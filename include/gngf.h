@@ -99,8 +99,9 @@ int gngf_vertex_grid_bwd(const void* tables, int feat_dtype, const int32_t* vert
  * privatised sub-grid image to partials (max_items * lds_bytes/4 floats), then a gather pass sums, per vertex, the
  * images of the items that cover it.  Inside a work item the sub-grids accumulate in 64-bit fixed point (LDS float
  * atomics are ~20x slower than 64-bit integer ones on gfx950); `chunk` = the binning chunk (bounds the term count).
- * genc_absmax (1 float, optional): a bound >= max |genc| that fixes the fixed-point scale; NULL: each work item scans its
- * own rows first.
+ * genc_absmax (optional): absmax_count floats, absmax_stride apart, whose maximum is a bound >= max |genc| that fixes the
+ * fixed-point scale (one value, or the per-slab maxima gngf_decoder_bwd leaves in its workspace); NULL: each work item
+ * scans its own rows first.
  * tile_level_off (4^tile_shift * Ls int32, optional): float offset of level l's sub-grid inside tile t's image at
  * [t * Ls + l], -1 when the level does not fit (levels are laid out back to back in ascending order, a level that
  * would exceed lds_bytes is skipped); NULL: the gather pass re-derives it per vertex. */
@@ -109,8 +110,9 @@ int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, const int32
                           void* stream);
 int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
                           const int32_t* tile_item_base, const int32_t* tile_level_off, const int32_t* n_ls,
-                          const int32_t* n_ls_host, const float* genc, const float* genc_absmax, float* dG, float* partials,
-                          int L, int Ls, int F, int tile_shift, int lds_bytes, int chunk, void* stream);
+                          const int32_t* n_ls_host, const float* genc, const float* genc_absmax, int absmax_count,
+                          int absmax_stride, float* dG, float* partials, int L, int Ls, int F, int tile_shift, int lds_bytes,
+                          int chunk, void* stream);
 /* vertex stage backward for the vertex-table source in SLOT order (order (NV*K) int32 = argsort of vert_idx, flat):
  * contention-free for any slot distribution (wave-level segmented reduction, one atomic per (wave, slot run));
  * dtables accumulated, dvert_w (NV,K) written without atomics (NULL when not needed). */
@@ -147,6 +149,11 @@ int gngf_decoder_bwd(const float* enc, const float* rgb, const float* drgb, cons
                      const float* b1, const float* W2, float* denc, float* dW0, float* db0, float* dW1, float* db1, float* dW2,
                      float* db2, float* slabs, float* denc_absmax, const float* hidden, int64_t P, int in_dim, int out_dim,
                      int leaky, void* stream);
+ /* The six gradient pointers may ALL be NULL: the kernel then stops at the slabs and gngf_decoder_reduce finishes (e.g. on a
+  * second stream, beside the encoder backward — which only needs max |denc|: the last float of every slab is that slab's
+  * maximum, i.e. genc_absmax = slabs + slab_floats - 1, absmax_count = gngf_decoder_bwd_slabs(P), absmax_stride = slab_floats). */
+int gngf_decoder_reduce(const float* slabs, float* dW0, float* db0, float* dW1, float* db1, float* dW2, float* db2,
+                        float* denc_absmax, int64_t P, int in_dim, int out_dim, void* stream);
 int gngf_decoder_bwd_slabs(int64_t P);
 int gngf_decoder_slab_floats(int in_dim, int out_dim);
 

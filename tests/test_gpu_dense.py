@@ -412,3 +412,31 @@ def test_js_kl_kernels_vs_float64_and_torch_expression(ops, L, T):
     pt2 = t(p).requires_grad_()
     ref = loss.js_kl_rows_torch(pt2)
     close(out, ref.detach().cpu().numpy(), 2e-4, 1e-8)
+
+
+def test_decoder_reduce_on_helper_stream_gives_the_same_gradients(ops):
+    """gngf_decoder_bwd without gradient pointers + gngf_decoder_reduce on the helper stream (ops.DECODER_REDUCE_ASIDE) ==
+    the one-call form, and the per-slab maxima it hands to the encoder backward bound |d enc|"""
+    rng = np.random.default_rng(4)
+    P = 5000
+    x = t(rng.standard_normal((P, 32)).astype(np.float32))
+    params = [t((rng.standard_normal(s) * 0.3).astype(np.float32)) for s in ((64, 32), (64,), (64, 64), (64,), (3, 64), (3,))]
+    gy = t(rng.standard_normal((P, 3)).astype(np.float32))
+    acts = (ops.ACT_RELU, ops.ACT_RELU, ops.ACT_SIGMOID)
+    res = {}
+    for aside in (False, True):
+        ops.DECODER_REDUCE_ASIDE = aside
+        try:
+            xs = x.clone().requires_grad_()
+            ps = [p.clone().requires_grad_() for p in params]
+            ops.decoder_apply(xs, acts, ps, fused=True).backward(gy)
+            torch.cuda.synchronize()
+            hint = ops._ABSMAX_HINTS.pop(xs.grad.data_ptr(), None)
+            res[aside] = ([xs.grad.clone()] + [p.grad.clone() for p in ps], hint)
+        finally:
+            ops.DECODER_REDUCE_ASIDE = False
+    for a, b in zip(res[False][0], res[True][0]):
+        assert torch.equal(a, b)
+    (am, count, stride), _ver = res[True][1]
+    bound = float(torch.stack([am[i * stride] for i in range(count)]).max())
+    assert bound == float(res[False][0][0].abs().max())
