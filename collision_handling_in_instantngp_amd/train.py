@@ -74,6 +74,10 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("betas and eps are shared by all groups (as in the reference's get_optimizer)")
         self._step = None            # device float: steps taken
         self._table = None           # device byte tensor: the packed segment list
+        self._host = None            # its pinned staging buffer
+        self._uploaded = None        # event: the last upload has consumed the staging buffer
+        self._captured = []          # staging buffers owned by captured steps (read again at every replay)
+        self._spares = []            # pinned buffers set aside for captures (no pinned allocation while capturing)
         self._table_key = None
         self._total_blocks = 0
 
@@ -112,23 +116,50 @@ class FusedAdam(torch.optim.Optimizer):
         if not segs:
             return loss
         key = tuple(s_[:6] for s_ in segs)
-        if key != self._table_key:                 # pointers moved (first step, new gradient buffers, loaded state)
+        capturing = torch.cuda.is_current_stream_capturing()
+        table, total_blocks = self._table, self._total_blocks
+        if capturing or key != self._table_key:    # pointers moved (first step, new gradient buffers, loaded state)
             blk = query("gngf_adam_block_elems")
             rec = np.zeros(len(segs), dtype=np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"),
                                                       ("first", "<i8"), ("group", "<i4"), ("pad", "<i4")]))
-            first = 0
+            total_blocks = 0
             for i, (pp, gp, mp, vp, n, gi, _keep) in enumerate(segs):
-                rec[i] = (pp, gp, mp, vp, n, first, gi, 0)
-                first += -(-n // blk)
-            self._total_blocks = first
+                rec[i] = (pp, gp, mp, vp, n, total_blocks, gi, 0)
+                total_blocks += -(-n // blk)
+            raw = rec.view(np.uint8).reshape(-1)
             dev = self._step.device
-            self._table = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
-            self._table_key = key
+            # Pinned staging + asynchronous copy.  Inside a hipGraph capture (gradients allocated from the graph's pool have
+            # their own addresses) the copy becomes a node of the graph, so the captured step owns a private staging buffer
+            # and device table that eager steps never touch.
+            if capturing:
+                # pinned memory cannot be allocated while a stream captures: take one of the buffers set aside by an eager step
+                spare = [h for h in self._spares if h.numel() == raw.size]
+                if not spare:
+                    raise RuntimeError("FusedAdam: run one eager step() before capturing a step in a graph")
+                host = spare[0]
+                self._spares.remove(host)
+                host.numpy()[:] = raw
+                table = torch.empty((raw.size,), dtype=torch.uint8, device=dev)
+                table.copy_(host, non_blocking=True)
+                self._captured.append(host)
+            else:
+                if self._host is None or self._host.numel() != raw.size:
+                    self._host = torch.empty((raw.size,), dtype=torch.uint8, pin_memory=True)
+                    self._table = torch.empty((raw.size,), dtype=torch.uint8, device=dev)
+                    self._uploaded = None
+                    self._spares = [torch.empty((raw.size,), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+                if self._uploaded is not None:
+                    self._uploaded.synchronize()   # the previous upload has read the staging buffer
+                self._host.numpy()[:] = raw
+                self._table.copy_(self._host, non_blocking=True)
+                self._uploaded = torch.cuda.Event()
+                self._uploaded.record()
+                self._table_key, self._total_blocks, table = key, total_blocks, self._table
         ng = len(self.param_groups)
         lr = (ctypes.c_float * ng)(*[float(g["lr"]) for g in self.param_groups])
         wd = (ctypes.c_float * ng)(*[float(g["weight_decay"]) for g in self.param_groups])
         b1, b2 = self.param_groups[0]["betas"]
-        call("gngf_adam_step", ptr(self._table), len(segs), self._total_blocks, ptr(self._step), lr, wd, ng, float(b1), float(b2),
+        call("gngf_adam_step", ptr(table), len(segs), total_blocks, ptr(self._step), lr, wd, ng, float(b1), float(b2),
              float(self.param_groups[0]["eps"]), stream_ptr())
         return loss
 

@@ -373,9 +373,12 @@ def test_fused_adam_step_replays_from_a_graph(ops):
     graph = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
+    static = [a.grad.clone() for a in pa]
     with torch.cuda.stream(side):
         with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
-            oa.step()
+            for a, g_ in zip(pa, static):
+                a.grad = g_ * 1.0                          # gradients allocated inside the capture: new addresses, so the
+            oa.step()                                      # segment table is uploaded by a copy node of the graph
     torch.cuda.current_stream().wait_stream(side)
     ob.step()                                             # capture does not execute: replay below is step 2
     graph.replay()
@@ -385,6 +388,15 @@ def test_fused_adam_step_replays_from_a_graph(ops):
     assert float(oa.state[pa[0]]["step"]) == 5.0
     for a, b in zip(pa, pb):
         close(a.detach(), b.detach().cpu().numpy(), 3e-6, 1e-6)
+    # an eager step between replays uses its own table; the next replay restores the captured one
+    for a, b, g_ in zip(pa, pb, static):
+        a.grad = g_.clone(); b.grad = g_.clone()
+    oa.step(); ob.step()
+    graph.replay(); ob.step()
+    torch.cuda.synchronize()
+    assert float(oa.state[pa[0]]["step"]) == 7.0
+    for a, b in zip(pa, pb):
+        close(a.detach(), b.detach().cpu().numpy(), 4e-6, 2e-6)
 
 
 @pytest.mark.parametrize("L,T", [(3, 1000), (16, 1 << 15), (1, 77)])
