@@ -272,6 +272,7 @@ def main():
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2 ** 20)
+    ap.add_argument("--ramp-steps", type=int, default=60, help="untimed steps before the W warm-up steps (clock ramp)")
     ap.add_argument("--backend", default="nccl", help="rehearsal only: 'gloo' runs the N>1 code path with ranks sharing one GPU")
     a = ap.parse_args()
 
@@ -328,6 +329,12 @@ def main():
                 if world > 1:
                     parallel.defer_vertex_stage(False)
                 step = make_step(net, models, mode, xy, target, world)
+        if mode != "gngf_learning":
+            # Clock ramp: the chip reaches its steady matrix-core clock only after ~15 ms of sustained work (the same kernel
+            # is ~10 % slower before; tools/perf_decoder_warm.py), and W warm-up steps of 0.65 ms do not get there.  Untimed
+            # steps first (every rank runs the same number, so collectives stay matched), then the W + K of the contract.
+            for _ in range(a.ramp_steps):
+                step()
         dt = timed(step, steps, warmup, world)
         results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                          "launch": launch}
