@@ -298,6 +298,7 @@ def main():
     xy, target, (h, w) = strawberry_batch(P, rank, dev)
 
     results = {}
+    in_graph_ms = None
     order = [a.mode] + ([m for m in ("gngf_learning", "hash", "gngf_frozen") if m != a.mode] if not a.no_extra_modes else [])
     kt = {}
     for mode in order:
@@ -338,6 +339,25 @@ def main():
         dt = timed(step, steps, warmup, world)
         results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                          "launch": launch}
+        if head and rank == 0 and launch.startswith("hipGraph"):
+            # decoder_bwd's duration INSIDE the replayed graph, from the device clock the kernel stamps (events cannot be
+            # recorded in a replayed hipGraph here): one sample per burst of replays
+            try:
+                import ctypes
+                from collision_handling_in_instantngp_amd import _lib
+                spans = []
+                for _ in range(10):
+                    for _ in range(8):
+                        step()
+                    torch.cuda.synchronize()
+                    ns = ctypes.c_double(0.0)
+                    _lib.call("gngf_decoder_bwd_last_span_ns", ctypes.byref(ns))
+                    spans.append(ns.value)
+                spans.sort()
+                in_graph_ms = spans[len(spans) // 2] * 1e-6
+            except Exception as e:  # pragma: no cover
+                in_graph_ms = None
+                print(f"[bench] in-graph span unavailable ({e!r})", file=sys.stderr)
         if head and world == 1 and a.graph and mode != "gngf_learning":
             # the same step with the optimizer in the graph (get_optimizer's Adam as one launch): reported, not the metric
             try:
@@ -415,6 +435,10 @@ def main():
             "modes": results, "kernel_ms": {k: (v * 1e3 if isinstance(v, float) else v) for k, v in kt.items()},
             "roofline": roof, "roofline_encoder": roof_enc,
         }
+        if roof is not None and roof.get("kernel") == "decoder_bwd" and in_graph_ms:
+            # same kernel, timed by its own device-clock stamps inside the replayed graph (agrees with rocprofv3's average)
+            roof["in_graph_launch_ms"] = in_graph_ms
+            roof["in_graph_frac"] = roof["algorithmic_flops_per_pixel"] * P / (in_graph_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.mode, a.cpu_sample)
         print(json.dumps(line))

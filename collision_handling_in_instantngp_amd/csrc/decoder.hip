@@ -157,6 +157,11 @@ __device__ __forceinline__ void fill_fwd_frags(float* A0, float* A1, const float
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
+// Device-clock span of the last decoder_bwd launch: [0] = constant 100 MHz counter when workgroup 0 started, [1] = the latest
+// workgroup end.  One plain store and one result-less atomic per workgroup: this is how bench.py sees the kernel's duration
+// INSIDE a replayed hipGraph, where HIP events cannot be recorded (gngf_decoder_bwd_last_span_ns).
+__device__ unsigned long long g_bwd_span[2];
+
 #if defined(GNGF_STAMPS)   // diagnostic build only (tools/perf_decoder.py --stamps): per-phase cycle shares of the backward loop
 __device__ unsigned long long g_stamps[16];
 __device__ unsigned long long g_fstamps[16];
@@ -401,6 +406,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   constexpr int S0 = KIN / 2;
   constexpr int TX = (KIN + 31) / 32;                    // 32-row tiles of the input width
   if (EXACT) in_dim = KIN;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { g_bwd_span[1] = 0ull; g_bwd_span[0] = wall_clock64(); }
 #if defined(GNGF_STAMPS)
   if (threadIdx.x == 0) g_blocktime[1][blockIdx.x & 255][0] = __builtin_readcyclecounter();
 #endif
@@ -913,6 +919,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
 #pragma unroll
     for (int w = 0; w < 4; ++w) { const unsigned v = __float_as_uint(smem[w * nslab + nslab - 1]); mx = v > mx ? v : mx; }
     out[nslab - 1] = __uint_as_float(mx);
+    atomicMax(&g_bwd_span[1], (unsigned long long)wall_clock64());
   }
 }
 
@@ -1061,6 +1068,17 @@ extern "C" int gngf_decoder_reduce(const float* slabs, float* dW0, float* db0, f
   decoder_reduce_kernel<<<dim3((unsigned)((nslab + 63) / 64)), dim3(1024), 0, as_stream(stream)>>>(
       slabs, gngf_decoder_bwd_slabs(P), nslab, in_dim, out_dim, dW0, db0, dW1, db1, dW2, db2, denc_absmax);
   GNGF_RETURN_LAUNCH();
+}
+
+// Duration of the most recent gngf_decoder_bwd main kernel on the device's constant 100 MHz clock (first workgroup start
+// to last workgroup end), in nanoseconds.  Synchronises the device.
+extern "C" int gngf_decoder_bwd_last_span_ns(double* ns) {
+  GNGF_CHECK_ARG(ns);
+  unsigned long long span[2] = {0ull, 0ull};
+  hipError_t e = hipMemcpyFromSymbol(span, HIP_SYMBOL(gngf::g_bwd_span), sizeof(span));
+  if (e != hipSuccess) return (int)e;
+  *ns = span[1] > span[0] ? (double)(span[1] - span[0]) * 10.0 : 0.0;
+  return 0;
 }
 
 #if defined(GNGF_STAMPS)

@@ -155,6 +155,10 @@ int gngf_decoder_bwd(const float* enc, const float* rgb, const float* drgb, cons
 int gngf_decoder_reduce(const float* slabs, float* dW0, float* db0, float* dW1, float* db1, float* dW2, float* db2,
                         float* denc_absmax, int64_t P, int in_dim, int out_dim, void* stream);
 int gngf_decoder_bwd_slabs(int64_t P);
+/* measurement: duration (ns, device 100 MHz clock; first workgroup start -> last workgroup end) of the most recent
+ * gngf_decoder_bwd main kernel — usable when the call sits inside a replayed hipGraph, where events cannot be recorded.
+ * Synchronises the device. */
+int gngf_decoder_bwd_last_span_ns(double* ns);
 int gngf_decoder_slab_floats(int in_dim, int out_dim);
 
 /* ---- a7/a8 tail, per DISTINCT vertex: Softmax(dim=-1) + nan_to_num + top-K (models.py:85,111,116; 5-19).

@@ -452,3 +452,23 @@ def test_decoder_reduce_on_helper_stream_gives_the_same_gradients(ops):
     (am, count, stride), _ver = res[True][1]
     bound = float(torch.stack([am[i * stride] for i in range(count)]).max())
     assert bound == float(res[False][0][0].abs().max())
+
+
+def test_decoder_bwd_reports_its_device_clock_span(ops):
+    """gngf_decoder_bwd_last_span_ns: first workgroup start -> last workgroup end of the most recent backward kernel"""
+    import ctypes
+    from collision_handling_in_instantngp_amd._lib import call
+    rng = np.random.default_rng(9)
+    P = 1 << 16
+    x = t(rng.standard_normal((P, 32)).astype(np.float32)).requires_grad_()
+    params = [t((rng.standard_normal(s) * 0.3).astype(np.float32)).requires_grad_()
+              for s in ((64, 32), (64,), (64, 64), (64,), (3, 64), (3,))]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    y = ops.decoder_apply(x, (ops.ACT_RELU, ops.ACT_RELU, ops.ACT_SIGMOID), params, fused=True)
+    g = torch.ones_like(y)
+    torch.cuda.synchronize()
+    e0.record(); y.backward(g); e1.record()
+    torch.cuda.synchronize()
+    ns = ctypes.c_double(-1.0)
+    call("gngf_decoder_bwd_last_span_ns", ctypes.byref(ns))
+    assert 1e3 < ns.value < e0.elapsed_time(e1) * 1e6          # longer than a microsecond, inside the bracketing events
