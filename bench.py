@@ -339,9 +339,10 @@ def main():
         dt = timed(step, steps, warmup, world)
         results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                          "launch": launch}
-        if head and rank == 0 and launch.startswith("hipGraph"):
+        if head and launch.startswith("hipGraph"):
             # decoder_bwd's duration INSIDE the replayed graph, from the device clock the kernel stamps (events cannot be
-            # recorded in a replayed hipGraph here): one sample per burst of replays
+            # recorded in a replayed hipGraph here): one sample per burst of replays.  Every rank runs it: at world > 1 a step
+            # carries the gradient exchange, and collectives must stay matched across ranks.
             try:
                 import ctypes
                 from collision_handling_in_instantngp_amd import _lib
