@@ -432,7 +432,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg2: strawberry.jpeg 339x508 pixel list shuffled+repeated to 2^20 px/GPU, L=16 F=2 T=2^19 "
                                    f"K=4 N 16->512, {a.mode} indexing, random-init weights, MSE loss, fwd+bwd (no optimizer)",
-                       "mode": a.mode, "pixels_per_gpu": P, "parallelism": f"dp{world}"},
+                       "mode": a.mode, "pixels_per_gpu": P, "parallelism": f"dp{world}",
+                       "untimed_ramp_steps_before_warmup": a.ramp_steps},
             "modes": results, "kernel_ms": {k: (v * 1e3 if isinstance(v, float) else v) for k, v in kt.items()},
             "roofline": roof, "roofline_encoder": roof_enc,
         }
