@@ -183,6 +183,12 @@ constexpr int kHiddenTileFloats = 2 * 4 * 8 * 64 * 4;
 #ifndef GNGF_HIDDEN_AUX
 #define GNGF_HIDDEN_AUX 2      // cache policy of the hidden-layer traffic: nt (streaming: written once, read once ~0.3 ms later; -15 us per step vs default)
 #endif
+#ifndef GNGF_HIDDEN_ST_AUX
+#define GNGF_HIDDEN_ST_AUX GNGF_HIDDEN_AUX
+#endif
+#ifndef GNGF_HIDDEN_LD_AUX
+#define GNGF_HIDDEN_LD_AUX GNGF_HIDDEN_AUX
+#endif
 __device__ __forceinline__ void hidden_store(float* hidden, int64_t tile, int which, unsigned hoff, const f32x16 (&v)[2]) {
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hidden + tile * kHiddenTileFloats, 0, kHiddenTileFloats * 4, 0x00020000);
 #pragma unroll
@@ -191,7 +197,7 @@ __device__ __forceinline__ void hidden_store(float* hidden, int64_t tile, int wh
     for (int g = 0; g < 4; ++g) {
       const u32x4 q = {__float_as_uint(v[t][4 * g]), __float_as_uint(v[t][4 * g + 1]), __float_as_uint(v[t][4 * g + 2]),
                        __float_as_uint(v[t][4 * g + 3])};
-      __builtin_amdgcn_raw_buffer_store_b128(q, rs, hoff, which * 32768 + (t * 4 + g) * 1024, GNGF_HIDDEN_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(q, rs, hoff, which * 32768 + (t * 4 + g) * 1024, GNGF_HIDDEN_ST_AUX);
     }
 }
 #ifndef GNGF_BWD_REVERSE
@@ -209,7 +215,7 @@ __device__ __forceinline__ void hidden_load(const float* hidden, int64_t tile, i
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, hoff, which * 32768 + (t * 4 + g) * 1024, GNGF_HIDDEN_AUX);
+      const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, hoff, which * 32768 + (t * 4 + g) * 1024, GNGF_HIDDEN_LD_AUX);
       v[t][4 * g] = __uint_as_float(q.x); v[t][4 * g + 1] = __uint_as_float(q.y);
       v[t][4 * g + 2] = __uint_as_float(q.z); v[t][4 * g + 3] = __uint_as_float(q.w);
     }
