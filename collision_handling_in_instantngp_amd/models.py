@@ -27,9 +27,10 @@ device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cp
 
 # Largest reference-shaped dense tensor the module materialises on request (the (P,L,4,T) distribution).
 DENSE_OUTPUT_LIMIT_BYTES = 4 << 30
-# Row-chunk budget of the per-vertex (rows, T) distribution scratch: sized for 288 GB of HBM (8192 rows at T = 2^19; the
-# learning step is 1.36 / 1.29 / 1.27 / 1.265 s at 2 / 4 / 8 / 16 GiB — fewer, larger launches; tools/ab_hpd_chunk.py).
-HPD_CHUNK_BYTES = 16 << 30
+# Row-chunk budget of the per-vertex (rows, T) distribution scratch: sized for 288 GB of HBM (4096 rows at T = 2^19; without
+# kept logits the learning step is 1.36 / 1.29 / 1.27 / 1.265 s at 2 / 4 / 8 / 16 GiB — fewer, larger launches; 8 GiB pieces
+# pack the kept-logits budget of ops.HPD_Z_CACHE_BYTES best: tools/ab_hpd_chunk.py).
+HPD_CHUNK_BYTES = 8 << 30
 
 
 def level_resolutions(n_min: int, n_max: int, num_levels: int) -> np.ndarray:

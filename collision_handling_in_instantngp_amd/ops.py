@@ -228,6 +228,12 @@ def expand_vertex_table(xy, n_ls, vstride, NV, src_idx=None, src_val=None, want_
     return vid, oi, ov
 
 
+# Logits kept from the forward to the backward of the chunked HPD (see HpdVertexFunction.forward): budget, and the free
+# device memory that must remain after keeping a chunk.
+HPD_Z_CACHE_BYTES = 216 << 30
+HPD_Z_CACHE_RESERVE = 40 << 30
+
+
 class HpdVertexFunction(torch.autograd.Function):
     """HashProbDistribution (reference models.py:45-123) evaluated ONCE PER DISTINCT VERTEX u (vid = gy*vstride+gx,
     u in [0, NV)), in row chunks so that the (rows, T) distribution never exceeds `chunk_bytes`.
@@ -264,10 +270,19 @@ class HpdVertexFunction(torch.autograd.Function):
             L = mw.shape[1]
             pbar = torch.zeros((L, T), dtype=_f32, device=dev)
         scratch = None if keep_probs else torch.empty((min(rows, NV), T), dtype=_f32, device=dev)
+        # Checkpointing policy sized for 288 GB of HBM: the backward needs every chunk's logits again; the chunks that fit
+        # HPD_Z_CACHE_BYTES (and leave HPD_Z_CACHE_RESERVE free on the device) keep theirs, the rest are recomputed.
+        zcache, cached = {}, 0
+        keep_z = (not keep_probs) and HPD_Z_CACHE_BYTES > 0 and any(ctx.needs_input_grad[6:])
         for u0 in range(0, NV, rows):
             n = min(rows, NV - u0)
             hs = HpdVertexFunction._hidden(vertex_coords(u0, n, vstride, dev), params, n_layers)
             z = probs[u0:u0 + n] if keep_probs else scratch[:n]
+            if keep_z:
+                need = n * T * 4
+                if cached + need <= HPD_Z_CACHE_BYTES and torch.cuda.mem_get_info(dev)[0] - need >= HPD_Z_CACHE_RESERVE:
+                    z = zcache[u0] = torch.empty((n, T), dtype=_f32, device=dev)
+                    cached += need
             call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(z), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
             if keep_probs:      # dense distribution requested (small shapes): softmax in place, p-bar by GEMM
                 call("gngf_softmax_topk", ptr(z), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), ptr(rowstat[u0:u0 + n]), n, T, K, stream_ptr())
@@ -279,6 +294,7 @@ class HpdVertexFunction(torch.autograd.Function):
         if pbar is not None and DP_MEAN is not None:
             DP_MEAN(pbar)      # the loss is a nonlinear function of the batch mean: average BEFORE the log (SURVEY §8e ii)
         ctx.cfg = (NV, vstride, K, rows, n_layers, T, keep_probs)
+        ctx.zcache = zcache
         ctx.save_for_backward(ti, mw, probs, rowstat, *params)
         ctx.mark_non_differentiable(ti)
         return tv, ti, pbar, probs
@@ -295,17 +311,26 @@ class HpdVertexFunction(torch.autograd.Function):
         g_pbar = _c(g_pbar) if (g_pbar is not None and mw is not None) else None
         g_probs = _c(g_probs) if g_probs is not None else None
         L = mw.shape[1] if mw is not None else 0
-        dz_buf = torch.empty((min(rows, NV), T), dtype=_f32, device=dev)
-        lowrank = g_probs is None           # no dense gradient on the distribution: stream from recomputed logits
+        lowrank = g_probs is None           # no dense gradient on the distribution: stream from (kept or recomputed) logits
+        zcache, ctx.zcache = (getattr(ctx, "zcache", None) or {}), None
+        if not lowrank:
+            zcache = {}
+        dz_buf = None
         if lowrank:
             scratch = torch.empty((min(rows, NV) * (1 + K),), dtype=_f32, device=dev)
         for u0 in range(0, NV, rows):
             n = min(rows, NV - u0)
             hs = HpdVertexFunction._hidden(vertex_coords(u0, n, vstride, dev), params, n_layers)
-            dz = dz_buf[:n]
+            dz = zcache.pop(u0, None)       # this chunk's logits, kept by the forward (freed as soon as the chunk is done)
+            have_z = dz is not None
+            if not have_z:
+                if dz_buf is None:
+                    dz_buf = torch.empty((min(rows, NV), T), dtype=_f32, device=dev)
+                dz = dz_buf[:n]
             if lowrank:
-                # logits again, then softmax / top-K / batch-mean backward in place; db of the last layer is fused in
-                call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(dz), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
+                # logits (again, unless kept), then softmax / top-K / batch-mean backward in place; db of the last layer is fused in
+                if not have_z:
+                    call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(dz), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
                 call("gngf_softmax_bwd_lowrank", ptr(dz), ptr(rowstat[u0:u0 + n]),
                      ptr(g_tv[u0:u0 + n] if g_tv is not None else None), ptr(ti[u0:u0 + n]),
                      ptr(mw[u0:u0 + n] if g_pbar is not None else None), ptr(g_pbar), L if g_pbar is not None else 0,

@@ -355,3 +355,35 @@ def test_distinct_slot_counts_kernel_vs_torch_unique(K):
             sl = idx[:, l] if K == 0 else idx[:, l, :, k]
             assert int(got[k, l]) == int(torch.unique(sl).numel()), (k, l)
     assert int(got[0, 1]) == 3 and int(got[0, 2]) == T
+
+
+def test_kept_logits_equal_recomputed_logits_in_the_hpd_backward(golden):
+    """ops.HPD_Z_CACHE_BYTES: chunks whose logits are kept from the forward give the same gradients as chunks that
+    recompute them (several chunks, budget for some of them only, and none)"""
+    from collision_handling_in_instantngp_amd import ops, models as M
+    net, g, models, train = build(golden, "gngf")
+    X, Y, h, w = strawberry(golden)
+    sl = t(g["perm"])[:4096]
+    loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
+    net.dense_probs = False
+    T = net._hash_table_size
+    old = (M.HPD_CHUNK_BYTES, ops.HPD_Z_CACHE_BYTES, ops.HPD_Z_CACHE_RESERVE)
+    outs = []
+    try:
+        M.HPD_CHUNK_BYTES = 64 * 4 * T                        # 64-row chunks: many chunks at this small shape
+        ops.HPD_Z_CACHE_RESERVE = 0
+        for budget in (0, 3 * 64 * 4 * T, 1 << 40):           # recompute everything / keep three chunks / keep all
+            ops.HPD_Z_CACHE_BYTES = budget
+            net.zero_grad()
+            rgb, probs, idx, _ = net(X[sl], 1 / 3)
+            empty = torch.tensor([], device=DEV)
+            mse, kls, coll = loss_fn(rgb, Y[sl], probs.shape[-1], probs, empty, empty)
+            train.assemble_loss(mse, kls, coll, 1, 1, 1e-3).backward()
+            outs.append({k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+    finally:
+        M.HPD_CHUNK_BYTES, ops.HPD_Z_CACHE_BYTES, ops.HPD_Z_CACHE_RESERVE = old
+    assert any(k.startswith("HPD") for k in outs[0])
+    for other in outs[1:]:
+        for k in outs[0]:                                     # float atomics (split-K GEMMs) reorder sums from run to run
+            scale = float(outs[0][k].abs().max()) + 1e-30
+            close(other[k], outs[0][k].cpu().numpy(), 1e-4, 2e-5 * scale, k)
