@@ -3,7 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from collision_handling_in_instantngp_amd import ops
-from oracle import gngf_oracle as orc
+from collision_handling_in_instantngp_amd import models as orc   # level_resolutions only (the CPU oracle is for tests)
 
 def timeit(fn, n=20, w=3):
     for _ in range(w): fn()
