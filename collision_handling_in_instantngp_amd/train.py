@@ -74,8 +74,8 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("betas and eps are shared by all groups (as in the reference's get_optimizer)")
         self._step = None            # device float: steps taken
         self._table = None           # device byte tensor: the packed segment list
-        self._host = None            # its pinned staging buffer
-        self._uploaded = None        # event: the last upload has consumed the staging buffer
+        self._host = None            # ring of [pinned staging buffer, event of the upload that last read it]
+        self._slot = 0
         self._captured = []          # staging buffers owned by captured steps (read again at every replay)
         self._spares = []            # pinned buffers set aside for captures (no pinned allocation while capturing)
         self._table_key = None
@@ -143,17 +143,21 @@ class FusedAdam(torch.optim.Optimizer):
                 table.copy_(host, non_blocking=True)
                 self._captured.append(host)
             else:
-                if self._host is None or self._host.numel() != raw.size:
-                    self._host = torch.empty((raw.size,), dtype=torch.uint8, pin_memory=True)
+                if self._host is None or self._host[0][0].numel() != raw.size:
+                    # a ring of staging buffers: gradient buffers that alternate between two addresses re-upload the table
+                    # every step, and waiting for the PREVIOUS upload would tie the host to the device each step
+                    self._host = [[torch.empty((raw.size,), dtype=torch.uint8, pin_memory=True), None] for _ in range(4)]
                     self._table = torch.empty((raw.size,), dtype=torch.uint8, device=dev)
-                    self._uploaded = None
+                    self._slot = 0
                     self._spares = [torch.empty((raw.size,), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
-                if self._uploaded is not None:
-                    self._uploaded.synchronize()   # the previous upload has read the staging buffer
-                self._host.numpy()[:] = raw
-                self._table.copy_(self._host, non_blocking=True)
-                self._uploaded = torch.cuda.Event()
-                self._uploaded.record()
+                slot = self._host[self._slot]
+                self._slot = (self._slot + 1) % len(self._host)
+                if slot[1] is not None:
+                    slot[1].synchronize()          # the upload issued four table changes ago has read this buffer
+                slot[0].numpy()[:] = raw
+                self._table.copy_(slot[0], non_blocking=True)
+                slot[1] = torch.cuda.Event()
+                slot[1].record()
                 self._table_key, self._total_blocks, table = key, total_blocks, self._table
         ng = len(self.param_groups)
         lr = (ctypes.c_float * ng)(*[float(g["lr"]) for g in self.param_groups])
