@@ -616,7 +616,8 @@ vertex_bwd_sorted_kernel(const TT* __restrict__ tables, const int32_t* __restric
   constexpr int NW = kVB / 64;
   __shared__ int s_n[GNGF_MAX_LEVELS];
   __shared__ int64_t s_goff[GNGF_MAX_LEVELS];
-  __shared__ int s_first[NW], s_last[NW], s_lstart[NW];
+  __shared__ int64_t s_first[NW], s_last[NW];               // (first level << 32 | slot) of each wave's first / last lane
+  __shared__ int s_nruns[NW], s_lstart[NW];
   __shared__ float s_tail[2][NW][F];
   if (threadIdx.x < Ls) s_n[threadIdx.x] = n_ls[threadIdx.x];
   __syncthreads();
@@ -629,34 +630,43 @@ vertex_bwd_sorted_kernel(const TT* __restrict__ tables, const int32_t* __restric
   const float w = live ? vert_w[e] : 0.f;
   const int vid = e / K;
   const int gy = vid / vstride, gx = vid - gy * vstride;
-  const int slot_dn = __shfl_down(slot, 1, 64);
-  // segment predicates of the DPP scan: does the lane 1/2/4/8 below in the 16-lane row, the last lane of the previous
-  // row (rows 1, 3), lane 31 (rows 2, 3) hold the same slot?  (out-of-row sources read as -1: never equal)
-  const bool p1 = dppi<0x111, 0xF>(slot) == slot, p2 = dppi<0x112, 0xF>(slot) == slot, p4 = dppi<0x114, 0xF>(slot) == slot,
-             p8 = dppi<0x118, 0xF>(slot) == slot, pA = dppi<0x142, 0xA>(slot) == slot, pB = dppi<0x143, 0xC>(slot) == slot;
-  float dw_acc = 0.f;
   // first level this lane's vertex belongs to (levels ascend, so it belongs to every later one); the workgroup starts at
   // the smallest such level among its lanes — with the (first level, slot) visiting order that is mostly the lanes' own.
-  __syncthreads();                                          // s_n, s_goff
   int lmin = Ls;
   if (live) { const int mg = gx > gy ? gx : gy; lmin = 0; while (lmin < Ls && mg > s_n[lmin] + 1) ++lmin; }
+  // Runs = maximal stretches of ADJACENT lanes with the same (first level, slot) key — the sort key of `order`.  The slot
+  // value alone is not enough: slots restart at every level-group boundary, so the same slot can sit on both sides of a
+  // boundary inside one wave (5, 9 | 5) and a value comparison would fold the first run into the third.  Run numbers
+  // (prefix count of key changes) make the segment predicates exact for any visiting order.
+  const int64_t key = ((int64_t)lmin << 32) | (uint32_t)slot;
+  const int slot_up = __shfl_up(slot, 1, 64), lmin_up = __shfl_up(lmin, 1, 64);
+  int rid = (lane == 0 || slot_up != slot || lmin_up != lmin) ? 1 : 0;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(rid, o, 64); if (lane >= o) rid += u; }
+  const int rid_dn = __shfl_down(rid, 1, 64);
+  // segment predicates of the DPP scan: does the lane 1/2/4/8 below in the 16-lane row, the last lane of the previous
+  // row (rows 1, 3), lane 31 (rows 2, 3) belong to the same run?  (out-of-row sources read as -1: never equal, rid >= 1)
+  const bool p1 = dppi<0x111, 0xF>(rid) == rid, p2 = dppi<0x112, 0xF>(rid) == rid, p4 = dppi<0x114, 0xF>(rid) == rid,
+             p8 = dppi<0x118, 0xF>(rid) == rid, pA = dppi<0x142, 0xA>(rid) == rid, pB = dppi<0x143, 0xC>(rid) == rid;
+  float dw_acc = 0.f;
   int lstart = lmin;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { const int ov = __shfl_xor(lstart, o, 64); lstart = ov < lstart ? ov : lstart; }
   // A freshly initialised HPD sends a million (vertex,k) entries to a few dozen slots: one atomic per (wave, run, level)
   // would still pile ~300 same-address float atomics on each table row.  The waves of the workgroup chain their runs
   // through LDS instead: a run that continues into the next wave hands its partial sum over, and only the wave in which the
-  // run ENDS (or the last wave of the workgroup) issues the atomic.  The chaining depends on the slots only, not the level.
-  const int first_slot = __shfl(slot, 0, 64), last_slot = __shfl(slot, 63, 64);
-  if (lane == 0) { s_first[wave] = first_slot; s_last[wave] = last_slot; s_lstart[wave] = lstart; }
+  // run ENDS (or the last wave of the workgroup) issues the atomic.  The chaining depends on the keys only, not the level.
+  const int64_t first_key = __shfl(key, 0, 64), last_key = __shfl(key, 63, 64);
+  const int nruns = __shfl(rid, 63, 64);
+  if (lane == 0) { s_first[wave] = first_key; s_last[wave] = last_key; s_nruns[wave] = nruns; s_lstart[wave] = lstart; }
   __syncthreads();
   int lblock = Ls;
 #pragma unroll
   for (int q = 0; q < NW; ++q) lblock = s_lstart[q] < lblock ? s_lstart[q] : lblock;
-  const bool continues = wave + 1 < NW && s_first[wave + 1] == last_slot;    // my last run goes on in the next wave
+  const bool continues = wave + 1 < NW && s_first[wave + 1] == last_key;     // my last run goes on in the next wave
   // lanes that emit the atomic of their run: its last lane, unless the run is handed to the next wave
-  const bool emit = live && ((lane == 63) ? !continues : (slot_dn != slot));
-  const bool in_first_run = slot == first_slot;             // (slots are sorted: equal means the same run)
+  const bool emit = live && ((lane == 63) ? !continues : (rid_dn != rid));
+  const bool in_first_run = rid == 1;
   for (int l = lblock; l < Ls; ++l) {
     const int n = s_n[l];
     const bool in = live && l >= lmin;
@@ -703,10 +713,10 @@ vertex_bwd_sorted_kernel(const TT* __restrict__ tables, const int32_t* __restric
 #pragma unroll
     for (int f = 0; f < F; ++f) carry[f] = 0.f;
     for (int q = wave - 1; q >= 0; --q) {                   // wave-uniform walk down the chain that ends in my first run
-      if (s_last[q] != first_slot) break;
+      if (s_last[q] != first_key) break;
 #pragma unroll
       for (int f = 0; f < F; ++f) carry[f] += tail[q][f];
-      if (s_first[q] != s_last[q]) break;                   // that wave's last run began inside it: the chain starts there
+      if (s_nruns[q] != 1) break;                           // that wave's last run began inside it: the chain starts there
     }
     if (emit) {
       float* d = dtables + ((int64_t)l * T + slot) * F;

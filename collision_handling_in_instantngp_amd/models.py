@@ -304,6 +304,12 @@ class GeneralNeuralGaugeFields(nn.Module):
         keep_topk = self._should_keep_topk_only
         dense_bytes = P * L * 4 * T * 4
         want_dense = (not keep_topk) and (self.dense_probs is True or (self.dense_probs == "auto" and dense_bytes <= DENSE_OUTPUT_LIMIT_BYTES))
+        extent = None
+        if want_dense and self.dense_probs == "auto":
+            # the dense tensor is gathered from per-vertex rows (NV, T): a handful of pixels spread over a fine grid at a
+            # large T has a small (P,L,4,T) but a huge bounding rectangle of vertices
+            extent = self._vertex_extent(x.detach())
+            want_dense = extent[1] * T * 4 <= DENSE_OUTPUT_LIMIT_BYTES
         need_pbar = (not keep_topk) and (not want_dense) and self.compute_pbar
         blend_code = ops.BLEND_CODES[should_softmax_topk_features]
         if self.hpd_is_frozen() and not want_dense and not need_pbar:
@@ -312,7 +318,7 @@ class GeneralNeuralGaugeFields(nn.Module):
             tv, ti, w, vstride, NV, order = self._frozen_vertex_table(blend_code)
             pbar = probs_u = None
         else:
-            vstride, NV = self._vertex_extent(x.detach())
+            vstride, NV = extent if extent is not None else self._vertex_extent(x.detach())
             mw = ops.vertex_multiplicity_weights(x.detach(), n_ls, vstride, NV) if need_pbar else None
             tv, ti, pbar, probs_u = ops.HpdVertexFunction.apply(NV, vstride, K, mw, want_dense, HPD_CHUNK_BYTES,
                                                                 *self.HPD.flat_params())

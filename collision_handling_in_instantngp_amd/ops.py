@@ -611,10 +611,15 @@ def run_deferred_vertex_stage(exchanged=False):
     other gradients)."""
     if DP_DEFERRED is None:
         return False
-    plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, order = DP_DEFERRED
+    plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, order, gout = DP_DEFERRED
     if DP_EXCHANGE is not None and not exchanged:
         DP_EXCHANGE(dG)
     _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, None, order)
+    if gout is not dtables:
+        # fp16 table storage: the gradient autograd received is a rounded COPY of the fp32 accumulation buffer, made before
+        # the vertex stage ran.  Only the staged levels are refreshed (the direct levels' slice of `gout` may already hold
+        # the all-reduced gradient; their fp32 rows here are still this rank's own).
+        gout[:plan.Ls].copy_(dtables[:plan.Ls])
     return True
 
 
@@ -692,6 +697,10 @@ class EncodeFunction(torch.autograd.Function):
         P, L, F, T, K, mode, vstride, NV, plan, ws = ctx.cfg
         genc = _c(genc)
         absmax = _take_absmax_hint(genc)
+        # data-parallel bookkeeping describes THIS backward only: a step that takes another path (direct form, no staged
+        # levels, no deferral) must not inherit the previous step's staged-level count or deferred vertex stage
+        globals()["DP_TABLES_REDUCED"] = 0
+        globals()["DP_DEFERRED"] = None
         pre, ctx.pre = ctx.pre, None                            # a second backward (retain_graph) allocates fresh buffers
         dtables = pre[0] if pre else _grad_buffer(tables)
         dvw = torch.zeros_like(vert_w) if (vert_w is not None and ctx.needs_input_grad[5]) else None
@@ -700,12 +709,13 @@ class EncodeFunction(torch.autograd.Function):
             _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax)
             if DP_EXCHANGE is not None and DP_DEFER_VERTEX and dvw is None:
                 # the caller exchanges dG and runs the vertex stage after backward (parallel.allreduce_gradients)
-                globals()["DP_DEFERRED"] = (plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, order)
-                globals()["DP_TABLES_REDUCED"] = plan.Ls
                 if plan.Ls < L:
                     call("gngf_encode_bwd", ptr(xy), *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc, _f32, "grad"),
                          ptr(dtables), ptr(dvw), P, L, F, T, K, mode, vstride, NV, plan.Ls, L, stream_ptr())
-                return None, None, None, _grad_out(dtables, tables), None, dvw, None, None
+                gout = _grad_out(dtables, tables)
+                globals()["DP_DEFERRED"] = (plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, order, gout)
+                globals()["DP_TABLES_REDUCED"] = plan.Ls
+                return None, None, None, gout, None, dvw, None, None
             if DP_EXCHANGE is not None:
                 DP_EXCHANGE(dG)                     # one small all-reduce instead of the staged levels' table gradient
                 globals()["DP_TABLES_REDUCED"] = plan.Ls

@@ -32,6 +32,8 @@ def enable_vertex_grid_exchange(world: int, group=None):
     dG -> dE is linear and identical on every rank, so reducing dG first gives the same table gradient with ~11x
     fewer bytes on the xGMI links.  Levels that run in the direct form (the finest levels of very fine grids) keep the
     table-gradient all-reduce, restricted to their own contiguous slice of the (L,T,F) buffer."""
+    ops.DP_TABLES_REDUCED = 0          # bookkeeping of a previous configuration does not carry over
+    ops.DP_DEFERRED = None
     if world <= 1:
         ops.DP_EXCHANGE = ops.DP_MEAN = ops.DP_MAX = None
         return
@@ -81,6 +83,7 @@ def defer_vertex_stage(on: bool = True):
     ops.DP_DEFER_VERTEX = bool(on)
     if not on:
         ops.DP_DEFERRED = None
+        ops.DP_TABLES_REDUCED = 0
 
 
 def average_tensors(tensors, world: int, group=None):

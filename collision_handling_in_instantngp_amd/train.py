@@ -66,6 +66,8 @@ class FusedAdam(torch.optim.Optimizer):
     reference's torch.optim.Adam load here and vice versa.  The step count is a device tensor advanced by the kernel:
     a step needs no host synchronisation and can be captured in a hipGraph together with forward and backward."""
 
+    DTYPES = (torch.float32,)
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         if len(self.param_groups) > 4:
@@ -185,11 +187,14 @@ def get_optimizer(net, encoding_lr, HPD_lr, MLP_lr, encoding_weight_decay, HPD_w
     """reference functions.py:96-127.  On the GPU the update runs as one launch of this package's Adam kernel
     (FusedAdam: same rule and state layout as torch.optim.Adam); host tensors (CPU tests of the training algebra) and
     fused_kernel=False use torch.optim.Adam itself."""
-    groups = [{"params": net.encoding.parameters(), "lr": encoding_lr, "weight_decay": encoding_weight_decay}]
+    groups = [{"params": list(net.encoding.parameters()), "lr": encoding_lr, "weight_decay": encoding_weight_decay}]
     if not models.should_use_hash_function:
-        groups.append({"params": net.HPD.parameters(), "lr": HPD_lr, "weight_decay": HPD_weight_decay})
-    groups.append({"params": net.mlp.parameters(), "lr": MLP_lr, "weight_decay": MLP_weight_decay})
-    on_gpu = all(p.is_cuda and p.dtype == torch.float32 for p in net.parameters())
+        groups.append({"params": list(net.HPD.parameters()), "lr": HPD_lr, "weight_decay": HPD_weight_decay})
+    groups.append({"params": list(net.mlp.parameters()), "lr": MLP_lr, "weight_decay": MLP_weight_decay})
+    # decided from the parameters the optimizer will actually update (hash mode also owns the int64, non-trainable
+    # `_prime_numbers` Parameter, which is in no group)
+    grouped = [p for g_ in groups for p in g_["params"]]
+    on_gpu = bool(grouped) and all(p.is_cuda and p.dtype in FusedAdam.DTYPES for p in grouped)
     if fused_kernel is None:
         fused_kernel = on_gpu
     if fused_kernel:

@@ -382,7 +382,223 @@ def g11(F_, U_, M, P_):
     save("G11_hash_L16_T19_curve", **out)
 
 
-GROUPS = {"G11": g11, "G10": g10, "G1": g1, "G2": g2_g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
+def seeded_hpd_last_layer(T, fan_in=128, seed=SEED + 12):
+    """The (T, 128) last HPD layer is 256 MiB at T=2^19 — too large for a fixture: both sides regenerate it from a seeded CPU
+    generator with nn.Linear's default bound 1/sqrt(fan_in)."""
+    gen = torch.Generator().manual_seed(seed)
+    bound = 1.0 / np.sqrt(fan_in)
+    W = (torch.rand((T, fan_in), generator=gen) * 2 - 1) * bound
+    b = (torch.rand((T,), generator=gen) * 2 - 1) * bound
+    return W, b
+
+
+def load_image(name):
+    from PIL import Image
+    return np.array(Image.open(os.path.join(rh.REF_ROOT, "images", name)).convert("RGB"))
+
+
+def g12(F_, U_, M, P_):
+    """HEADLINE shape, GNGF indexing, through the reference itself (models.py:90-123, 5-19, 394-484): L=16, F=2, T=2^19,
+    K=4, N 16->512, P=8 strawberry pixels, one forward + Loss + backward (~35 s, ~12 GiB).  Pins HPD / top-K at T=2^19.
+    Large tensors are stored sparsely / sampled: table gradients as (level, slot, value) triples, the last HPD layer's
+    gradient and p-bar at the slots any top-K touches plus a seeded sample of other slots."""
+    mods = (F_, U_, M)
+    img, X, Y, h, w = load_strawberry()
+    L, T, Fd, K, Pn = 16, 2 ** 19, 2, 4, 8
+    net = make_net(M, mods, hash_mode=False, T=T, L=L, n_min=16, n_max=512, F=Fd, K=K)
+    tabs = seeded_tables(L, T, Fd, SEED + 13)
+    W_last, b_last = seeded_hpd_last_layer(T)
+    with torch.no_grad():
+        for l in range(L):
+            net.encoding._hash_tables[l].weight.copy_(tabs[l])
+        net.HPD.module_list[3][0].weight.copy_(W_last)
+        net.HPD.module_list[3][0].bias.copy_(b_last)
+    out = {"cfg": np.array([L, T, Fd, K, 16, 512])}
+    for k_, v_ in net.state_dict().items():
+        if k_.startswith("mlp.") or (k_.startswith("HPD.") and not k_.startswith("HPD.module_list.3.")):
+            out["init_" + k_.replace(".", "_")] = np32(v_)
+    gen = torch.Generator().manual_seed(SEED + 12)
+    sel = torch.randperm(h * w, generator=gen)[:Pn]
+    sel[0] = 0                                   # the (0,0) corner pixel: vertices (0,0),(1,0),(0,1),(1,1) at every level
+    sel[1] = h * w - 1                           # the far corner
+    out["sel"] = sel.numpy().astype(np.int64)
+    bx, by = X[sel], Y[sel]
+    loss_fn = U_.Loss(delta=1, gamma=-2, epsilon=1)
+    net.zero_grad()
+    import time
+    t0 = time.time()
+    rgb, probs, idx, counts = net(bx, 1.0, should_calc_counts=False)
+    mse, kls, coll = loss_fn(rgb, by, probs.shape[-1], probs, torch.tensor([]), torch.tensor([]))
+    loss = 1 * mse + ((1 * kls) + 1).sum(0)      # functions.py:243-245 with empty previous_collisions
+    loss.backward()
+    print("reference fwd+loss+bwd at T=2^19, P=8: %.1f s" % (time.time() - t0))
+    out["rgb"] = np32(rgb)
+    out["mse"] = np32(mse)
+    out["kls"] = np32(kls)
+    out["loss"] = np32(loss)
+    out["topk_idx"] = np32(idx).astype(np.int32)                       # (P,L,4,K)
+    tp, ti = torch.topk(probs.detach(), K + 1, dim=-1)
+    assert torch.equal(ti[..., :K], idx)
+    out["topk_probs"] = np32(tp[..., :K])
+    out["next_prob"] = np32(tp[..., K])                                # the (K+1)-th probability: tie detector for the checker
+    pbar = probs.detach().sum(0).sum(1) / (probs.shape[0] * probs.shape[2])      # (L,T)
+    touched = torch.unique(idx.reshape(-1))
+    extra = torch.randperm(T, generator=gen)[:4096]
+    slots = torch.unique(torch.cat([touched, extra]))
+    out["slots"] = slots.numpy().astype(np.int64)
+    out["pbar_at_slots"] = np32(pbar[:, slots])
+    out["pbar_rowsum"] = np32(pbar.double().sum(1))
+    out["pbar_max"] = np32(pbar.max(1).values)
+    for k_, p_ in net.named_parameters():
+        if p_.grad is None:
+            continue
+        key = "grad_" + k_.replace(".", "_")
+        if k_.startswith("encoding."):
+            continue
+        if k_ == "HPD.module_list.3.0.weight":
+            out[key + "_at_slots"] = np32(p_.grad[slots])
+            out[key + "_abs_sum"] = np32(p_.grad.double().abs().sum())
+        elif k_ == "HPD.module_list.3.0.bias":
+            out[key + "_at_slots"] = np32(p_.grad[slots])
+            out[key + "_abs_sum"] = np32(p_.grad.double().abs().sum())
+        else:
+            out[key] = np32(p_.grad)
+    dt = torch.stack([net.encoding._hash_tables[l].weight.grad for l in range(L)])   # (L,T,F), almost all zero
+    nz = torch.nonzero(dt.abs().sum(-1))
+    out["dtables_nz"] = nz.numpy().astype(np.int32)                   # (n,2) = (level, slot)
+    out["dtables_val"] = np32(dt[nz[:, 0], nz[:, 1]])
+    print("table grad rows:", nz.shape[0], "slots kept:", slots.numel())
+    save("G12_gngf_T19_reference", **out)
+
+
+def g13(F_, U_, M, P_):
+    """-hwp mode (models.py:364-371) and the reference's five checkpoint files (functions.py:761-781), cfg1 shape: a model is
+    trained for two steps and saved BY THE REFERENCE (torch.save of state dicts = data); a second reference model is built
+    with HPD_weights_path= (frozen HPD) and takes one step.  Written: tests/golden/ref_ckpt_cfg1/*.pt + G13 npz."""
+    mods = (F_, U_, M)
+    img, X, Y, h, w = load_strawberry()
+    torch.manual_seed(SEED)
+    perm = torch.randperm(h * w)
+    B = 4096
+    net = make_net(M, mods, hash_mode=False, T=256, L=4, n_min=8, n_max=32, K=4)
+    loss_fn = U_.Loss(delta=1, gamma=-2, epsilon=1)
+    opt = F_.get_optimizer(net, 1e-4, 1e-3, 1e-3, 0, 1e-6, 1e-6)
+    for step in range(2):
+        sl = perm[step * B:(step + 1) * B]
+        opt.zero_grad()
+        rgb, probs, idx, _ = net(X[sl], 1 / 3)
+        mse, kls, coll = loss_fn(rgb, Y[sl], probs.shape[-1], probs, torch.tensor([]), torch.tensor([]))
+        (1 * mse + ((1 * kls) + 1).sum(0)).backward()
+        opt.step()
+    folder = os.path.join(OUT, "ref_ckpt_cfg1")
+    os.makedirs(folder, exist_ok=True)
+    torch.save(net.state_dict(), os.path.join(folder, "whole_model.pt"))            # functions.py:768
+    torch.save(opt.state_dict(), os.path.join(folder, "whole_opt.pt"))              # :769
+    torch.save(net.encoding.state_dict(), os.path.join(folder, "encoding_model.pt"))  # :773
+    torch.save(net.HPD.state_dict(), os.path.join(folder, "HPD_model.pt"))          # :776
+    torch.save(net.mlp.state_dict(), os.path.join(folder, "MLP_model.pt"))          # :780
+    out = {"perm": perm[: 4 * B].numpy().astype(np.int64)}
+    # resumed step of the saved model+optimizer (whole_model.pt + whole_opt.pt loaded into fresh objects)
+    net_r = make_net(M, mods, hash_mode=False, T=256, L=4, n_min=8, n_max=32, K=4)
+    net_r.load_state_dict(torch.load(os.path.join(folder, "whole_model.pt")))
+    opt_r = F_.get_optimizer(net_r, 1e-4, 1e-3, 1e-3, 0, 1e-6, 1e-6)
+    opt_r.load_state_dict(torch.load(os.path.join(folder, "whole_opt.pt")))
+    sl = perm[2 * B:3 * B]
+    opt_r.zero_grad()
+    rgb, probs, idx, _ = net_r(X[sl], 1 / 3)
+    mse, kls, coll = loss_fn(rgb, Y[sl], probs.shape[-1], probs, torch.tensor([]), torch.tensor([]))
+    (1 * mse + ((1 * kls) + 1).sum(0)).backward()
+    opt_r.step()
+    out["resume_rgb"] = np32(rgb)
+    out["resume_mse"] = np32(mse)
+    for k_, p_ in net_r.named_parameters():
+        out["resume_param_" + k_.replace(".", "_")] = np32(p_)
+    # -hwp: frozen HPD loaded from HPD_model.pt, fresh tables/decoder (seeded), one training step
+    torch.manual_seed(SEED + 1)
+    net_f = M.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=256, num_levels=4, n_min=8, n_max=32,
+                                       MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
+                                       HPD_out_features=256, feature_dim=2, topk_k=4,
+                                       HPD_weights_path=os.path.join(folder, "HPD_model.pt"))
+    assert all(not p.requires_grad for p in net_f.HPD.parameters())
+    for k_, v_ in net_f.state_dict().items():
+        if not k_.startswith("HPD."):
+            out["hwp_init_" + k_.replace(".", "_")] = np32(v_)
+    opt_f = torch.optim.Adam([{"params": net_f.encoding.parameters(), "lr": 1e-4, "weight_decay": 0},
+                              {"params": net_f.mlp.parameters(), "lr": 1e-3, "weight_decay": 1e-6}], betas=(0.9, 0.99), eps=1e-15)
+    sl = perm[3 * B:4 * B]
+    opt_f.zero_grad()
+    rgb, probs, idx, _ = net_f(X[sl], 1 / 3)
+    mse, kls, coll = loss_fn(rgb, Y[sl], probs.shape[-1], probs, torch.tensor([]), torch.tensor([]))
+    (1 * mse + ((1 * kls) + 1).sum(0)).backward()
+    out["hwp_rgb"] = np32(rgb)
+    out["hwp_mse"] = np32(mse)
+    out["hwp_kls"] = np32(kls)
+    out["hwp_idx"] = np32(idx).astype(np.int32)
+    for k_, p_ in net_f.named_parameters():
+        if p_.grad is not None:
+            out["hwp_grad_" + k_.replace(".", "_")] = np32(p_.grad)
+    assert all(p.grad is None for p in net_f.HPD.parameters())
+    save("G13_hwp_and_checkpoints", **out)
+
+
+def g14(F_, U_, M, P_):
+    """cfg3's own pixels: macaw.jpg decoded (PIL) + one hash-mode step at the headline table shape on 4096 of its pixels."""
+    mods = (F_, U_, M)
+    img = load_image("macaw.jpg")
+    save("macaw_rgb", img=img)
+    h, w = img.shape[:2]
+    rows, cols = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    X = torch.tensor(np.stack([rows, cols], -1).reshape(-1, 2)).float() / (max(w, h) - 1)
+    Y = torch.tensor(img.reshape(-1, 3) / 255).float()
+    L, T, Fd = 16, 2 ** 19, 2
+    net = make_net(M, mods, hash_mode=True, T=T, L=L, n_min=16, n_max=512, F=Fd)
+    tabs = seeded_tables(L, T, Fd, SEED + 14)
+    with torch.no_grad():
+        for l in range(L):
+            net.encoding._hash_tables[l].weight.copy_(tabs[l])
+            net.encoding._hash_tables[l].weight.mul_(100.0)      # 1e-2-scale features: the image signal reaches the output
+    out = {"hw": np.array([h, w])}
+    for k_, v_ in net.mlp.state_dict().items():
+        out["init_mlp_" + k_.replace(".", "_")] = np32(v_)
+    gen = torch.Generator().manual_seed(SEED + 14)
+    sel = torch.randperm(h * w, generator=gen)[:4096]
+    out["sel"] = sel.numpy().astype(np.int64)
+    loss_fn = U_.Loss(delta=1, gamma=-2, epsilon=1)
+    net.zero_grad()
+    rgb, _, idx, _ = net(X[sel], 1.0)
+    mse, _, _ = loss_fn(rgb, Y[sel], None, None, None, None)
+    mse.backward()
+    out["rgb"] = np32(rgb)
+    out["mse"] = np32(mse)
+    out["idx_checksum"] = np.array([int(idx.sum()), int((idx * torch.arange(1, 4097)[:, None, None]).sum() % (2 ** 61 - 1))], dtype=np.int64)
+    for k_, p_ in net.mlp.named_parameters():
+        out["grad_mlp_" + k_.replace(".", "_")] = np32(p_.grad)
+    dt = torch.stack([net.encoding._hash_tables[l].weight.grad for l in range(L)])
+    nz = torch.nonzero(dt.abs().sum(-1))
+    out["dtables_nz"] = nz.numpy().astype(np.int32)
+    out["dtables_val"] = np32(dt[nz[:, 0], nz[:, 1]])
+    rh.set_flag(mods, "should_use_hash_function", False)
+    save("G14_macaw_hash", **out)
+
+
+def g3b(F_, U_, M, P_):
+    """Hash indices at the large-table shapes of BASELINE configs 4 and 5 (T = 2^22 with N 16->4096; T = 2^24 with N 16->8192)."""
+    mods = (F_, U_, M)
+    gen = torch.Generator().manual_seed(SEED + 3)
+    x = edge_coords(512, gen)
+    out = {"x": np32(x)}
+    for tag, (a, b, L, T) in {"cfg4": (16, 4096, 16, 2 ** 22), "cfg5": (16, 8192, 16, 2 ** 24)}.items():
+        net = make_net(M, mods, hash_mode=True, T=T, L=L, n_min=a, n_max=b)
+        scaled, grid = net._scale_to_grid(x)
+        out[f"{tag}_n_ls"] = np32(net._n_ls).reshape(-1)
+        out[f"{tag}_grid"] = np32(grid)
+        out[f"{tag}_hash"] = np32(net._fast_hash(grid.int()))
+        out[f"{tag}_cfg"] = np.array([a, b, L, T])
+    rh.set_flag(mods, "should_use_hash_function", False)
+    save("G3b_hash_large_tables", **out)
+
+
+GROUPS = {"G3b": g3b, "G11": g11, "G12": g12, "G13": g13, "G14": g14, "G10": g10, "G1": g1, "G2": g2_g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -39,3 +39,66 @@ def golden():
             cache[name] = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
         return cache[name]
     return load
+
+
+# ------------------------------------------------------------------------------------------------ achieved-error report
+class ParityRecorder:
+    """Every tolerance check of the parity tests also records the ACHIEVED error, so that the numbers behind
+    "matches to <= X" are on file (PARITY.md is generated from the GPU run's report by tools/make_parity_md.py)."""
+
+    def __init__(self):
+        self.rows = []
+
+    def record(self, quantity, got, want, rtol, atol):
+        got = np.asarray(got, np.float64)
+        want = np.asarray(want, np.float64)
+        if got.shape != want.shape or got.size == 0:
+            return
+        err = np.abs(got - want)
+        ref_max = float(np.abs(want).max())
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rel = err / np.abs(want)
+        big = np.abs(want) > 1e-3 * ref_max if ref_max > 0 else np.zeros(want.shape, bool)
+        self.rows.append({
+            "test": os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0],
+            "quantity": quantity, "n": int(got.size),
+            "max_abs_err": float(err.max()), "ref_max_abs": ref_max,
+            "max_err_over_ref_max": float(err.max() / ref_max) if ref_max > 0 else 0.0,
+            "max_rel_err_significant": float(rel[big].max()) if big.any() else 0.0,
+            "rtol": float(rtol), "atol": float(atol),
+        })
+
+
+PARITY = ParityRecorder()
+
+
+def parity_close(got, want, rtol, atol, quantity=""):
+    """np.testing.assert_allclose(got, want, rtol, atol) + a row in the achieved-error report."""
+    try:
+        import torch
+        if isinstance(got, torch.Tensor):
+            got = got.detach().cpu().numpy()
+        if isinstance(want, torch.Tensor):
+            want = want.detach().cpu().numpy()
+    except ImportError:  # pragma: no cover
+        pass
+    PARITY.record(quantity, got, want, rtol, atol)
+    np.testing.assert_allclose(np.asarray(got, np.float64), np.asarray(want, np.float64), rtol=rtol, atol=atol, err_msg=quantity)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not PARITY.rows:
+        return
+    import json
+    try:
+        import torch
+        kind = "gpu" if torch.cuda.is_available() else "cpu"
+    except Exception:  # pragma: no cover
+        kind = "cpu"
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, f"parity_{kind}.json"), "w") as f:
+            json.dump({"kind": kind, "exitstatus": int(exitstatus), "rows": PARITY.rows}, f, indent=0)
+    except OSError:  # pragma: no cover
+        pass

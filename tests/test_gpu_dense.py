@@ -13,9 +13,14 @@ def t(a, dtype=None):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(DEV)
 
 
-def close(a, b, rtol, atol):
-    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
-    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=atol)
+def close(a, b, rtol, atol, msg=""):
+    """assert_allclose + a row in the achieved-error report (tests/conftest.py: ParityRecorder)"""
+    import inspect
+    from conftest import parity_close
+    if not msg:
+        ctx = inspect.stack()[1].code_context
+        msg = (ctx[0].strip() if ctx else "")[:100]
+    parity_close(a, b, rtol, atol, msg)
 
 
 @pytest.fixture(scope="module")

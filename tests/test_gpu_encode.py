@@ -14,9 +14,14 @@ def t(a, dtype=None):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(DEV)
 
 
-def close(a, b, rtol, atol):
-    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
-    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=atol)
+def close(a, b, rtol, atol, msg=""):
+    """assert_allclose + a row in the achieved-error report (tests/conftest.py: ParityRecorder)"""
+    import inspect
+    from conftest import parity_close
+    if not msg:
+        ctx = inspect.stack()[1].code_context
+        msg = (ctx[0].strip() if ctx else "")[:100]
+    parity_close(a, b, rtol, atol, msg)
 
 
 @pytest.fixture(scope="module")
@@ -252,3 +257,54 @@ def test_fp16_tables_vs_oracle_on_rounded_tables(ops, mode, path):
     enc.backward(t(g))
     assert tt.grad.dtype == torch.float16
     close(tt.grad.float(), dt, 1e-3, 1e-3 * float(np.abs(dt).max()))
+
+
+def _degenerate_tables(kind, NV, K, T, rng):
+    if kind == "one_slot":                       # every (vertex, k) entry -> slot 3: one run spanning every wave and workgroup
+        return np.full((NV, K), 3 % T, np.int32)
+    if kind == "few_slots":                      # a fresh HPD: ~46 slots in a few hundred runs
+        pool = rng.choice(T, size=min(46, T), replace=False)
+        return pool[rng.integers(0, len(pool), (NV, K))].astype(np.int32)
+    if kind == "k_equal":                        # all K entries of a vertex on the same slot, slots vary slowly with the vertex
+        return np.repeat((np.arange(NV) // 97 % T)[:, None], K, 1).astype(np.int32)
+    if kind == "two_slots_alternating":          # (5, 9 | 5 ...) patterns across the level-group boundaries of the visiting order
+        return np.where((np.arange(NV)[:, None] + np.arange(K)[None]) % 2 == 0, 5 % T, 9 % T).astype(np.int32)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["one_slot", "few_slots", "k_equal", "two_slots_alternating"])
+@pytest.mark.parametrize("cfg", [(2, 24, 6, 2, 16, 1, 6000), (4, 40, 5, 2, 64, 4, 9000), (16, 512, 16, 2, 2 ** 12, 4, 30000),
+                                 (3, 11, 4, 4, 8, 3, 2000)])
+def test_sorted_vertex_backward_degenerate_slot_distributions_vs_oracle(ops, cfg, kind):
+    """vertex_bwd_sorted_kernel (runs merged by a wave-level segmented scan and chained across the 8 waves of a workgroup):
+    slot distributions with very long runs, runs that span several workgroups, tiny level groups with K = 1 and the same
+    slot on both sides of a level-group boundary — table gradient AND d vert_w against the per-instance oracle."""
+    n_min, n_max, L, F, T, K, P = cfg
+    rng = np.random.default_rng(hash((cfg, kind)) % (2 ** 31))
+    x = _coords(P, rng)
+    tables = (rng.random((L, T, F), dtype=np.float32) - 0.5) * 2e-1
+    n_ls = orc.level_resolutions(n_min, n_max, L)
+    vstride = n_max + 2
+    NV = vstride * vstride
+    vidx = _degenerate_tables(kind, NV, K, T, rng)
+    vw = rng.random((NV, K), dtype=np.float32)
+    _, grid = orc.scale_to_grid(x, n_ls)
+    gi = grid.astype(np.int64)
+    vid = gi[:, 1] * vstride + gi[:, 0]
+    idx_inst, w_inst = vidx[vid].astype(np.int64), vw[vid]
+    g = rng.standard_normal((P, L * F)).astype(np.float32)
+    dt, dw_inst = orc.encoding_backward(tables, idx_inst, w_inst, None, orc.bilinear_backward(x, n_ls, g, F))
+    dvw = np.zeros((NV, K), np.float64)
+    np.add.at(dvw, vid.reshape(-1), dw_inst.reshape(-1, K).astype(np.float64))
+    n_host = [int(n) for n in n_ls]
+    for with_dw in (True, False):
+        tt = t(tables).requires_grad_()
+        tw = t(vw).requires_grad_(with_dw)
+        enc = ops.encode_apply(t(x), t(n_ls, torch.int32), n_host, tt, t(vidx), tw, vstride, path="tiled")
+        plan = ops.EncodePlan(P, n_host, F, "tiled")
+        assert plan.Ls > 0
+        enc.backward(t(g))
+        # sums of up to P*4 terms per row in fp32 (any order): tolerance relative to the largest row
+        close(tt.grad, dt, 2e-4, 2e-5 * float(np.abs(dt).max()), f"sorted vertex bwd [{kind}] table gradient, dw={with_dw}")
+        if with_dw:
+            close(tw.grad, dvw, 2e-4, 2e-5 * float(np.abs(dvw).max()), f"sorted vertex bwd [{kind}] d vert_w")

@@ -13,8 +13,13 @@ def t(a, dtype=None):
 
 
 def close(a, b, rtol, atol, msg=""):
-    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
-    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=atol, err_msg=msg)
+    """assert_allclose + a row in the achieved-error report (tests/conftest.py: ParityRecorder)"""
+    import inspect
+    from conftest import parity_close
+    if not msg:
+        ctx = inspect.stack()[1].code_context
+        msg = (ctx[0].strip() if ctx else "")[:100]
+    parity_close(a, b, rtol, atol, msg)
 
 
 def strawberry(golden):
@@ -79,15 +84,34 @@ def test_three_training_steps_match_reference(golden, mode):
                     if gk in g:
                         scale = np.abs(g[gk]).max() + 1e-30
                         close(p_.grad, g[gk], 5e-3, 2e-4 * scale, k_)
+            before = {k_: p_.detach().clone() for k_, p_ in net.named_parameters()} if step == 0 else None
             opt.step()
             if step == 0:
+                # Adam's first step moves a weight by lr * g / (|g| + eps), eps = 1e-15: exactly -lr * sign(g) wherever the
+                # gradient is not round-off noise, and not at all where it is exactly zero.  Checked entry by entry where
+                # the reference's |g| is well above the noise floor, with a tolerance << lr: a tensor that was not updated,
+                # or moved the wrong way, fails.
+                checked = 0
                 for k_, p_ in net.named_parameters():
-                    gk = s + "param_" + k_.replace(".", "_")
-                    if gk in g:
-                        # Adam's first step moves each weight by ~lr*sign(g): entries whose gradient is pure round-off
-                        # noise may flip, so compare at 2*lr absolute
-                        lr = 1e-4 if "hash_tables" in k_ else 1e-3
-                        close(p_, g[gk], 0, 2.01 * lr, k_)
+                    gk, gg = s + "param_" + k_.replace(".", "_"), s + "grad_" + k_.replace(".", "_")
+                    if gk not in g or gg not in g:
+                        continue
+                    lr = 1e-4 if "hash_tables" in k_ else 1e-3
+                    wd = 0.0 if "hash_tables" in k_ else 1e-6
+                    init = g["init_" + k_.replace(".", "_")]
+                    g_eff = g[gg] + wd * init                                 # torch.optim.Adam: L2-style weight decay
+                    floor = 1e-2 * np.abs(g_eff).max()
+                    mask = np.abs(g_eff) > floor
+                    assert mask.any(), k_
+                    moved = (p_.detach() - before[k_]).cpu().numpy()
+                    want_moved = g[gk] - init
+                    assert np.all(np.abs(want_moved[mask]) > 0.9 * lr), k_     # the reference took a full step there
+                    close(moved[mask], want_moved[mask], 0, 0.02 * lr, f"Adam step 1, {k_}: update where |g| > 1e-2 max|g| (lr {lr:g})")
+                    untouched = (g[gg] == 0) & (p_.grad.detach().cpu().numpy() == 0)
+                    if wd == 0.0 and untouched.any():
+                        assert np.all(moved[untouched] == 0), k_               # zero gradient, no weight decay: bit-identical
+                    checked += int(mask.sum())
+                assert checked > 1000
     finally:
         models.should_use_hash_function = False
 

@@ -26,6 +26,8 @@ def _grads(net):
 
 def _make(models, mode):
     mode = mode.replace("_deferred", "")
+    half = mode.endswith("_fp16")
+    mode = mode.replace("_fp16", "")
     models.should_use_hash_function = (mode.startswith("hash"))
     torch.manual_seed(7)
     # "hash_partial": n_max = 1024 at 2^15 pixels leaves the finest levels to the direct form (N_l^2 > 4 P): the exchange
@@ -33,7 +35,12 @@ def _make(models, mode):
     net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=2 ** 14, num_levels=8, n_min=16,
                                           n_max=(1024 if mode == "hash_partial" else 128),
                                           MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
-                                          HPD_out_features=2 ** 14, feature_dim=2, topk_k=4)
+                                          HPD_out_features=2 ** 14, feature_dim=2, topk_k=4,
+                                          table_dtype=(torch.float16 if half else torch.float32))
+    if half:
+        with torch.no_grad():
+            for m in net.encoding._hash_tables:
+                m.weight.mul_(100.0)                  # 1e-2-scale features: gradients well above fp16 subnormals
     net.return_indices = False
     net.dense_probs = False
     if mode == "gngf_frozen":
@@ -64,7 +71,7 @@ def _worker(rank, world, port, mode, ret):
         if mode.startswith("gngf_learning"):      # MSE + KL/JS of the batch-mean distribution (functions.py:243-245)
             mse, kls, coll = loss_fn(rgb, by, probs.shape[-1], probs, empty, empty)
             return train.assemble_loss(mse, kls, coll, 1, 1, 1e-3)
-        return torch.nn.functional.mse_loss(rgb, by)
+        return torch.nn.functional.mse_loss(rgb, by) * (4096.0 if "fp16" in mode else 1.0)     # loss scaling for fp16 gradients
 
     # single-rank reference on the whole batch (rank 0 only)
     ref = None
@@ -86,8 +93,10 @@ def _worker(rank, world, port, mode, ret):
     ok = True
     if rank == 0:
         for k in ref:
-            scale = np.abs(ref[k]).max() + 1e-30
-            ok &= bool(np.abs(got[k] - ref[k]).max() <= 2e-4 * scale)
+            scale = np.abs(ref[k].astype(np.float64)).max() + 1e-30
+            tol = 2e-3 if ref[k].dtype == np.float16 else 2e-4           # fp16 gradients: one rounding each side
+            assert scale > 1e-20, k                                     # a gradient that is all zero proves nothing
+            ok &= bool(np.abs(got[k].astype(np.float64) - ref[k].astype(np.float64)).max() <= tol * scale)
     ret[rank] = (ok, int(reduced_flag))
     parallel.enable_vertex_grid_exchange(1)
     models.should_use_hash_function = False
@@ -96,7 +105,7 @@ def _worker(rank, world, port, mode, ret):
 
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("mode", ["hash", "gngf_frozen", "gngf_learning", "hash_partial", "hash_deferred", "gngf_frozen_deferred",
-                                  "hash_partial_deferred"])
+                                  "hash_partial_deferred", "hash_partial_fp16_deferred", "hash_fp16_deferred", "hash_partial_fp16"])
 def test_two_rank_sharded_step_equals_single_rank(mode):
     mgr = mp.Manager()
     ret = mgr.dict()

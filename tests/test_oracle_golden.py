@@ -6,8 +6,14 @@ import pytest
 from oracle import gngf_oracle as orc
 
 
-def close(a, b, rtol, atol):
-    np.testing.assert_allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), rtol=rtol, atol=atol)
+def close(a, b, rtol, atol, msg=""):
+    """assert_allclose + a row in the achieved-error report (tests/conftest.py: ParityRecorder)"""
+    import inspect
+    from conftest import parity_close
+    if not msg:
+        ctx = inspect.stack()[1].code_context
+        msg = (ctx[0].strip() if ctx else "")[:100]
+    parity_close(a, b, rtol, atol, msg)
 
 
 def test_g1_level_resolutions(golden):
