@@ -2,68 +2,156 @@
 """Headline benchmark: Mpixel/s forward+backward of the hash-grid encoder path (coords -> encoder -> decoder ->
 MSE gradient -> decoder/table gradients) at L=16, F=2, T=2^19, batch 2^20 pixels per GPU (BASELINE.json configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W            # N>1: launched by torch.distributed.run, one rank per GPU
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(WORLD_SIZE set), or bare (`python bench.py --gpus N`): the parent then starts the N ranks itself — before it has touched
+the GPU — and exits with their status.  A WORLD_SIZE that disagrees with --gpus is refused.
 
 One JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP-event timed on the
-launch stream) and `cpu_baseline` (CPU oracle timed on the host cores, bounded sample, rank 0, N=1 only).
+launch stream), `roofline_encoder`, `roofline_step` and `cpu_baseline` (CPU oracle timed on the host cores, bounded
+sample, rank 0, N=1 only).
 
-Modes (all at the same shape; --mode picks the headline, the others are reported in the same line under "modes"):
-  gngf_frozen    GNGF indexing with a frozen HashProbDistribution (the reference's -hwp mode, models.py:364-371):
+Modes (--mode picks the headline; the others are reported in the same line under "modes"):
+  gngf_frozen    cfg2, GNGF indexing with a frozen HashProbDistribution (the reference's -hwp mode, models.py:364-371):
                  the per-vertex top-K table is a function of frozen weights and is rebuilt only when they change.
-  gngf_learning  GNGF indexing with a trainable HPD: every step re-evaluates the HPD on every distinct vertex
+  gngf_learning  cfg2, GNGF indexing with a trainable HPD: every step re-evaluates the HPD on every distinct vertex
                  (MFMA-bound: U x 128 x T contraction) and back-propagates into it.
-  hash           plain spatial-hash indexing (should_use_hash_function=True), BASELINE.json configs[2] shape.
+  hash           cfg2 shape with plain spatial-hash indexing (should_use_hash_function=True) = BASELINE.json configs[2].
+  cfg4_hash      BASELINE.json configs[3] per-GPU shape: synthetic 4096^2 image, T = 2^22, N 16->4095, 2^20 px per GPU.
+  cfg5_hash_fp16 BASELINE.json configs[4] per-GPU shape: synthetic 8192^2 image, F = 4, T = 2^24, fp16 tables, N 16->8191.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-L, F, T, K_TOP = 16, 2, 2 ** 19, 4
-N_MIN, N_MAX = 16, 512
 P_PER_GPU = 2 ** 20
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
 
+SHAPES = {     # L, F, T, K, n_min, n_max, fp16 tables, image
+    "cfg2": dict(L=16, F=2, T=2 ** 19, K=4, n_min=16, n_max=512, half=False, image="strawberry"),
+    "cfg4": dict(L=16, F=2, T=2 ** 22, K=4, n_min=16, n_max=4096, half=False, image=4096),
+    "cfg5": dict(L=16, F=4, T=2 ** 24, K=4, n_min=16, n_max=8192, half=True, image=8192),
+}
+MODES = {"gngf_frozen": "cfg2", "gngf_learning": "cfg2", "hash": "cfg2", "cfg4_hash": "cfg4", "cfg5_hash_fp16": "cfg5"}
 
-def algorithmic_bytes(mode):
-    """algorithmic bytes per pixel (fp32, ~0 reuse assumed)."""
-    sf = 4
-    Ke = 1 if mode == "hash" else K_TOP
-    J = 0 if mode == "hash" else 8 * K_TOP
+
+def is_hash(mode):
+    return mode == "hash" or mode.startswith("cfg")
+
+
+def survey_bytes(mode):
+    """algorithmic bytes per pixel of the per-instance formulation (~0 reuse assumed)."""
+    c = SHAPES[MODES[mode]]
+    L, F, K = c["L"], c["F"], c["K"]
+    sf = 2 if c["half"] else 4
+    Ke = 1 if is_hash(mode) else K
+    J = 0 if is_hash(mode) else 8 * K
     b_fwd = 8 + L * 4 * Ke * F * sf + L * 4 * J + L * F * 4
-    b_bwd = 8 + L * F * 4 + L * 4 * J + 2 * L * 4 * Ke * F * sf + (L * 4 * K_TOP * F * sf if mode != "hash" else 0)
+    b_bwd = 8 + L * F * 4 + L * 4 * J + 2 * L * 4 * Ke * F * sf + (L * 4 * K * F * sf if not is_hash(mode) else 0)
     return b_fwd, b_bwd
 
 
-def strawberry_batch(P, rank, dev):
-    """cfg2 input: the 339x508 strawberry pixel list (coords = (row,col)/507, main.py:50-51), shuffled and repeated
-    to P pixels (the image has only 172 212 pixels)."""
-    img = np.load(os.path.join(ROOT, "tests", "golden", "strawberry_rgb.npz"))["img"]
-    h, w = img.shape[:2]
+def compulsory_bytes(mode):
+    """Bytes per pixel the IMPLEMENTATION must move in the pixel stage of the tiled form: one 16-byte binned
+    pixel record in, one (L*F*4)-byte row of enc out (forward) or of d enc in (backward).  The per-vertex table traffic is
+    ~1 % of it at cfg2 (0.72 M vertex rows against 2^20 pixels x 16 levels) and lives in L2 / Infinity Cache."""
+    c = SHAPES[MODES[mode]]
+    row = c["L"] * c["F"] * 4
+    return 16 + row, 16 + row
+
+
+# ------------------------------------------------------------------------------------------------ launching N ranks
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks as CHILD processes through torch.distributed.run and exit
+    with their status.  Nothing here has touched the GPU (no CUDA call before this point, and none in this process at all)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="gngf_frozen", choices=list(MODES))
+    ap.add_argument("--pixels", type=int, default=P_PER_GPU, help="pixels per GPU per step")
+    ap.add_argument("--no-extra-modes", action="store_true")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2 ** 20)
+    ap.add_argument("--ramp-steps", type=int, default=60, help="untimed steps before the W warm-up steps (clock ramp)")
+    ap.add_argument("--backend", default="nccl", help="rehearsal only: 'gloo' runs the N>1 code path with ranks sharing one GPU")
+    return ap.parse_args(argv)
+
+
+def resolve_world(a, environ=None):
+    """(action, world): 'spawn' when N ranks must be started from here, 'run' otherwise.  Refuses (SystemExit 2) a launcher
+    world size that disagrees with --gpus: the line's n_gpus must be what actually ran."""
+    environ = os.environ if environ is None else environ
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in environ:
+        return ("spawn", a.gpus) if a.gpus > 1 else ("run", 1)
+    world = int(environ["WORLD_SIZE"])
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a mislabelled run",
+              file=sys.stderr)
+        raise SystemExit(2)
+    return "run", world
+
+
+# ------------------------------------------------------------------------------------------------ workload
+def make_batch(cfg_name, P, rank, dev):
+    """cfg2: the 339x508 strawberry pixel list (coords = (row,col)/507, main.py:50-51), shuffled and repeated to P pixels
+    (the image has only 172 212 pixels).  cfg4 / cfg5: P pixels drawn from a synthetic S x S uniform-random RGB image
+    (coords (row, col) / (S - 1)), seed 65535 + rank."""
+    import numpy as np
+    import torch
+    c = SHAPES[cfg_name]
     g = torch.Generator().manual_seed(65535 + rank)
-    sel = torch.cat([torch.randperm(h * w, generator=g) for _ in range(-(-P // (h * w)))])[:P]
-    rows, cols = sel // w, sel % w
-    xy = torch.stack([rows, cols], 1).float() / (max(w, h) - 1)
-    rgb = torch.from_numpy(img.reshape(-1, 3))[sel].float() / 255
-    return xy.to(dev).contiguous(), rgb.to(dev).contiguous(), (h, w)
+    if c["image"] == "strawberry":
+        img = np.load(os.path.join(ROOT, "tests", "golden", "strawberry_rgb.npz"))["img"]
+        h, w = img.shape[:2]
+        sel = torch.cat([torch.randperm(h * w, generator=g) for _ in range(-(-P // (h * w)))])[:P]
+        rows, cols = sel // w, sel % w
+        xy = torch.stack([rows, cols], 1).float() / (max(w, h) - 1)
+        rgb = torch.from_numpy(img.reshape(-1, 3))[sel].float() / 255
+        bounds = (1.0, (min(h, w) - 1) / (max(h, w) - 1))
+    else:
+        S = int(c["image"])
+        rc = torch.randint(0, S, (P, 2), generator=g)
+        xy = rc.float() / (S - 1)
+        rgb = torch.randint(0, 256, (P, 3), generator=g).float() / 255
+        bounds = (1.0, 1.0)
+    return xy.to(dev).contiguous(), rgb.to(dev).contiguous(), bounds
 
 
-def build_model(mode, dev):
+def build_model(mode, dev, bounds):
+    import torch
     from collision_handling_in_instantngp_amd import models
-    models.should_use_hash_function = (mode == "hash")
+    c = SHAPES[MODES[mode]]
+    models.should_use_hash_function = is_hash(mode)
     torch.manual_seed(65535)
-    net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=T, num_levels=L, n_min=N_MIN, n_max=N_MAX,
+    net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=c["T"], num_levels=c["L"], n_min=c["n_min"], n_max=c["n_max"],
                                           MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
-                                          HPD_out_features=T, feature_dim=F, topk_k=K_TOP).to(dev)
+                                          HPD_out_features=c["T"], feature_dim=c["F"], topk_k=c["K"],
+                                          table_dtype=(torch.float16 if c["half"] else torch.float32)).to(dev)
     net.return_indices = False          # the (P,L,4,K) int64 diagnostics tensor (2 GiB/step) is not part of fwd+bwd
     net.dense_probs = False             # the dense (P,L,4,T) tensor is 128 MiB *per pixel* at this shape
     if mode == "gngf_frozen":
@@ -71,51 +159,35 @@ def build_model(mode, dev):
             p.requires_grad = False
         net.compute_pbar = False        # the KL/JS term has no trainable input when the HPD is frozen
     if mode == "gngf_learning":
-        net.coord_bounds = (1.0, 338.0 / 507.0)
+        net.coord_bounds = bounds
     return net, models
 
 
-def make_step(net, models, mode, xy, target, world, exchange=True):
-    """One training step: forward, loss, backward (+ the gradient exchange when world > 1 and `exchange`)."""
+def eager_step_fn(net, mode, xy, target, world, exchange=True):
+    """One training step launched eagerly: forward, loss, backward (+ the gradient exchange when world > 1 and `exchange`)."""
+    import torch
     from collision_handling_in_instantngp_amd import train, parallel
     loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
     params = [p for p in net.parameters() if p.requires_grad]
     empty = torch.tensor([], device=xy.device)
     one = torch.ones((), device=xy.device)          # the seed of backward(): loss.backward() would fill a fresh one per step
+    T = net._hash_table_size
 
     def step():
         for p in params:
             p.grad = None
         rgb, probs, _idx, _c = net(xy, 1.0)
-        if mode == "gngf_learning":
-            mse, kls, coll = loss_fn(rgb, target, T, probs, empty, empty)
-            loss = train.assemble_loss(mse, kls, coll, 1, 1, 1e-3)
-        else:
-            loss = loss_fn._mse(rgb, target)      # frozen HPD / hash: the KL-JS and collision terms carry no gradient
+        mse, kls, coll = loss_fn(rgb, target, None if probs is None else T, probs, empty, empty)
+        loss = train.assemble_loss(mse, kls, coll, 1, 1, 1e-3)    # frozen HPD / hash: the MSE term alone (no p-bar, no gradient in the rest)
         loss.backward(gradient=one)
         if world > 1 and exchange:
             parallel.allreduce_gradients(net, world)
     return step
 
 
-def graphed(step, warm=3):
-    """Capture one whole step (forward + backward, every launch of ours and torch's) into a hipGraph: the step is
-    ~15 short kernels, so eager launch gaps and Python dispatch are a visible fraction of a ~1 ms step."""
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        for _ in range(warm):
-            step()
-    torch.cuda.current_stream().wait_stream(s)
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    # thread_local: other threads of the process (the RCCL watchdog at world > 1) may query events while we capture
-    with torch.cuda.graph(g, capture_error_mode="thread_local"):
-        step()
-    return g.replay
-
-
 def timed(step, steps, warmup, world):
+    import torch
+    import torch.distributed as dist
     for _ in range(warmup):
         step()
     if world > 1:
@@ -144,8 +216,8 @@ ENTRY_NAMES = {"gngf_bin_pixels": "bin_pixels", "gngf_vertex_grid_fwd": "vertex_
 def kernel_times_in_step(eager_step, n=20, warm=3):
     """Average launch duration of every C-ABI entry point INSIDE the training step: HIP events recorded on the stream
     each kernel is launched on (torch's current stream at the call; the helper stream for the vertex stage), bracketing
-    every call of n eagerly launched steps.  `decoder_bwd` = decoder_bwd_kernel + decoder_reduce_kernel,
-    `encode_bwd:tiled` = tiled_bwd_kernel + gather_partials_kernel (one entry point each)."""
+    every call of n eagerly launched steps.  Returns ({name: seconds per step}, {name: calls per step})."""
+    import torch
     from collision_handling_in_instantngp_amd import _lib
     for _ in range(warm):
         eager_step()
@@ -158,57 +230,23 @@ def kernel_times_in_step(eager_step, n=20, warm=3):
         prof = _lib.PROFILE
     finally:
         _lib.PROFILE = None
-    out = {}
+    out, calls = {}, {}
     for name, pairs in prof.items():
         key = ENTRY_NAMES.get(name, name)
         ms = [a.elapsed_time(b) for a, b in pairs]
-        out[key] = out.get(key, 0.0) + sum(ms) / n * 1e-3          # seconds per step (entry points called once per step)
-    return out
-
-
-def kernel_times(net, models, mode, xy, n=20):
-    """Fallback: HIP-event timing (on the launch stream = torch's current stream) of each hot kernel launched alone."""
-    from collision_handling_in_instantngp_amd import ops
-    dev = xy.device
-    n_ls = net._n_ls_flat(dev)
-    tables = net.encoding.packed_tables()
-    P = xy.shape[0]
-    if mode == "hash":
-        ti = w = None
-        vstride = 0
-    else:
-        with torch.no_grad():
-            _tv, ti, w, vstride, _NV, _o = net._frozen_vertex_table(0) if net.hpd_is_frozen() else (None,) * 6
-        if ti is None:
-            return {}
-    genc = torch.randn((P, L * F), device=dev)
-    out = {}
-
-    def ev(fn):
-        for _ in range(3):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n * 1e-3
-
-    for name, fn in ops.encode_kernels(xy, n_ls, net._n_ls_host, tables, ti, w, vstride, genc).items():
-        out[name] = ev(fn)
-    if ops.decoder_fused_ok((ops.ACT_RELU, ops.ACT_RELU, ops.ACT_SIGMOID), net._decoder_params()):
-        drgb = torch.randn((P, 3), device=dev) / P
-        for name, fn in ops.decoder_kernels(genc, net._decoder_params(), False, drgb).items():
-            out[name] = ev(fn)
-    return out
+        out[key] = out.get(key, 0.0) + sum(ms) / n * 1e-3
+        calls[key] = calls.get(key, 0) + len(pairs) / n
+    return out, calls
 
 
 def cpu_baseline(mode, sample_pixels):
     """The CPU oracle timed on this host's cores (kind "port"): forward + backward of the same path (encoder with the
     index table given, decoder, MSE gradient) on a bounded sample of the same workload.  Uses the C/OpenMP
     restatement (oracle/gngf_oracle_c.c) when built, else the numpy one.  Checker code is only timed here."""
+    import numpy as np
     from oracle import gngf_oracle as orc, c_oracle
+    c = SHAPES["cfg2"]
+    L, F, T, K_TOP, N_MIN, N_MAX = c["L"], c["F"], c["T"], c["K"], c["n_min"], c["n_max"]
     rng = np.random.default_rng(0)
     img = np.load(os.path.join(ROOT, "tests", "golden", "strawberry_rgb.npz"))["img"]
     h, w = img.shape[:2]
@@ -222,7 +260,7 @@ def cpu_baseline(mode, sample_pixels):
     db = [np.zeros(dims[i + 1], np.float32) for i in range(3)]
     vstride = N_MAX + 2
     vidx = vw = None
-    if mode != "hash":
+    if not is_hash(mode):
         vidx = rng.integers(0, T, (vstride * vstride, K_TOP)).astype(np.int32)
         vw = rng.random((vstride * vstride, K_TOP), dtype=np.float32)
 
@@ -237,7 +275,7 @@ def cpu_baseline(mode, sample_pixels):
     else:
         def step():
             _, grid = orc.scale_to_grid(x, n_ls)
-            if mode == "hash":
+            if is_hash(mode):
                 idx, probs = orc.spatial_hash(grid.astype(np.int32), T), None
             else:
                 gi = grid.astype(np.int64)
@@ -257,28 +295,31 @@ def cpu_baseline(mode, sample_pixels):
         if dt > 10.0 or n >= 16:
             break
     return {"value": sample_pixels * n / dt / 1e6, "unit": "Mpixel/s", "cores": cores, "kind": "port",
-            "sample": f"{n} x {sample_pixels} strawberry pixels, fwd+bwd (encoder + decoder + MSE grad), {mode} indexing with the "
-                      f"index table given, {impl}, {dt:.1f} s"}
+            "sample": f"{n} x {sample_pixels} strawberry pixels, fwd+bwd (encoder + decoder + MSE grad), "
+                      f"{'hash' if is_hash(mode) else 'vertex-table'} indexing with the index table given, {impl}, {dt:.1f} s"}
+
+
+def learning_flops(stats, Kdim=128):
+    """FLOP of the last HPD layer per learning step: logits (2*U*128*T), dW and dh (the same each), plus the logits GEMM again
+    for every chunk whose logits were not kept from the forward."""
+    U, T = stats["rows_total"], stats["T"]
+    gemm = 2.0 * U * Kdim * T
+    recomputed = stats["chunks"] - stats["chunks_kept"]
+    return 3.0 * gemm + gemm * recomputed / max(1, stats["chunks"]), gemm
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", default="gngf_frozen", choices=["gngf_frozen", "gngf_learning", "hash"])
-    ap.add_argument("--pixels", type=int, default=P_PER_GPU, help="pixels per GPU per step")
-    ap.add_argument("--no-extra-modes", action="store_true")
-    ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2 ** 20)
-    ap.add_argument("--ramp-steps", type=int, default=60, help="untimed steps before the W warm-up steps (clock ramp)")
-    ap.add_argument("--backend", default="nccl", help="rehearsal only: 'gloo' runs the N>1 code path with ranks sharing one GPU")
-    a = ap.parse_args()
+    a = parse_args()
+    action, world = resolve_world(a)
+    if action == "spawn":
+        sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    collective_ranks = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -288,57 +329,77 @@ def main():
         else:
             torch.cuda.set_device(0)
             dist.init_process_group(a.backend)
+        probe = torch.ones(1, device="cuda" if a.backend == "nccl" else "cpu")
+        dist.all_reduce(probe)                       # how many ranks actually take part in a collective
+        collective_ranks = int(probe.item())
+        if collective_ranks != world or dist.get_world_size() != world:
+            raise SystemExit(f"bench.py: {collective_ranks} ranks answered the all-reduce, WORLD_SIZE says {world}")
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
+    from collision_handling_in_instantngp_amd import ops, parallel, train
     if world > 1:
-        from collision_handling_in_instantngp_amd import parallel
         parallel.enable_vertex_grid_exchange(world)
     P = a.pixels
-    xy, target, (h, w) = strawberry_batch(P, rank, dev)
 
     results = {}
     in_graph_ms = None
-    order = [a.mode] + ([m for m in ("gngf_learning", "hash", "gngf_frozen") if m != a.mode] if not a.no_extra_modes else [])
-    kt = {}
-    for mode in order:
+    extra = [] if a.no_extra_modes else [m for m in ("gngf_learning", "hash", "gngf_frozen", "cfg4_hash", "cfg5_hash_fp16") if m != a.mode]
+    kt, kcalls = {}, {}
+    batches = {}
+    for mode in [a.mode] + extra:
         head = mode == a.mode
-        steps, warmup = (a.steps, a.warmup) if head else ((2, 1) if mode == "gngf_learning" else (max(5, a.steps // 2), 2))
-        if mode == "gngf_learning" and head:
+        cfg_name = MODES[mode]
+        if cfg_name not in batches:
+            batches.clear()
+            batches[cfg_name] = make_batch(cfg_name, P, rank, dev)
+        xy, target, bounds = batches[cfg_name]
+        learning = mode == "gngf_learning"
+        steps, warmup = (a.steps, a.warmup) if head else ((2, 1) if learning else (max(5, a.steps // 2), 2))
+        if learning and head:
             steps, warmup = min(a.steps, 5), min(a.warmup, 1)
-        net, models = build_model(mode, dev)
-        step = make_step(net, models, mode, xy, target, world)
+        net, models = build_model(mode, dev, bounds)
+        loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
+        step = eager_step_fn(net, mode, xy, target, world)
         launch = "eager"
-        if a.graph and mode != "gngf_learning":
+        if a.graph and not learning:
             # world > 1: the vertex stage of the encoder backward is deferred behind the dG exchange, so forward + backward
             # hold no collective and replay from one hipGraph; the exchange (RCCL) and the vertex stage follow eagerly.
             try:
                 if world > 1:
-                    from collision_handling_in_instantngp_amd import parallel
                     parallel.defer_vertex_stage(True)
-                    replay = graphed(make_step(net, models, mode, xy, target, world, exchange=False))
-
-                    def step(replay=replay, net=net):
-                        replay()
+                gs = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3)
+                gs(xy, target)                          # captures; the batch stays in the static buffers
+                if world > 1:
+                    def step(gs=gs, net=net):
+                        gs.replay_only()
                         parallel.allreduce_gradients(net, world, keep_tables_flag=True)
                     launch = "hipGraph + eager exchange"
                 else:
-                    step = graphed(step)
+                    step = gs.replay_only
                     launch = "hipGraph"
             except Exception as e:  # pragma: no cover
                 print(f"[bench] graph capture failed ({e!r}); running eagerly", file=sys.stderr)
                 if world > 1:
                     parallel.defer_vertex_stage(False)
-                step = make_step(net, models, mode, xy, target, world)
-        if mode != "gngf_learning":
+                step = eager_step_fn(net, mode, xy, target, world)
+        if not learning:
             # Clock ramp: the chip reaches its steady matrix-core clock only after ~15 ms of sustained work (the same kernel
-            # is ~10 % slower before; tools/perf_decoder_warm.py), and W warm-up steps of 0.65 ms do not get there.  Untimed
+            # is ~10 % slower before; tools/perf_decoder_warm.py), and W warm-up steps of 0.6 ms do not get there.  Untimed
             # steps first (every rank runs the same number, so collectives stay matched), then the W + K of the contract.
             for _ in range(a.ramp_steps):
                 step()
         dt = timed(step, steps, warmup, world)
-        results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
-                         "launch": launch}
+        res = results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+                               "launch": launch, "shape": {k: v for k, v in SHAPES[cfg_name].items()}}
+        if learning:
+            st = dict(ops.HPD_LAST_STATS)
+            fl, gemm = learning_flops(st)
+            res["hpd"] = st
+            res["roofline"] = {"bound": "mfma", "kernel": "last HPD layer: logits / dW / dh GEMMs (128 x T per distinct vertex), fp32 MFMA",
+                               "achieved": fl / (dt / steps) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": fl / (dt / steps) / 1e12 / MFMA_F32_PEAK_TFLOPS, "flop_per_step": fl, "traffic": None,
+                               "note": "whole-step time against the FLOP of the three GEMMs (+ recomputed logits chunks)"}
         if head and launch.startswith("hipGraph"):
             # decoder_bwd's duration INSIDE the replayed graph, from the device clock the kernel stamps (events cannot be
             # recorded in a replayed hipGraph here): one sample per burst of replays.  Every rank runs it: at world > 1 a step
@@ -359,42 +420,45 @@ def main():
             except Exception as e:  # pragma: no cover
                 in_graph_ms = None
                 print(f"[bench] in-graph span unavailable ({e!r})", file=sys.stderr)
-        if head and world == 1 and a.graph and mode != "gngf_learning":
+        if head and world == 1 and a.graph and not learning:
             # the same step with the optimizer in the graph (get_optimizer's Adam as one launch): reported, not the metric
             try:
-                from collision_handling_in_instantngp_amd import train
                 opt = train.get_optimizer(net, 1e-2, 1e-3, 1e-3, 0.0, 0.0, 1e-6)
-                plain = make_step(net, models, mode, xy, target, world)
-
-                def with_opt(plain=plain, opt=opt):
-                    plain()
-                    opt.step()
-                dto = timed(graphed(with_opt), steps, warmup, world)
-                results[mode]["with_adam_ms_per_step"] = dto / steps * 1e3
-                del opt
+                gso = train.GraphedStep(net, loss_fn, opt, 1, 1, 1e-3)
+                gso(xy, target)
+                dto = timed(gso.replay_only, steps, warmup, world)
+                res["with_adam_ms_per_step"] = dto / steps * 1e3
+                del opt, gso
             except Exception as e:  # pragma: no cover
-                results[mode]["with_adam_ms_per_step"] = repr(e)
-        if head and rank == 0 and world == 1:
+                res["with_adam_ms_per_step"] = repr(e)
+        if (head or learning) and rank == 0 and world == 1:
             try:
-                kt = kernel_times_in_step(make_step(net, models, mode, xy, target, world), n=(3 if mode == "gngf_learning" else 20),
-                                          warm=(0 if mode == "gngf_learning" else 3))
+                k_t, k_c = kernel_times_in_step(eager_step_fn(net, mode, xy, target, world), n=(2 if learning else 20),
+                                                warm=(0 if learning else 3))
+                if head:
+                    kt, kcalls = k_t, k_c
+                if learning:
+                    res["entry_ms"] = {k: v * 1e3 for k, v in sorted(k_t.items(), key=lambda kv: -kv[1])[:12]}
+                    gemm_t = sum(v for k, v in k_t.items() if k in ("gngf_linear_fwd", "gngf_gemm_acc", "gngf_linear_bwd_weight", "gngf_hpd_last_bwd"))
+                    if gemm_t > 0 and "roofline" in res:
+                        fl, _ = learning_flops(res["hpd"])
+                        res["roofline"]["gemm_entries_ms"] = gemm_t * 1e3
+                        res["roofline"]["gemm_entries_frac"] = min(1.0, fl / gemm_t / 1e12 / MFMA_F32_PEAK_TFLOPS)
             except Exception as e:  # pragma: no cover
-                kt = {"error": repr(e)}
-        elif head and rank == 0:
-            try:
-                kt = kernel_times(net, models, mode, xy)
-            except Exception as e:  # pragma: no cover
-                kt = {"error": repr(e)}
+                if head:
+                    kt = {"error": repr(e)}
         models.should_use_hash_function = False
         if world > 1:
-            from collision_handling_in_instantngp_amd import parallel as _par
-            _par.defer_vertex_stage(False)
+            parallel.defer_vertex_stage(False)
         del net, step
         torch.cuda.empty_cache()
 
     if rank == 0:
         head = results[a.mode]
-        b_fwd, b_bwd = algorithmic_bytes(a.mode)
+        c = SHAPES[MODES[a.mode]]
+        L, F = c["L"], c["F"]
+        s_fwd, s_bwd = survey_bytes(a.mode)
+        c_fwd, c_bwd = compulsory_bytes(a.mode)
         times = {k: v for k, v in kt.items() if isinstance(v, float)}
         dec_flops = 2 * (L * F * 64 + 64 * 64 + 64 * 3)          # per pixel, forward; backward (dX + dW) = 2x
         traffic = {}
@@ -402,20 +466,28 @@ def main():
         if os.path.isfile(tr_path):
             traffic = json.load(open(tr_path))
 
+        def pmc(name):
+            return (traffic.get(name) or {}).get("hbm_bytes_per_launch")
+
         def roof_of(name):
             t = times[name]
             base = name.split(":")[0]
             if base in ("encode_fwd", "encode_bwd"):
-                per_px = b_fwd if base == "encode_fwd" else b_bwd
+                fwd = base == "encode_fwd"
+                per_px = c_fwd if fwd else c_bwd
                 ach = per_px * P / t / 1e9
                 return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": (traffic.get(name) or {}).get("hbm_bytes_per_launch"),
-                        "avg_launch_ms": t * 1e3, "algorithmic_bytes_per_pixel": per_px, "pixels_per_launch": P}
+                        "frac": min(1.0, ach / HBM_PEAK_GBS), "traffic": pmc(name), "avg_launch_ms": t * 1e3,
+                        "compulsory_bytes_per_pixel": per_px, "pixels_per_launch": P,
+                        "algorithmic_survey_bytes": (s_fwd if fwd else s_bwd) * P,
+                        "note": "achieved/frac use the bytes this implementation must move per launch (binned pixel record + one "
+                                "enc / d-enc row per pixel); SURVEY §8(d)'s per-instance figure (zero reuse, one table gather per "
+                                "pixel-corner) is kept as algorithmic_survey_bytes: the per-vertex de-duplication removes that traffic"}
             if base in ("decoder_fwd", "decoder_bwd"):
                 fl = dec_flops * (1 if base == "decoder_fwd" else 2)
                 ach = fl * P / t / 1e12
                 return {"bound": "mfma", "kernel": name, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": (traffic.get(name) or {}).get("hbm_bytes_per_launch"),
+                        "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc(name),
                         "avg_launch_ms": t * 1e3, "algorithmic_flops_per_pixel": fl, "pixels_per_launch": P}
             return None
 
@@ -426,16 +498,29 @@ def main():
             enc_k = [k for k in ranked if k.startswith("encode_")]
             if enc_k:
                 roof_enc = roof_of(enc_k[0])                      # dominant ENCODER kernel (the HBM-bound part of the path)
+        step_s = head["ms_per_step"] * 1e-3
+        step_flop = 3 * dec_flops * P
+        step_bytes = sum(v for v in (pmc(k) for k in traffic) if v)
+        roof_step = {"flop_per_step": step_flop, "tflops": step_flop / step_s / 1e12 * world / max(world, 1),
+                     "mfma_frac": step_flop / step_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                     "hbm_bytes_per_step_pmc": step_bytes or None,
+                     "hbm_frac": (step_bytes / step_s / 1e9 / HBM_PEAK_GBS) if step_bytes else None,
+                     "survey_bytes_per_step": (s_fwd + s_bwd) * P,
+                     "note": "per GPU; FLOP = decoder fwd + bwd (the encoder has no MFMA work); bytes = sum of the per-kernel PMC traffic "
+                             "in profiles/traffic.json (measured on the round's profiled run of this same command)"}
         line = {
             "metric": "Mpixels/sec fwd+bwd at L=16,F=2,T=2^19", "value": head["mpix_s"], "unit": "Mpixel/s",
             "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"], "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cfg2: strawberry.jpeg 339x508 pixel list shuffled+repeated to 2^20 px/GPU, L=16 F=2 T=2^19 "
-                                   f"K=4 N 16->512, {a.mode} indexing, random-init weights, MSE loss, fwd+bwd (no optimizer)",
+            "config": {"workload": f"{MODES[a.mode]}: " + ("strawberry.jpeg 339x508 pixel list shuffled+repeated to 2^20 px/GPU, L=16 F=2 T=2^19 K=4 N 16->512"
+                                                          if MODES[a.mode] == "cfg2" else f"synthetic {c['image']}^2 image, L={L} F={F} T={c['T']} N {c['n_min']}->{c['n_max']}")
+                                   + f", {a.mode} indexing, random-init weights, MSE loss, fwd+bwd (no optimizer)",
                        "mode": a.mode, "pixels_per_gpu": P, "parallelism": f"dp{world}",
                        "untimed_ramp_steps_before_warmup": a.ramp_steps},
+            "collective_ranks": collective_ranks, "rccl_ranks": (collective_ranks if (world > 1 and a.backend == "nccl") else None),
+            "backend": (a.backend if world > 1 else None),
             "modes": results, "kernel_ms": {k: (v * 1e3 if isinstance(v, float) else v) for k, v in kt.items()},
-            "roofline": roof, "roofline_encoder": roof_enc,
+            "roofline": roof, "roofline_encoder": roof_enc, "roofline_step": roof_step,
         }
         if roof is not None and roof.get("kernel") == "decoder_bwd" and in_graph_ms:
             # same kernel, timed by its own device-clock stamps inside the replayed graph (agrees with rocprofv3's average)
@@ -443,6 +528,7 @@ def main():
             roof["in_graph_frac"] = roof["algorithmic_flops_per_pixel"] * P / (in_graph_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.mode, a.cpu_sample)
+        assert line["n_gpus"] == a.gpus
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -21,8 +21,8 @@ _F = _c.c_float
 SIGNATURES = {
     "gngf_abi_version": [],
     "gngf_hash_indices": [_P, _P, _P, _L, _I, _L, _P],
-    "gngf_mrhe_fwd": [_P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _P],
-    "gngf_mrhe_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _P],
+    "gngf_mrhe_fwd": [_P, _I, _P, _P, _P, _L, _I, _I, _L, _I, _I, _P],
+    "gngf_mrhe_bwd": [_P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _P],
     "gngf_bilinear_fwd": [_P, _P, _P, _P, _L, _I, _I, _P],
     "gngf_bilinear_bwd": [_P, _P, _P, _P, _L, _I, _I, _P],
     "gngf_encode_fwd": [_P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _L, _I, _I, _P],
@@ -64,9 +64,10 @@ SIGNATURES = {
     "gngf_slot_bitmap_words": [_I, _I, _L],
     "gngf_distinct_slot_counts": [_P, _L, _I, _I, _I, _L, _P, _P, _P],
     "gngf_adam_block_elems": [],
-    "gngf_adam_step": [_P, _I, _L, _P, _P, _P, _I, _F, _F, _F, _P],
+    "gngf_adam_step": [_P, _I, _L, _P, _P, _P, _I, _F, _F, _F, _F, _P],
 }
 
+ABI_VERSION = 4
 _RETURNS_INT64 = {"gngf_decoder_hidden_floats", "gngf_slot_bitmap_words"}
 _lib = None
 
@@ -93,8 +94,8 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _L if name in _RETURNS_INT64 else _I
     ver = lib.gngf_abi_version()
-    if ver != 3:
-        raise GngfLibraryError(f"ABI version mismatch: library {ver}, binding 3")
+    if ver != ABI_VERSION:
+        raise GngfLibraryError(f"ABI version mismatch: library {ver}, binding {ABI_VERSION}")
     _lib = lib
     return lib
 

@@ -71,9 +71,9 @@ __device__ __forceinline__ void blend_backward(const float* q, const float* w, i
 // ------------------------------------------------------------------------------------------------
 // a10/a11: MultiResHashEncoding.forward at the module boundary.  One lane per (p, l, v).
 // out (P,F,L,4): for fixed (p,f) the (l,v) plane is contiguous, so a wave writes 256 contiguous bytes per f.
-template <int F>
+template <int F, typename TT>
 __global__ void __launch_bounds__(kBlock)
-mrhe_fwd_kernel(const float* __restrict__ tables, const int64_t* __restrict__ idx, const float* __restrict__ probs,
+mrhe_fwd_kernel(const TT* __restrict__ tables, const int64_t* __restrict__ idx, const float* __restrict__ probs,
                 float* __restrict__ out, int64_t total /* P*L*4 */, int L, int64_t T, int K, int blend) {
   const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (gid >= total) return;
@@ -81,23 +81,23 @@ mrhe_fwd_kernel(const float* __restrict__ tables, const int64_t* __restrict__ id
   const int64_t p = gid / L4;
   const int lv = (int)(gid - p * L4);
   const int l = lv >> 2;
-  const float* tab = tables + (int64_t)l * T * F;
+  const TT* tab = tables + (int64_t)l * T * F;
   float acc[F];
 #pragma unroll
   for (int f = 0; f < F; ++f) acc[f] = 0.f;
   if (K == 0) {
     const int64_t row = idx[gid];
-    const float* r = tab + row * F;
+    const TT* r = tab + row * F;
 #pragma unroll
-    for (int f = 0; f < F; ++f) acc[f] = r[f];
+    for (int f = 0; f < F; ++f) acc[f] = tload(r + f);
   } else {
     float q[GNGF_MAX_TOPK], w[GNGF_MAX_TOPK];
     for (int k = 0; k < K; ++k) q[k] = probs[gid * K + k];
     blend_weights<GNGF_MAX_TOPK>(q, K, blend, w);
     for (int k = 0; k < K; ++k) {
-      const float* r = tab + idx[gid * K + k] * F;
+      const TT* r = tab + idx[gid * K + k] * F;
 #pragma unroll
-      for (int f = 0; f < F; ++f) acc[f] += r[f] * w[k];
+      for (int f = 0; f < F; ++f) acc[f] += tload(r + f) * w[k];
     }
   }
   float* o = out + p * (int64_t)F * L4 + lv;
@@ -105,9 +105,9 @@ mrhe_fwd_kernel(const float* __restrict__ tables, const int64_t* __restrict__ id
   for (int f = 0; f < F; ++f) o[(int64_t)f * L4] = acc[f];
 }
 
-template <int F>
+template <int F, typename TT>
 __global__ void __launch_bounds__(kBlock)
-mrhe_bwd_kernel(const float* __restrict__ tables, const int64_t* __restrict__ idx, const float* __restrict__ probs,
+mrhe_bwd_kernel(const TT* __restrict__ tables, const int64_t* __restrict__ idx, const float* __restrict__ probs,
                 const float* __restrict__ gout, float* __restrict__ dtables, float* __restrict__ dprobs,
                 int64_t total, int L, int64_t T, int K, int blend) {
   const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -116,7 +116,7 @@ mrhe_bwd_kernel(const float* __restrict__ tables, const int64_t* __restrict__ id
   const int64_t p = gid / L4;
   const int lv = (int)(gid - p * L4);
   const int l = lv >> 2;
-  const float* tab = tables + (int64_t)l * T * F;
+  const TT* tab = tables + (int64_t)l * T * F;
   float* dtab = dtables + (int64_t)l * T * F;
   float g[F];
   const float* gp = gout + p * (int64_t)F * L4 + lv;
@@ -133,11 +133,11 @@ mrhe_bwd_kernel(const float* __restrict__ tables, const int64_t* __restrict__ id
   blend_weights<GNGF_MAX_TOPK>(q, K, blend, w);
   for (int k = 0; k < K; ++k) {
     const int64_t row = idx[gid * K + k];
-    const float* r = tab + row * F;
+    const TT* r = tab + row * F;
     float dot = 0.f;
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-      dot += g[f] * r[f];
+      dot += g[f] * tload(r + f);
       atomicAdd(dtab + row * F + f, g[f] * w[k]);
     }
     d[k] = dot;
@@ -277,6 +277,11 @@ encode_bwd_kernel(const float2* __restrict__ xy, const TT* __restrict__ tables,
 
 using namespace gngf;
 
+#define DISPATCH_TT(dt, ...)                                                          \
+  if ((dt) == GNGF_FEAT_F32) { using TT = float; __VA_ARGS__; }                       \
+  else if ((dt) == GNGF_FEAT_F16) { using TT = __half; __VA_ARGS__; }                 \
+  else return (int)hipErrorInvalidValue;
+
 #define DISPATCH_F(F, ...)                          \
   switch (F) {                                      \
     case 1: { constexpr int kF = 1; __VA_ARGS__; } break; \
@@ -299,19 +304,20 @@ extern "C" int gngf_hash_indices(const float* xy, const int32_t* n_ls, int64_t* 
   GNGF_RETURN_LAUNCH();
 }
 
-extern "C" int gngf_mrhe_fwd(const float* tables, const int64_t* idx, const float* probs, float* out,
+extern "C" int gngf_mrhe_fwd(const void* tables, int feat_dtype, const int64_t* idx, const float* probs, float* out,
                              int64_t P, int L, int F, int64_t T, int K, int blend, void* stream) {
   GNGF_CHECK_ARG(P >= 0 && L > 0 && L <= GNGF_MAX_LEVELS && T > 0 && K >= 0 && K <= GNGF_MAX_TOPK);
   GNGF_CHECK_ARG(blend >= 0 && blend <= 2);
   if (P == 0) return 0;
   GNGF_CHECK_ARG(tables && idx && out && (K == 0 || probs));
   const int64_t total = P * L * 4;
-  DISPATCH_F(F, (mrhe_fwd_kernel<kF><<<dim3((unsigned)ceil_div(total, kBlock)), dim3(kBlock), 0, as_stream(stream)>>>(
-                    tables, idx, probs, out, total, L, T, K, blend)));
+  DISPATCH_TT(feat_dtype, DISPATCH_F(F, (mrhe_fwd_kernel<kF, TT><<<dim3((unsigned)ceil_div(total, kBlock)), dim3(kBlock), 0,
+                                                                  as_stream(stream)>>>(
+                              static_cast<const TT*>(tables), idx, probs, out, total, L, T, K, blend))));
   GNGF_RETURN_LAUNCH();
 }
 
-extern "C" int gngf_mrhe_bwd(const float* tables, const int64_t* idx, const float* probs, const float* gout,
+extern "C" int gngf_mrhe_bwd(const void* tables, int feat_dtype, const int64_t* idx, const float* probs, const float* gout,
                              float* dtables, float* dprobs, int64_t P, int L, int F, int64_t T, int K, int blend,
                              void* stream) {
   GNGF_CHECK_ARG(P >= 0 && L > 0 && L <= GNGF_MAX_LEVELS && T > 0 && K >= 0 && K <= GNGF_MAX_TOPK);
@@ -319,8 +325,9 @@ extern "C" int gngf_mrhe_bwd(const float* tables, const int64_t* idx, const floa
   if (P == 0) return 0;
   GNGF_CHECK_ARG(tables && idx && gout && dtables && (K == 0 || probs));
   const int64_t total = P * L * 4;
-  DISPATCH_F(F, (mrhe_bwd_kernel<kF><<<dim3((unsigned)ceil_div(total, kBlock)), dim3(kBlock), 0, as_stream(stream)>>>(
-                    tables, idx, probs, gout, dtables, dprobs, total, L, T, K, blend)));
+  DISPATCH_TT(feat_dtype, DISPATCH_F(F, (mrhe_bwd_kernel<kF, TT><<<dim3((unsigned)ceil_div(total, kBlock)), dim3(kBlock), 0,
+                                                                  as_stream(stream)>>>(
+                              static_cast<const TT*>(tables), idx, probs, gout, dtables, dprobs, total, L, T, K, blend))));
   GNGF_RETURN_LAUNCH();
 }
 
@@ -345,11 +352,6 @@ extern "C" int gngf_bilinear_bwd(const float* xy, const int32_t* n_ls, const flo
                     reinterpret_cast<const float2*>(xy), n_ls, genc, dfeats, total, L)));
   GNGF_RETURN_LAUNCH();
 }
-
-#define DISPATCH_TT(dt, ...)                                                          \
-  if ((dt) == GNGF_FEAT_F32) { using TT = float; __VA_ARGS__; }                       \
-  else if ((dt) == GNGF_FEAT_F16) { using TT = __half; __VA_ARGS__; }                 \
-  else return (int)hipErrorInvalidValue;
 
 extern "C" int gngf_encode_fwd(const float* xy, const void* tables_v, int feat_dtype, const int32_t* vert_idx, const float* vert_w,
                                const int32_t* n_ls, float* enc, int64_t P, int L, int F, int64_t T, int K,

@@ -9,22 +9,24 @@
 
 namespace gngf {
 
-struct AdamSegment {        // mirrored by the host packer (train.py); 56 bytes
-  float* param;
-  const float* grad;
+struct AdamSegment {        // mirrored by the host packer (train.py); 64 bytes
+  void* param;              // fp32, or fp16 storage when flags & 1 (BASELINE config 5: fp16 level tables)
+  const void* grad;         // same type as param
   float* exp_avg;
   float* exp_avg_sq;
+  float* master;            // fp16 storage only: the fp32 master copy the update is applied to (param = round(master))
   int64_t n;
   int64_t first_block;
   int32_t group;
-  int32_t pad;
+  int32_t flags;            // bit 0: param / grad are __half
 };
-static_assert(sizeof(AdamSegment) == 56, "host packer layout");
+static_assert(sizeof(AdamSegment) == 64, "host packer layout");
 
 struct AdamHyper {
   float lr[GNGF_ADAM_MAX_GROUPS];
   float weight_decay[GNGF_ADAM_MAX_GROUPS];
   float beta1, beta2, eps;
+  float inv_grad_scale;     // gradients are multiplied by this first (1 / loss scale of fp16 training; 1 = off)
 };
 
 constexpr int kAdamBlock = 2048;     // elements per block: 256 threads x 2 x float4
@@ -60,30 +62,68 @@ adam_multi_kernel(const AdamSegment* __restrict__ segs, int nseg, const float* _
   const AdamSegment sg = segs[s_seg];
   const float step_size = s_corr[0], bc2_sqrt = s_corr[1];
   const float wd = h.weight_decay[sg.group];
+  const float gs = h.inv_grad_scale;
   const int64_t e0 = (blk - sg.first_block) * kAdamBlock;
-  const bool vec = ((reinterpret_cast<uintptr_t>(sg.param) | reinterpret_cast<uintptr_t>(sg.grad) |
+  if (sg.flags & 1) {
+    // fp16 storage: fp16 gradient in, fp32 master weight + fp32 moments updated, fp16 parameter = round(master)
+    __half* ph = static_cast<__half*>(sg.param);
+    const __half* gh = static_cast<const __half*>(sg.grad);
+    const bool vec = ((reinterpret_cast<uintptr_t>(ph) | reinterpret_cast<uintptr_t>(gh)) & 7) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(sg.master) | reinterpret_cast<uintptr_t>(sg.exp_avg) |
+                       reinterpret_cast<uintptr_t>(sg.exp_avg_sq)) & 15) == 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int64_t e = e0 + (int64_t)(half * 256 + threadIdx.x) * 4;
+      if (e >= sg.n) continue;
+      if (vec && e + 4 <= sg.n) {
+        float4 p = *reinterpret_cast<float4*>(sg.master + e);
+        float4 m = *reinterpret_cast<float4*>(sg.exp_avg + e);
+        float4 v = *reinterpret_cast<float4*>(sg.exp_avg_sq + e);
+        const __half2 g01 = *reinterpret_cast<const __half2*>(gh + e), g23 = *reinterpret_cast<const __half2*>(gh + e + 2);
+        adam_one(p.x, __low2float(g01) * gs, m.x, v.x, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
+        adam_one(p.y, __high2float(g01) * gs, m.y, v.y, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
+        adam_one(p.z, __low2float(g23) * gs, m.z, v.z, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
+        adam_one(p.w, __high2float(g23) * gs, m.w, v.w, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
+        *reinterpret_cast<float4*>(sg.master + e) = p;
+        *reinterpret_cast<float4*>(sg.exp_avg + e) = m;
+        *reinterpret_cast<float4*>(sg.exp_avg_sq + e) = v;
+        *reinterpret_cast<__half2*>(ph + e) = __floats2half2_rn(p.x, p.y);
+        *reinterpret_cast<__half2*>(ph + e + 2) = __floats2half2_rn(p.z, p.w);
+      } else {
+        for (int64_t q = e; q < e + 4 && q < sg.n; ++q) {
+          float p = sg.master[q], m = sg.exp_avg[q], v = sg.exp_avg_sq[q];
+          adam_one(p, __half2float(gh[q]) * gs, m, v, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
+          sg.master[q] = p; sg.exp_avg[q] = m; sg.exp_avg_sq[q] = v; ph[q] = __float2half_rn(p);
+        }
+      }
+    }
+    return;
+  }
+  float* pf = static_cast<float*>(sg.param);
+  const float* gf = static_cast<const float*>(sg.grad);
+  const bool vec = ((reinterpret_cast<uintptr_t>(pf) | reinterpret_cast<uintptr_t>(gf) |
                      reinterpret_cast<uintptr_t>(sg.exp_avg) | reinterpret_cast<uintptr_t>(sg.exp_avg_sq)) & 15) == 0;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     const int64_t e = e0 + (int64_t)(half * 256 + threadIdx.x) * 4;
     if (e >= sg.n) continue;
     if (vec && e + 4 <= sg.n) {
-      float4 p = *reinterpret_cast<float4*>(sg.param + e);
-      const float4 g = *reinterpret_cast<const float4*>(sg.grad + e);
+      float4 p = *reinterpret_cast<float4*>(pf + e);
+      const float4 g = *reinterpret_cast<const float4*>(gf + e);
       float4 m = *reinterpret_cast<float4*>(sg.exp_avg + e);
       float4 v = *reinterpret_cast<float4*>(sg.exp_avg_sq + e);
-      adam_one(p.x, g.x, m.x, v.x, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
-      adam_one(p.y, g.y, m.y, v.y, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
-      adam_one(p.z, g.z, m.z, v.z, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
-      adam_one(p.w, g.w, m.w, v.w, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
-      *reinterpret_cast<float4*>(sg.param + e) = p;
+      adam_one(p.x, g.x * gs, m.x, v.x, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
+      adam_one(p.y, g.y * gs, m.y, v.y, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
+      adam_one(p.z, g.z * gs, m.z, v.z, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
+      adam_one(p.w, g.w * gs, m.w, v.w, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
+      *reinterpret_cast<float4*>(pf + e) = p;
       *reinterpret_cast<float4*>(sg.exp_avg + e) = m;
       *reinterpret_cast<float4*>(sg.exp_avg_sq + e) = v;
     } else {
       for (int64_t q = e; q < e + 4 && q < sg.n; ++q) {
-        float p = sg.param[q], m = sg.exp_avg[q], v = sg.exp_avg_sq[q];
-        adam_one(p, sg.grad[q], m, v, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
-        sg.param[q] = p; sg.exp_avg[q] = m; sg.exp_avg_sq[q] = v;
+        float p = pf[q], m = sg.exp_avg[q], v = sg.exp_avg_sq[q];
+        adam_one(p, gf[q] * gs, m, v, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
+        pf[q] = p; sg.exp_avg[q] = m; sg.exp_avg_sq[q] = v;
       }
     }
   }
@@ -95,12 +135,14 @@ using namespace gngf;
 
 extern "C" int gngf_adam_block_elems(void) { return kAdamBlock; }
 
-// One Adam step over `nseg` tensors.  segments: device array of 56-byte records {param, grad, exp_avg, exp_avg_sq, n,
-// first_block, group, pad} with first_block = running sum of ceil(n / gngf_adam_block_elems()); total_blocks = that sum.
+// One Adam step over `nseg` tensors.  segments: device array of 64-byte records {param, grad, exp_avg, exp_avg_sq, master,
+// n, first_block, group, flags} with first_block = running sum of ceil(n / gngf_adam_block_elems()); total_blocks = that
+// sum.  flags bit 0: param and grad are fp16 and `master` is the fp32 master copy (else master is ignored).
 // step: device float, incremented by this call before it is used (t = 1 on the first step).  lr / weight_decay: host
-// arrays of ngroups <= GNGF_ADAM_MAX_GROUPS values.
+// arrays of ngroups <= GNGF_ADAM_MAX_GROUPS values.  inv_grad_scale multiplies every gradient first (1 / loss scale).
 extern "C" int gngf_adam_step(const void* segments, int nseg, int64_t total_blocks, float* step, const float* lr,
-                              const float* weight_decay, int ngroups, float beta1, float beta2, float eps, void* stream) {
+                              const float* weight_decay, int ngroups, float beta1, float beta2, float eps,
+                              float inv_grad_scale, void* stream) {
   GNGF_CHECK_ARG(nseg >= 0 && total_blocks >= 0 && ngroups > 0 && ngroups <= GNGF_ADAM_MAX_GROUPS && total_blocks < INT32_MAX);
   GNGF_CHECK_ARG(step && lr && weight_decay);
   hipStream_t s = as_stream(stream);
@@ -112,7 +154,7 @@ extern "C" int gngf_adam_step(const void* segments, int nseg, int64_t total_bloc
     h.lr[g] = g < ngroups ? lr[g] : 0.f;
     h.weight_decay[g] = g < ngroups ? weight_decay[g] : 0.f;
   }
-  h.beta1 = beta1; h.beta2 = beta2; h.eps = eps;
+  h.beta1 = beta1; h.beta2 = beta2; h.eps = eps; h.inv_grad_scale = inv_grad_scale;
   adam_multi_kernel<<<dim3((unsigned)total_blocks), dim3(256), 0, s>>>(static_cast<const AdamSegment*>(segments), nseg, step, h);
   GNGF_RETURN_LAUNCH();
 }

@@ -150,9 +150,6 @@ class MultiResHashEncoding(nn.Module):
         """hashed_indices (P,L,4) [hash] or (P,L,4,K) [GNGF] int64; hashed_probs_topk (P,L,4,K) | None -> (P,F,L,4)."""
         base = self.packed_tables()
         tables = ops.TableViewFunction.apply(base, self, *[m.weight for m in self._hash_tables])
-        if base.dtype != torch.float32:
-            raise TypeError("MultiResHashEncoding.forward (the per-instance module boundary) is fp32 only; fp16 tables run "
-                            "through GeneralNeuralGaugeFields' fused encoder")
         if should_use_hash_function:
             if hashed_indices.dim() != 3:
                 raise ValueError("hash mode expects indices of shape (P, L, 4)")

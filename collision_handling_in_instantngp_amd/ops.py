@@ -57,7 +57,7 @@ class MrheFunction(torch.autograd.Function):
         if K:
             probs = _c(probs)
         out = torch.empty((P, F, L, 4), dtype=_f32, device=tables.device)
-        call("gngf_mrhe_fwd", ptr(tables, _f32, "tables"), ptr(idx, _i64, "indices"),
+        call("gngf_mrhe_fwd", *_tab(tables), ptr(idx, _i64, "indices"),
              ptr(probs if K else None, _f32, "probs"), ptr(out), P, L, F, T, K, blend_code, stream_ptr())
         ctx.save_for_backward(tables, idx, probs if K else None)
         ctx.cfg = (P, L, F, T, K, blend_code)
@@ -68,11 +68,11 @@ class MrheFunction(torch.autograd.Function):
         tables, idx, probs = ctx.saved_tensors
         P, L, F, T, K, blend_code = ctx.cfg
         gout = _c(gout)
-        dtables = torch.zeros_like(tables)
+        dtables = _grad_buffer(tables)
         dprobs = torch.empty_like(probs) if (K and ctx.needs_input_grad[2]) else None
-        call("gngf_mrhe_bwd", ptr(tables), ptr(idx), ptr(probs), ptr(gout, _f32, "grad"), ptr(dtables), ptr(dprobs),
+        call("gngf_mrhe_bwd", *_tab(tables), ptr(idx), ptr(probs), ptr(gout, _f32, "grad"), ptr(dtables), ptr(dprobs),
              P, L, F, T, K, blend_code, stream_ptr())
-        return dtables, None, dprobs, None
+        return _grad_out(dtables, tables), None, dprobs, None
 
 
 class BilinearFunction(torch.autograd.Function):
@@ -232,6 +232,7 @@ def expand_vertex_table(xy, n_ls, vstride, NV, src_idx=None, src_val=None, want_
 # device memory that must remain after keeping a chunk.
 HPD_Z_CACHE_BYTES = 216 << 30
 HPD_Z_CACHE_RESERVE = 40 << 30
+HPD_LAST_STATS = {}          # shape of the last chunked HPD evaluation (bench.py prices the step's GEMM FLOP with it)
 
 
 class HpdVertexFunction(torch.autograd.Function):
@@ -293,6 +294,7 @@ class HpdVertexFunction(torch.autograd.Function):
                      ptr(mw[u0:u0 + n] if pbar is not None else None), L if pbar is not None else 0, ptr(pbar), n, T, K, stream_ptr())
         if pbar is not None and DP_MEAN is not None:
             DP_MEAN(pbar)      # the loss is a nonlinear function of the batch mean: average BEFORE the log (SURVEY §8e ii)
+        HPD_LAST_STATS.update(rows_total=int(NV), T=int(T), rows_per_chunk=int(rows), chunks=-(-NV // rows), chunks_kept=len(zcache))
         ctx.cfg = (NV, vstride, K, rows, n_layers, T, keep_probs)
         ctx.zcache = zcache
         ctx.save_for_backward(ti, mw, probs, rowstat, *params)

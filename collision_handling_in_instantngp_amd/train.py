@@ -54,6 +54,10 @@ class Loss(torch.nn.Module):
         collisions_losses = collisions / (min_possible_collisions + self._delta)
         if isinstance(prob, VertexDistribution):
             pbar = prob.pbar
+            if pbar is None:
+                # net.compute_pbar = False: the caller opted out of the batch-mean distribution (with a frozen HPD the
+                # distribution term is a constant without gradient) — the term is not evaluated, not faked
+                return mse_loss, None, collisions_losses
         else:
             pbar = prob.sum(0).sum(1) / (prob.shape[0] * prob.shape[2])          # (L,N)
         return mse_loss, self.js_kl_rows(pbar), collisions_losses
@@ -66,7 +70,7 @@ class FusedAdam(torch.optim.Optimizer):
     reference's torch.optim.Adam load here and vice versa.  The step count is a device tensor advanced by the kernel:
     a step needs no host synchronisation and can be captured in a hipGraph together with forward and backward."""
 
-    DTYPES = (torch.float32,)
+    DTYPES = (torch.float32, torch.float16)
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
@@ -74,6 +78,7 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("at most 4 parameter groups (GNGF_ADAM_MAX_GROUPS)")
         if len({(g["betas"], g["eps"]) for g in self.param_groups}) != 1:
             raise ValueError("betas and eps are shared by all groups (as in the reference's get_optimizer)")
+        self.grad_scale = 1.0        # loss scale of fp16 training: every gradient is divided by it inside the kernel
         self._step = None            # device float: steps taken
         self._table = None           # device byte tensor: the packed segment list
         self._host = None            # ring of [pinned staging buffer, event of the upload that last read it]
@@ -83,18 +88,26 @@ class FusedAdam(torch.optim.Optimizer):
         self._table_key = None
         self._total_blocks = 0
 
+    _RECORD = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("w", "<u8"), ("n", "<i8"), ("first", "<i8"),
+                        ("group", "<i4"), ("flags", "<i4")])          # csrc/optim.hip: AdamSegment (64 bytes)
+
     def _segments(self):
+        """fp32 parameters: torch.optim.Adam's state layout.  fp16 parameters (fp16 level tables, BASELINE config 5): fp32
+        moments plus `master`, the fp32 copy the update is applied to; the fp16 parameter is its rounding."""
         segs = []
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
                 if p.grad is None:
                     continue
-                if p.grad.is_sparse or p.dtype != torch.float32 or not p.is_cuda:
-                    raise RuntimeError("FusedAdam handles dense fp32 device parameters")
+                if p.grad.is_sparse or p.dtype not in self.DTYPES or not p.is_cuda or p.grad.dtype != p.dtype:
+                    raise RuntimeError("FusedAdam handles dense fp32 / fp16 device parameters (gradient of the same type)")
+                half = p.dtype == torch.float16
                 st = self.state[p]
                 if "exp_avg" not in st:
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg"] = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+                    st["exp_avg_sq"] = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+                if half and "master" not in st:
+                    st["master"] = p.detach().float().contiguous()
                 if self._step is None:
                     prev = st.get("step", 0.0)
                     self._step = torch.full((), float(prev), dtype=torch.float32, device=p.device)
@@ -103,8 +116,18 @@ class FusedAdam(torch.optim.Optimizer):
                 for t_ in (p, st["exp_avg"], st["exp_avg_sq"]):
                     if not t_.is_contiguous():
                         raise RuntimeError("FusedAdam needs contiguous parameters and moments")
-                segs.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), gi, g))
+                segs.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                             st["master"].data_ptr() if half else 0, p.numel(), gi, int(half), g))
         return segs
+
+    def prepare_capture(self):
+        """Sets aside the pinned staging buffers a hipGraph capture of step() needs (pinned memory cannot be allocated while a
+        stream captures) WITHOUT taking a step: call after one backward pass, before capturing."""
+        segs = self._segments()
+        size = len(segs) * self._RECORD.itemsize
+        have = [h for h in self._spares if h.numel() == size]
+        for _ in range(max(0, 2 - len(have))):
+            self._spares.append(torch.empty((size,), dtype=torch.uint8, pin_memory=True))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -117,16 +140,15 @@ class FusedAdam(torch.optim.Optimizer):
         segs = self._segments()
         if not segs:
             return loss
-        key = tuple(s_[:6] for s_ in segs)
+        key = tuple(s_[:8] for s_ in segs)
         capturing = torch.cuda.is_current_stream_capturing()
         table, total_blocks = self._table, self._total_blocks
         if capturing or key != self._table_key:    # pointers moved (first step, new gradient buffers, loaded state)
             blk = query("gngf_adam_block_elems")
-            rec = np.zeros(len(segs), dtype=np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"),
-                                                      ("first", "<i8"), ("group", "<i4"), ("pad", "<i4")]))
+            rec = np.zeros(len(segs), dtype=self._RECORD)
             total_blocks = 0
-            for i, (pp, gp, mp, vp, n, gi, _keep) in enumerate(segs):
-                rec[i] = (pp, gp, mp, vp, n, total_blocks, gi, 0)
+            for i, (pp, gp, mp, vp, wp, n, gi, flags, _keep) in enumerate(segs):
+                rec[i] = (pp, gp, mp, vp, wp, n, total_blocks, gi, flags)
                 total_blocks += -(-n // blk)
             raw = rec.view(np.uint8).reshape(-1)
             dev = self._step.device
@@ -134,10 +156,10 @@ class FusedAdam(torch.optim.Optimizer):
             # their own addresses) the copy becomes a node of the graph, so the captured step owns a private staging buffer
             # and device table that eager steps never touch.
             if capturing:
-                # pinned memory cannot be allocated while a stream captures: take one of the buffers set aside by an eager step
+                # pinned memory cannot be allocated while a stream captures: take one of the buffers set aside beforehand
                 spare = [h for h in self._spares if h.numel() == raw.size]
                 if not spare:
-                    raise RuntimeError("FusedAdam: run one eager step() before capturing a step in a graph")
+                    raise RuntimeError("FusedAdam: call prepare_capture() (or run one eager step()) before capturing a step in a graph")
                 host = spare[0]
                 self._spares.remove(host)
                 host.numpy()[:] = raw
@@ -166,7 +188,7 @@ class FusedAdam(torch.optim.Optimizer):
         wd = (ctypes.c_float * ng)(*[float(g["weight_decay"]) for g in self.param_groups])
         b1, b2 = self.param_groups[0]["betas"]
         call("gngf_adam_step", ptr(table), len(segs), total_blocks, ptr(self._step), lr, wd, ng, float(b1), float(b2),
-             float(self.param_groups[0]["eps"]), stream_ptr())
+             float(self.param_groups[0]["eps"]), 1.0 / float(self.grad_scale), stream_ptr())
         return loss
 
     def state_dict(self):
@@ -178,6 +200,17 @@ class FusedAdam(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        # torch casts loaded state to the parameter's dtype: the fp32 moments / master copy of an fp16 parameter are put back
+        from itertools import chain
+        ids = list(chain.from_iterable(g["params"] for g in state_dict["param_groups"]))
+        params = list(chain.from_iterable(g["params"] for g in self.param_groups))
+        for i, p in zip(ids, params):
+            src = state_dict["state"].get(i)
+            if src is None or p.dtype != torch.float16:
+                continue
+            for k in ("exp_avg", "exp_avg_sq", "master"):
+                if k in src:
+                    self.state[p][k] = src[k].detach().to(device=p.device, dtype=torch.float32).clone()
         self._step = None                          # re-read from the loaded per-parameter `step`
         self._table_key = None
 
@@ -205,41 +238,215 @@ def get_optimizer(net, encoding_lr, HPD_lr, MLP_lr, encoding_weight_decay, HPD_w
 def assemble_loss(mse, kls, colls, l_mse, l_js_kl, l_collisions):
     """reference functions.py:243-245, including the '+1 per level while previous_collisions is empty' quirk."""
     loss = l_mse * mse
-    if not models.should_use_hash_function:
+    if not models.should_use_hash_function and kls is not None:
         loss = loss + ((l_js_kl * kls) + (l_collisions * colls if colls.nelement() != 0 else 1)).sum(0)
     return loss
 
 
-def train_step(net, loss_fn, optimizer, x, target, w, h, l_mse, l_js_kl, l_collisions, batch_percentage=1.0,
-               should_shuffle=True, shuffled_indices=None, previous_collisions=None, previous_min_possible_collisions=None):
-    """One epoch = ceil(1/batch_percentage) mini-batches of zero_grad -> net -> Loss -> weighted sum -> backward -> step
-    (reference functions.py:183-281).  Returns (mean loss, mean mse, outputs (P,3) in batch order)."""
+class GraphedStep:
+    """One optimisation step — zero_grad, net(batch), Loss, the weighted sum of functions.py:243-245, backward and
+    optimizer.step() — captured ONCE into a hipGraph per batch shape and replayed for every further batch: the step is
+    ~15 short kernels, so eager launch gaps and Python dispatch are a visible fraction of it (0.72 ms eager vs 0.61 ms
+    replayed at 2^20 pixels).  Batches are copied into static device buffers; results come back in static buffers that
+    the next replay overwrites.
+
+        gs = GraphedStep(net, loss_fn, optimizer, l_mse, l_js_kl, l_collisions, coord_bounds=(max_row, max_col))
+        r = gs(batch_x, batch_target)            # r.out (P,C), r.loss, r.mse, r.kls, r.colls, r.idx
+
+    optimizer: a FusedAdam (its step is capturable and needs no host synchronisation) or None (forward + backward only).
+    GNGF indexing with a trainable HPD, or with the dense distribution returned, needs `coord_bounds` (an upper bound of
+    the coordinates of EVERY batch) so that the vertex rectangle is fixed and no device->host read happens in the step."""
+
+    class Result:
+        __slots__ = ("out", "probs", "idx", "loss", "mse", "kls", "colls")
+
+    def __init__(self, net, loss_fn, optimizer, l_mse=1.0, l_js_kl=1.0, l_collisions=1e-3, batch_percentage=1.0,
+                 coord_bounds=None, warm=2):
+        if optimizer is not None and not isinstance(optimizer, FusedAdam):
+            raise TypeError("GraphedStep captures FusedAdam.step(); torch.optim.Adam's step is not capturable here")
+        self.net, self.loss_fn, self.optimizer = net, loss_fn, optimizer
+        self.weights = (l_mse, l_js_kl, l_collisions)
+        self.batch_percentage = batch_percentage
+        self.warm = int(warm)
+        if coord_bounds is not None:
+            net.coord_bounds = (float(coord_bounds[0]), float(coord_bounds[1]))
+        self._graphs = {}
+
+    def _body(self, st):
+        net, (l_mse, l_js_kl, l_collisions) = self.net, self.weights
+        for p in st["params"]:
+            p.grad = None
+        out, probs, idx, _counts = net(st["x"], self.batch_percentage, should_calc_counts=False)
+        mse, kls, colls = self.loss_fn(out, st["y"], None if probs is None else probs.shape[-1], probs, st["pc"], st["pm"])
+        loss = assemble_loss(mse, kls, colls, l_mse, l_js_kl, l_collisions)
+        loss.backward(gradient=st["one"].to(loss.dtype))
+        r = GraphedStep.Result()
+        r.out, r.probs, r.idx, r.loss, r.mse, r.kls, r.colls = out.detach(), probs, idx, loss.detach(), mse.detach(), kls, colls
+        return r
+
+    def _build(self, key, bx, by, pc, pm):
+        net = self.net
+        if not models.should_use_hash_function and getattr(net, "coord_bounds", None) is None:
+            frozen_fast = (net.hpd_is_frozen() and net.dense_probs is False and not net.compute_pbar
+                           and not net._should_keep_topk_only)
+            if not frozen_fast:
+                raise RuntimeError("GraphedStep: GNGF indexing reads the batch's coordinate bounds on the host; pass coord_bounds= "
+                                   "(an upper bound over every batch) so that the step has no device->host read")
+        st = {"x": bx.detach().clone().contiguous(), "y": by.detach().clone().contiguous(), "pc": pc.detach().clone(),
+              "pm": pm.detach().clone(), "one": torch.ones((), device=bx.device),
+              "params": [p for p in net.parameters() if p.requires_grad]}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, self.warm)):        # lazy initialisation (workspaces, cached tables) happens here, not in the capture
+                self._body(st)
+            if self.optimizer is not None:
+                self.optimizer.prepare_capture()      # no optimizer step is taken before the first real batch
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        # thread_local: other threads of the process (the RCCL watchdog at world > 1) may query events while we capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            st["result"] = self._body(st)
+            if self.optimizer is not None:
+                self.optimizer.step()
+        st["graph"] = g
+        self._graphs[key] = st
+        return st
+
+    def replay_only(self, key=None):
+        """Replays the (only, or the named) captured step on the batch already in its static buffers (benchmarks)."""
+        st = self._graphs[key] if key is not None else next(iter(self._graphs.values()))
+        st["graph"].replay()
+        return st["result"]
+
+    def __call__(self, batch_x, batch_target, previous_collisions=None, previous_min_possible_collisions=None):
+        dev = batch_x.device
+        empty = torch.tensor([], device=dev)
+        pc = empty if previous_collisions is None else previous_collisions.to(dev)
+        pm = empty if previous_min_possible_collisions is None else previous_min_possible_collisions.to(dev)
+        key = (tuple(batch_x.shape), tuple(batch_target.shape), tuple(pc.shape), tuple(pm.shape), bool(models.should_use_hash_function))
+        st = self._graphs.get(key)
+        if st is None:
+            st = self._build(key, batch_x, batch_target, pc, pm)
+        st["x"].copy_(batch_x)
+        st["y"].copy_(batch_target)
+        if pc.numel():
+            st["pc"].copy_(pc)
+            st["pm"].copy_(pm)
+        st["graph"].replay()
+        return st["result"]
+
+
+def train_epoch(net, loss_fn, optimizer, x, target, w, h, l_mse, l_js_kl, l_collisions, batch_percentage=1.0,
+                should_shuffle=True, shuffled_indices=None, previous_collisions=None, previous_min_possible_collisions=None,
+                should_calc_counts=False, graph=False):
+    """The batch loop of the reference's train_step (functions.py:183-281): ceil(1/batch_percentage) mini-batches of
+    zero_grad -> net -> Loss -> weighted sum -> backward -> step.  graph=True replays each step from a hipGraph
+    (GraphedStep, cached on the net per batch shape).  Returns a dict of per-batch device tensors and the outputs /
+    indices in batch order; nothing is read back to the host inside the loop."""
     net.train()
     shape = w * h
     num_batches = int(np.ceil(shape / (shape * batch_percentage)))
     step = int(batch_percentage * shape)
     dev = x.device
     empty = torch.tensor([], device=dev)
-    previous_collisions = empty if previous_collisions is None else previous_collisions
-    previous_min_possible_collisions = empty if previous_min_possible_collisions is None else previous_min_possible_collisions
-    outputs = torch.empty((shape, target.shape[1]), device=dev)
-    losses, mses = [], []
+    previous_collisions = empty if previous_collisions is None else previous_collisions.to(dev)
+    previous_min_possible_collisions = empty if previous_min_possible_collisions is None else previous_min_possible_collisions.to(dev)
+    outputs = torch.zeros((shape, target.shape[1]), device=dev)     # (the reference leaves unvisited rows uninitialised)
+    indices = None
+    rec = {"loss": [], "mse": [], "kls": [], "colls": [], "counts": []}
     one = torch.ones((), device=dev)                 # seed of backward(): the same d loss / d loss = 1, without a fill per batch
+    gs = None
+    if graph:
+        gs = getattr(net, "_graphed_step", None)
+        cfg = (id(loss_fn), id(optimizer), l_mse, l_js_kl, l_collisions, batch_percentage)
+        if gs is None or gs._cfg != cfg:
+            bounds = None if models.should_use_hash_function else (float(x[:, 0].max()), float(x[:, 1].max()))
+            gs = GraphedStep(net, loss_fn, optimizer, l_mse, l_js_kl, l_collisions, batch_percentage, coord_bounds=bounds)
+            gs._cfg = cfg
+            net._graphed_step = gs
     for b in range(num_batches):
         lo, hi = b * step, (b + 1) * step
         sel = shuffled_indices[lo:hi].long() if should_shuffle else slice(lo, hi)
         bx, by = x[sel], target[sel]
-        optimizer.zero_grad()
-        out, probs, _idx, _counts = net(bx, batch_percentage, should_calc_counts=False)
-        outputs[lo:hi] = out.detach()
-        mse, kls, colls = loss_fn(out, by, None if probs is None else probs.shape[-1], probs,
-                                  previous_collisions, previous_min_possible_collisions)
-        loss = assemble_loss(mse, kls, colls, l_mse, l_js_kl, l_collisions)
-        loss.backward(gradient=one.to(loss.dtype))
-        optimizer.step()
-        losses.append(loss.detach())
-        mses.append(mse.detach())
-    return torch.stack(losses).mean().item(), torch.stack(mses).mean().item(), outputs
+        if bx.shape[0] == 0:
+            continue
+        if gs is not None and not should_calc_counts:
+            r = gs(bx, by, previous_collisions, previous_min_possible_collisions)
+            out, idx, loss, mse, kls, colls, counts = r.out, r.idx, r.loss, r.mse, r.kls, r.colls, []
+        else:
+            optimizer.zero_grad()
+            out, probs, idx, counts = net(bx, batch_percentage, should_calc_counts=should_calc_counts)
+            mse, kls, colls = loss_fn(out, by, None if probs is None else probs.shape[-1], probs,
+                                      previous_collisions, previous_min_possible_collisions)
+            loss = assemble_loss(mse, kls, colls, l_mse, l_js_kl, l_collisions)
+            loss.backward(gradient=one.to(loss.dtype))
+            optimizer.step()
+        outputs[lo:lo + out.shape[0]] = out.detach()
+        if idx is not None:
+            if indices is None:
+                indices = torch.zeros((shape, *idx.shape[1:]), dtype=idx.dtype, device=dev)
+            indices[lo:lo + idx.shape[0]] = idx
+        rec["loss"].append(loss.detach().clone())
+        rec["mse"].append(mse.detach().clone())
+        if kls is not None:
+            rec["kls"].append(kls.detach().clone())
+            rec["colls"].append(colls.detach().clone() if colls.nelement() != 0 else torch.ones_like(kls.detach()))
+        rec["counts"].append(counts)
+    rec["outputs"], rec["indices"] = outputs, indices
+    return rec
+
+
+def train_step(net, loss_fn, optimizer, x, target, w, h, hash_table_size, topk_k, l_mse, l_js_kl, l_collisions,
+               batch_percentage=1, num_levels=4, should_bw=False, should_calc_counts=False, should_shuffle=True,
+               shuffled_indices=None, reordered_indices=None, previous_collisions=None,
+               previous_min_possible_collisions=None, *, graph=False):
+    """reference functions.py:139-355 — same positional signature and the same 9-tuple:
+        (loss, to_show_img (h,w,3) int32 numpy, collisions, min_possible_collisions, counts_per_level, mse,
+         kl_div_losses (L,) | None, collisions_losses (L,) | None, indices_per_level)
+    Differences, all in host-side bookkeeping: values are read back once per epoch instead of per batch; pixels that no
+    batch visits (int(batch_percentage * w * h) * num_batches < w * h) show as zeros where the reference shows
+    uninitialised memory; collision statistics are taken over each pixel's own top-K indices (the reference allocates
+    topk_k / batch_size index slots per pixel and fills topk_k of them, so its statistic is partly uninitialised memory —
+    SURVEY.md §8f.3).  graph=True (keyword-only, extension) replays every step from a hipGraph."""
+    import collections
+    import functools
+    import operator
+    rec = train_epoch(net, loss_fn, optimizer, x, target, w, h, l_mse, l_js_kl, l_collisions, batch_percentage=batch_percentage,
+                      should_shuffle=should_shuffle, shuffled_indices=shuffled_indices, previous_collisions=previous_collisions,
+                      previous_min_possible_collisions=previous_min_possible_collisions, should_calc_counts=should_calc_counts,
+                      graph=graph)
+    hash_mode = bool(models.should_use_hash_function)
+    loss_item = float(torch.stack(rec["loss"]).double().mean().item())            # np.mean over batches (functions.py:286)
+    mse_loss = float(torch.stack(rec["mse"]).double().mean().item())
+    no_dist = hash_mode or not rec["kls"]
+    kl_div_losses = None if no_dist else torch.stack(rec["kls"]).double().mean(0).cpu().numpy()
+    collisions_losses = None if no_dist else torch.stack(rec["colls"]).double().mean(0).cpu().numpy()
+    outputs, indices = rec["outputs"], rec["indices"]
+    if should_shuffle:
+        ro = reordered_indices
+        if ro is None:                                  # inverse permutation (main.py:55-58)
+            ro = torch.empty_like(shuffled_indices)
+            ro[shuffled_indices.long()] = torch.arange(shuffled_indices.numel(), device=shuffled_indices.device, dtype=ro.dtype)
+        ro = ro.long().to(outputs.device)
+        outputs = outputs[ro]
+        indices = indices[ro] if indices is not None else None
+    indices_per_level = []
+    if should_calc_counts and indices is not None:
+        flat = indices.permute(1, 0, *range(2, indices.dim())).reshape(indices.shape[1], -1).cpu().numpy()
+        indices_per_level = [dict(zip(*np.unique(level, return_counts=True))) for level in flat]
+    if indices is not None:
+        collisions, min_possible_collisions = net.calc_hash_collisions(indices)
+    else:                                               # return_indices = False: the statistic is skipped
+        collisions, min_possible_collisions = torch.tensor([]), torch.tensor([])
+    to_show_img = (outputs * 255).reshape((h, w, 3) if not should_bw else (h, w)).int().detach().cpu().numpy()
+    counts_per_level = [
+        dict(functools.reduce(operator.add, map(collections.Counter, [c[i] for c in rec["counts"]])))
+        for i in range(num_levels) if should_calc_counts
+    ]
+    return (loss_item, to_show_img, collisions, min_possible_collisions, counts_per_level, mse_loss, kl_div_losses,
+            collisions_losses, indices_per_level)
 
 
 def calc_psnr(pred: np.ndarray, target: np.ndarray) -> float:

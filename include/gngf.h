@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNGF_ABI_VERSION 3
+#define GNGF_ABI_VERSION 4
 #define GNGF_MAX_LEVELS 32
 #define GNGF_MAX_TOPK 32
 
@@ -49,10 +49,10 @@ int gngf_hash_indices(const float* xy, const int32_t* n_ls, int64_t* idx, int64_
 
 /* ---- a10/a11: MultiResHashEncoding.forward (models.py:173-229).
  * idx (P,L,4) when K == 0 (hash branch) or (P,L,4,K) (GNGF branch); probs (P,L,4,K) or NULL; out (P,F,L,4). */
-int gngf_mrhe_fwd(const float* tables, const int64_t* idx, const float* probs, float* out,
+int gngf_mrhe_fwd(const void* tables, int feat_dtype, const int64_t* idx, const float* probs, float* out,
                   int64_t P, int L, int F, int64_t T, int K, int blend, void* stream);
 /* a15 at the same boundary: dtables (L,T,F) is ACCUMULATED into (caller zero-fills), dprobs (P,L,4,K) is written. */
-int gngf_mrhe_bwd(const float* tables, const int64_t* idx, const float* probs, const float* gout,
+int gngf_mrhe_bwd(const void* tables, int feat_dtype, const int64_t* idx, const float* probs, const float* gout,
                   float* dtables, float* dprobs, int64_t P, int L, int F, int64_t T, int K, int blend, void* stream);
 
 /* ---- a12: _bilinear_interpolate (models.py:621-655): feats (P,F,L,4) -> enc (P,L*F); bwd writes dfeats. */
@@ -231,17 +231,21 @@ int gngf_distinct_slot_counts(const int64_t* indices, int64_t P, int L, int V, i
 /* ---- optimizer (row f2: the caller of the path) ---------------------------------------------------------------------
  * torch.optim.Adam as get_optimizer builds it (functions.py:96-127: betas (0.9, 0.99), eps 1e-15, L2-style weight
  * decay, dense moments, per-group lr), every tensor of every group in ONE launch.
- * segments: device array of nseg 56-byte records
- *     { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; int64_t n; int64_t first_block;
- *       int32_t group; int32_t pad; }
+ * segments: device array of nseg 64-byte records
+ *     { void* param; const void* grad; float* exp_avg; float* exp_avg_sq; float* master; int64_t n; int64_t first_block;
+ *       int32_t group; int32_t flags; }
  * with first_block = running sum of ceil(n / gngf_adam_block_elems()) and total_blocks that sum over all segments.
+ * flags bit 0: param and grad are fp16 (fp16 level tables, BASELINE.json config 5) and `master` is the fp32 master copy
+ * the update is applied to (param = round(master)); moments are fp32 either way.  inv_grad_scale multiplies every gradient
+ * before use (1 / loss scale of fp16 training; 1 = off).
  * step: device float holding the number of steps taken so far; the call increments it and uses the new value (bias
  * corrections in double precision), so a step is capturable in a hipGraph.  lr, weight_decay: HOST arrays of ngroups
  * (<= GNGF_ADAM_MAX_GROUPS) values, indexed by a segment's `group`. */
 #define GNGF_ADAM_MAX_GROUPS 4
 int gngf_adam_block_elems(void);
 int gngf_adam_step(const void* segments, int nseg, int64_t total_blocks, float* step, const float* lr,
-                   const float* weight_decay, int ngroups, float beta1, float beta2, float eps, void* stream);
+                   const float* weight_decay, int ngroups, float beta1, float beta2, float eps, float inv_grad_scale,
+                   void* stream);
 
 #ifdef __cplusplus
 }

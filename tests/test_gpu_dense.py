@@ -477,3 +477,40 @@ def test_decoder_bwd_reports_its_device_clock_span(ops):
     ns = ctypes.c_double(-1.0)
     call("gngf_decoder_bwd_last_span_ns", ctypes.byref(ns))
     assert 1e3 < ns.value < e0.elapsed_time(e1) * 1e6          # longer than a microsecond, inside the bracketing events
+
+
+def test_fused_adam_fp16_parameters_keep_fp32_master_and_moments(ops):
+    """fp16 level tables (BASELINE config 5): the update is applied to an fp32 master copy with fp32 moments and the fp16
+    parameter is its rounding — compared with torch.optim.Adam on fp32 clones fed the same (un-scaled) gradients, 10 steps,
+    mixed with fp32 parameters in the same launch; loss scaling through `grad_scale`; state dict round trip keeps fp32."""
+    from collision_handling_in_instantngp_amd.train import FusedAdam
+    g = torch.Generator().manual_seed(21)
+    shapes = [(1 << 15, 4), (999,), (3, 7)]
+    p16 = [torch.nn.Parameter((torch.randn(s, generator=g) * 1e-2).half().to(DEV)) for s in shapes]
+    p32 = [torch.nn.Parameter(torch.randn((64, 32), generator=g).to(DEV))]
+    ref = [torch.nn.Parameter(p.detach().float().clone()) for p in p16] + [torch.nn.Parameter(p32[0].detach().clone())]
+    scale = 1024.0
+    oa = FusedAdam([{"params": p16, "lr": 1e-3, "weight_decay": 0.0}, {"params": p32, "lr": 1e-2, "weight_decay": 1e-6}],
+                   betas=(0.9, 0.99), eps=1e-15)
+    oa.grad_scale = scale
+    ob = torch.optim.Adam([{"params": ref[:3], "lr": 1e-3, "weight_decay": 0.0}, {"params": ref[3:], "lr": 1e-2, "weight_decay": 1e-6}],
+                          betas=(0.9, 0.99), eps=1e-15)
+    for step in range(10):
+        for a, b in zip(p16 + p32, ref):
+            gr = torch.randn(a.shape, generator=g).to(DEV) * 1e-3
+            a.grad = (gr * scale).to(a.dtype)                       # what a scaled loss hands the optimizer
+            b.grad = a.grad.float() / scale                         # the same values, un-scaled, in fp32
+        oa.step(); ob.step()
+    for a, b in zip(p16, ref[:3]):
+        st = oa.state[a]
+        assert st["master"].dtype == torch.float32 and st["exp_avg"].dtype == torch.float32
+        close(st["master"], b.detach().cpu().numpy(), 2e-6, 1e-8)                          # fp32 trajectory
+        assert torch.equal(a.detach(), st["master"].half())                                 # parameter = round(master)
+        close(st["exp_avg_sq"], ob.state[b]["exp_avg_sq"].cpu().numpy(), 1e-5, 1e-14)
+    close(p32[0].detach(), ref[3].detach().cpu().numpy(), 2e-6, 1e-6)
+    sd = oa.state_dict()
+    ob2 = FusedAdam([{"params": p16, "lr": 1e-3, "weight_decay": 0.0}, {"params": p32, "lr": 1e-2, "weight_decay": 1e-6}],
+                    betas=(0.9, 0.99), eps=1e-15)
+    ob2.load_state_dict(sd)
+    assert ob2.state[p16[0]]["master"].dtype == torch.float32 and ob2.state[p16[0]]["exp_avg_sq"].dtype == torch.float32
+    assert torch.equal(ob2.state[p16[0]]["master"], oa.state[p16[0]]["master"])

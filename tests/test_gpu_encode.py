@@ -308,3 +308,30 @@ def test_sorted_vertex_backward_degenerate_slot_distributions_vs_oracle(ops, cfg
         close(tt.grad, dt, 2e-4, 2e-5 * float(np.abs(dt).max()), f"sorted vertex bwd [{kind}] table gradient, dw={with_dw}")
         if with_dw:
             close(tw.grad, dvw, 2e-4, 2e-5 * float(np.abs(dvw).max()), f"sorted vertex bwd [{kind}] d vert_w")
+
+
+@pytest.mark.parametrize("K", [0, 4])
+def test_mrhe_boundary_fp16_tables_cfg5_feature_width_vs_oracle(ops, K):
+    """MultiResHashEncoding.forward at the module boundary on fp16 tables (F = 4, BASELINE config 5): fp32 arithmetic on the
+    stored values — oracle = fp32 restatement on the fp16-rounded tables; gradient returned in fp16 (tolerance 1e-3)."""
+    rng = np.random.default_rng(50 + K)
+    L, T, F, P = 16, 2 ** 14, 4, 3000
+    tables16 = ((rng.random((L, T, F), dtype=np.float32) - 0.5) * 2e-2).astype(np.float16)
+    tables = tables16.astype(np.float32)
+    if K == 0:
+        idx, probs = rng.integers(0, T, (P, L, 4)), None
+    else:
+        idx, probs = rng.integers(0, T, (P, L, 4, K)), (rng.random((P, L, 4, K), dtype=np.float32) * 0.01 + 1e-3)
+    want = orc.encoding_forward(tables, idx, probs, True)
+    gout = rng.standard_normal(want.shape).astype(np.float32)
+    dt, dp = orc.encoding_backward(tables, idx, probs, True, gout)
+    tt = t(tables16).requires_grad_()
+    tp = t(probs).requires_grad_() if K else None
+    out = ops.MrheFunction.apply(tt, t(idx), tp, 0)
+    assert out.dtype == torch.float32
+    close(out, want, 2e-6, 1e-9)
+    out.backward(t(gout))
+    assert tt.grad.dtype == torch.float16
+    close(tt.grad.float(), dt, 1e-3, 1e-3 * float(np.abs(dt).max()))
+    if K:
+        close(tp.grad, dp, 1e-4, 1e-6)

@@ -145,28 +145,35 @@ def test_compact_distribution_equals_dense(golden):
         close(outs[False][1][k], outs[True][1][k], 2e-3, 1e-4 * scale, k)
 
 
-def test_training_curve_matches_reference_three_epochs(golden):
+@pytest.mark.parametrize("graph", [False, True])
+def test_training_curve_matches_reference_three_epochs(golden, graph):
     """cfg1 (BASELINE configs[0]: strawberry.jpeg, params-ID 4061, L=4 T=2^8 K=4, 3 batches/epoch): MSE and PSNR of the
-    first three epochs vs the reference's own train_step run (G8).  PSNR must agree within 0.01 dB (north-star bar)."""
-    from collision_handling_in_instantngp_amd import train
+    first three epochs vs the reference's own train_step run (G8), called with the reference's positional signature and
+    read through its 9-tuple.  PSNR must agree within 0.01 dB (north-star bar).  graph=True: every step replayed from a
+    hipGraph (train.GraphedStep), previous-epoch collision statistics fed back as in functions.py:654-672."""
+    from collision_handling_in_instantngp_amd import data, train
     net, g7, models, _ = build(golden, "gngf")
     g = golden("G8_train_curve")
     img = golden("strawberry_rgb")["img"]
     X, Y, h, w = strawberry(golden)
     shuffled = t(g["shuffled"].astype(np.int64))
+    reordered = torch.empty_like(shuffled)
+    reordered[shuffled] = torch.arange(shuffled.numel(), device=DEV)
     loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
     opt = train.get_optimizer(net, 1e-4, 1e-3, 1e-3, 0, 1e-6, 1e-6)
+    prev_c = prev_m = None
     for e in range(3):
-        loss, mse, outputs = train.train_step(net, loss_fn, opt, X, Y, w, h, 1, 1, 1e-3, batch_percentage=1 / 3,
-                                              should_shuffle=True, shuffled_indices=shuffled)
-        n = outputs.shape[0] // 3 * 3                      # reference quirk: int(1/3 * shape) * 3 pixels are visited
-        out_img = torch.zeros_like(outputs)
-        out_img[shuffled[:n]] = outputs[:n]
-        show = (out_img * 255).reshape(h, w, 3).int().cpu().numpy()
-        if n == outputs.shape[0]:
-            psnr = train.calc_psnr(show, img)
-            assert abs(psnr - float(g["psnr"][e])) < 0.01, (e, psnr, float(g["psnr"][e]))
-        np.testing.assert_allclose(mse, float(g["mse"][e]), rtol=2e-3)
+        r = train.train_step(net, loss_fn, opt, X, Y, w, h, 256, 4, 1, 1, 1e-3, 1 / 3, 4, False, False, True, shuffled, reordered,
+                             prev_c, prev_m, graph=graph)
+        loss, show, prev_c, prev_m, counts, mse, kls, colls, ipl = r
+        assert show.shape == (h, w, 3) and show.dtype == np.int32 and kls.shape == (4,) and colls.shape == (4,)
+        assert counts == [] and ipl == []
+        psnr = train.calc_psnr(show, img)
+        assert abs(psnr - float(g["psnr"][e])) < 0.01, (e, psnr, float(g["psnr"][e]))
+        close(np.array(psnr), g["psnr"][e], 0, 0.01, f"G8 cfg1 PSNR epoch {e} (graph={graph})")
+        close(np.array(mse), g["mse"][e], 2e-3, 0, f"G8 cfg1 MSE epoch {e} (graph={graph})")
+        if e == 0:          # later epochs feed back collision statistics, which the reference takes over uninitialised slots
+            close(np.array(loss), g["loss"][e], 2e-3, 0, f"G8 cfg1 loss epoch {e} (graph={graph})")
 
 
 @pytest.mark.parametrize("mode", ["hash", "gngf"])
@@ -286,7 +293,8 @@ def test_fp16_table_storage_model_matches_fp32_model_on_rounded_tables(golden):
         models.should_use_hash_function = False
 
 
-def test_headline_shape_hash_training_curve_matches_reference(golden):
+@pytest.mark.parametrize("graph", [False, True])
+def test_headline_shape_hash_training_curve_matches_reference(golden, graph):
     """L=16, F=2, T=2^19, N 16->512 (the headline table shape), hash indexing, strawberry.jpeg: two epochs of three
     1/3-image batches vs the reference's own train_step run on CPU (G11): PSNR within 0.01 dB.  The 64 MiB tables are
     regenerated from the same seeded CPU generator the golden script used."""
@@ -313,25 +321,25 @@ def test_headline_shape_hash_training_curve_matches_reference(golden):
         shuffled = t(g["shuffled"].astype(np.int64))
         loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
         opt = train.get_optimizer(net, 1e-4, 1e-3, 1e-3, 0, 1e-6, 1e-6)
+        assert isinstance(opt, train.FusedAdam)               # hash mode too (the int64 _prime_numbers is in no group)
         for e in range(2):
-            loss, mse, outputs = train.train_step(net, loss_fn, opt, X, Y, w, h, 1, 1, 1e-3, batch_percentage=1 / 3,
-                                                  should_shuffle=True, shuffled_indices=shuffled)
-            out_img = torch.zeros_like(outputs)
-            out_img[shuffled] = outputs
-            show = (out_img * 255).reshape(h, w, 3).int().cpu().numpy()
+            r = train.train_step(net, loss_fn, opt, X, Y, w, h, T, 4, 1, 1, 1e-3, batch_percentage=1 / 3, num_levels=Lv,
+                                 should_shuffle=True, shuffled_indices=shuffled, graph=graph)
+            loss, show, coll, minc, _cnt, mse, kls, colls, _ipl = r
+            assert kls is None and colls is None and coll.shape == (Lv,)
             psnr = train.calc_psnr(show, img)
             assert abs(psnr - float(g["psnr"][e])) < 0.01, (e, psnr, float(g["psnr"][e]))
-            np.testing.assert_allclose(mse, float(g["mse"][e]), rtol=2e-3)
+            close(np.array(psnr), g["psnr"][e], 0, 0.01, f"G11 headline-shape hash PSNR epoch {e} (graph={graph})")
+            close(np.array(mse), g["mse"][e], 2e-3, 0, f"G11 headline-shape hash MSE epoch {e} (graph={graph})")
     finally:
         models.should_use_hash_function = False
 
 
 @pytest.mark.parametrize("mode", ["hash", "gngf_frozen"])
 def test_hipgraph_replay_of_a_step_equals_eager(golden, mode):
-    """bench.py replays one captured forward+backward (helper stream, hint hand-off, per-call workspaces included):
-    the replayed gradients must equal the eager ones."""
-    import bench
-    from collision_handling_in_instantngp_amd import models
+    """train.GraphedStep replays one captured forward + backward (helper stream, hint hand-off, per-call workspaces
+    included): the replayed gradients must equal the eager ones, for the captured batch and for a different one."""
+    from collision_handling_in_instantngp_amd import models, train
     models.should_use_hash_function = (mode == "hash")
     try:
         torch.manual_seed(1)
@@ -345,18 +353,26 @@ def test_hipgraph_replay_of_a_step_equals_eager(golden, mode):
                 p.requires_grad = False
             net.compute_pbar = False
         X, Y, h, w = strawberry(golden)
-        xy, tgt = X[:60000].contiguous(), Y[:60000].contiguous()
-        step = bench.make_step(net, models, mode, xy, tgt, 1)
-        step()
-        eager = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
-        replay = bench.graphed(step)
-        for _ in range(2):
-            replay()
-        torch.cuda.synchronize()
-        for k, p in net.named_parameters():
-            if k in eager:
-                scale = float(eager[k].abs().max()) + 1e-30
-                assert float((p.grad - eager[k]).abs().max()) <= 2e-5 * scale, k
+        loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
+        gs = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3)
+        for lo in (0, 60000):
+            xy, tgt = X[lo:lo + 60000].contiguous(), Y[lo:lo + 60000].contiguous()
+            net.zero_grad(set_to_none=True)
+            rgb, probs, _i, _c = net(xy, 1.0)
+            mse, kls, coll = loss_fn(rgb, tgt, None, probs, torch.tensor([], device=DEV), torch.tensor([], device=DEV))
+            assert kls is None
+            train.assemble_loss(mse, kls, coll, 1, 1, 1e-3).backward()
+            eager = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+            eager_rgb = rgb.detach().clone()
+            r = gs(xy, tgt)
+            r = gs(xy, tgt)
+            torch.cuda.synchronize()
+            assert torch.equal(r.out, eager_rgb)
+            for k, p in net.named_parameters():
+                if k in eager:
+                    scale = float(eager[k].abs().max()) + 1e-30
+                    assert float((p.grad - eager[k]).abs().max()) <= 2e-5 * scale, k
+        assert len(gs._graphs) == 1                      # one capture serves both batches
     finally:
         models.should_use_hash_function = False
 
@@ -411,3 +427,53 @@ def test_kept_logits_equal_recomputed_logits_in_the_hpd_backward(golden):
         for k in outs[0]:                                     # float atomics (split-K GEMMs) reorder sums from run to run
             scale = float(outs[0][k].abs().max()) + 1e-30
             close(other[k], outs[0][k].cpu().numpy(), 1e-4, 2e-5 * scale, k)
+
+
+def test_fp16_table_model_trains_with_fused_adam_like_the_fp32_master_model(golden):
+    """cfg5 flavour end to end (F = 4, fp16 table storage): get_optimizer returns FusedAdam, whose fp32 master copy follows
+    the trajectory of an fp32 model started from the same (fp16-representable) tables; MultiResHashEncoding.forward accepts
+    the fp16 tables at the per-instance boundary."""
+    from collision_handling_in_instantngp_amd import models, train
+    X, Y, h, w = strawberry(golden)
+    models.should_use_hash_function = True
+    try:
+        kw = dict(input_dim=2, hash_table_size=2 ** 14, num_levels=8, n_min=16, n_max=256, MLP_hidden_layers_widths=[64, 64],
+                  HPD_hidden_layers_widths=[32, 64, 128], HPD_out_features=2 ** 14, feature_dim=4, topk_k=4)
+        torch.manual_seed(3)
+        n16 = models.GeneralNeuralGaugeFields(**kw, table_dtype=torch.float16)
+        with torch.no_grad():
+            for m in n16.encoding._hash_tables:
+                m.weight.mul_(100.0)
+        n32 = models.GeneralNeuralGaugeFields(**kw)
+        n32.load_state_dict({k: (v.float() if "hash_tables" in k else v) for k, v in n16.state_dict().items()})
+        o16 = train.get_optimizer(n16, 1e-3, 1e-3, 1e-3, 0, 1e-6, 1e-6)
+        o32 = train.get_optimizer(n32, 1e-3, 1e-3, 1e-3, 0, 1e-6, 1e-6)
+        assert isinstance(o16, train.FusedAdam) and isinstance(o32, train.FusedAdam)
+        scale = 4096.0
+        o16.grad_scale = scale
+        xb, yb = X[:40000], Y[:40000]
+        losses = {16: [], 32: []}
+        for _ in range(5):
+            for net, opt, sc, tag in ((n16, o16, scale, 16), (n32, o32, 1.0, 32)):
+                opt.zero_grad()
+                rgb, _, _, _ = net(xb, 1.0)
+                loss = torch.nn.functional.mse_loss(rgb, yb)
+                (loss * sc).backward()
+                opt.step()
+                losses[tag].append(float(loss))
+        assert losses[16][-1] < losses[16][0]
+        close(np.array(losses[16]), np.array(losses[32]), 2e-3, 0, "fp16-table model vs fp32 model: MSE over 5 Adam steps")
+        w16 = n16.encoding._hash_tables[5].weight
+        master = o16.state[w16]["master"]
+        assert w16.dtype == torch.float16 and torch.equal(w16.detach(), master.half())
+        ref = n32.encoding._hash_tables[5].weight.detach()
+        moved = (ref - n16.state_dict()["encoding._hash_tables.5.weight"].float()).abs().max()
+        close(master, ref.cpu().numpy(), 0, 2e-3 * 5, "fp32 master of the fp16 tables vs fp32 tables after 5 steps (lr 1e-3)")
+        # the per-instance module boundary on fp16 tables
+        idx = torch.randint(0, 2 ** 14, (512, 8, 4), device=DEV)
+        feats = n16.encoding(idx, None)
+        assert feats.shape == (512, 4, 8, 4) and feats.dtype == torch.float32
+        want = torch.stack([n16.encoding._hash_tables[l].weight.detach().float()[idx[:, l]] for l in range(8)], 1)   # (P,L,4,F)
+        assert torch.equal(feats, want.permute(0, 3, 1, 2))
+    finally:
+        models.should_use_hash_function = False
