@@ -539,6 +539,26 @@ def _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G):
          0 if vert_idx is None else vert_idx.shape[1], mode, vstride, 0 if vert_idx is None else vert_idx.shape[0], stream_ptr())
 
 
+_FIRST_LEVEL_KEYS = {}
+
+
+def _first_level_keys(n_ls_host, vstride, NV, K, device):
+    """(NV*K,) int64: (first level the vertex belongs to) << 32, per (vertex, k) entry — geometry only, so it is built once
+    per (resolutions, table extent) with scalar comparisons (no host->device copy: usable while a stream captures) and kept."""
+    key = (n_ls_host, vstride, NV, K, str(device))
+    hit = _FIRST_LEVEL_KEYS.get(key)
+    if hit is None:
+        if len(_FIRST_LEVEL_KEYS) > 16:
+            _FIRST_LEVEL_KEYS.clear()
+        vid = torch.arange(NV, device=device, dtype=_i64)
+        m = torch.maximum(vid % vstride, vid // vstride)                 # max(gx, gy)
+        lmin = torch.zeros_like(m)
+        for n in n_ls_host:                                              # first level with max(gx,gy) <= n_l + 1
+            lmin += (m > n + 1).to(_i64)
+        hit = _FIRST_LEVEL_KEYS[key] = (lmin << 32).repeat_interleave(K)
+    return hit
+
+
 def slot_order(vert_idx, n_ls_host=None, vstride=None):
     """Visiting order of the contention-free vertex backward: (vertex,k) entries sorted by (first level the vertex
     belongs to, slot).  Equal slots stay adjacent inside a level group (wave-level segmented reduction), and a wave
@@ -547,12 +567,7 @@ def slot_order(vert_idx, n_ls_host=None, vstride=None):
     NV, K = vert_idx.shape
     flat = vert_idx.reshape(-1).to(_i64)
     if n_ls_host is not None and vstride:
-        T_bits = int(flat.max().item()).bit_length() if flat.numel() else 1
-        vid = torch.arange(NV, device=vert_idx.device, dtype=_i64)
-        m = torch.maximum(vid % vstride, vid // vstride)                 # max(gx, gy)
-        bounds = torch.tensor([n + 1 for n in n_ls_host], device=vert_idx.device, dtype=_i64)
-        lmin = torch.searchsorted(bounds, m)                             # first level with max(gx,gy) <= n_l + 1
-        flat = (lmin.repeat_interleave(K) << T_bits) | flat
+        flat = _first_level_keys(tuple(int(n) for n in n_ls_host), int(vstride), int(NV), int(K), vert_idx.device) | flat
     return torch.sort(flat, stable=True)[1].to(_i32)
 
 
@@ -643,7 +658,10 @@ _SIDE_STREAMS = {}
 def _side_stream(device):
     """One helper stream per device: work that does not depend on the binned pixels (vertex stage, zero-filling the
     gradient buffers the backward will need) runs beside the binning kernels; joins are explicit (capturable)."""
-    key = (device.type, device.index)
+    # one helper per (device, main stream): a helper that has exchanged events with the legacy default stream must not
+    # later join a hipGraph capture started on another stream (hipStreamEndCapture crashed on exactly that history:
+    # tools/dbg_graphed.py), and two main streams must not serialise through one shared helper anyway
+    key = (device.type, device.index, torch.cuda.current_stream(device).stream_id)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]

@@ -274,12 +274,20 @@ class GraphedStep:
 
     def _body(self, st):
         net, (l_mse, l_js_kl, l_collisions) = self.net, self.weights
-        for p in st["params"]:
-            p.grad = None
-        out, probs, idx, _counts = net(st["x"], self.batch_percentage, should_calc_counts=False)
+        shadow = st["shadow"]
+        for s_ in shadow.values():
+            s_.grad = None
+        # The step runs on SHADOW leaves (detached aliases of the parameters: same storage, fresh autograd identity).  An
+        # autograd leaf's AccumulateGrad node is bound to the stream that was current when it was first created, and it stays
+        # alive as long as any earlier graph does (a kept `loss` from an eager step on the default stream is enough): the
+        # captured backward would then hop onto the legacy default stream, which cannot take part in a capture
+        # (hipStreamEndCapture crashes; tools/dbg_graphed.py).  Fresh leaves get their nodes on the capturing stream.
+        out, probs, idx, _counts = torch.func.functional_call(net, shadow, (st["x"], self.batch_percentage), {"should_calc_counts": False})
         mse, kls, colls = self.loss_fn(out, st["y"], None if probs is None else probs.shape[-1], probs, st["pc"], st["pm"])
         loss = assemble_loss(mse, kls, colls, l_mse, l_js_kl, l_collisions)
         loss.backward(gradient=st["one"].to(loss.dtype))
+        for name, p in st["named"]:
+            p.grad = shadow[name].grad             # the parameters' own .grad: what the optimizer and the caller read
         r = GraphedStep.Result()
         r.out, r.probs, r.idx, r.loss, r.mse, r.kls, r.colls = out.detach(), probs, idx, loss.detach(), mse.detach(), kls, colls
         return r
@@ -292,9 +300,11 @@ class GraphedStep:
             if not frozen_fast:
                 raise RuntimeError("GraphedStep: GNGF indexing reads the batch's coordinate bounds on the host; pass coord_bounds= "
                                    "(an upper bound over every batch) so that the step has no device->host read")
+        named = [(n, p) for n, p in net.named_parameters()]
         st = {"x": bx.detach().clone().contiguous(), "y": by.detach().clone().contiguous(), "pc": pc.detach().clone(),
               "pm": pm.detach().clone(), "one": torch.ones((), device=bx.device),
-              "params": [p for p in net.parameters() if p.requires_grad]}
+              "named": [(n, p) for n, p in named if p.requires_grad],
+              "shadow": {n: p.detach().requires_grad_(p.requires_grad) for n, p in named}}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
