@@ -275,15 +275,24 @@ class HpdVertexFunction(torch.autograd.Function):
         # HPD_Z_CACHE_BYTES (and leave HPD_Z_CACHE_RESERVE free on the device) keep theirs, the rest are recomputed.
         zcache, cached = {}, 0
         keep_z = (not keep_probs) and HPD_Z_CACHE_BYTES > 0 and any(ctx.needs_input_grad[6:])
+        budget = 0
+        if keep_z:
+            # one query per forward: memory the driver reports free plus what torch's allocator holds in unused cached blocks
+            # (the previous step's kept chunks come back from there), minus the reserve for the backward's own buffers
+            free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+            budget = min(HPD_Z_CACHE_BYTES, free - HPD_Z_CACHE_RESERVE)
         for u0 in range(0, NV, rows):
             n = min(rows, NV - u0)
             hs = HpdVertexFunction._hidden(vertex_coords(u0, n, vstride, dev), params, n_layers)
             z = probs[u0:u0 + n] if keep_probs else scratch[:n]
             if keep_z:
                 need = n * T * 4
-                if cached + need <= HPD_Z_CACHE_BYTES and torch.cuda.mem_get_info(dev)[0] - need >= HPD_Z_CACHE_RESERVE:
-                    z = zcache[u0] = torch.empty((n, T), dtype=_f32, device=dev)
-                    cached += need
+                if cached + need <= budget:
+                    try:
+                        z = zcache[u0] = torch.empty((n, T), dtype=_f32, device=dev)
+                        cached += need
+                    except torch.OutOfMemoryError:      # another process took the memory meanwhile: recompute from here on
+                        budget = 0
             call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(z), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
             if keep_probs:      # dense distribution requested (small shapes): softmax in place, p-bar by GEMM
                 call("gngf_softmax_topk", ptr(z), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), ptr(rowstat[u0:u0 + n]), n, T, K, stream_ptr())
