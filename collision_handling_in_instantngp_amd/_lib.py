@@ -31,10 +31,11 @@ SIGNATURES = {
     "gngf_vertex_grid_fwd": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L, _P],
     "gngf_vertex_grid_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L, _P],
     "gngf_encode_tiled_fwd": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "gngf_encode_tiled_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gngf_encode_tiled_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I,
+                              _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "gngf_vertex_grid_bwd_sorted": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _L, _P],
-    "gngf_decoder_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
-    "gngf_decoder_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "gngf_decoder_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "gngf_decoder_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gngf_decoder_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "gngf_decoder_bwd_last_span_ns": [_P],
     "gngf_decoder_hidden_floats": [_L],

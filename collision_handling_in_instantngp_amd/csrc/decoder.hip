@@ -228,7 +228,8 @@ __global__ void __launch_bounds__(kDecThreads, 1)
 decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, const float* __restrict__ b0,
                    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
                    const float* __restrict__ b2, float* __restrict__ Y, float* __restrict__ hidden, int64_t P, int in_dim,
-                   int out_dim) {
+                   int out_dim, const float* __restrict__ target, float* __restrict__ mse_out, double* __restrict__ mse_acc,
+                   unsigned* __restrict__ mse_ticket) {
   constexpr int S0 = KIN / 2;
   if (EXACT) in_dim = KIN;
 #if defined(GNGF_STAMPS)
@@ -302,7 +303,10 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
   // iteration — including the 12-20 stores the previous tile issued after its loads, i.e. for the full write latency at
   // the top of every tile (+2.8 k cycles per tile with the hidden-layer stores).  The exact-width path therefore issues
   // the row loads through inline asm and waits for them itself: kStoresPerTile memory operations follow them in a tile.
+  // (+4: with a fused pixel loss the tile's target values are requested right behind the next tile's rows)
   constexpr int kStoresPerTile = (SAVE ? 16 : 0) + 4;
+  const bool fused_loss = target != nullptr;              // wave-uniform
+  float se = 0.f;                                         // this lane's sum of squared errors (torch.nn.MSELoss, utils.py:99)
   if (EXACT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if defined(GNGF_STAMPS)
   unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast;
@@ -311,7 +315,8 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     STAMP(0);
     if (EXACT) {                                           // the row loads of this tile (issued a tile ago) have landed
-      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kStoresPerTile) : "memory");
+      if (fused_loss) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kStoresPerTile + 4) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kStoresPerTile) : "memory");
 #pragma unroll
       for (int sx = 0; sx < S0; ++sx) asm volatile("" : "+v"(xr[sx]));
     }
@@ -328,6 +333,15 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
     MFMA_DRAIN(acc1[0], acc1[1]);
     __builtin_amdgcn_sched_barrier(0);
     fetch(tile + gridDim.x, xr);
+    float tn[4] = {0.f, 0.f, 0.f, 0.f};
+    if (fused_loss) {                                      // this tile's target values: they land under layer 2
+      int64_t rem = (P - tile * 128) * out_dim * 4;
+      rem = rem > 128 * out_dim * 4 ? 128 * out_dim * 4 : rem;
+      const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(target) + tile * 128 * out_dim, 0, (int)rem, 0x00020000);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        tn[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rt, (h == 0 && c < out_dim) ? yoff + 4u * c : 0x40000000u, 0, 0));
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -372,9 +386,37 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
         const float y = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
         const unsigned off = (h == 0 && c < out_dim) ? yoff + 4u * c : 0x40000000u;
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs, off, 0, 0);
+        if (fused_loss) {                                  // pixels past the end and the idle lane half contribute nothing
+          const bool live = h == 0 && c < out_dim && (tile * 128 + wave * 32 + i) < P;
+          const float d = y - tn[c];
+          se += live ? d * d : 0.f;
+        }
       }
     }
     STAMP(4);
+  }
+  if (fused_loss) {
+    // loss = sum / n in the SAME launch: workgroup partials meet in a double-precision atomic and a ticket counter whose
+    // request depends on the atomic's return value (no release fence: see csrc/loss.hip); the last ticket holder writes
+    // the loss and resets both words for the next launch.
+    __shared__ float red[kDecThreads / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+    if (lane == 0) red[wave] = se;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double b = 0.0;
+#pragma unroll
+      for (int w = 0; w < kDecThreads / 64; ++w) b += (double)red[w];
+      const double before = atomicAdd(mse_acc, b);
+      const unsigned ticket = atomicAdd(mse_ticket, before < 0.0 ? 2u : 1u);   // sums of squares are never negative: always 1
+      if (ticket == gridDim.x - 1) {
+        const double total = atomicAdd(mse_acc, 0.0);
+        *mse_out = (float)(total / (double)(P * out_dim));
+        atomicExch(reinterpret_cast<unsigned long long*>(mse_acc), 0ull);
+        atomicExch(mse_ticket, 0u);
+      }
+    }
   }
 #if defined(GNGF_STAMPS)
   if (blockIdx.x == 7 && threadIdx.x == 0)
@@ -407,7 +449,8 @@ __global__ void __launch_bounds__(kDecThreads, 1)
 decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, const float* __restrict__ dY,
                    const float* __restrict__ W0, const float* __restrict__ b0, const float* __restrict__ W1,
                    const float* __restrict__ b1, const float* __restrict__ W2, float* __restrict__ dX,
-                   float* __restrict__ slabs, const float* __restrict__ hidden, int64_t P, int in_dim, int out_dim) {
+                   float* __restrict__ slabs, const float* __restrict__ hidden, int64_t P, int in_dim, int out_dim,
+                   const float* __restrict__ target, const float* __restrict__ gloss) {
   using FF = FwdFrags<KIN>;
   constexpr int S0 = KIN / 2;
   constexpr int TX = (KIN + 31) / 32;                    // 32-row tiles of the input width
@@ -496,6 +539,11 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   // image is written), y and dy of tile t+1 once dz3 of tile t is dead; both land long before the next tile starts, and
   // the d-enc stores at the end of a tile are issued after them, so no wait ever covers a store (vmcnt counts in order).
   float xr[S0], yn[4], dyn[4], dz3[4];
+  // fused pixel loss (torch.nn.MSELoss backward, csrc/loss.hip::mse_bwd_kernel): d rgb = gloss * 2/n * (rgb - target) is formed
+  // here from the target instead of being read from a tensor a separate kernel wrote — the same expression, the same bits
+  const bool fused_loss = target != nullptr;              // wave-uniform
+  const float* dsrc = fused_loss ? target : dY;
+  const float kloss = fused_loss ? gloss[0] * (2.0f / (float)(P * out_dim)) : 0.f;
   auto tile_window = [&](int64_t t, int64_t& tt, int& rows) {
     tt = t < ntiles ? bwd_tile(t, ntiles) : ntiles;      // past the end: an empty window, every lane reads zeros
     int64_t rem = P - tt * 128;
@@ -524,7 +572,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     int64_t tt; int rows;
     tile_window(t, tt, rows);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Yout) + tt * 128 * out_dim, 0, rows * out_dim * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dY) + tt * 128 * out_dim, 0, rows * out_dim * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dsrc) + tt * 128 * out_dim, 0, rows * out_dim * 4, 0x00020000);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const unsigned off = c < out_dim ? yoff + 4u * c : 0x40000000u;
@@ -535,7 +583,8 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   auto make_dz3 = [&]() {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      dz3[c] = dyn[c] * (yn[c] * (1.f - yn[c]));          // Sigmoid backward; 0 for padding pixels and channels
+      const float dy = fused_loss ? kloss * (yn[c] - dyn[c]) : dyn[c];
+      dz3[c] = dy * (yn[c] * (1.f - yn[c]));              // Sigmoid backward; 0 for padding pixels and channels
       asm volatile("" : "+v"(dz3[c]));                   // (keeps dz3 in registers: it is selected by lane half below)
       db2acc[c] += dz3[c];
     }
@@ -929,39 +978,13 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   }
 }
 
-// sums the per-workgroup slabs and writes the six gradient tensors.  64 elements x 16 slab-groups per block.
+// sums the per-workgroup slabs and writes the six gradient tensors.  64 elements x 16 slab-groups per block
+// (body: decoder_reduce_block in gngf_common.h — the tiled encoder backward can run it in extra workgroups of its own launch).
 __global__ void __launch_bounds__(1024)
 decoder_reduce_kernel(const float* __restrict__ slabs, int nslabs, int nslab, int in_dim, int out_dim,
                       float* __restrict__ dW0, float* __restrict__ db0, float* __restrict__ dW1, float* __restrict__ db1,
                       float* __restrict__ dW2, float* __restrict__ db2, float* __restrict__ absmax) {
-  __shared__ float red[16][64];
-  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + c;
-  const bool is_max = e == nslab - 1;                    // last slot: max of bit patterns, not a sum
-  float s = 0.f;
-  if (e < nslab)
-    for (int b = q; b < nslabs; b += 16) {
-      const float v = slabs[(int64_t)b * nslab + e];
-      s = is_max ? (__float_as_uint(v) > __float_as_uint(s) ? v : s) : s + v;
-    }
-  red[q][c] = s;
-  __syncthreads();
-  if (q != 0 || e >= nslab) return;
-  if (is_max) {
-#pragma unroll
-    for (int k = 1; k < 16; ++k) s = __float_as_uint(red[k][c]) > __float_as_uint(s) ? red[k][c] : s;
-    if (absmax) *absmax = s;
-    return;
-  }
-#pragma unroll
-  for (int k = 1; k < 16; ++k) s += red[k][c];
-  const int o0 = kH * in_dim, o1 = o0 + kH * kH, o2 = o1 + out_dim * kH, o3 = o2 + kH, o4 = o3 + kH;
-  if (e < o0) dW0[e] = s;
-  else if (e < o1) dW1[e - o0] = s;
-  else if (e < o2) dW2[e - o1] = s;
-  else if (e < o3) db0[e - o2] = s;
-  else if (e < o4) db1[e - o3] = s;
-  else db2[e - o4] = s;
+  decoder_reduce_block(blockIdx.x, slabs, nslabs, nslab, in_dim, out_dim, dW0, db0, dW1, db1, dW2, db2, absmax);
 }
 
 template <int KIN>
@@ -996,17 +1019,18 @@ extern "C" int64_t gngf_decoder_hidden_floats(int64_t P) { return ((P + 127) / 1
 // rgb (P,out_dim) = decoder(enc (P,in_dim)); hidden widths fixed at 64/64, in_dim <= 64, out_dim <= 4.
 // hidden (optional): gngf_decoder_hidden_floats(P) floats that receive the activated hidden layers for gngf_decoder_bwd.
 extern "C" int gngf_decoder_fwd(const float* enc, const float* W0, const float* b0, const float* W1, const float* b1,
-                                const float* W2, const float* b2, float* rgb, float* hidden, int64_t P, int in_dim, int out_dim,
-                                int leaky, void* stream) {
+                                const float* W2, const float* b2, float* rgb, float* hidden, const float* target, float* mse,
+                                float* mse_workspace, int64_t P, int in_dim, int out_dim, int leaky, void* stream) {
   GNGF_CHECK_ARG(P >= 0 && in_dim > 0 && in_dim <= 64 && out_dim > 0 && out_dim <= 4);
   if (P == 0) return 0;
   GNGF_CHECK_ARG(enc && W0 && b0 && W1 && b1 && W2 && b2 && rgb);
+  GNGF_CHECK_ARG(!target || (mse && mse_workspace && (reinterpret_cast<uintptr_t>(mse_workspace) & 7) == 0));
   const int64_t tiles = (P + 127) / 128;
   const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);       // one persistent workgroup per CU
   const size_t smem = sizeof(float) * (size_t)raw_offsets(in_dim).total;
   DISPATCH_KIN(in_dim, {
     using Kern = void (*)(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
-                          float*, int64_t, int, int);
+                          float*, int64_t, int, int, const float*, float*, double*, unsigned*);
     const bool exact = in_dim == kKIN;
     Kern fn;
     if (hidden)
@@ -1015,7 +1039,9 @@ extern "C" int gngf_decoder_fwd(const float* enc, const float* W0, const float* 
     else
       fn = leaky ? (exact ? decoder_fwd_kernel<kKIN, true, true, false> : decoder_fwd_kernel<kKIN, true, false, false>)
                  : (exact ? decoder_fwd_kernel<kKIN, false, true, false> : decoder_fwd_kernel<kKIN, false, false, false>);
-    fn<<<dim3(grid), dim3(kDecThreads), smem, as_stream(stream)>>>(enc, W0, b0, W1, b1, W2, b2, rgb, hidden, P, in_dim, out_dim);
+    fn<<<dim3(grid), dim3(kDecThreads), smem, as_stream(stream)>>>(enc, W0, b0, W1, b1, W2, b2, rgb, hidden, P, in_dim, out_dim, target,
+                                                                   mse, reinterpret_cast<double*>(mse_workspace),
+                                                                   reinterpret_cast<unsigned*>(mse_workspace + 2));
   });
   GNGF_RETURN_LAUNCH();
 }
@@ -1023,7 +1049,8 @@ extern "C" int gngf_decoder_fwd(const float* enc, const float* W0, const float* 
 // d enc (P,in_dim) and the six parameter gradients (each WRITTEN, not accumulated).  rgb = the forward output.
 // slabs: workspace of gngf_decoder_bwd_slabs(P) * gngf_decoder_slab_floats(in_dim, out_dim) floats.
 // hidden (optional): the buffer gngf_decoder_fwd filled for the SAME enc / weights; NULL: the hidden layers are recomputed.
-extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float* drgb, const float* W0, const float* b0,
+extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float* drgb, const float* target, const float* gloss,
+                                const float* W0, const float* b0,
                                 const float* W1, const float* b1, const float* W2, float* denc, float* dW0, float* db0,
                                 float* dW1, float* db1, float* dW2, float* db2, float* slabs, float* denc_absmax,
                                 const float* hidden, int64_t P, int in_dim, int out_dim, int leaky, void* stream) {
@@ -1037,11 +1064,11 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
     hipError_t e = hipMemsetAsync(slabs, 0, sizeof(float) * (size_t)nslab, s);
     if (e != hipSuccess) return (int)e;
   } else {
-    GNGF_CHECK_ARG(enc && rgb && drgb && W0 && b0 && W1 && b1 && W2 && denc);
+    GNGF_CHECK_ARG(enc && rgb && (target ? gloss != nullptr : drgb != nullptr) && W0 && b0 && W1 && b1 && W2 && denc);
     DISPATCH_KIN(in_dim, {
       const size_t smem = bwd_smem_bytes<kKIN>(in_dim, out_dim);
       using Kern = void (*)(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
-                            const float*, float*, float*, const float*, int64_t, int, int);
+                            const float*, float*, float*, const float*, int64_t, int, int, const float*, const float*);
       const bool exact = in_dim == kKIN;
       Kern fn;
       if (hidden)
@@ -1052,7 +1079,8 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
                    : (exact ? decoder_bwd_kernel<kKIN, false, true, true> : decoder_bwd_kernel<kKIN, false, false, true>);
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
-      fn<<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, hidden, P, in_dim, out_dim);
+      fn<<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, hidden, P, in_dim, out_dim,
+                                                                 target, gloss);
     });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

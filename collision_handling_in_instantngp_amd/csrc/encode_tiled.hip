@@ -220,6 +220,14 @@ vertex_bwd_kernel(const TT* __restrict__ tables, const int32_t* __restrict__ ver
 }
 
 // ---------------------------------------------------------------------------------------------- pixel stage
+// A decoder slab reduction (gngf_common.h: decoder_reduce_block) that rides on the tiled backward's launch: workgroups
+// [first_block, first_block + ceil(nslab / 64)) run it instead of a work item.  slabs == nullptr: none.
+struct RideAlong {
+  const float* slabs;
+  float *dW0, *db0, *dW1, *db1, *dW2, *db2;
+  int nslabs, nslab, in_dim, out_dim, first_block;
+};
+
 struct TileMeta {          // per-level placement of the tile's sub-grid (in LDS)
   int n[GNGF_MAX_LEVELS], gw[GNGF_MAX_LEVELS], cx[GNGF_MAX_LEVELS], cy[GNGF_MAX_LEVELS], wx[GNGF_MAX_LEVELS],
       wy[GNGF_MAX_LEVELS], loff[GNGF_MAX_LEVELS];
@@ -384,10 +392,16 @@ __global__ void __launch_bounds__(kTB)
 tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ items, const int32_t* __restrict__ n_items,
                  const int32_t* __restrict__ n_ls, const float* __restrict__ genc, float* __restrict__ dG,
                  float* __restrict__ partials, const float* __restrict__ gmax_hint, int hint_count, int hint_stride, int L,
-                 int Ls, int tile_shift, int lds_floats, int log2_chunk) {
+                 int Ls, int tile_shift, int lds_floats, int log2_chunk, RideAlong ride) {
   extern __shared__ unsigned long long acc64[];
   __shared__ TileMeta m;
   __shared__ float wmax[kTB / 64];
+  if (ride.slabs && (int)blockIdx.x >= ride.first_block) {
+    static_assert(kTB == 1024, "decoder_reduce_block is written for 1024-thread workgroups");
+    decoder_reduce_block((int)blockIdx.x - ride.first_block, ride.slabs, ride.nslabs, ride.nslab, ride.in_dim, ride.out_dim, ride.dW0,
+                         ride.db0, ride.dW1, ride.db1, ride.dW2, ride.db2, nullptr);
+    return;
+  }
   if ((int)blockIdx.x >= *n_items) return;
   const int4 it = items[blockIdx.x];
   const int tid = threadIdx.x;
@@ -843,26 +857,41 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
                                      const int32_t* tile_item_base, const int32_t* tile_level_off, const int32_t* n_ls,
                                      const int32_t* n_ls_host, const float* genc, const float* genc_absmax, int absmax_count,
                                      int absmax_stride, float* dG, float* partials, int L, int Ls, int F, int tile_shift,
-                                     int lds_bytes, int chunk, void* stream) {
+                                     int lds_bytes, int chunk, const float* ride_slabs, float* ride_dW0, float* ride_db0,
+                                     float* ride_dW1, float* ride_db1, float* ride_dW2, float* ride_db2, int64_t ride_P,
+                                     int ride_in_dim, int ride_out_dim, void* stream) {
   GNGF_CHECK_ARG(max_items >= 0 && L > 0 && Ls > 0 && Ls <= L && L <= GNGF_MAX_LEVELS && lds_bytes >= 0 && lds_bytes <= 64 * 1024);
+  RideAlong ride = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+  int ride_blocks = 0;
+  if (ride_slabs) {
+    GNGF_CHECK_ARG(ride_dW0 && ride_db0 && ride_dW1 && ride_db1 && ride_dW2 && ride_db2 && ride_P >= 0 && ride_in_dim > 0 &&
+                   ride_in_dim <= 64 && ride_out_dim > 0 && ride_out_dim <= 4);
+    ride.slabs = ride_slabs; ride.dW0 = ride_dW0; ride.db0 = ride_db0; ride.dW1 = ride_dW1; ride.db1 = ride_db1;
+    ride.dW2 = ride_dW2; ride.db2 = ride_db2;
+    ride.nslabs = gngf_decoder_bwd_slabs(ride_P);
+    ride.nslab = gngf_decoder_slab_floats(ride_in_dim, ride_out_dim);
+    ride.in_dim = ride_in_dim; ride.out_dim = ride_out_dim; ride.first_block = max_items;
+    ride_blocks = (ride.nslab + 63) / 64;
+  }
   GNGF_CHECK_ARG(chunk > 0 && chunk <= (1 << 20) && (!genc_absmax || (absmax_count > 0 && absmax_stride >= 0)));
   int log2_chunk = 0;
   while ((1 << log2_chunk) < chunk) ++log2_chunk;
-  if (max_items == 0) return 0;
-  GNGF_CHECK_ARG(sorted && items && n_items && tile_item_base && n_ls && n_ls_host && genc && dG && partials);
-  const int side = max_grid_side(n_ls_host, Ls);
+  if (max_items == 0 && ride_blocks == 0) return 0;
+  GNGF_CHECK_ARG(max_items == 0 || (sorted && items && n_items && tile_item_base && n_ls && n_ls_host && genc && dG && partials));
+  const int side = max_items > 0 ? max_grid_side(n_ls_host, Ls) : 0;
   DISPATCH_F(F, {
     if (2 * lds_bytes > 48 * 1024) {       // 64-bit accumulators: twice the forward image
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiled_bwd_kernel<kF>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * lds_bytes);
       if (e != hipSuccess) return (int)e;
     }
-    tiled_bwd_kernel<kF><<<dim3((unsigned)max_items), dim3(kTB), (size_t)2 * lds_bytes, as_stream(stream)>>>(
+    tiled_bwd_kernel<kF><<<dim3((unsigned)(max_items + ride_blocks)), dim3(kTB), (size_t)2 * lds_bytes, as_stream(stream)>>>(
         reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, n_ls, genc, dG, partials,
-        genc_absmax, absmax_count, absmax_stride, L, Ls, tile_shift, lds_bytes / 4, log2_chunk);
-    gather_partials_kernel<kF><<<dim3((unsigned)ceil_div((int64_t)side * side, 256), (unsigned)Ls), dim3(256), 0,
-                                 as_stream(stream)>>>(partials, tile_item_base, tile_level_off, n_ls, dG, Ls, tile_shift,
-                                                      lds_bytes / 4);
+        genc_absmax, absmax_count, absmax_stride, L, Ls, tile_shift, lds_bytes / 4, log2_chunk, ride);
+    if (max_items > 0)
+      gather_partials_kernel<kF><<<dim3((unsigned)ceil_div((int64_t)side * side, 256), (unsigned)Ls), dim3(256), 0,
+                                   as_stream(stream)>>>(partials, tile_item_base, tile_level_off, n_ls, dG, Ls, tile_shift,
+                                                        lds_bytes / 4);
   });
   GNGF_RETURN_LAUNCH();
 }

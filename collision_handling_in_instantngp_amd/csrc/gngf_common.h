@@ -51,4 +51,44 @@ __device__ __forceinline__ Cell make_cell(float x, float y, int n) {
 
 __device__ __forceinline__ bool is_pow2(int64_t v) { return (v & (v - 1)) == 0; }
 
+// Decoder backward, second half (csrc/decoder.hip): sums the per-workgroup gradient slabs
+//   dW0 [64*in_dim] | dW1 [64*64] | dW2 [out_dim*64] | db0 [64] | db1 [64] | db2 [out_dim] | max |d enc| (bit pattern)
+// into the six gradient tensors; block `blk` of 1024 threads owns elements [64 blk, 64 blk + 64) (64 elements x 16
+// slab-groups).  The last slot takes the maximum of bit patterns instead of a sum.  Called by decoder_reduce_kernel and,
+// as extra workgroups riding on its own launch, by the tiled encoder backward (one kernel launch less on the step's
+// critical path: a launch costs ~6 us inside a replayed step).
+__device__ __forceinline__ void decoder_reduce_block(int blk, const float* __restrict__ slabs, int nslabs, int nslab, int in_dim,
+                                                     int out_dim, float* __restrict__ dW0, float* __restrict__ db0,
+                                                     float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
+                                                     float* __restrict__ db2, float* __restrict__ absmax) {
+  __shared__ float red[16][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int e = blk * 64 + c;
+  const bool is_max = e == nslab - 1;                    // last slot: max of bit patterns, not a sum
+  float s = 0.f;
+  if (e < nslab)
+    for (int b = q; b < nslabs; b += 16) {
+      const float v = slabs[(int64_t)b * nslab + e];
+      s = is_max ? (__float_as_uint(v) > __float_as_uint(s) ? v : s) : s + v;
+    }
+  red[q][c] = s;
+  __syncthreads();
+  if (q != 0 || e >= nslab) return;
+  if (is_max) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s = __float_as_uint(red[k][c]) > __float_as_uint(s) ? red[k][c] : s;
+    if (absmax) *absmax = s;
+    return;
+  }
+#pragma unroll
+  for (int k = 1; k < 16; ++k) s += red[k][c];
+  const int o0 = 64 * in_dim, o1 = o0 + 64 * 64, o2 = o1 + out_dim * 64, o3 = o2 + 64, o4 = o3 + 64;
+  if (e < o0) dW0[e] = s;
+  else if (e < o1) dW1[e - o0] = s;
+  else if (e < o2) dW2[e - o1] = s;
+  else if (e < o3) db0[e - o2] = s;
+  else if (e < o4) db1[e - o3] = s;
+  else db2[e - o4] = s;
+}
+
 }  // namespace gngf

@@ -233,6 +233,7 @@ class GeneralNeuralGaugeFields(nn.Module):
         self.coord_bounds = None
         self.compute_pbar = True           # batch-mean distribution for the loss when probs is returned compact
         self._frozen_table = None          # cached per-vertex (idx, w, q) when the HPD is frozen
+        self._fused_mse_target = None      # see fused_mse()
         self.to(device)
 
     # ------------------------------------------------------------------ helpers
@@ -250,7 +251,25 @@ class GeneralNeuralGaugeFields(nn.Module):
     def _decode(self, enc):
         n = len(self.mlp)
         hidden = ops.ACT_LEAKY if self._leaky else ops.ACT_RELU
-        return ops.decoder_apply(enc, tuple([hidden] * (n - 1) + [ops.ACT_SIGMOID]), self._decoder_params())
+        return ops.decoder_apply(enc, tuple([hidden] * (n - 1) + [ops.ACT_SIGMOID]), self._decoder_params(),
+                                 mse_target=self._fused_mse_target)
+
+    def fused_mse(self, target):
+        """Context manager: forward passes inside it also evaluate torch.nn.MSELoss()(rgb, target) in the decoder kernels and
+        attach the value to the returned rgb; train.Loss (ops.mse_loss) picks it up when it is given that rgb and this very
+        `target` tensor, instead of launching the loss kernels.  Results are those of the separate kernels (gradients bit
+        for bit).  The training loops of train.py use it; it is never required."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            prev = self._fused_mse_target
+            self._fused_mse_target = target
+            try:
+                yield self
+            finally:
+                self._fused_mse_target = prev
+        return scope()
 
     def _vertex_extent(self, x):
         """(vstride, NV) of the dense per-vertex table covering every corner of every level for this batch."""

@@ -625,9 +625,15 @@ def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None):
     """absmax: None or (tensor, count, stride) — `count` floats `stride` apart whose maximum bounds |genc|."""
     partials = torch.empty((plan.max_items * (plan.lds_bytes // 4),), dtype=_f32, device=genc.device)
     am, am_count, am_stride = absmax if absmax is not None else (None, 0, 0)
+    ride = _take_pending_reduce(genc.device)        # a decoder slab reduction waiting for a launch to ride on
+    if ride is None:
+        ride_args = [ptr(None)] * 7 + [0, 0, 0]
+    else:
+        ride_args = [ptr(ride["slabs"])] + [ptr(g) for g in ride["grads"]] + [ride["P"], ride["in_dim"], ride["out_dim"]]
     call("gngf_encode_tiled_bwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(ws.tile_item_base),
          ptr(tile_level_offsets(plan, genc.device)), ptr(n_ls), plan.n_ls_c, ptr(genc, _f32, "grad"), ptr(am),
-         int(am_count), int(am_stride), ptr(dG), ptr(partials), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, plan.chunk, stream_ptr())
+         int(am_count), int(am_stride), ptr(dG), ptr(partials), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, plan.chunk,
+         *ride_args, stream_ptr())
 
 
 def run_deferred_vertex_stage(exchanged=False):
@@ -805,6 +811,11 @@ class MseFunction(torch.autograd.Function):
 
 
 def mse_loss(pred, label):
+    """torch.nn.MSELoss()(pred, label).  A prediction that came out of the fused decoder together with the loss against this
+    very label tensor (decoder_apply(..., mse_target=label)) hands that value over instead of launching the loss kernels."""
+    fused = getattr(pred, "_gngf_fused_mse", None)
+    if fused is not None and fused[0] is label and pred._version == 0:
+        return fused[1]
     return MseFunction.apply(pred, label)
 
 
@@ -843,19 +854,111 @@ def js_kl_rows(pbar, gamma, eps):
 # stores and loads ride under the MFMAs of kernels that leave most of the HBM bandwidth unused (decoder backward 345 -> ~230 us
 # at 2^20 px).  False: recompute (no extra memory).
 DECODER_SAVE_HIDDEN = True
-# Reduce the decoder backward's gradient slabs on the helper stream, beside the encoder backward (see DecoderFunction.backward).
-# Measured: a loss — the 8 us reduction takes 47 us next to the pixel stage, which fills every CU, and slows it by 5 us
-# (step 0.65 -> 0.67 ms).  Off; the split entry points stay for callers with idle CUs at that point.
-DECODER_REDUCE_ASIDE = False
+# The slab reduction of the decoder backward (8 us + a launch gap of ~6 us inside a replayed step) rides on the NEXT launch of
+# the backward pass — the tiled encoder backward, which comes right behind it and only needs max |d enc| (taken from the
+# slabs' last words) — as extra workgroups of that kernel.  If no tiled encoder backward follows, the reduction is launched
+# on its own when the backward pass ends.
+DECODER_REDUCE_RIDES = True
+
+_PENDING_REDUCE = []          # [{slabs, grads, P, in_dim, out_dim, device, stream}]: decoder reductions not yet launched
 
 
-def _join_at_end_of_backward(cur, side):
-    """Makes `cur` wait for `side` when the running backward pass ends (autograd engine callback); outside a backward pass
-    (a Function's backward called by hand) the join happens at once."""
+def _take_pending_reduce(device):
+    cur = torch.cuda.current_stream(device).cuda_stream
+    for k, r in enumerate(_PENDING_REDUCE):
+        if r["device"] == device and r["stream"] == cur:
+            return _PENDING_REDUCE.pop(k)
+    return None
+
+
+def _flush_pending_reduces():
+    """Launches every decoder slab reduction nobody picked up (no tiled encoder backward followed the decoder backward)."""
+    while _PENDING_REDUCE:
+        r = _PENDING_REDUCE.pop()
+        with torch.cuda.stream(torch.cuda.ExternalStream(r["stream"], device=r["device"])):
+            call("gngf_decoder_reduce", ptr(r["slabs"]), *[ptr(g) for g in r["grads"]], ptr(None), r["P"], r["in_dim"], r["out_dim"],
+                 stream_ptr())
+
+
+def _at_end_of_backward(fn):
+    """Runs fn when the running backward pass ends (autograd engine callback); outside a backward pass (a Function's
+    backward called by hand) at once."""
     try:
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: cur.wait_stream(side))
+        torch.autograd.Variable._execution_engine.queue_callback(fn)
     except RuntimeError:
-        cur.wait_stream(side)
+        fn()
+
+
+def _decoder_fwd(ctx, enc, leaky, ws, target):
+    enc = _c(enc)
+    ws = [_c(w) for w in ws]
+    P, in_dim = enc.shape
+    out_dim = ws[4].shape[0]
+    dev = enc.device
+    rgb = torch.empty((P, out_dim), dtype=_f32, device=dev)
+    hidden = None
+    if DECODER_SAVE_HIDDEN and P > 0 and any(ctx.needs_input_grad):
+        hidden = torch.empty((_lib.query("gngf_decoder_hidden_floats", P),), dtype=_f32, device=dev)
+    mse = wsp = None
+    if target is not None:
+        if P == 0:
+            raise ValueError("MSE of an empty batch")
+        target = _c(target)
+        if tuple(target.shape) != (P, out_dim) or target.dtype != _f32:
+            raise ValueError(f"target {tuple(target.shape)} / {target.dtype} does not match the decoder output ({P}, {out_dim}) float32")
+        wsp = _MSE_WORKSPACE.get(dev)
+        if wsp is None:
+            wsp = _MSE_WORKSPACE[dev] = torch.zeros(query("gngf_mse_workspace_floats"), dtype=_f32, device=dev)
+        mse = torch.empty((), dtype=_f32, device=dev)
+    call("gngf_decoder_fwd", ptr(enc, _f32, "enc"), *[ptr(w, _f32) for w in ws], ptr(rgb), ptr(hidden), ptr(target), ptr(mse), ptr(wsp),
+         P, in_dim, out_dim, int(leaky), stream_ptr())
+    ctx.save_for_backward(enc, rgb, target, *ws)
+    ctx.hidden = hidden
+    ctx.cfg = (P, in_dim, out_dim, int(leaky))
+    return rgb, mse
+
+
+def _decoder_bwd(ctx, drgb, gloss):
+    """drgb (P,out_dim) | None and gloss (0-dim) | None: gradient w.r.t. rgb and, for the fused loss, w.r.t. the MSE value."""
+    enc, rgb, target, W0, b0, W1, b1, W2, b2 = ctx.saved_tensors
+    P, in_dim, out_dim, leaky = ctx.cfg
+    dev = enc.device
+    if gloss is not None and drgb is not None:
+        # rgb ALSO feeds something else: fold both into one explicit gradient (plain framework ops; not the training step's path)
+        drgb = drgb + gloss * (2.0 / (P * out_dim)) * (rgb - target)
+        gloss = None
+    fused = gloss is not None
+    if fused:
+        gloss = _c(gloss.to(_f32))
+    else:
+        drgb = _c(drgb) if drgb is not None else torch.zeros_like(rgb)
+    denc = torch.empty_like(enc)
+    # the six parameter gradients are consecutive views of ONE buffer: the data-parallel exchange all-reduces that
+    # buffer in place (parallel.allreduce_gradients) instead of packing and unpacking a bucket
+    ws = (W0, b0, W1, b1, W2, b2)
+    flat = torch.empty((sum(w.numel() for w in ws),), dtype=_f32, device=dev)
+    grads, off = [], 0
+    for w in ws:
+        grads.append(flat[off:off + w.numel()].view(w.shape))
+        off += w.numel()
+    nslabs, nslab = _lib.query("gngf_decoder_bwd_slabs", P), _lib.query("gngf_decoder_slab_floats", in_dim, out_dim)
+    slabs = torch.empty((nslabs * nslab,), dtype=_f32, device=dev)
+    common = (ptr(enc), ptr(rgb), ptr(None if fused else drgb, _f32, "grad"), ptr(target if fused else None), ptr(gloss if fused else None),
+              ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(denc))
+    if DECODER_REDUCE_RIDES and P > 0:
+        call("gngf_decoder_bwd", *common, *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(ctx.hidden), P, in_dim, out_dim, leaky, stream_ptr())
+        _PENDING_REDUCE.append({"slabs": slabs, "grads": grads, "P": P, "in_dim": in_dim, "out_dim": out_dim, "device": dev,
+                                "stream": torch.cuda.current_stream(dev).cuda_stream, "flat": flat})
+        _at_end_of_backward(_flush_pending_reduces)
+        hint = (slabs[nslab - 1:], nslabs, nslab)         # the per-slab maxima: all the encoder backward needs from the slabs
+    else:
+        absmax = torch.empty((1,), dtype=_f32, device=dev)
+        call("gngf_decoder_bwd", *common, *[ptr(g) for g in grads], ptr(slabs), ptr(absmax), ptr(ctx.hidden), P, in_dim, out_dim, leaky,
+             stream_ptr())
+        hint = (absmax, 1, 0)
+    ctx.hidden = None
+    _ABSMAX_HINTS[denc.data_ptr()] = (hint, denc._version)
+    return denc, grads
 
 
 class DecoderFunction(torch.autograd.Function):
@@ -864,62 +967,33 @@ class DecoderFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, enc, leaky, W0, b0, W1, b1, W2, b2):
-        enc = _c(enc)
-        ws = [_c(w) for w in (W0, b0, W1, b1, W2, b2)]
-        P, in_dim = enc.shape
-        out_dim = ws[4].shape[0]
-        rgb = torch.empty((P, out_dim), dtype=_f32, device=enc.device)
-        hidden = None
-        if DECODER_SAVE_HIDDEN and P > 0 and any(ctx.needs_input_grad):
-            hidden = torch.empty((_lib.query("gngf_decoder_hidden_floats", P),), dtype=_f32, device=enc.device)
-        call("gngf_decoder_fwd", ptr(enc, _f32, "enc"), *[ptr(w, _f32) for w in ws], ptr(rgb), ptr(hidden), P, in_dim, out_dim,
-             int(leaky), stream_ptr())
-        ctx.save_for_backward(enc, rgb, *ws)
-        ctx.hidden = hidden
-        ctx.cfg = (P, in_dim, out_dim, int(leaky))
+        rgb, _ = _decoder_fwd(ctx, enc, leaky, (W0, b0, W1, b1, W2, b2), None)
         return rgb
 
     @staticmethod
     def backward(ctx, drgb):
-        enc, rgb, W0, b0, W1, b1, W2, b2 = ctx.saved_tensors
-        P, in_dim, out_dim, leaky = ctx.cfg
-        drgb = _c(drgb)
-        dev = enc.device
-        denc = torch.empty_like(enc)
-        # the six parameter gradients are consecutive views of ONE buffer: the data-parallel exchange all-reduces that
-        # buffer in place (parallel.allreduce_gradients) instead of packing and unpacking a bucket
-        ws = (W0, b0, W1, b1, W2, b2)
-        flat = torch.empty((sum(w.numel() for w in ws),), dtype=_f32, device=dev)
-        grads, off = [], 0
-        for w in ws:
-            grads.append(flat[off:off + w.numel()].view(w.shape))
-            off += w.numel()
-        slabs = torch.empty((_lib.query("gngf_decoder_bwd_slabs", P) * _lib.query("gngf_decoder_slab_floats", in_dim, out_dim),),
-                            dtype=_f32, device=dev)
-        absmax = torch.empty((1,), dtype=_f32, device=dev)
-        nslab = _lib.query("gngf_decoder_slab_floats", in_dim, out_dim)
-        if DECODER_REDUCE_ASIDE and P > 0:
-            # The slab reduction (8 us + a launch gap) leaves the critical path: the encoder backward, which comes next,
-            # only needs max |d enc| and takes it from the slabs' last words; the six gradients are not read before the
-            # backward pass ends, where the helper stream is joined again.
-            call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb, _f32, "grad"), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2),
-                 ptr(denc), *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(ctx.hidden), P, in_dim, out_dim, leaky, stream_ptr())
-            cur, side = torch.cuda.current_stream(), _side_stream(dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                call("gngf_decoder_reduce", ptr(slabs), *[ptr(g) for g in grads], ptr(absmax), P, in_dim, out_dim, stream_ptr())
-            for buf in (slabs, flat, absmax):
-                buf.record_stream(side)
-            _join_at_end_of_backward(cur, side)
-            hint = (slabs[nslab - 1:], _lib.query("gngf_decoder_bwd_slabs", P), nslab)
-        else:
-            call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb, _f32, "grad"), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2),
-                 ptr(denc), *[ptr(g) for g in grads], ptr(slabs), ptr(absmax), ptr(ctx.hidden), P, in_dim, out_dim, leaky,
-                 stream_ptr())
-            hint = (absmax, 1, 0)
-        ctx.hidden = None
-        _ABSMAX_HINTS[denc.data_ptr()] = (hint, denc._version)
+        denc, grads = _decoder_bwd(ctx, drgb, None)
         return (denc, None, *grads)
+
+
+class DecoderMseFunction(torch.autograd.Function):
+    """Decoder + the pixel loss of the training step in the same two launches: apply(enc, target, leaky, W0 .. b2) ->
+    (rgb, mse) with mse = torch.nn.MSELoss()(rgb, target) (reference utils.py:99).  The loss value comes out of the forward
+    kernel's epilogue, its gradient 2 (rgb - target) / n is formed in the backward kernel's prologue: the two loss kernels
+    (~20 us of a 0.6 ms step, mostly launch latency) and the d rgb round trip disappear.  Same arithmetic as ops.MseFunction."""
+
+    @staticmethod
+    def forward(ctx, enc, target, leaky, W0, b0, W1, b1, W2, b2):
+        ctx.set_materialize_grads(False)
+        rgb, mse = _decoder_fwd(ctx, enc, leaky, (W0, b0, W1, b1, W2, b2), target.detach())
+        return rgb, mse
+
+    @staticmethod
+    def backward(ctx, drgb, gloss):
+        if drgb is None and gloss is None:
+            return (None,) * 9
+        denc, grads = _decoder_bwd(ctx, drgb, gloss)
+        return (denc, None, None, *grads)
 
 
 def decoder_fused_ok(acts, params):
@@ -929,10 +1003,16 @@ def decoder_fused_ok(acts, params):
     return W0.shape[0] == 64 and tuple(W1.shape) == (64, 64) and W2.shape[1] == 64 and W0.shape[1] <= 64 and W2.shape[0] <= 4
 
 
-def decoder_apply(enc, acts, params, fused=None):
+def decoder_apply(enc, acts, params, fused=None, mse_target=None):
     """Decoder MLP dispatch (reference models.py:382-392,469-470): the fused kernel for the default 64/64 widths,
-    the generic MFMA linear chain otherwise."""
+    the generic MFMA linear chain otherwise.  mse_target (P,out) float32: also evaluate MSELoss(rgb, mse_target) inside the
+    fused kernels; the 0-dim loss is attached to the returned rgb as `rgb._gngf_fused_mse = (mse_target, loss)`."""
     if (fused is None or fused) and decoder_fused_ok(acts, params):
+        if (mse_target is not None and enc.shape[0] > 0 and mse_target.is_cuda and mse_target.dtype == _f32
+                and tuple(mse_target.shape) == (enc.shape[0], params[4].shape[0])):
+            rgb, mse = DecoderMseFunction.apply(enc, mse_target, acts[0] == ACT_LEAKY, *params)
+            rgb._gngf_fused_mse = (mse_target, mse)
+            return rgb
         return DecoderFunction.apply(enc, acts[0] == ACT_LEAKY, *params)
     if fused:
         raise ValueError("fused decoder needs hidden widths [64, 64], in <= 64, out <= 4")
@@ -989,11 +1069,11 @@ def decoder_kernels(enc, params, leaky, drgb):
     hidden = torch.empty((_lib.query("gngf_decoder_hidden_floats", P),), dtype=_f32, device=enc.device) if DECODER_SAVE_HIDDEN else None
 
     def fwd():
-        call("gngf_decoder_fwd", ptr(enc), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(rgb), ptr(hidden), P, in_dim,
-             out_dim, int(leaky), stream_ptr())
+        call("gngf_decoder_fwd", ptr(enc), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(rgb), ptr(hidden), ptr(None), ptr(None),
+             ptr(None), P, in_dim, out_dim, int(leaky), stream_ptr())
 
     def bwd():
-        call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(denc),
+        call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(None), ptr(None), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(denc),
              *[ptr(g) for g in grads], ptr(slabs), ptr(None), ptr(hidden), P, in_dim, out_dim, int(leaky), stream_ptr())
 
     fwd()

@@ -1,6 +1,8 @@
 """Callers of the hot path, mirrored from the reference so that parity tests read like the reference's own
 training loop: Loss (utils.py:78-174), get_optimizer (functions.py:96-127), train_step
 (functions.py:139-355, batching + loss assembly only; no wandb / plotting / collision diagnostics)."""
+import contextlib
+
 import numpy as np
 import torch
 
@@ -282,7 +284,8 @@ class GraphedStep:
         # alive as long as any earlier graph does (a kept `loss` from an eager step on the default stream is enough): the
         # captured backward would then hop onto the legacy default stream, which cannot take part in a capture
         # (hipStreamEndCapture crashes; tools/dbg_graphed.py).  Fresh leaves get their nodes on the capturing stream.
-        out, probs, idx, _counts = torch.func.functional_call(net, shadow, (st["x"], self.batch_percentage), {"should_calc_counts": False})
+        with net.fused_mse(st["y"]):                 # the pixel loss rides in the decoder kernels (same values, two launches less)
+            out, probs, idx, _counts = torch.func.functional_call(net, shadow, (st["x"], self.batch_percentage), {"should_calc_counts": False})
         mse, kls, colls = self.loss_fn(out, st["y"], None if probs is None else probs.shape[-1], probs, st["pc"], st["pm"])
         loss = assemble_loss(mse, kls, colls, l_mse, l_js_kl, l_collisions)
         loss.backward(gradient=st["one"].to(loss.dtype))
@@ -387,7 +390,9 @@ def train_epoch(net, loss_fn, optimizer, x, target, w, h, l_mse, l_js_kl, l_coll
             out, idx, loss, mse, kls, colls, counts = r.out, r.idx, r.loss, r.mse, r.kls, r.colls, []
         else:
             optimizer.zero_grad()
-            out, probs, idx, counts = net(bx, batch_percentage, should_calc_counts=should_calc_counts)
+            by = by.contiguous()
+            with (net.fused_mse(by) if hasattr(net, "fused_mse") else contextlib.nullcontext()):
+                out, probs, idx, counts = net(bx, batch_percentage, should_calc_counts=should_calc_counts)
             mse, kls, colls = loss_fn(out, by, None if probs is None else probs.shape[-1], probs,
                                       previous_collisions, previous_min_possible_collisions)
             loss = assemble_loss(mse, kls, colls, l_mse, l_js_kl, l_collisions)

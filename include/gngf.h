@@ -112,7 +112,11 @@ int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32
                           const int32_t* tile_item_base, const int32_t* tile_level_off, const int32_t* n_ls,
                           const int32_t* n_ls_host, const float* genc, const float* genc_absmax, int absmax_count,
                           int absmax_stride, float* dG, float* partials, int L, int Ls, int F, int tile_shift, int lds_bytes,
-                          int chunk, void* stream);
+                          int chunk, const float* ride_slabs, float* ride_dW0, float* ride_db0, float* ride_dW1, float* ride_db1,
+                          float* ride_dW2, float* ride_db2, int64_t ride_P, int ride_in_dim, int ride_out_dim, void* stream);
+/* ride_* (optional, ride_slabs NULL = none): the slab reduction of a preceding gngf_decoder_bwd that was called without
+ * gradient pointers (= gngf_decoder_reduce(ride_slabs, ride_dW0 .. ride_db2, NULL, ride_P, ride_in_dim, ride_out_dim)) runs in
+ * extra workgroups of this launch instead of a launch of its own (one dependent launch less on the step's critical path). */
 /* vertex stage backward for the vertex-table source in SLOT order (order (NV*K) int32 = argsort of vert_idx, flat):
  * contention-free for any slot distribution (wave-level segmented reduction, one atomic per (wave, slot run));
  * dtables accumulated, dvert_w (NV,K) written without atomics (NULL when not needed). */
@@ -138,17 +142,24 @@ int gngf_gemm_acc(const float* A, const float* B, float* C, int64_t M, int64_t N
  * gngf_decoder_bwd — the stores ride under the forward kernel's MFMAs, and the backward kernel then reads them back
  * instead of recomputing them (96 of its 292 MFMAs per 32 pixels). */
 int gngf_decoder_fwd(const float* enc, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
-                     const float* b2, float* rgb, float* hidden, int64_t P, int in_dim, int out_dim, int leaky, void* stream);
+                     const float* b2, float* rgb, float* hidden, const float* target, float* mse, float* mse_workspace,
+                     int64_t P, int in_dim, int out_dim, int leaky, void* stream);
+/* target (P,out_dim), optional: the pixel loss of the training step, torch.nn.MSELoss()(rgb, target) (utils.py:99), is
+ * evaluated in the same launch: mse (1 float) = mean((rgb - target)^2); mse_workspace = gngf_mse_workspace_floats() floats,
+ * 8-byte aligned, zero-filled once before the first call (the kernel resets it).  NULL: rgb only. */
 int64_t gngf_decoder_hidden_floats(int64_t P);
 /* backward: denc (P,in_dim) and the six parameter gradients, each WRITTEN (not accumulated); rgb = the forward output.
  * slabs: workspace of gngf_decoder_bwd_slabs(P) * gngf_decoder_slab_floats(in_dim, out_dim) floats.
  * denc_absmax (1 float, optional): receives max |denc| (NaN if any element is NaN) — a bound the tiled encoder backward
  * can take instead of scanning its input once more.
  * hidden (optional): the buffer gngf_decoder_fwd filled for the same enc and weights; NULL: recompute. */
-int gngf_decoder_bwd(const float* enc, const float* rgb, const float* drgb, const float* W0, const float* b0, const float* W1,
+int gngf_decoder_bwd(const float* enc, const float* rgb, const float* drgb, const float* target, const float* gloss,
+                     const float* W0, const float* b0, const float* W1,
                      const float* b1, const float* W2, float* denc, float* dW0, float* db0, float* dW1, float* db1, float* dW2,
                      float* db2, float* slabs, float* denc_absmax, const float* hidden, int64_t P, int in_dim, int out_dim,
                      int leaky, void* stream);
+/* target + gloss (1 float), optional, instead of drgb: the gradient of the fused pixel loss,
+ * d rgb = gloss[0] * 2 / (P * out_dim) * (rgb - target) (MSELoss backward), is formed inside the kernel (drgb may be NULL). */
  /* The six gradient pointers may ALL be NULL: the kernel then stops at the slabs and gngf_decoder_reduce finishes (e.g. on a
   * second stream, beside the encoder backward — which only needs max |denc|: the last float of every slab is that slab's
   * maximum, i.e. genc_absmax = slabs + slab_floats - 1, absmax_count = gngf_decoder_bwd_slabs(P), absmax_stride = slab_floats). */

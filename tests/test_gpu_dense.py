@@ -431,32 +431,89 @@ def test_js_kl_kernels_vs_float64_and_torch_expression(ops, L, T):
     close(out, ref.detach().cpu().numpy(), 2e-4, 1e-8)
 
 
-def test_decoder_reduce_on_helper_stream_gives_the_same_gradients(ops):
-    """gngf_decoder_bwd without gradient pointers + gngf_decoder_reduce on the helper stream (ops.DECODER_REDUCE_ASIDE) ==
-    the one-call form, and the per-slab maxima it hands to the encoder backward bound |d enc|"""
+def test_decoder_slab_reduction_riding_on_the_encoder_backward_gives_the_same_gradients(ops):
+    """ops.DECODER_REDUCE_RIDES: gngf_decoder_bwd stops at its slabs and the reduction runs as extra workgroups of the tiled
+    encoder backward's launch (or, when none follows, on its own at the end of the backward pass) == the one-call form, bit
+    for bit; the per-slab maxima handed to the encoder backward bound |d enc|."""
+    from oracle import gngf_oracle as orc
     rng = np.random.default_rng(4)
-    P = 5000
-    x = t(rng.standard_normal((P, 32)).astype(np.float32))
+    P = 40000
     params = [t((rng.standard_normal(s) * 0.3).astype(np.float32)) for s in ((64, 32), (64,), (64, 64), (64,), (3, 64), (3,))]
     gy = t(rng.standard_normal((P, 3)).astype(np.float32))
     acts = (ops.ACT_RELU, ops.ACT_RELU, ops.ACT_SIGMOID)
+    n_ls = orc.level_resolutions(16, 256, 16)
+    n_host = [int(n) for n in n_ls]
+    xy = t(rng.random((P, 2), dtype=np.float32))
+    tables = t((rng.random((16, 4096, 2), dtype=np.float32) - 0.5) * 2e-1)
+    x = t(rng.standard_normal((P, 32)).astype(np.float32))
     res = {}
-    for aside in (False, True):
-        ops.DECODER_REDUCE_ASIDE = aside
-        try:
+    for with_encoder in (False, True):
+        for rides in (False, True):
+            ops.DECODER_REDUCE_RIDES = rides
+            try:
+                ps = [p.clone().requires_grad_() for p in params]
+                if with_encoder:
+                    tt = tables.clone().requires_grad_()
+                    xs = ops.encode_apply(xy, t(n_ls, torch.int32), n_host, tt, None, None, 0, path="tiled")
+                else:
+                    tt = None
+                    xs = x.clone().requires_grad_()
+                ops.decoder_apply(xs, acts, ps, fused=True).backward(gy)
+                torch.cuda.synchronize()
+                assert not ops._PENDING_REDUCE                      # picked up by the encoder backward, or flushed at the end
+                lead = tt.grad if with_encoder else xs.grad
+                res[(with_encoder, rides)] = [lead.clone()] + [p.grad.clone() for p in ps]
+                if not with_encoder and rides:
+                    (am, count, stride), _ver = ops._ABSMAX_HINTS.pop(xs.grad.data_ptr())
+                    bound = float(torch.stack([am[i * stride] for i in range(count)]).max())
+                    assert bound == float(xs.grad.abs().max())
+            finally:
+                ops.DECODER_REDUCE_RIDES = True
+        for a, b in zip(res[(with_encoder, False)], res[(with_encoder, True)]):
+            assert torch.equal(a, b)
+
+
+def test_fused_pixel_loss_equals_the_separate_loss_kernels(ops):
+    """DecoderMseFunction (loss value in the decoder forward's epilogue, loss gradient formed in the backward's prologue) ==
+    decoder + ops.MseFunction: every gradient bit for bit (the same d rgb expression), the value to the rounding of a
+    different summation order; ragged sizes, a scaled loss, one output channel, and rgb feeding a second consumer."""
+    rng = np.random.default_rng(12)
+    acts = (ops.ACT_RELU, ops.ACT_RELU, ops.ACT_SIGMOID)
+    for P, in_dim, out_dim in ((40001, 32, 3), (130, 32, 3), (5000, 8, 1), (2 ** 16, 64, 4)):
+        params = [t((rng.standard_normal(s) * 0.3).astype(np.float32)) for s in ((64, in_dim), (64,), (64, 64), (64,), (out_dim, 64), (out_dim,))]
+        x = t(rng.standard_normal((P, in_dim)).astype(np.float32))
+        tgt = t(rng.random((P, out_dim), dtype=np.float32))
+        res = {}
+        for fused in (False, True):
             xs = x.clone().requires_grad_()
             ps = [p.clone().requires_grad_() for p in params]
-            ops.decoder_apply(xs, acts, ps, fused=True).backward(gy)
-            torch.cuda.synchronize()
-            hint = ops._ABSMAX_HINTS.pop(xs.grad.data_ptr(), None)
-            res[aside] = ([xs.grad.clone()] + [p.grad.clone() for p in ps], hint)
-        finally:
-            ops.DECODER_REDUCE_ASIDE = False
-    for a, b in zip(res[False][0], res[True][0]):
-        assert torch.equal(a, b)
-    (am, count, stride), _ver = res[True][1]
-    bound = float(torch.stack([am[i * stride] for i in range(count)]).max())
-    assert bound == float(res[False][0][0].abs().max())
+            rgb = ops.decoder_apply(xs, acts, ps, fused=True, mse_target=(tgt if fused else None))
+            assert (getattr(rgb, "_gngf_fused_mse", None) is not None) == fused
+            loss = ops.mse_loss(rgb, tgt)
+            (loss * 3.0).backward()
+            res[fused] = (loss.detach().clone(), rgb.detach().clone(), [xs.grad.clone()] + [p.grad.clone() for p in ps])
+        assert torch.equal(res[False][1], res[True][1])
+        close(res[True][0], res[False][0].cpu().numpy(), 2e-6, 0, f"fused MSE value vs mse_fwd kernel (P={P})")
+        want = ((res[False][1].double() - tgt.double()) ** 2).mean()
+        close(res[True][0], want.cpu().numpy(), 2e-6, 0, f"fused MSE value vs float64 (P={P})")
+        for a, b in zip(res[False][2], res[True][2]):
+            assert torch.equal(a, b)
+    # rgb also feeds another consumer: gradients add up
+    xs = x.clone().requires_grad_()
+    ps = [p.clone().requires_grad_() for p in params]
+    rgb = ops.decoder_apply(xs, acts, ps, fused=True, mse_target=tgt)
+    (ops.mse_loss(rgb, tgt) + 0.5 * rgb.sum()).backward()
+    xs2 = x.clone().requires_grad_()
+    ps2 = [p.clone().requires_grad_() for p in params]
+    rgb2 = ops.decoder_apply(xs2, acts, ps2, fused=True)
+    (ops.mse_loss(rgb2, tgt) + 0.5 * rgb2.sum()).backward()
+    for a, b in zip([xs.grad] + [p.grad for p in ps], [xs2.grad] + [p.grad for p in ps2]):
+        scale = float(b.abs().max())
+        close(a, b.cpu().numpy(), 1e-5, 1e-6 * scale)
+    # a different label tensor does not pick the fused value up
+    other = tgt.clone()
+    rgb3 = ops.decoder_apply(x, acts, params, fused=True, mse_target=tgt)
+    assert ops.mse_loss(rgb3, other) is not rgb3._gngf_fused_mse[1]
 
 
 def test_decoder_bwd_reports_its_device_clock_span(ops):
