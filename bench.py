@@ -208,7 +208,7 @@ def timed(step, steps, warmup, world):
     return dt
 
 
-ENTRY_NAMES = {"gngf_bin_pixels": "bin_pixels", "gngf_vertex_grid_fwd": "vertex_fwd", "gngf_encode_tiled_fwd": "encode_fwd:tiled",
+ENTRY_NAMES = {"gngf_bin_pixels": "bin_pixels", "gngf_encode_tiled_prepare": "prepare(bin+vertex_fwd+clears)", "gngf_vertex_grid_fwd": "vertex_fwd", "gngf_encode_tiled_fwd": "encode_fwd:tiled",
                "gngf_encode_tiled_bwd": "encode_bwd:tiled", "gngf_vertex_grid_bwd_sorted": "vertex_bwd", "gngf_vertex_grid_bwd": "vertex_bwd",
                "gngf_decoder_fwd": "decoder_fwd", "gngf_decoder_bwd": "decoder_bwd", "gngf_decoder_reduce": "decoder_reduce", "gngf_mse_fwd": "mse_fwd", "gngf_mse_bwd": "mse_bwd",
                "gngf_encode_fwd": "encode_fwd:direct", "gngf_encode_bwd": "encode_bwd:direct"}

@@ -28,13 +28,15 @@ SIGNATURES = {
     "gngf_encode_fwd": [_P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _L, _I, _I, _P],
     "gngf_encode_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _L, _I, _I, _P],
     "gngf_bin_pixels": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "gngf_encode_tiled_prepare": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L,
+                                  _P, _L, _P],
     "gngf_vertex_grid_fwd": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L, _P],
     "gngf_vertex_grid_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L, _P],
     "gngf_encode_tiled_fwd": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gngf_encode_tiled_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I,
-                              _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+                              _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _L, _P],
     "gngf_vertex_grid_bwd_sorted": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _L, _P],
-    "gngf_decoder_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "gngf_decoder_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gngf_decoder_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gngf_decoder_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "gngf_decoder_bwd_last_span_ns": [_P],
@@ -57,6 +59,7 @@ SIGNATURES = {
     "gngf_multiplicity_weights": [_P, _P, _L, _I, _F, _P],
     "gngf_expand_vertex_table": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _L, _P],
     "gngf_mse_workspace_floats": [],
+    "gngf_mse_blocks": [_L],
     "gngf_mse_fwd": [_P, _P, _P, _P, _L, _P],
     "gngf_mse_bwd": [_P, _P, _P, _P, _L, _P],
     "gngf_js_kl_workspace_doubles": [_I],

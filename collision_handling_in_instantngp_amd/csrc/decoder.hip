@@ -228,8 +228,7 @@ __global__ void __launch_bounds__(kDecThreads, 1)
 decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, const float* __restrict__ b0,
                    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
                    const float* __restrict__ b2, float* __restrict__ Y, float* __restrict__ hidden, int64_t P, int in_dim,
-                   int out_dim, const float* __restrict__ target, float* __restrict__ mse_out, double* __restrict__ mse_acc,
-                   unsigned* __restrict__ mse_ticket) {
+                   int out_dim) {
   constexpr int S0 = KIN / 2;
   if (EXACT) in_dim = KIN;
 #if defined(GNGF_STAMPS)
@@ -303,10 +302,7 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
   // iteration — including the 12-20 stores the previous tile issued after its loads, i.e. for the full write latency at
   // the top of every tile (+2.8 k cycles per tile with the hidden-layer stores).  The exact-width path therefore issues
   // the row loads through inline asm and waits for them itself: kStoresPerTile memory operations follow them in a tile.
-  // (+4: with a fused pixel loss the tile's target values are requested right behind the next tile's rows)
   constexpr int kStoresPerTile = (SAVE ? 16 : 0) + 4;
-  const bool fused_loss = target != nullptr;              // wave-uniform
-  float se = 0.f;                                         // this lane's sum of squared errors (torch.nn.MSELoss, utils.py:99)
   if (EXACT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if defined(GNGF_STAMPS)
   unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast;
@@ -315,8 +311,7 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     STAMP(0);
     if (EXACT) {                                           // the row loads of this tile (issued a tile ago) have landed
-      if (fused_loss) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kStoresPerTile + 4) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kStoresPerTile) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kStoresPerTile) : "memory");
 #pragma unroll
       for (int sx = 0; sx < S0; ++sx) asm volatile("" : "+v"(xr[sx]));
     }
@@ -333,15 +328,6 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
     MFMA_DRAIN(acc1[0], acc1[1]);
     __builtin_amdgcn_sched_barrier(0);
     fetch(tile + gridDim.x, xr);
-    float tn[4] = {0.f, 0.f, 0.f, 0.f};
-    if (fused_loss) {                                      // this tile's target values: they land under layer 2
-      int64_t rem = (P - tile * 128) * out_dim * 4;
-      rem = rem > 128 * out_dim * 4 ? 128 * out_dim * 4 : rem;
-      const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(target) + tile * 128 * out_dim, 0, (int)rem, 0x00020000);
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        tn[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rt, (h == 0 && c < out_dim) ? yoff + 4u * c : 0x40000000u, 0, 0));
-    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -386,37 +372,9 @@ decoder_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W0, co
         const float y = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
         const unsigned off = (h == 0 && c < out_dim) ? yoff + 4u * c : 0x40000000u;
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs, off, 0, 0);
-        if (fused_loss) {                                  // pixels past the end and the idle lane half contribute nothing
-          const bool live = h == 0 && c < out_dim && (tile * 128 + wave * 32 + i) < P;
-          const float d = y - tn[c];
-          se += live ? d * d : 0.f;
-        }
       }
     }
     STAMP(4);
-  }
-  if (fused_loss) {
-    // loss = sum / n in the SAME launch: workgroup partials meet in a double-precision atomic and a ticket counter whose
-    // request depends on the atomic's return value (no release fence: see csrc/loss.hip); the last ticket holder writes
-    // the loss and resets both words for the next launch.
-    __shared__ float red[kDecThreads / 64];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
-    if (lane == 0) red[wave] = se;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double b = 0.0;
-#pragma unroll
-      for (int w = 0; w < kDecThreads / 64; ++w) b += (double)red[w];
-      const double before = atomicAdd(mse_acc, b);
-      const unsigned ticket = atomicAdd(mse_ticket, before < 0.0 ? 2u : 1u);   // sums of squares are never negative: always 1
-      if (ticket == gridDim.x - 1) {
-        const double total = atomicAdd(mse_acc, 0.0);
-        *mse_out = (float)(total / (double)(P * out_dim));
-        atomicExch(reinterpret_cast<unsigned long long*>(mse_acc), 0ull);
-        atomicExch(mse_ticket, 0u);
-      }
-    }
   }
 #if defined(GNGF_STAMPS)
   if (blockIdx.x == 7 && threadIdx.x == 0)
@@ -1019,18 +977,17 @@ extern "C" int64_t gngf_decoder_hidden_floats(int64_t P) { return ((P + 127) / 1
 // rgb (P,out_dim) = decoder(enc (P,in_dim)); hidden widths fixed at 64/64, in_dim <= 64, out_dim <= 4.
 // hidden (optional): gngf_decoder_hidden_floats(P) floats that receive the activated hidden layers for gngf_decoder_bwd.
 extern "C" int gngf_decoder_fwd(const float* enc, const float* W0, const float* b0, const float* W1, const float* b1,
-                                const float* W2, const float* b2, float* rgb, float* hidden, const float* target, float* mse,
-                                float* mse_workspace, int64_t P, int in_dim, int out_dim, int leaky, void* stream) {
+                                const float* W2, const float* b2, float* rgb, float* hidden, int64_t P, int in_dim, int out_dim,
+                                int leaky, void* stream) {
   GNGF_CHECK_ARG(P >= 0 && in_dim > 0 && in_dim <= 64 && out_dim > 0 && out_dim <= 4);
   if (P == 0) return 0;
   GNGF_CHECK_ARG(enc && W0 && b0 && W1 && b1 && W2 && b2 && rgb);
-  GNGF_CHECK_ARG(!target || (mse && mse_workspace && (reinterpret_cast<uintptr_t>(mse_workspace) & 7) == 0));
   const int64_t tiles = (P + 127) / 128;
   const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);       // one persistent workgroup per CU
   const size_t smem = sizeof(float) * (size_t)raw_offsets(in_dim).total;
   DISPATCH_KIN(in_dim, {
     using Kern = void (*)(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
-                          float*, int64_t, int, int, const float*, float*, double*, unsigned*);
+                          float*, int64_t, int, int);
     const bool exact = in_dim == kKIN;
     Kern fn;
     if (hidden)
@@ -1039,9 +996,7 @@ extern "C" int gngf_decoder_fwd(const float* enc, const float* W0, const float* 
     else
       fn = leaky ? (exact ? decoder_fwd_kernel<kKIN, true, true, false> : decoder_fwd_kernel<kKIN, true, false, false>)
                  : (exact ? decoder_fwd_kernel<kKIN, false, true, false> : decoder_fwd_kernel<kKIN, false, false, false>);
-    fn<<<dim3(grid), dim3(kDecThreads), smem, as_stream(stream)>>>(enc, W0, b0, W1, b1, W2, b2, rgb, hidden, P, in_dim, out_dim, target,
-                                                                   mse, reinterpret_cast<double*>(mse_workspace),
-                                                                   reinterpret_cast<unsigned*>(mse_workspace + 2));
+    fn<<<dim3(grid), dim3(kDecThreads), smem, as_stream(stream)>>>(enc, W0, b0, W1, b1, W2, b2, rgb, hidden, P, in_dim, out_dim);
   });
   GNGF_RETURN_LAUNCH();
 }

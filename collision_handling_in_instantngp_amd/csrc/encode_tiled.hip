@@ -41,21 +41,26 @@ __device__ __forceinline__ int tile_of(float x, float y, int tile_shift) {
 
 // ---------------------------------------------------------------------------------------------- binning
 // K1: per-block histogram over a contiguous pixel range -> blockhist[tile][block]
-__global__ void __launch_bounds__(kBinThreads)
-bin_count_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB,
-                 int32_t* __restrict__ blockhist) {
-  extern __shared__ int hist[];
+__device__ __forceinline__ void bin_count_body(int blk, const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift,
+                                               int NB, int32_t* __restrict__ blockhist, int* hist) {
   const int ntiles = 1 << (2 * tile_shift);
   for (int i = threadIdx.x; i < ntiles; i += kBinThreads) hist[i] = 0;
   __syncthreads();
-  const int64_t lo = (int64_t)blockIdx.x * per_block;
+  const int64_t lo = (int64_t)blk * per_block;
   const int64_t hi = lo + per_block < P ? lo + per_block : P;
   for (int64_t p = lo + threadIdx.x; p < hi; p += kBinThreads) {
     const float2 c = xy[p];
     atomicAdd(&hist[tile_of(c.x, c.y, tile_shift)], 1);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < ntiles; i += kBinThreads) blockhist[(int64_t)i * NB + blockIdx.x] = hist[i];
+  for (int i = threadIdx.x; i < ntiles; i += kBinThreads) blockhist[(int64_t)i * NB + blk] = hist[i];
+}
+
+__global__ void __launch_bounds__(kBinThreads)
+bin_count_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB,
+                 int32_t* __restrict__ blockhist) {
+  extern __shared__ int hist[];
+  bin_count_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, hist);
 }
 
 // K2a: one WAVE per tile row of blockhist [tile][NB] (NB <= 512: 8 consecutive entries per lane): exclusive scan inside the
@@ -121,20 +126,45 @@ bin_scan_kernel(const int32_t* __restrict__ tot, int tile_shift, int chunk, int3
 }
 
 // K3: scatter (x, y, original index) into tile order.  Same pixel->block partition as K1.
-__global__ void __launch_bounds__(kBinThreads)
-bin_scatter_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB,
-                   const int32_t* __restrict__ blockhist, const int32_t* __restrict__ tile_off, float4* __restrict__ sorted) {
-  extern __shared__ int cursor[];
+__device__ __forceinline__ void bin_scatter_body(int blk, const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift,
+                                                 int NB, const int32_t* __restrict__ blockhist, const int32_t* __restrict__ tile_off,
+                                                 float4* __restrict__ sorted, int* cursor) {
   const int ntiles = 1 << (2 * tile_shift);
-  for (int i = threadIdx.x; i < ntiles; i += kBinThreads) cursor[i] = tile_off[i] + blockhist[(int64_t)i * NB + blockIdx.x];
+  for (int i = threadIdx.x; i < ntiles; i += kBinThreads) cursor[i] = tile_off[i] + blockhist[(int64_t)i * NB + blk];
   __syncthreads();
-  const int64_t lo = (int64_t)blockIdx.x * per_block;
+  const int64_t lo = (int64_t)blk * per_block;
   const int64_t hi = lo + per_block < P ? lo + per_block : P;
   for (int64_t p = lo + threadIdx.x; p < hi; p += kBinThreads) {
     const float2 c = xy[p];
     const int pos = atomicAdd(&cursor[tile_of(c.x, c.y, tile_shift)], 1);
     sorted[pos] = make_float4(c.x, c.y, __int_as_float((int)p), 0.f);
   }
+}
+
+__global__ void __launch_bounds__(kBinThreads)
+bin_scatter_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB,
+                   const int32_t* __restrict__ blockhist, const int32_t* __restrict__ tile_off, float4* __restrict__ sorted) {
+  extern __shared__ int cursor[];
+  bin_scatter_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, tile_off, sorted, cursor);
+}
+
+// The same scatter with a ZERO-FILL riding on the launch: workgroups [NB, NB + zblocks) clear `zero` (nvec float4) instead —
+// the gradient buffer the backward pass will accumulate into.  The scatter keeps 128 of the 256 CUs busy for ~14 us; the
+// fill (64 MiB at T = 2^19) runs on the others in the same time, instead of being a launch (or a stream) of its own.
+__global__ void __launch_bounds__(kBinThreads)
+bin_scatter_ride_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB,
+                        const int32_t* __restrict__ blockhist, const int32_t* __restrict__ tile_off, float4* __restrict__ sorted,
+                        float4* __restrict__ zero, int64_t nvec, int zblocks) {
+  extern __shared__ int cursor[];
+  if ((int)blockIdx.x < NB) {
+    bin_scatter_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, tile_off, sorted, cursor);
+    return;
+  }
+  const int64_t zb = (int)blockIdx.x - NB;
+  const int64_t per = (nvec + zblocks - 1) / zblocks;
+  const int64_t lo = zb * per, hi = lo + per < nvec ? lo + per : nvec;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t e = lo + threadIdx.x; e < hi; e += kBinThreads) zero[e] = z;
 }
 
 // ---------------------------------------------------------------------------------------------- vertex stage
@@ -146,15 +176,11 @@ __device__ __forceinline__ int64_t level_offset(const int32_t* n_ls, int l) {
   return o;
 }
 
+// one (level, vertex): i = gy * (N_l + 2) + gx inside level l, goff = the level's offset in G (vertices)
 template <int F, bool VT, typename TT>
-__global__ void __launch_bounds__(256)
-vertex_fwd_kernel(const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
-                  const int32_t* __restrict__ n_ls, float* __restrict__ G, int64_t T, int K, int vstride, int64_t NV,
-                  bool pow2) {
-  const int l = blockIdx.y;
-  const int gw = n_ls[l] + 2;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= gw * gw) return;
+__device__ __forceinline__ void vertex_fwd_lane(const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx,
+                                                const float* __restrict__ vert_w, float* __restrict__ G, float* __restrict__ dG_zero,
+                                                int64_t T, int K, int vstride, int64_t NV, bool pow2, int l, int gw, int i, int64_t goff) {
   const int gy = i / gw, gx = i - gy * gw;
   const TT* tab = tables + (int64_t)l * T * F;
   float acc[F];
@@ -175,9 +201,49 @@ vertex_fwd_kernel(const TT* __restrict__ tables, const int32_t* __restrict__ ver
       }
     }
   }
-  float* o = G + (level_offset(n_ls, l) + i) * F;
+  float* o = G + (goff + i) * F;
 #pragma unroll
   for (int f = 0; f < F; ++f) o[f] = acc[f];
+  if (dG_zero) {                                  // the vertex-grid gradient of the coming backward pass starts from zero
+    float* z = dG_zero + (goff + i) * F;
+#pragma unroll
+    for (int f = 0; f < F; ++f) z[f] = 0.f;
+  }
+}
+
+template <int F, bool VT, typename TT>
+__global__ void __launch_bounds__(256)
+vertex_fwd_kernel(const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
+                  const int32_t* __restrict__ n_ls, float* __restrict__ G, int64_t T, int K, int vstride, int64_t NV,
+                  bool pow2) {
+  const int l = blockIdx.y;
+  const int gw = n_ls[l] + 2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= gw * gw) return;
+  vertex_fwd_lane<F, VT, TT>(tables, vert_idx, vert_w, G, nullptr, T, K, vstride, NV, pow2, l, gw, i, level_offset(n_ls, l));
+}
+
+// K1 with the VERTEX STAGE FORWARD riding on the launch: workgroups [NB, NB + ceil(vtot / 1024)) evaluate one (level, vertex)
+// per thread (flat over the level grids) — work that does not depend on the binned pixels and used to be a launch on a
+// helper stream.  Measured: parallel branches of a replayed hipGraph run on different hardware queues, and every
+// cross-queue dependency costs ~10 us (+ ~12 us between replays); one linear chain with riders has no such gaps.
+template <int F, bool VT, typename TT>
+__global__ void __launch_bounds__(kBinThreads)
+bin_count_ride_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB,
+                      int32_t* __restrict__ blockhist, const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx,
+                      const float* __restrict__ vert_w, const int32_t* __restrict__ n_ls, float* __restrict__ G,
+                      float* __restrict__ dG_zero, int Ls, int64_t T, int K, int vstride, int64_t NV, bool pow2, int64_t vtot) {
+  extern __shared__ int hist[];
+  if ((int)blockIdx.x < NB) {
+    bin_count_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, hist);
+    return;
+  }
+  const int64_t e = (int64_t)((int)blockIdx.x - NB) * kBinThreads + threadIdx.x;
+  if (e >= vtot) return;
+  int l = 0, gw = n_ls[0] + 2;
+  int64_t goff = 0;
+  while (l + 1 < Ls && e >= goff + (int64_t)gw * gw) { goff += (int64_t)gw * gw; ++l; gw = n_ls[l] + 2; }
+  vertex_fwd_lane<F, VT, TT>(tables, vert_idx, vert_w, G, dG_zero, T, K, vstride, NV, pow2, l, gw, (int)(e - goff), goff);
 }
 
 template <int F, bool VT, typename TT>
@@ -226,6 +292,18 @@ struct RideAlong {
   const float* slabs;
   float *dW0, *db0, *dW1, *db1, *dW2, *db2;
   int nslabs, nslab, in_dim, out_dim, first_block;
+};
+
+// The value of the fused pixel loss (gngf_common.h: mse_sum_block) riding on the same launch: workgroups
+// [first_block, first_block + nblocks).  pred == nullptr: none.
+struct MseRide {
+  const float* pred;
+  const float* label;
+  float* loss;
+  double* acc;
+  unsigned* counter;
+  int64_t n;
+  int first_block, nblocks;
 };
 
 struct TileMeta {          // per-level placement of the tile's sub-grid (in LDS)
@@ -392,10 +470,15 @@ __global__ void __launch_bounds__(kTB)
 tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ items, const int32_t* __restrict__ n_items,
                  const int32_t* __restrict__ n_ls, const float* __restrict__ genc, float* __restrict__ dG,
                  float* __restrict__ partials, const float* __restrict__ gmax_hint, int hint_count, int hint_stride, int L,
-                 int Ls, int tile_shift, int lds_floats, int log2_chunk, RideAlong ride) {
+                 int Ls, int tile_shift, int lds_floats, int log2_chunk, RideAlong ride, MseRide mride) {
   extern __shared__ unsigned long long acc64[];
   __shared__ TileMeta m;
   __shared__ float wmax[kTB / 64];
+  if (mride.pred && (int)blockIdx.x >= mride.first_block) {
+    mse_sum_block((int)blockIdx.x - mride.first_block, mride.nblocks, mride.pred, mride.label, mride.loss, mride.acc, mride.counter,
+                  mride.n);
+    return;
+  }
   if (ride.slabs && (int)blockIdx.x >= ride.first_block) {
     static_assert(kTB == 1024, "decoder_reduce_block is written for 1024-thread workgroups");
     decoder_reduce_block((int)blockIdx.x - ride.first_block, ride.slabs, ride.nslabs, ride.nslab, ride.in_dim, ride.out_dim, ride.dW0,
@@ -787,6 +870,51 @@ extern "C" int gngf_bin_pixels(const float* xy, int64_t P, int tile_shift, int N
   GNGF_RETURN_LAUNCH();
 }
 
+// Everything in front of the pixel stage in FOUR launches of one chain: binning (as gngf_bin_pixels) with the vertex stage
+// forward (as gngf_vertex_grid_fwd, levels [0, Ls)) riding on the count launch and two buffer clears riding along:
+// dG_zero (the vertex-grid gradient, same shape as G; NULL: none) is cleared by the vertex riders, zero_fill (zero_floats
+// floats, a multiple of 4, 16-byte aligned; NULL: none) by riders of the scatter launch.
+extern "C" int gngf_encode_tiled_prepare(const float* xy, int64_t P, int tile_shift, int NB, int chunk, int32_t* blockhist,
+                                         int32_t* tile_off, int32_t* tile_item_base, int32_t* items, int32_t* n_items,
+                                         float* sorted, const void* tables, int feat_dtype, const int32_t* vert_idx,
+                                         const float* vert_w, const int32_t* n_ls, const int32_t* n_ls_host, float* G,
+                                         float* dG_zero, int Ls, int F, int64_t T, int K, int mode, int vstride, int64_t NV,
+                                         float* zero_fill, int64_t zero_floats, void* stream) {
+  GNGF_CHECK_ARG(P >= 0 && P < (1ll << 31) && tile_shift >= 0 && tile_shift <= 6 && NB > 0 && NB <= kBinMaxBlocks && chunk > 0);
+  GNGF_CHECK_ARG(xy && blockhist && tile_off && tile_item_base && items && n_items && sorted);
+  GNGF_CHECK_ARG(Ls > 0 && Ls <= GNGF_MAX_LEVELS && T > 0 && tables && n_ls && n_ls_host && G);
+  GNGF_CHECK_ARG(mode == GNGF_MODE_HASH || (vert_idx && vert_w && K > 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0));
+  GNGF_CHECK_ARG(!zero_fill || (zero_floats >= 0 && (zero_floats & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_fill) & 15) == 0));
+  const int ntiles = 1 << (2 * tile_shift);
+  const int64_t per_block = ceil_div(ceil_div(P, NB), kBinThreads) * kBinThreads;
+  hipStream_t s = as_stream(stream);
+  const size_t smem = (size_t)ntiles * sizeof(int);
+  int64_t vtot = 0;
+  for (int l = 0; l < Ls; ++l) vtot += (int64_t)(n_ls_host[l] + 2) * (n_ls_host[l] + 2);
+  const int vblocks = (int)ceil_div(vtot, kBinThreads);
+  const bool pow2 = (T & (T - 1)) == 0;
+  const float2* xy2 = reinterpret_cast<const float2*>(xy);
+  if (mode == GNGF_MODE_HASH) {
+    DISPATCH_TT(feat_dtype, DISPATCH_F(F, (bin_count_ride_kernel<kF, false, TT><<<dim3((unsigned)(NB + vblocks)), dim3(kBinThreads), smem, s>>>(
+                                xy2, P, per_block, tile_shift, NB, blockhist, static_cast<const TT*>(tables), nullptr, nullptr, n_ls, G,
+                                dG_zero, Ls, T, 0, 0, 0, pow2, vtot))));
+  } else {
+    DISPATCH_TT(feat_dtype, DISPATCH_F(F, (bin_count_ride_kernel<kF, true, TT><<<dim3((unsigned)(NB + vblocks)), dim3(kBinThreads), smem, s>>>(
+                                xy2, P, per_block, tile_shift, NB, blockhist, static_cast<const TT*>(tables), vert_idx, vert_w, n_ls, G,
+                                dG_zero, Ls, T, K, vstride, NV, pow2, vtot))));
+  }
+  int32_t* tot = blockhist + (int64_t)ntiles * NB;
+  bin_rowscan_kernel<<<dim3((unsigned)ceil_div(ntiles, 4)), dim3(256), 0, s>>>(blockhist, NB, ntiles, tot);
+  bin_scan_kernel<<<dim3(1), dim3(kBinThreads), 0, s>>>(tot, tile_shift, chunk, tile_off, tile_item_base,
+                                                         reinterpret_cast<int4*>(items), n_items);
+  const int64_t nvec = zero_fill ? zero_floats / 4 : 0;
+  const int zblocks = nvec > 0 ? (int)(ceil_div(nvec, 4096) < 1024 ? ceil_div(nvec, 4096) : 1024) : 0;
+  bin_scatter_ride_kernel<<<dim3((unsigned)(NB + zblocks)), dim3(kBinThreads), smem, s>>>(
+      xy2, P, per_block, tile_shift, NB, blockhist, tile_off, reinterpret_cast<float4*>(sorted), reinterpret_cast<float4*>(zero_fill),
+      nvec, zblocks);
+  GNGF_RETURN_LAUNCH();
+}
+
 static int max_grid_side(const int32_t* n_ls_host, int Ls) {
   int m = 0;
   for (int l = 0; l < Ls; ++l) m = n_ls_host[l] + 2 > m ? n_ls_host[l] + 2 : m;
@@ -859,7 +987,8 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
                                      int absmax_stride, float* dG, float* partials, int L, int Ls, int F, int tile_shift,
                                      int lds_bytes, int chunk, const float* ride_slabs, float* ride_dW0, float* ride_db0,
                                      float* ride_dW1, float* ride_db1, float* ride_dW2, float* ride_db2, int64_t ride_P,
-                                     int ride_in_dim, int ride_out_dim, void* stream) {
+                                     int ride_in_dim, int ride_out_dim, const float* mse_pred, const float* mse_label,
+                                     float* mse_loss, float* mse_workspace, int64_t mse_n, void* stream) {
   GNGF_CHECK_ARG(max_items >= 0 && L > 0 && Ls > 0 && Ls <= L && L <= GNGF_MAX_LEVELS && lds_bytes >= 0 && lds_bytes <= 64 * 1024);
   RideAlong ride = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
   int ride_blocks = 0;
@@ -872,6 +1001,15 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
     ride.nslab = gngf_decoder_slab_floats(ride_in_dim, ride_out_dim);
     ride.in_dim = ride_in_dim; ride.out_dim = ride_out_dim; ride.first_block = max_items;
     ride_blocks = (ride.nslab + 63) / 64;
+  }
+  MseRide mride = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+  if (mse_pred) {
+    GNGF_CHECK_ARG(mse_label && mse_loss && mse_workspace && mse_n > 0 && (reinterpret_cast<uintptr_t>(mse_pred) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(mse_label) & 15) == 0 && (reinterpret_cast<uintptr_t>(mse_workspace) & 7) == 0);
+    mride.pred = mse_pred; mride.label = mse_label; mride.loss = mse_loss;
+    mride.acc = reinterpret_cast<double*>(mse_workspace); mride.counter = reinterpret_cast<unsigned*>(mse_workspace + 2);
+    mride.n = mse_n; mride.first_block = max_items + ride_blocks; mride.nblocks = gngf_mse_blocks(mse_n);
+    ride_blocks += mride.nblocks;
   }
   GNGF_CHECK_ARG(chunk > 0 && chunk <= (1 << 20) && (!genc_absmax || (absmax_count > 0 && absmax_stride >= 0)));
   int log2_chunk = 0;
@@ -887,7 +1025,7 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
     }
     tiled_bwd_kernel<kF><<<dim3((unsigned)(max_items + ride_blocks)), dim3(kTB), (size_t)2 * lds_bytes, as_stream(stream)>>>(
         reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, n_ls, genc, dG, partials,
-        genc_absmax, absmax_count, absmax_stride, L, Ls, tile_shift, lds_bytes / 4, log2_chunk, ride);
+        genc_absmax, absmax_count, absmax_stride, L, Ls, tile_shift, lds_bytes / 4, log2_chunk, ride, mride);
     if (max_items > 0)
       gather_partials_kernel<kF><<<dim3((unsigned)ceil_div((int64_t)side * side, 256), (unsigned)Ls), dim3(256), 0,
                                    as_stream(stream)>>>(partials, tile_item_base, tile_level_off, n_ls, dG, Ls, tile_shift,

@@ -51,6 +51,54 @@ __device__ __forceinline__ Cell make_cell(float x, float y, int n) {
 
 __device__ __forceinline__ bool is_pow2(int64_t v) { return (v & (v - 1)) == 0; }
 
+// torch.nn.MSELoss() value (csrc/loss.hip): block `blk` of `nblocks` 1024-thread blocks adds its share of sum((pred-label)^2)
+// to a double and takes a ticket (the atomic's RETURN value feeds the ticket request, so the add is performed before the
+// ticket exists — no release fence, which writes the whole L2 back on this chip); the last ticket holder writes
+// loss = total / n and resets both words.  Called by mse_fwd_kernel and, as extra workgroups riding on its launch, by
+// the tiled encoder backward.
+__device__ __forceinline__ void mse_sum_block(int blk, int nblocks, const float* __restrict__ pred, const float* __restrict__ label,
+                                              float* __restrict__ loss, double* __restrict__ acc, unsigned* __restrict__ counter,
+                                              int64_t n) {
+  constexpr int kThreads = 1024;
+  __shared__ float mse_red[kThreads / 64];
+  float s = 0.f, s2 = 0.f;
+  const int64_t n4 = n >> 2;
+  const float4* p4 = reinterpret_cast<const float4*>(pred);
+  const float4* l4 = reinterpret_cast<const float4*>(label);
+  const int64_t stride = (int64_t)nblocks * kThreads;
+  int64_t e = (int64_t)blk * kThreads + threadIdx.x;
+  for (; e + stride < n4; e += 2 * stride) {              // two independent load pairs in flight per trip
+    const float4 a = p4[e], b = l4[e], c = p4[e + stride], d = l4[e + stride];
+    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
+    const float ex = c.x - d.x, ey = c.y - d.y, ez = c.z - d.z, ew = c.w - d.w;
+    s += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    s2 += (ex * ex + ey * ey) + (ez * ez + ew * ew);
+  }
+  if (e < n4) {
+    const float4 a = p4[e], b = l4[e];
+    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
+    s += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+  }
+  s += s2;
+  if (blk == 0)
+    for (int64_t t = (n4 << 2) + threadIdx.x; t < n; t += kThreads) { const float d = pred[t] - label[t]; s += d * d; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) mse_red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double b = 0.0;
+#pragma unroll
+  for (int w = 0; w < kThreads / 64; ++w) b += (double)mse_red[w];
+  const double before = atomicAdd(acc, b);
+  const unsigned ticket = atomicAdd(counter, before < 0.0 ? 2u : 1u);      // sums of squares are never negative: always 1
+  if (ticket != (unsigned)nblocks - 1u) return;
+  const double total = atomicAdd(acc, 0.0);
+  *loss = (float)(total / (double)n);
+  atomicExch(reinterpret_cast<unsigned long long*>(acc), 0ull);
+  atomicExch(counter, 0u);
+}
+
 // Decoder backward, second half (csrc/decoder.hip): sums the per-workgroup gradient slabs
 //   dW0 [64*in_dim] | dW1 [64*64] | dW2 [out_dim*64] | db0 [64] | db1 [64] | db2 [out_dim] | max |d enc| (bit pattern)
 // into the six gradient tensors; block `blk` of 1024 threads owns elements [64 blk, 64 blk + 64) (64 elements x 16

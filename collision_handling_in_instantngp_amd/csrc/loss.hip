@@ -16,43 +16,8 @@ constexpr int kLossBlocks = 64;                       // few workgroups: their t
 __global__ void __launch_bounds__(kLossThreads)
 mse_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ label, float* __restrict__ loss,
                double* __restrict__ acc, unsigned* __restrict__ counter, int64_t n) {
-  __shared__ float red[kLossThreads / 64];
-  float s = 0.f, s2 = 0.f;
-  const int64_t n4 = n >> 2;
-  const float4* p4 = reinterpret_cast<const float4*>(pred);
-  const float4* l4 = reinterpret_cast<const float4*>(label);
-  const int64_t stride = (int64_t)gridDim.x * kLossThreads;
-  int64_t e = (int64_t)blockIdx.x * kLossThreads + threadIdx.x;
-  for (; e + stride < n4; e += 2 * stride) {              // two independent load pairs in flight per trip
-    const float4 a = p4[e], b = l4[e], c = p4[e + stride], d = l4[e + stride];
-    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
-    const float ex = c.x - d.x, ey = c.y - d.y, ez = c.z - d.z, ew = c.w - d.w;
-    s += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-    s2 += (ex * ex + ey * ey) + (ez * ez + ew * ew);
-  }
-  if (e < n4) {
-    const float4 a = p4[e], b = l4[e];
-    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
-    s += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-  }
-  s += s2;
-  if (blockIdx.x == 0)
-    for (int64_t t = (n4 << 2) + threadIdx.x; t < n; t += kLossThreads) { const float d = pred[t] - label[t]; s += d * d; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  double b = 0.0;
-#pragma unroll
-  for (int w = 0; w < kLossThreads / 64; ++w) b += (double)red[w];
-  const double before = atomicAdd(acc, b);
-  const unsigned ticket = atomicAdd(counter, before < 0.0 ? 2u : 1u);      // sums of squares are never negative: always 1
-  if (ticket != gridDim.x - 1) return;
-  const double total = atomicAdd(acc, 0.0);
-  *loss = (float)(total / (double)n);
-  atomicExch(reinterpret_cast<unsigned long long*>(acc), 0ull);
-  atomicExch(counter, 0u);
+  static_assert(kLossThreads == 1024, "mse_sum_block is written for 1024-thread workgroups");
+  mse_sum_block((int)blockIdx.x, (int)gridDim.x, pred, label, loss, acc, counter, n);     // body: gngf_common.h
 }
 
 // dpred = gout * 2 (pred - label) / n
@@ -77,6 +42,10 @@ mse_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ label, 
 using namespace gngf;
 
 extern "C" int gngf_mse_workspace_floats(void) { return 4; }
+extern "C" int gngf_mse_blocks(int64_t n) {            // workgroups gngf_mse_fwd uses for n elements (riders use the same)
+  const int64_t want = (n / 4 + kLossThreads - 1) / kLossThreads;
+  return (int)(want < 1 ? 1 : (want > kLossBlocks ? kLossBlocks : want));
+}
 
 // loss (1) = mean((pred - label)^2) over n elements.  workspace: gngf_mse_workspace_floats() floats, 8-byte aligned and
 // zero-filled once before the first call (an accumulator and a ticket counter the kernel itself resets).

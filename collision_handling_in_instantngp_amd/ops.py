@@ -1,5 +1,8 @@
 """torch.autograd.Function wrappers over the C-ABI (include/gngf.h).  Device memory + stream plumbing only;
 all arithmetic happens in the HIP kernels.  CPU tensors raise (no fallback)."""
+import ctypes as _ct
+import math as _math
+
 import torch
 
 from . import _lib
@@ -451,9 +454,6 @@ class TableViewFunction(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ tiled encoder
-import ctypes as _ct
-import math as _math
-
 ENCODE_PATH = "auto"        # "auto" | "direct" | "tiled"  (tests force a path; auto = tiled when it pays)
 DP_EXCHANGE = None          # data parallel: callable that sum-all-reduces + averages the vertex-grid gradient in place
 DP_TABLES_REDUCED = 0       # number of leading levels whose table gradient of the last backward came out of an exchanged dG
@@ -528,7 +528,9 @@ class EncodePlan:
 class TiledWorkspace:
     """Device buffers of one forward/backward pair (binning result is shared by both)."""
 
-    def __init__(self, plan, xy):
+    def __init__(self, plan, xy, vertex=None, zero_dG=None, zero=None):
+        """vertex = (tables, vert_idx, vert_w, n_ls, vstride, G): also run the vertex stage forward into G (riding on the binning
+        launches); zero_dG (same shape as G) and zero (any fp32 buffer, typically the table gradient): cleared on the way."""
         dev = xy.device
         P = plan.P
         self.blockhist = torch.empty((plan.ntiles * (plan.NB + 1),), dtype=_i32, device=dev)
@@ -537,8 +539,22 @@ class TiledWorkspace:
         self.items = torch.empty((plan.max_items, 4), dtype=_i32, device=dev)
         self.n_items = torch.empty((1,), dtype=_i32, device=dev)
         self.sorted = torch.empty((max(P, 1), 4), dtype=_f32, device=dev)
-        call("gngf_bin_pixels", ptr(xy, _f32, "xy"), P, plan.tile_shift, plan.NB, plan.chunk, ptr(self.blockhist),
-             ptr(self.tile_off), ptr(self.tile_item_base), ptr(self.items), ptr(self.n_items), ptr(self.sorted), stream_ptr())
+        if vertex is None:
+            call("gngf_bin_pixels", ptr(xy, _f32, "xy"), P, plan.tile_shift, plan.NB, plan.chunk, ptr(self.blockhist),
+                 ptr(self.tile_off), ptr(self.tile_item_base), ptr(self.items), ptr(self.n_items), ptr(self.sorted), stream_ptr())
+        else:
+            # binning + vertex stage forward + the clears of the backward's gradient buffers: one chain of four launches
+            tables, vert_idx, vert_w, n_ls, vstride, G = vertex
+            L, T, F = tables.shape
+            mode = MODE_HASH if vert_idx is None else MODE_VERTEX_TABLE
+            if zero is not None and (zero.numel() % 4 or zero.data_ptr() % 16 or zero.dtype != _f32):
+                zero.zero_()
+                zero = None
+            call("gngf_encode_tiled_prepare", ptr(xy, _f32, "xy"), P, plan.tile_shift, plan.NB, plan.chunk, ptr(self.blockhist),
+                 ptr(self.tile_off), ptr(self.tile_item_base), ptr(self.items), ptr(self.n_items), ptr(self.sorted),
+                 *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), plan.n_ls_c, ptr(G), ptr(zero_dG), plan.Ls, F, T,
+                 0 if vert_idx is None else vert_idx.shape[1], mode, vstride, 0 if vert_idx is None else vert_idx.shape[0],
+                 ptr(zero), 0 if zero is None else zero.numel(), stream_ptr())
 
 
 def _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G):
@@ -629,7 +645,12 @@ def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None):
     if ride is None:
         ride_args = [ptr(None)] * 7 + [0, 0, 0]
     else:
-        ride_args = [ptr(ride["slabs"])] + [ptr(g) for g in ride["grads"]] + [ride["P"], ride["in_dim"], ride["out_dim"]]
+        ride_args = [ptr(ride["slabs"])] + [_ct.c_void_p(a) for a in ride["gptrs"]] + [ride["P"], ride["in_dim"], ride["out_dim"]]
+    lv = _take_pending_loss_value(genc.device)      # ... and a loss value nobody on the critical path reads
+    if lv is None:
+        ride_args += [ptr(None)] * 4 + [0]
+    else:
+        ride_args += [ptr(lv["pred"]), ptr(lv["label"]), ptr(lv["loss"]), ptr(lv["ws"]), lv["pred"].numel()]
     call("gngf_encode_tiled_bwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(ws.tile_item_base),
          ptr(tile_level_offsets(plan, genc.device)), ptr(n_ls), plan.n_ls_c, ptr(genc, _f32, "grad"), ptr(am),
          int(am_count), int(am_stride), ptr(dG), ptr(partials), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, plan.chunk,
@@ -668,6 +689,7 @@ def _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw,
 
 
 _SIDE_STREAMS = {}
+USE_SIDE_STREAM = True      # False: helper-stream work is issued in line on the current stream (measurement)
 
 
 def _side_stream(device):
@@ -676,6 +698,8 @@ def _side_stream(device):
     # one helper per (device, main stream): a helper that has exchanged events with the legacy default stream must not
     # later join a hipGraph capture started on another stream (hipStreamEndCapture crashed on exactly that history:
     # tools/dbg_graphed.py), and two main streams must not serialise through one shared helper anyway
+    if not USE_SIDE_STREAM:
+        return torch.cuda.current_stream(device)
     key = (device.type, device.index, torch.cuda.current_stream(device).stream_id)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
@@ -701,20 +725,14 @@ class EncodeFunction(torch.autograd.Function):
             order = slot_order(vert_idx, plan.n_ls_host[:plan.Ls], vstride)
         pre = None
         if plan.Ls > 0 and P > 0:
-            cur = torch.cuda.current_stream()
-            side = _side_stream(tables.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):                      # beside the binning: vertex stage + gradient buffers
-                G = torch.empty((plan.vtot, F), dtype=_f32, device=tables.device)
-                _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G)
-                if ctx.needs_input_grad[3]:
-                    pre = [_grad_buffer(tables), torch.zeros((plan.vtot, F), dtype=_f32, device=tables.device)]
-            ws = TiledWorkspace(plan, xy)
+            # binning, vertex stage and the clears of the backward's gradient buffers: ONE chain of four launches (the vertex
+            # stage and the clears ride on the binning kernels as extra workgroups: ops.TiledWorkspace)
+            G = torch.empty((plan.vtot, F), dtype=_f32, device=tables.device)
             if ctx.needs_input_grad[3]:
+                pre = [torch.empty(tables.shape, dtype=_f32, device=tables.device), torch.empty((plan.vtot, F), dtype=_f32, device=tables.device)]
                 tile_level_offsets(plan, tables.device)        # cached; built here so that no backward (or graph capture) uploads it
-            cur.wait_stream(side)
-            for buf in [G] + (pre or []):
-                buf.record_stream(cur)
+            ws = TiledWorkspace(plan, xy, vertex=(tables, vert_idx, vert_w, n_ls, vstride, G),
+                                zero_dG=pre[1] if pre else None, zero=pre[0] if pre else None)
             call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), ptr(G),
                  ptr(enc), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, stream_ptr())
         if plan.Ls < L:
@@ -861,6 +879,25 @@ DECODER_SAVE_HIDDEN = True
 DECODER_REDUCE_RIDES = True
 
 _PENDING_REDUCE = []          # [{slabs, grads, P, in_dim, out_dim, device, stream}]: decoder reductions not yet launched
+# The fused decoder's loss value on the helper stream (see _decoder_fwd): only for callers that join before anything reads it
+LOSS_VALUE_ASIDE = False
+_LOSS_VALUE_PENDING = []      # [{pred, label, loss, ws, device, stream, stream_obj}]
+
+
+def _take_pending_loss_value(device):
+    cur = torch.cuda.current_stream(device).cuda_stream
+    for k, r in enumerate(_LOSS_VALUE_PENDING):
+        if r["device"] == device and r["stream"] == cur:
+            return _LOSS_VALUE_PENDING.pop(k)
+    return None
+
+
+def join_loss_value():
+    """Launches every deferred loss value that found no launch to ride on (end of the step)."""
+    while _LOSS_VALUE_PENDING:
+        r = _LOSS_VALUE_PENDING.pop()
+        with torch.cuda.stream(r["stream_obj"]):
+            call("gngf_mse_fwd", ptr(r["pred"]), ptr(r["label"]), ptr(r["loss"]), ptr(r["ws"]), r["pred"].numel(), stream_ptr())
 
 
 def _take_pending_reduce(device):
@@ -875,9 +912,10 @@ def _flush_pending_reduces():
     """Launches every decoder slab reduction nobody picked up (no tiled encoder backward followed the decoder backward)."""
     while _PENDING_REDUCE:
         r = _PENDING_REDUCE.pop()
-        with torch.cuda.stream(torch.cuda.ExternalStream(r["stream"], device=r["device"])):
-            call("gngf_decoder_reduce", ptr(r["slabs"]), *[ptr(g) for g in r["grads"]], ptr(None), r["P"], r["in_dim"], r["out_dim"],
-                 stream_ptr())
+        with torch.cuda.stream(r["stream_obj"]):      # (the Stream object itself: an ExternalStream wrapped around the default
+            # stream's raw handle is a different stream to torch — reductions launched through one came out corrupted)
+            call("gngf_decoder_reduce", ptr(r["slabs"]), *[_ct.c_void_p(a) for a in r["gptrs"]], ptr(None), r["P"], r["in_dim"],
+                 r["out_dim"], stream_ptr())
 
 
 def _at_end_of_backward(fn):
@@ -899,19 +937,29 @@ def _decoder_fwd(ctx, enc, leaky, ws, target):
     hidden = None
     if DECODER_SAVE_HIDDEN and P > 0 and any(ctx.needs_input_grad):
         hidden = torch.empty((_lib.query("gngf_decoder_hidden_floats", P),), dtype=_f32, device=dev)
-    mse = wsp = None
     if target is not None:
         if P == 0:
             raise ValueError("MSE of an empty batch")
         target = _c(target)
         if tuple(target.shape) != (P, out_dim) or target.dtype != _f32:
             raise ValueError(f"target {tuple(target.shape)} / {target.dtype} does not match the decoder output ({P}, {out_dim}) float32")
+    call("gngf_decoder_fwd", ptr(enc, _f32, "enc"), *[ptr(w, _f32) for w in ws], ptr(rgb), ptr(hidden), P, in_dim, out_dim, int(leaky),
+         stream_ptr())
+    mse = None
+    if target is not None:
+        # The loss VALUE (csrc/loss.hip::mse_fwd_kernel).  Nothing in the step's critical path reads it — the backward kernel
+        # forms the loss gradient from rgb and the target itself — so a caller that owns the whole step (train.GraphedStep)
+        # defers it: it then rides on the tiled encoder backward's launch as extra workgroups (or is launched by
+        # join_loss_value() at the end of the step); otherwise it is launched here, in stream order.
         wsp = _MSE_WORKSPACE.get(dev)
         if wsp is None:
             wsp = _MSE_WORKSPACE[dev] = torch.zeros(query("gngf_mse_workspace_floats"), dtype=_f32, device=dev)
         mse = torch.empty((), dtype=_f32, device=dev)
-    call("gngf_decoder_fwd", ptr(enc, _f32, "enc"), *[ptr(w, _f32) for w in ws], ptr(rgb), ptr(hidden), ptr(target), ptr(mse), ptr(wsp),
-         P, in_dim, out_dim, int(leaky), stream_ptr())
+        if LOSS_VALUE_ASIDE:
+            _LOSS_VALUE_PENDING.append({"pred": rgb, "label": target, "loss": mse, "ws": wsp, "device": dev,
+                                        "stream": torch.cuda.current_stream(dev).cuda_stream, "stream_obj": torch.cuda.current_stream(dev)})
+        else:
+            call("gngf_mse_fwd", ptr(rgb), ptr(target), ptr(mse), ptr(wsp), rgb.numel(), stream_ptr())
     ctx.save_for_backward(enc, rgb, target, *ws)
     ctx.hidden = hidden
     ctx.cfg = (P, in_dim, out_dim, int(leaky))
@@ -947,8 +995,11 @@ def _decoder_bwd(ctx, drgb, gloss):
               ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(denc))
     if DECODER_REDUCE_RIDES and P > 0:
         call("gngf_decoder_bwd", *common, *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(ctx.hidden), P, in_dim, out_dim, leaky, stream_ptr())
-        _PENDING_REDUCE.append({"slabs": slabs, "grads": grads, "P": P, "in_dim": in_dim, "out_dim": out_dim, "device": dev,
-                                "stream": torch.cuda.current_stream(dev).cuda_stream, "flat": flat})
+        # (addresses, not the view tensors: a second reference to a gradient tensor would make autograd's AccumulateGrad
+        # CLONE it — before the reduction has filled it — instead of adopting it; `flat`, their base, keeps the memory alive)
+        _PENDING_REDUCE.append({"slabs": slabs, "flat": flat, "gptrs": [g.data_ptr() for g in grads], "P": P, "in_dim": in_dim,
+                                "out_dim": out_dim, "device": dev, "stream": torch.cuda.current_stream(dev).cuda_stream,
+                                "stream_obj": torch.cuda.current_stream(dev)})
         _at_end_of_backward(_flush_pending_reduces)
         hint = (slabs[nslab - 1:], nslabs, nslab)         # the per-slab maxima: all the encoder backward needs from the slabs
     else:
@@ -978,9 +1029,11 @@ class DecoderFunction(torch.autograd.Function):
 
 class DecoderMseFunction(torch.autograd.Function):
     """Decoder + the pixel loss of the training step in the same two launches: apply(enc, target, leaky, W0 .. b2) ->
-    (rgb, mse) with mse = torch.nn.MSELoss()(rgb, target) (reference utils.py:99).  The loss value comes out of the forward
-    kernel's epilogue, its gradient 2 (rgb - target) / n is formed in the backward kernel's prologue: the two loss kernels
-    (~20 us of a 0.6 ms step, mostly launch latency) and the d rgb round trip disappear.  Same arithmetic as ops.MseFunction."""
+    (rgb, mse) with mse = torch.nn.MSELoss()(rgb, target) (reference utils.py:99).  The loss gradient 2 (rgb - target) / n is
+    formed in the backward kernel's prologue (no loss-backward launch, no d rgb round trip), and the loss value — which nothing
+    on the critical path needs — is a launch that train.GraphedStep moves onto a parallel branch of the step.  Same arithmetic,
+    same bits as ops.MseFunction.  (Folding the value into the forward kernel's epilogue was tried: +25 us on that kernel
+    inside the step for a 14 us launch saved.)"""
 
     @staticmethod
     def forward(ctx, enc, target, leaky, W0, b0, W1, b1, W2, b2):

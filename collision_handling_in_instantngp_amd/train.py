@@ -239,7 +239,7 @@ def get_optimizer(net, encoding_lr, HPD_lr, MLP_lr, encoding_weight_decay, HPD_w
 
 def assemble_loss(mse, kls, colls, l_mse, l_js_kl, l_collisions):
     """reference functions.py:243-245, including the '+1 per level while previous_collisions is empty' quirk."""
-    loss = l_mse * mse
+    loss = mse if (isinstance(l_mse, (int, float)) and l_mse == 1) else l_mse * mse     # (x * 1 is a kernel launch of its own)
     if not models.should_use_hash_function and kls is not None:
         loss = loss + ((l_js_kl * kls) + (l_collisions * colls if colls.nelement() != 0 else 1)).sum(0)
     return loss
@@ -284,11 +284,21 @@ class GraphedStep:
         # alive as long as any earlier graph does (a kept `loss` from an eager step on the default stream is enough): the
         # captured backward would then hop onto the legacy default stream, which cannot take part in a capture
         # (hipStreamEndCapture crashes; tools/dbg_graphed.py).  Fresh leaves get their nodes on the capturing stream.
-        with net.fused_mse(st["y"]):                 # the pixel loss rides in the decoder kernels (same values, two launches less)
-            out, probs, idx, _counts = torch.func.functional_call(net, shadow, (st["x"], self.batch_percentage), {"should_calc_counts": False})
+        # the pixel loss is fused into the decoder: its gradient is formed inside the backward kernel, and its VALUE — which no
+        # kernel of the step reads when it enters the total with weight 1 — runs on a parallel branch, joined at the end
+        aside = isinstance(l_mse, (int, float)) and l_mse == 1 and (models.should_use_hash_function or getattr(net, "compute_pbar", True) is False)
+        ops.LOSS_VALUE_ASIDE = bool(aside)
+        try:
+            with net.fused_mse(st["y"]):
+                out, probs, idx, _counts = torch.func.functional_call(net, shadow, (st["x"], self.batch_percentage), {"should_calc_counts": False})
+        finally:
+            ops.LOSS_VALUE_ASIDE = False
         mse, kls, colls = self.loss_fn(out, st["y"], None if probs is None else probs.shape[-1], probs, st["pc"], st["pm"])
         loss = assemble_loss(mse, kls, colls, l_mse, l_js_kl, l_collisions)
+        if loss is not mse:
+            ops.join_loss_value()                      # the total is computed from the value: it has to be there
         loss.backward(gradient=st["one"].to(loss.dtype))
+        ops.join_loss_value()
         for name, p in st["named"]:
             p.grad = shadow[name].grad             # the parameters' own .grad: what the optimizer and the caller read
         r = GraphedStep.Result()

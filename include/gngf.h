@@ -84,6 +84,16 @@ int gngf_encode_bwd(const float* xy, const void* tables, int feat_dtype, const i
  *   int32. */
 int gngf_bin_pixels(const float* xy, int64_t P, int tile_shift, int NB, int chunk, int32_t* blockhist, int32_t* tile_off,
                     int32_t* tile_item_base, int32_t* items, int32_t* n_items, float* sorted, void* stream);
+/* gngf_encode_tiled_prepare: everything in front of the pixel stage as ONE chain of four launches — gngf_bin_pixels plus
+ *   gngf_vertex_grid_fwd (levels [0, Ls), riding on the count launch as extra workgroups) plus two buffer clears:
+ *   dG_zero (same shape as G; NULL: none) and zero_fill (zero_floats floats, a multiple of 4, 16-byte aligned — the table
+ *   gradient buffer; NULL: none; riding on the scatter launch).  Parallel branches of a replayed hipGraph cost ~10 us per
+ *   cross-queue dependency on this stack; riders on one chain cost nothing. */
+int gngf_encode_tiled_prepare(const float* xy, int64_t P, int tile_shift, int NB, int chunk, int32_t* blockhist,
+                              int32_t* tile_off, int32_t* tile_item_base, int32_t* items, int32_t* n_items, float* sorted,
+                              const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w,
+                              const int32_t* n_ls, const int32_t* n_ls_host, float* G, float* dG_zero, int Ls, int F, int64_t T,
+                              int K, int mode, int vstride, int64_t NV, float* zero_fill, int64_t zero_floats, void* stream);
 /* vertex stage: G[(goff_l + gy*(N_l+2) + gx)*F + f] for levels [0, Ls), goff_l = sum_{j<l} (N_j+2)^2.
  * n_ls_host mirrors n_ls on the host (grid sizing only). */
 int gngf_vertex_grid_fwd(const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w, const int32_t* n_ls,
@@ -113,10 +123,14 @@ int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32
                           const int32_t* n_ls_host, const float* genc, const float* genc_absmax, int absmax_count,
                           int absmax_stride, float* dG, float* partials, int L, int Ls, int F, int tile_shift, int lds_bytes,
                           int chunk, const float* ride_slabs, float* ride_dW0, float* ride_db0, float* ride_dW1, float* ride_db1,
-                          float* ride_dW2, float* ride_db2, int64_t ride_P, int ride_in_dim, int ride_out_dim, void* stream);
+                          float* ride_dW2, float* ride_db2, int64_t ride_P, int ride_in_dim, int ride_out_dim,
+                          const float* mse_pred, const float* mse_label, float* mse_loss, float* mse_workspace, int64_t mse_n,
+                          void* stream);
 /* ride_* (optional, ride_slabs NULL = none): the slab reduction of a preceding gngf_decoder_bwd that was called without
  * gradient pointers (= gngf_decoder_reduce(ride_slabs, ride_dW0 .. ride_db2, NULL, ride_P, ride_in_dim, ride_out_dim)) runs in
- * extra workgroups of this launch instead of a launch of its own (one dependent launch less on the step's critical path). */
+ * extra workgroups of this launch instead of a launch of its own (one dependent launch less on the step's critical path).
+ * mse_* (optional, mse_pred NULL = none): likewise gngf_mse_fwd(mse_pred, mse_label, mse_loss, mse_workspace, mse_n) — the
+ * VALUE of the pixel loss, which no kernel of the step reads. */
 /* vertex stage backward for the vertex-table source in SLOT order (order (NV*K) int32 = argsort of vert_idx, flat):
  * contention-free for any slot distribution (wave-level segmented reduction, one atomic per (wave, slot run));
  * dtables accumulated, dvert_w (NV,K) written without atomics (NULL when not needed). */
@@ -142,11 +156,7 @@ int gngf_gemm_acc(const float* A, const float* B, float* C, int64_t M, int64_t N
  * gngf_decoder_bwd — the stores ride under the forward kernel's MFMAs, and the backward kernel then reads them back
  * instead of recomputing them (96 of its 292 MFMAs per 32 pixels). */
 int gngf_decoder_fwd(const float* enc, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
-                     const float* b2, float* rgb, float* hidden, const float* target, float* mse, float* mse_workspace,
-                     int64_t P, int in_dim, int out_dim, int leaky, void* stream);
-/* target (P,out_dim), optional: the pixel loss of the training step, torch.nn.MSELoss()(rgb, target) (utils.py:99), is
- * evaluated in the same launch: mse (1 float) = mean((rgb - target)^2); mse_workspace = gngf_mse_workspace_floats() floats,
- * 8-byte aligned, zero-filled once before the first call (the kernel resets it).  NULL: rgb only. */
+                     const float* b2, float* rgb, float* hidden, int64_t P, int in_dim, int out_dim, int leaky, void* stream);
 int64_t gngf_decoder_hidden_floats(int64_t P);
 /* backward: denc (P,in_dim) and the six parameter gradients, each WRITTEN (not accumulated); rgb = the forward output.
  * slabs: workspace of gngf_decoder_bwd_slabs(P) * gngf_decoder_slab_floats(in_dim, out_dim) floats.
@@ -218,6 +228,7 @@ int gngf_expand_vertex_table(const float* xy, const int32_t* n_ls, const int32_t
  * workspace: gngf_mse_workspace_floats() floats, 8-byte aligned, zero-filled once before the first call (the kernel
  * resets it).  One launch; workgroup partials meet in a double-precision atomic. */
 int gngf_mse_workspace_floats(void);
+int gngf_mse_blocks(int64_t n);      /* workgroups gngf_mse_fwd launches for n elements */
 int gngf_mse_fwd(const float* pred, const float* label, float* loss, float* workspace, int64_t n, void* stream);
 /* its backward: dpred (n) = gout[0] * 2 (pred - label) / n   (gout: device scalar, the gradient of the loss value) */
 int gngf_mse_bwd(const float* pred, const float* label, const float* gout, float* dpred, int64_t n, void* stream);

@@ -469,8 +469,11 @@ def test_decoder_slab_reduction_riding_on_the_encoder_backward_gives_the_same_gr
                     assert bound == float(xs.grad.abs().max())
             finally:
                 ops.DECODER_REDUCE_RIDES = True
-        for a, b in zip(res[(with_encoder, False)], res[(with_encoder, True)]):
-            assert torch.equal(a, b)
+        for k, (a, b) in enumerate(zip(res[(with_encoder, False)], res[(with_encoder, True)])):
+            if with_encoder and k == 0:          # table gradient: float atomics of the hash vertex stage, any order
+                assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+            else:
+                assert torch.equal(a, b)
 
 
 def test_fused_pixel_loss_equals_the_separate_loss_kernels(ops):
