@@ -1087,17 +1087,18 @@ def encode_kernels(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, genc,
     s = stream_ptr
     out = {}
     if plan.Ls > 0:
-        ws = TiledWorkspace(plan, xy)
         G = torch.empty((plan.vtot, F), dtype=_f32, device=xy.device)
         dG = torch.zeros_like(G)
-        _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G)
+        ws = TiledWorkspace(plan, xy, vertex=(tables, vert_idx, vert_w, n_ls, vstride, G))     # as the training step does (pixels sorted inside the items)
+        am = genc.abs().max().reshape(1)
+        out["prepare"] = lambda: TiledWorkspace(plan, xy, vertex=(tables, vert_idx, vert_w, n_ls, vstride, G), zero_dG=dG, zero=dtables)
         out["bin_pixels"] = lambda: TiledWorkspace(plan, xy)
         out["vertex_fwd"] = lambda: _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G)
         out["encode_fwd:tiled"] = lambda: call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items),
                                                plan.max_items, ptr(n_ls), ptr(G), ptr(enc), L, plan.Ls, F, plan.tile_shift,
                                                plan.lds_bytes, s())
         order = slot_order(vert_idx, plan.n_ls_host[:plan.Ls], vstride) if vert_idx is not None else None
-        out["encode_bwd:tiled"] = lambda: _pixel_bwd(plan, ws, n_ls, genc, dG, L, F)
+        out["encode_bwd:tiled"] = lambda: _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, (am, 1, 0))
         out["vertex_bwd"] = lambda: _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, None, order)
     if plan.Ls < L:
         out["encode_fwd:direct"] = lambda: call("gngf_encode_fwd", ptr(xy), *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls),

@@ -5,7 +5,7 @@ from collision_handling_in_instantngp_amd import ops
 from collision_handling_in_instantngp_amd import models as orc   # level_resolutions only (the CPU oracle is for tests)
 import bench
 dev = torch.device("cuda")
-xy, target, _ = bench.strawberry_batch(2**20, 0, dev)
+xy, target, _b = bench.make_batch("cfg2", 2**20, 0, dev)
 n_host = [int(v) for v in orc.level_resolutions(16, 512, 16)]
 n_ls = torch.tensor(n_host, dtype=torch.int32, device=dev)
 tables = (torch.rand((16, 2**19, 2), device=dev) - 0.5) * 2e-4
