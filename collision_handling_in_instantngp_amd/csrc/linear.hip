@@ -355,6 +355,151 @@ gemm128_fast_kernel(const float* __restrict__ A, const float* __restrict__ B, fl
   }
 }
 
+// ---------------------------------------------------------------------------------------------- split-bf16 variant
+// The same 128x128 GEMM with every fp32 operand value split EXACTLY into three bf16 terms, x = hi + mid + lo (8 + 8 + 8
+// significant bits), and the product formed from six of the nine cross terms on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation:  a b ~= hi hi + hi mid + mid hi + hi lo + lo hi + mid mid.   The dropped terms (mid lo, lo mid, lo lo) are
+// below 2^-24 |a b| each, i.e. the result carries an error of <= ~2e-7 sum |a_k b_k| — at or below the rounding an fp32
+// fma chain over the same K accumulates — while the bf16 matrix pipe runs 16x the fp32 one per instruction: six bf16 MFMAs
+// cost 3/8 of the fp32 MFMA they replace, and the VALU work of the splitting issues in the bf16 MFMA's free issue slots
+// (an fp32 MFMA shares the fp32 ALUs with VALU instructions; a bf16 MFMA does not).  Used for the T-wide last layer of
+// the HashProbDistribution (logits, dW, dh: 3 x 2.4e13 FLOP per training step at T = 2^19), switchable
+// (gngf_set_gemm_split_bf16) — the exact-fp32 kernel above stays the default for everything else.
+using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned d;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+struct Split3 { u32x4 hi, mid, lo; };
+// exact three-way split of eight fp32 values (one bf16 MFMA fragment: k = 8 h + 0..7 of a row)
+__device__ __forceinline__ Split3 split8(const float (&x)[8]) {
+  Split3 r;
+  unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float a = x[2 * q], b = x[2 * q + 1];
+    const unsigned h = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);       // exact
+    const unsigned m = cvt_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);     // exact
+    hi[q] = h; mid[q] = m; lo[q] = cvt_pk_bf16(sa, sb);
+  }
+  r.hi = u32x4{hi[0], hi[1], hi[2], hi[3]}; r.mid = u32x4{mid[0], mid[1], mid[2], mid[3]}; r.lo = u32x4{lo[0], lo[1], lo[2], lo[3]};
+  return r;
+}
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// Same staging and tile order as gemm128_fast_kernel (fp32 K-blocks in LDS, k-major); every wave splits the fragments it
+// reads.  (A variant that splits once per workgroup on the way into LDS — bf16 planes, 16-byte fragment reads — was not
+// faster on any of the three shapes, and slower where both operands are staged transposed: the kernel is bound by its
+// per-K-block barriers and the short K = 128 of the logits product, not by the splitting.)
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256, 3)
+gemm128_split_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                     int64_t lda, int64_t ldb, int64_t ldc, const float* __restrict__ bias, int act, int64_t K,
+                     int64_t kchunk, int atomic_out, int tiles_m, int tiles_n) {
+  constexpr int BKF = 32;
+  constexpr int NV4 = BKF / 8;
+  __shared__ float As[BKF * LDS2];
+  __shared__ float Bs[BKF * LDS2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
+  int64_t t = blockIdx.x;
+  const int64_t ntiles = (int64_t)tiles_m * tiles_n;
+  if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);
+  const int64_t m0 = (tiles_m <= tiles_n ? t % tiles_m : t / tiles_n) * BM2;
+  const int64_t n0 = (tiles_m <= tiles_n ? t / tiles_m : t % tiles_n) * BN2;
+  const int64_t kbeg = (int64_t)blockIdx.y * kchunk;
+  const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+  const int nkb = (int)((kend - kbeg) / BKF);
+  const float* Aw = TA ? A + kbeg * lda + m0 : A + m0 * lda + kbeg;
+  const float* Bw = !TB ? B + kbeg * ldb + n0 : B + n0 * ldb + kbeg;
+  const int64_t sa = TA ? (int64_t)BKF * lda : BKF, sb = !TB ? (int64_t)BKF * ldb : BKF;
+  unsigned oa[NV4], ob[NV4];
+#pragma unroll
+  for (int e = 0; e < NV4; ++e) {
+    const int li = tid + e * 256;
+    oa[e] = 4u * (TA ? (unsigned)(li >> 5) * (unsigned)lda + (li & 31) * 4 : (unsigned)(li / (BKF / 4)) * (unsigned)lda + (li % (BKF / 4)) * 4);
+    ob[e] = 4u * (!TB ? (unsigned)(li >> 5) * (unsigned)ldb + (li & 31) * 4 : (unsigned)(li / (BKF / 4)) * (unsigned)ldb + (li % (BKF / 4)) * 4);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = 0;
+  u32x4 va[NV4], vb[NV4];
+  auto fetch = [&](int kb) {
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Aw + kb * sa), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bw + kb * sb), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int e = 0; e < NV4; ++e) {
+      va[e] = __builtin_amdgcn_raw_buffer_load_b128(rsa, oa[e], 0, 0);
+      vb[e] = __builtin_amdgcn_raw_buffer_load_b128(rsb, ob[e], 0, 0);
+    }
+  };
+  fetch(0);
+  // lane (i, h) of the bf16 MFMA holds k = 8 h + j (j = 0..7) of row / column i: eight LDS words 8 h + j rows down the
+  // k-major image, read with immediate offsets from one base per operand
+  const unsigned ra = lds_base(As + 8 * h * LDS2 + wm * 64 + i), rb = lds_base(Bs + 8 * h * LDS2 + wn * 64 + i);
+  for (int kb = 0; kb < nkb; ++kb) {
+    stash128<TA, BKF>(As, va, tid);
+    stash128<!TB, BKF>(Bs, vb, tid);
+    __syncthreads();
+    if (kb + 1 < nkb) fetch(kb + 1);
+    unrolled<BKF / 16>([&](auto KS) {
+      constexpr int ks = KS.value;
+      Split3 fa[2], fb[2];
+      unrolled<2>([&](auto TT_) {
+        constexpr int tt = TT_.value;
+        float xa[8], xb[8];
+        unrolled<8>([&](auto J) {
+          constexpr int j = J.value;
+          constexpr int o = ((16 * ks + j) * LDS2 + 32 * tt) * 4;
+          xa[j] = ds_ld<o>(ra);
+          xb[j] = ds_ld<o>(rb);
+        });
+        ds_wait<0>();                                          // (with its scheduling barrier: the consumers stay below the wait)
+        fa[tt] = split8(xa);
+        fb[tt] = split8(xb);
+      });
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+          f32x16 c = acc[ta][tb];                              // small terms first
+          c = mfma_bf16(fa[ta].lo, fb[tb].hi, c);
+          c = mfma_bf16(fa[ta].hi, fb[tb].lo, c);
+          c = mfma_bf16(fa[ta].mid, fb[tb].mid, c);
+          c = mfma_bf16(fa[ta].mid, fb[tb].hi, c);
+          c = mfma_bf16(fa[ta].hi, fb[tb].mid, c);
+          c = mfma_bf16(fa[ta].hi, fb[tb].hi, c);
+          acc[ta][tb] = c;
+        }
+    });
+    __syncthreads();
+  }
+  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(C + m0 * ldc + n0, 0, 0x7fffffff, 0x00020000);
+  const unsigned oc = 4u * ((unsigned)(wm * 64 + 4 * h) * (unsigned)ldc + wn * 64 + i);
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const float bv = (bias && blockIdx.y == 0) ? bias[n0 + wn * 64 + tn * 32 + i] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned so = 4u * ((unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)ldc + tn * 32);
+        const float v = acc[tm][tn][r] + bv;
+        if (atomic_out) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rsc, oc, so, 0);
+        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(act_fwd(v, act)), rsc, oc, so, 0);
+      }
+  }
+}
+
+static int g_split_bf16 = 0;       // see gngf_set_gemm_split_bf16
+
 // column sums of dZ = dY * act'(Y):  db[n] = sum_m dZ[m][n].  grid.x = ceil(N/64), grid.y = row slices; atomics.
 __global__ void __launch_bounds__(256)
 colsum_kernel(const float* __restrict__ dY, const float* __restrict__ Ymask, int mask_act, float* __restrict__ db,
@@ -394,6 +539,11 @@ static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int6
     const bool windows32 = lda < (1 << 22) && ldb < (1 << 22) && ldc < (1 << 22);   // 128 rows * ld * 4 B < 2^31
     if (M % BM2 == 0 && N % BN2 == 0 && !amask && aligned && windows32) {
       const dim3 gridf(grid2.x * grid2.y, (unsigned)splitk);
+      if (g_split_bf16 && K % 32 == 0 && kchunk % 32 == 0) {
+        gemm128_split_kernel<TA, TB><<<gridf, dim3(256), 0, s>>>(A, B, C, lda, ldb, ldc, bias, act, K, kchunk,
+                                                                    (splitk > 1 || force_atomic) ? 1 : 0, (int)grid2.y, (int)grid2.x);
+        return (int)hipGetLastError();
+      }
       if (K % kFastBK == 0 && kchunk % kFastBK == 0) {
         gemm128_fast_kernel<TA, TB, kFastBK><<<gridf, dim3(256), 0, s>>>(A, B, C, lda, ldb, ldc, bias, act, K, kchunk,
                                                                         (splitk > 1 || force_atomic) ? 1 : 0, (int)grid2.y, (int)grid2.x);
@@ -418,6 +568,14 @@ static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int6
 }  // namespace gngf
 
 using namespace gngf;
+
+// Large aligned GEMMs (full 128 x 128 tiles, K % 32 == 0) of the entry points below run on the split-bf16 kernel while this
+// is on (process-wide switch; returns the previous setting).  Off by default.
+extern "C" int gngf_set_gemm_split_bf16(int on) {
+  const int prev = g_split_bf16;
+  g_split_bf16 = on ? 1 : 0;
+  return prev;
+}
 
 // Y[M,N] = act(X[M,K] * W[N,K]^T + b)          nn.Linear + activation (models.py:84-85, 386-389)
 extern "C" int gngf_linear_fwd(const float* X, const float* W, const float* b, float* Y, int64_t M, int N, int K, int act,

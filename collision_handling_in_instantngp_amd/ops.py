@@ -238,6 +238,26 @@ HPD_Z_CACHE_RESERVE = 40 << 30
 HPD_LAST_STATS = {}          # shape of the last chunked HPD evaluation (bench.py prices the step's GEMM FLOP with it)
 
 
+# The three T-wide products of the HPD's last layer (logits, dW, dh: 3 x 2 U 128 T FLOP per training step) run on the
+# split-bf16 GEMM (csrc/linear.hip: every fp32 value split exactly into three bf16 terms, six cross products accumulated in
+# fp32; measured error against float64 equal to or below the exact-fp32 MFMA kernel's, 1.2-1.3x its speed).  False: exact
+# fp32 MFMA for these as well.
+HPD_GEMM_SPLIT_BF16 = True
+
+
+class _split_gemm:
+    """scope in which large aligned GEMMs of this process use the split-bf16 kernel (when HPD_GEMM_SPLIT_BF16)"""
+
+    def __enter__(self):
+        self.prev = query("gngf_set_gemm_split_bf16", 1) if HPD_GEMM_SPLIT_BF16 else None
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            query("gngf_set_gemm_split_bf16", self.prev)
+        return False
+
+
 class HpdVertexFunction(torch.autograd.Function):
     """HashProbDistribution (reference models.py:45-123) evaluated ONCE PER DISTINCT VERTEX u (vid = gy*vstride+gx,
     u in [0, NV)), in row chunks so that the (rows, T) distribution never exceeds `chunk_bytes`.
@@ -296,7 +316,8 @@ class HpdVertexFunction(torch.autograd.Function):
                         cached += need
                     except torch.OutOfMemoryError:      # another process took the memory meanwhile: recompute from here on
                         budget = 0
-            call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(z), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
+            with _split_gemm():
+                call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(z), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
             if keep_probs:      # dense distribution requested (small shapes): softmax in place, p-bar by GEMM
                 call("gngf_softmax_topk", ptr(z), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), ptr(rowstat[u0:u0 + n]), n, T, K, stream_ptr())
                 if pbar is not None:
@@ -344,12 +365,14 @@ class HpdVertexFunction(torch.autograd.Function):
             if lowrank:
                 # logits (again, unless kept), then softmax / top-K / batch-mean backward in place; db of the last layer is fused in
                 if not have_z:
-                    call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(dz), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
+                    with _split_gemm():
+                        call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(dz), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
                 call("gngf_softmax_bwd_lowrank", ptr(dz), ptr(rowstat[u0:u0 + n]),
                      ptr(g_tv[u0:u0 + n] if g_tv is not None else None), ptr(ti[u0:u0 + n]),
                      ptr(mw[u0:u0 + n] if g_pbar is not None else None), ptr(g_pbar), L if g_pbar is not None else 0,
                      ptr(grads[-1]), ptr(scratch), n, T, K if g_tv is not None else 0, stream_ptr())
-                linear_bwd_weight(dz, None, hs[-1], grads[-2], None, ACT_NONE)
+                with _split_gemm():
+                    linear_bwd_weight(dz, None, hs[-1], grads[-2], None, ACT_NONE)
             else:
                 if keep_probs:
                     p_chunk = probs[u0:u0 + n]
@@ -364,7 +387,8 @@ class HpdVertexFunction(torch.autograd.Function):
                      K if g_tv is not None else 0, stream_ptr())
                 linear_bwd_weight(dz, None, hs[-1], grads[-2], grads[-1], ACT_NONE)
             g = torch.zeros((n, W_last.shape[1]), dtype=_f32, device=dev)
-            gemm_acc(dz, W_last, g, n, W_last.shape[1], T, ta=False, tb=False)     # dh = dz @ W_last, split over T
+            with _split_gemm():
+                gemm_acc(dz, W_last, g, n, W_last.shape[1], T, ta=False, tb=False)     # dh = dz @ W_last, split over T
             for i in range(n_layers - 2, -1, -1):
                 linear_bwd_weight(g, hs[i + 1], hs[i], grads[2 * i], grads[2 * i + 1], ACT_RELU)
                 if i > 0:

@@ -138,6 +138,11 @@ int gngf_vertex_grid_bwd_sorted(const void* tables, int feat_dtype, const int32_
                                 const int32_t* n_ls, const float* dG, float* dtables, float* dvert_w, int Ls, int F, int64_t T,
                                 int K, int vstride, int64_t NV, void* stream);
 
+/* Large aligned GEMMs (full 128 x 128 tiles, contraction a multiple of 32) of the dense-layer entry points run on the
+ * split-bf16 kernel while this is on: every fp32 operand is split exactly into three bf16 terms and six of the nine cross
+ * products are accumulated in fp32 on the bf16 matrix pipe (error <= ~2e-7 sum |a_k b_k|, at or below the rounding of an
+ * fp32 fma chain; 2-2.7x the fp32-MFMA rate).  Process-wide; returns the previous setting.  Default off (exact fp32 MFMA). */
+int gngf_set_gemm_split_bf16(int on);
 /* ---- dense layers on the matrix cores (exact-fp32 MFMA).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.01), 3 Sigmoid.
  * nn.Linear + activation of HashProbDistribution (models.py:80-88,105-106) and of the decoder (models.py:382-392). */
 int gngf_linear_fwd(const float* X, const float* W, const float* b, float* Y, int64_t M, int N, int K, int act, void* stream);
