@@ -113,33 +113,56 @@ void orc_encode_bwd(const float* xy, const float* tables, const int32_t* vert_id
     }
 }
 
-/* decoder in -> 64 -> 64 -> out (ReLU, ReLU, Sigmoid).  W* are (out,in).  h1,h2 (P,64) kept for backward. */
+/* decoder in -> 64 -> 64 -> out (ReLU, ReLU, Sigmoid).  W* are (out,in).  h1,h2 (P,64) kept for backward.
+ * Every dot product keeps its k-ordered chain of separately rounded multiply-adds (what a scalar port does), but the loops
+ * run over the OUTPUT index innermost on transposed weights, so that the compiler vectorises them (a dependent sum over k
+ * cannot be vectorised without re-association): the port is not a straw man next to the reference's MKL GEMMs. */
+static void transpose(const float* W, float* WT, int rows, int cols) {      /* W (rows, cols) -> WT (cols, rows) */
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) WT[c * rows + r] = W[r * cols + c];
+}
+
 void orc_decoder_fwd(const float* x, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
                      const float* b2, float* h1, float* h2, float* y, int64_t P, int in_dim, int out_dim) {
+  float* W0T = (float*)malloc(sizeof(float) * (size_t)in_dim * HID);
+  float* W1T = (float*)malloc(sizeof(float) * HID * HID);
+  transpose(W0, W0T, HID, in_dim);
+  transpose(W1, W1T, HID, HID);
 #pragma omp parallel for schedule(static)
   for (int64_t p = 0; p < P; ++p) {
     const float* xp = x + p * in_dim;
     float* a1 = h1 + p * HID;
     float* a2 = h2 + p * HID;
-    for (int j = 0; j < HID; ++j) {
-      float s = b0[j];
-      for (int k = 0; k < in_dim; ++k) s += W0[j * in_dim + k] * xp[k];
-      a1[j] = s > 0.f ? s : 0.f;
+    float s[HID];
+    for (int j = 0; j < HID; ++j) s[j] = b0[j];
+    for (int k = 0; k < in_dim; ++k) {
+      const float xk = xp[k];
+      const float* w = W0T + k * HID;
+#pragma omp simd
+      for (int j = 0; j < HID; ++j) s[j] += w[j] * xk;
     }
-    for (int j = 0; j < HID; ++j) {
-      float s = b1[j];
-      for (int k = 0; k < HID; ++k) s += W1[j * HID + k] * a1[k];
-      a2[j] = s > 0.f ? s : 0.f;
+#pragma omp simd
+    for (int j = 0; j < HID; ++j) a1[j] = s[j] > 0.f ? s[j] : 0.f;
+    for (int j = 0; j < HID; ++j) s[j] = b1[j];
+    for (int k = 0; k < HID; ++k) {
+      const float ak = a1[k];
+      const float* w = W1T + k * HID;
+#pragma omp simd
+      for (int j = 0; j < HID; ++j) s[j] += w[j] * ak;
     }
+#pragma omp simd
+    for (int j = 0; j < HID; ++j) a2[j] = s[j] > 0.f ? s[j] : 0.f;
     for (int c = 0; c < out_dim; ++c) {
-      float s = b2[c];
-      for (int k = 0; k < HID; ++k) s += W2[c * HID + k] * a2[k];
-      y[p * out_dim + c] = 1.0f / (1.0f + expf(-s));
+      float t = b2[c];
+      for (int k = 0; k < HID; ++k) t += W2[c * HID + k] * a2[k];
+      y[p * out_dim + c] = 1.0f / (1.0f + expf(-t));
     }
   }
+  free(W0T);
+  free(W1T);
 }
 
-/* dx (P,in) and dW0,db0,dW1,db1,dW2,db2 (written).  Per-thread partial weight gradients, summed at the end. */
+/* dx (P,in) and dW0,db0,dW1,db1,dW2,db2 (written).  Per-thread partial weight gradients (double), summed at the end. */
 void orc_decoder_bwd(const float* x, const float* h1, const float* h2, const float* y, const float* dy, const float* W0,
                      const float* W1, const float* W2, float* dx, float* dW0, float* db0, float* dW1, float* db1, float* dW2,
                      float* db2, int64_t P, int in_dim, int out_dim) {
@@ -157,33 +180,59 @@ void orc_decoder_bwd(const float* x, const float* h1, const float* h2, const flo
     double *g0 = g, *gb0 = g0 + n0, *g1 = gb0 + HID, *gb1 = g1 + n1, *g2 = gb1 + HID, *gb2 = g2 + n2;
 #pragma omp for schedule(static)
     for (int64_t p = 0; p < P; ++p) {
-      float dz3[4], d2[HID], d1[HID];
+      float dz3[4], d2[HID], d1[HID], s[HID];
+      const float* h1p = h1 + p * HID;
+      const float* h2p = h2 + p * HID;
+      const float* xp = x + p * in_dim;
       for (int c = 0; c < out_dim; ++c) {
         float yy = y[p * out_dim + c];
         dz3[c] = dy[p * out_dim + c] * (yy * (1.f - yy));
         gb2[c] += dz3[c];
-        for (int k = 0; k < HID; ++k) g2[c * HID + k] += dz3[c] * h2[p * HID + k];
+        const float dc = dz3[c];
+        double* gr = g2 + c * HID;
+#pragma omp simd
+        for (int k = 0; k < HID; ++k) gr[k] += dc * h2p[k];
       }
-      for (int k = 0; k < HID; ++k) {
-        float s = 0.f;
-        for (int c = 0; c < out_dim; ++c) s += W2[c * HID + k] * dz3[c];
-        d2[k] = h2[p * HID + k] > 0.f ? s : 0.f;
-        gb1[k] += d2[k];
+      for (int k = 0; k < HID; ++k) s[k] = 0.f;
+      for (int c = 0; c < out_dim; ++c) {
+        const float dc = dz3[c];
+        const float* w = W2 + c * HID;
+#pragma omp simd
+        for (int k = 0; k < HID; ++k) s[k] += w[k] * dc;
       }
-      for (int j = 0; j < HID; ++j)
-        for (int k = 0; k < HID; ++k) g1[j * HID + k] += d2[j] * h1[p * HID + k];
-      for (int k = 0; k < HID; ++k) {
-        float s = 0.f;
-        for (int j = 0; j < HID; ++j) s += W1[j * HID + k] * d2[j];
-        d1[k] = h1[p * HID + k] > 0.f ? s : 0.f;
-        gb0[k] += d1[k];
+#pragma omp simd
+      for (int k = 0; k < HID; ++k) { d2[k] = h2p[k] > 0.f ? s[k] : 0.f; gb1[k] += d2[k]; }
+      for (int j = 0; j < HID; ++j) {
+        const float dj = d2[j];
+        double* gr = g1 + j * HID;
+#pragma omp simd
+        for (int k = 0; k < HID; ++k) gr[k] += dj * h1p[k];
       }
-      for (int j = 0; j < HID; ++j)
-        for (int k = 0; k < in_dim; ++k) g0[j * in_dim + k] += d1[j] * x[p * in_dim + k];
-      for (int k = 0; k < in_dim; ++k) {
-        float s = 0.f;
-        for (int j = 0; j < HID; ++j) s += W0[j * in_dim + k] * d1[j];
-        dx[p * in_dim + k] = s;
+      for (int k = 0; k < HID; ++k) s[k] = 0.f;
+      for (int j = 0; j < HID; ++j) {
+        const float dj = d2[j];
+        const float* w = W1 + j * HID;
+#pragma omp simd
+        for (int k = 0; k < HID; ++k) s[k] += w[k] * dj;
+      }
+#pragma omp simd
+      for (int k = 0; k < HID; ++k) { d1[k] = h1p[k] > 0.f ? s[k] : 0.f; gb0[k] += d1[k]; }
+      for (int j = 0; j < HID; ++j) {
+        const float dj = d1[j];
+        double* gr = g0 + j * in_dim;
+#pragma omp simd
+        for (int k = 0; k < in_dim; ++k) gr[k] += dj * xp[k];
+      }
+      {
+        float t[64];
+        for (int k = 0; k < in_dim; ++k) t[k] = 0.f;
+        for (int j = 0; j < HID; ++j) {
+          const float dj = d1[j];
+          const float* w = W0 + j * in_dim;
+#pragma omp simd
+          for (int k = 0; k < in_dim; ++k) t[k] += w[k] * dj;
+        }
+        for (int k = 0; k < in_dim; ++k) dx[p * in_dim + k] = t[k];
       }
     }
   }
@@ -192,9 +241,9 @@ void orc_decoder_bwd(const float* x, const float* h1, const float* h2, const flo
   int off = 0;
   for (int a = 0; a < 6; ++a) {
     for (int e = 0; e < sizes[a]; ++e) {
-      double s = 0.0;
-      for (int t = 0; t < nt; ++t) s += part[(size_t)t * tot + off + e];
-      outs[a][e] = (float)s;
+      double t = 0.0;
+      for (int th = 0; th < nt; ++th) t += part[(size_t)th * tot + off + e];
+      outs[a][e] = (float)t;
     }
     off += sizes[a];
   }
