@@ -94,6 +94,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra-modes", action="store_true")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-unroll", dest="unroll", action="store_false", help="one step per replayed graph")
     ap.add_argument("--cpu-sample", type=int, default=2 ** 20)
     ap.add_argument("--ramp-steps", type=int, default=60, help="untimed steps before the W warm-up steps (clock ramp)")
     ap.add_argument("--backend", default="nccl", help="rehearsal only: 'gloo' runs the N>1 code path with ranks sharing one GPU")
@@ -363,14 +364,20 @@ def main():
         loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
         step = eager_step_fn(net, mode, xy, target, world)
         launch = "eager"
+        unroll = 1
         if a.graph and not learning:
             # world > 1: the vertex stage of the encoder backward is deferred behind the dG exchange, so forward + backward
             # hold no collective and replay from one hipGraph; the exchange (RCCL) and the vertex stage follow eagerly.
             try:
                 if world > 1:
                     parallel.defer_vertex_stage(True)
-                gs = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3)
-                gs(xy, target)                          # captures; the batch stays in the static buffers
+                # steps % 4 == 0: four steps per replayed graph (a replay costs ~9 us of launch latency whatever it holds)
+                unroll = 4 if (world == 1 and steps % 4 == 0 and warmup >= 0 and a.unroll) else 1
+                gs = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3, unroll=unroll)
+                if unroll > 1:
+                    gs.run_many([(xy, target)] * unroll)
+                else:
+                    gs(xy, target)                      # captures; the batch stays in the static buffers
                 if world > 1:
                     def step(gs=gs, net=net):
                         gs.replay_only()
@@ -378,7 +385,7 @@ def main():
                     launch = "hipGraph + eager exchange"
                 else:
                     step = gs.replay_only
-                    launch = "hipGraph"
+                    launch = "hipGraph" if unroll == 1 else f"hipGraph ({unroll} steps per replay)"
             except Exception as e:  # pragma: no cover
                 print(f"[bench] graph capture failed ({e!r}); running eagerly", file=sys.stderr)
                 if world > 1:
@@ -388,9 +395,10 @@ def main():
             # Clock ramp: the chip reaches its steady matrix-core clock only after ~15 ms of sustained work (the same kernel
             # is ~10 % slower before; tools/perf_decoder_warm.py), and W warm-up steps of 0.6 ms do not get there.  Untimed
             # steps first (every rank runs the same number, so collectives stay matched), then the W + K of the contract.
-            for _ in range(a.ramp_steps):
+            for _ in range(a.ramp_steps // (unroll if launch.startswith("hipGraph (") else 1)):
                 step()
-        dt = timed(step, steps, warmup, world)
+        per = unroll if (a.graph and not learning and launch.startswith("hipGraph (")) else 1
+        dt = timed(step, steps // per, -(-warmup // per), world)       # exactly `steps` steps: steps / per replays of `per` steps each
         res = results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                                "launch": launch, "shape": {k: v for k, v in SHAPES[cfg_name].items()}}
         if learning:

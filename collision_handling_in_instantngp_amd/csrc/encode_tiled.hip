@@ -148,16 +148,15 @@ bin_scatter_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, 
   bin_scatter_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, tile_off, sorted, cursor);
 }
 
-// The same scatter with a ZERO-FILL riding on the launch: workgroups [NB, NB + zblocks) clear `zero` (nvec float4) instead —
-// the gradient buffer the backward pass will accumulate into.  The scatter keeps 128 of the 256 CUs busy for ~14 us; the
-// fill (64 MiB at T = 2^19) runs on the others in the same time, instead of being a launch (or a stream) of its own.
+// K1 with a ZERO-FILL riding on the launch: workgroups [NB, NB + zblocks) clear `zero` (nvec float4) instead — the gradient
+// buffer the backward pass will accumulate into (64 MiB at T = 2^19).  The count keeps 128 of the 256 CUs busy for ~8 us;
+// the fill runs on the others, instead of being a launch (or a stream) of its own.
 __global__ void __launch_bounds__(kBinThreads)
-bin_scatter_ride_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB,
-                        const int32_t* __restrict__ blockhist, const int32_t* __restrict__ tile_off, float4* __restrict__ sorted,
-                        float4* __restrict__ zero, int64_t nvec, int zblocks) {
-  extern __shared__ int cursor[];
+bin_count_ride_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB,
+                      int32_t* __restrict__ blockhist, float4* __restrict__ zero, int64_t nvec, int zblocks) {
+  extern __shared__ int hist[];
   if ((int)blockIdx.x < NB) {
-    bin_scatter_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, tile_off, sorted, cursor);
+    bin_count_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, hist);
     return;
   }
   const int64_t zb = (int)blockIdx.x - NB;
@@ -223,19 +222,22 @@ vertex_fwd_kernel(const TT* __restrict__ tables, const int32_t* __restrict__ ver
   vertex_fwd_lane<F, VT, TT>(tables, vert_idx, vert_w, G, nullptr, T, K, vstride, NV, pow2, l, gw, i, level_offset(n_ls, l));
 }
 
-// K1 with the VERTEX STAGE FORWARD riding on the launch: workgroups [NB, NB + ceil(vtot / 1024)) evaluate one (level, vertex)
+// K3 with the VERTEX STAGE FORWARD riding on the launch: workgroups [NB, NB + ceil(vtot / 1024)) evaluate one (level, vertex)
 // per thread (flat over the level grids) — work that does not depend on the binned pixels and used to be a launch on a
 // helper stream.  Measured: parallel branches of a replayed hipGraph run on different hardware queues, and every
 // cross-queue dependency costs ~10 us (+ ~12 us between replays); one linear chain with riders has no such gaps.
+// (The riders sit on the SCATTER launch, 13 us alone, and the gradient clear on the count launch, 8 us alone: the other way
+// round the scatter launch took 21 us.)
 template <int F, bool VT, typename TT>
 __global__ void __launch_bounds__(kBinThreads)
-bin_count_ride_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB,
-                      int32_t* __restrict__ blockhist, const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx,
-                      const float* __restrict__ vert_w, const int32_t* __restrict__ n_ls, float* __restrict__ G,
-                      float* __restrict__ dG_zero, int Ls, int64_t T, int K, int vstride, int64_t NV, bool pow2, int64_t vtot) {
-  extern __shared__ int hist[];
+bin_scatter_ride_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB,
+                        const int32_t* __restrict__ blockhist, const int32_t* __restrict__ tile_off, float4* __restrict__ sorted,
+                        const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx,
+                        const float* __restrict__ vert_w, const int32_t* __restrict__ n_ls, float* __restrict__ G,
+                        float* __restrict__ dG_zero, int Ls, int64_t T, int K, int vstride, int64_t NV, bool pow2, int64_t vtot) {
+  extern __shared__ int cursor[];
   if ((int)blockIdx.x < NB) {
-    bin_count_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, hist);
+    bin_scatter_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, tile_off, sorted, cursor);
     return;
   }
   const int64_t e = (int64_t)((int)blockIdx.x - NB) * kBinThreads + threadIdx.x;
@@ -894,24 +896,24 @@ extern "C" int gngf_encode_tiled_prepare(const float* xy, int64_t P, int tile_sh
   const int vblocks = (int)ceil_div(vtot, kBinThreads);
   const bool pow2 = (T & (T - 1)) == 0;
   const float2* xy2 = reinterpret_cast<const float2*>(xy);
-  if (mode == GNGF_MODE_HASH) {
-    DISPATCH_TT(feat_dtype, DISPATCH_F(F, (bin_count_ride_kernel<kF, false, TT><<<dim3((unsigned)(NB + vblocks)), dim3(kBinThreads), smem, s>>>(
-                                xy2, P, per_block, tile_shift, NB, blockhist, static_cast<const TT*>(tables), nullptr, nullptr, n_ls, G,
-                                dG_zero, Ls, T, 0, 0, 0, pow2, vtot))));
-  } else {
-    DISPATCH_TT(feat_dtype, DISPATCH_F(F, (bin_count_ride_kernel<kF, true, TT><<<dim3((unsigned)(NB + vblocks)), dim3(kBinThreads), smem, s>>>(
-                                xy2, P, per_block, tile_shift, NB, blockhist, static_cast<const TT*>(tables), vert_idx, vert_w, n_ls, G,
-                                dG_zero, Ls, T, K, vstride, NV, pow2, vtot))));
-  }
+  const int64_t nvec = zero_fill ? zero_floats / 4 : 0;
+  const int zblocks = nvec > 0 ? (int)(ceil_div(nvec, 4096) < 1024 ? ceil_div(nvec, 4096) : 1024) : 0;
+  bin_count_ride_kernel<<<dim3((unsigned)(NB + zblocks)), dim3(kBinThreads), smem, s>>>(xy2, P, per_block, tile_shift, NB, blockhist,
+                                                                                       reinterpret_cast<float4*>(zero_fill), nvec, zblocks);
   int32_t* tot = blockhist + (int64_t)ntiles * NB;
   bin_rowscan_kernel<<<dim3((unsigned)ceil_div(ntiles, 4)), dim3(256), 0, s>>>(blockhist, NB, ntiles, tot);
   bin_scan_kernel<<<dim3(1), dim3(kBinThreads), 0, s>>>(tot, tile_shift, chunk, tile_off, tile_item_base,
                                                          reinterpret_cast<int4*>(items), n_items);
-  const int64_t nvec = zero_fill ? zero_floats / 4 : 0;
-  const int zblocks = nvec > 0 ? (int)(ceil_div(nvec, 4096) < 1024 ? ceil_div(nvec, 4096) : 1024) : 0;
-  bin_scatter_ride_kernel<<<dim3((unsigned)(NB + zblocks)), dim3(kBinThreads), smem, s>>>(
-      xy2, P, per_block, tile_shift, NB, blockhist, tile_off, reinterpret_cast<float4*>(sorted), reinterpret_cast<float4*>(zero_fill),
-      nvec, zblocks);
+  float4* sorted4 = reinterpret_cast<float4*>(sorted);
+  if (mode == GNGF_MODE_HASH) {
+    DISPATCH_TT(feat_dtype, DISPATCH_F(F, (bin_scatter_ride_kernel<kF, false, TT><<<dim3((unsigned)(NB + vblocks)), dim3(kBinThreads), smem, s>>>(
+                                xy2, P, per_block, tile_shift, NB, blockhist, tile_off, sorted4, static_cast<const TT*>(tables), nullptr,
+                                nullptr, n_ls, G, dG_zero, Ls, T, 0, 0, 0, pow2, vtot))));
+  } else {
+    DISPATCH_TT(feat_dtype, DISPATCH_F(F, (bin_scatter_ride_kernel<kF, true, TT><<<dim3((unsigned)(NB + vblocks)), dim3(kBinThreads), smem, s>>>(
+                                xy2, P, per_block, tile_shift, NB, blockhist, tile_off, sorted4, static_cast<const TT*>(tables), vert_idx,
+                                vert_w, n_ls, G, dG_zero, Ls, T, K, vstride, NV, pow2, vtot))));
+  }
   GNGF_RETURN_LAUNCH();
 }
 

@@ -122,13 +122,13 @@ class FusedAdam(torch.optim.Optimizer):
                              st["master"].data_ptr() if half else 0, p.numel(), gi, int(half), g))
         return segs
 
-    def prepare_capture(self):
-        """Sets aside the pinned staging buffers a hipGraph capture of step() needs (pinned memory cannot be allocated while a
-        stream captures) WITHOUT taking a step: call after one backward pass, before capturing."""
+    def prepare_capture(self, steps=1):
+        """Sets aside the pinned staging buffers a hipGraph capture of `steps` step() calls needs (pinned memory cannot be
+        allocated while a stream captures) WITHOUT taking a step: call after one backward pass, before capturing."""
         segs = self._segments()
         size = len(segs) * self._RECORD.itemsize
         have = [h for h in self._spares if h.numel() == size]
-        for _ in range(max(0, 2 - len(have))):
+        for _ in range(max(0, 1 + int(steps) - len(have))):
             self._spares.append(torch.empty((size,), dtype=torch.uint8, pin_memory=True))
 
     @torch.no_grad()
@@ -263,7 +263,10 @@ class GraphedStep:
         __slots__ = ("out", "probs", "idx", "loss", "mse", "kls", "colls")
 
     def __init__(self, net, loss_fn, optimizer, l_mse=1.0, l_js_kl=1.0, l_collisions=1e-3, batch_percentage=1.0,
-                 coord_bounds=None, warm=2):
+                 coord_bounds=None, warm=2, unroll=1):
+        """unroll = k > 1: ONE graph holds k consecutive steps on k batches (run_many): a replay costs ~9 us of launch latency
+        on top of its kernels whatever it contains, so k steps per replay spread it over k steps."""
+        self.unroll = int(unroll)
         if optimizer is not None and not isinstance(optimizer, FusedAdam):
             raise TypeError("GraphedStep captures FusedAdam.step(); torch.optim.Adam's step is not capturable here")
         self.net, self.loss_fn, self.optimizer = net, loss_fn, optimizer
@@ -318,24 +321,54 @@ class GraphedStep:
               "pm": pm.detach().clone(), "one": torch.ones((), device=bx.device),
               "named": [(n, p) for n, p in named if p.requires_grad],
               "shadow": {n: p.detach().requires_grad_(p.requires_grad) for n, p in named}}
+        # further batches of an unrolled graph: their own input buffers, everything else shared
+        st["more"] = [dict(st, x=torch.empty_like(st["x"]), y=torch.empty_like(st["y"])) for _ in range(self.unroll - 1)]
+        for m in st["more"]:
+            m["x"].copy_(st["x"])
+            m["y"].copy_(st["y"])
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, self.warm)):        # lazy initialisation (workspaces, cached tables) happens here, not in the capture
                 self._body(st)
             if self.optimizer is not None:
-                self.optimizer.prepare_capture()      # no optimizer step is taken before the first real batch
+                self.optimizer.prepare_capture(self.unroll)      # no optimizer step is taken before the first real batch
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         # thread_local: other threads of the process (the RCCL watchdog at world > 1) may query events while we capture
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            st["result"] = self._body(st)
-            if self.optimizer is not None:
-                self.optimizer.step()
+            st["results"] = []
+            for sub in [st] + st["more"]:
+                st["results"].append(self._body(sub))
+                if self.optimizer is not None:
+                    self.optimizer.step()
+            st["result"] = st["results"][0]
         st["graph"] = g
         self._graphs[key] = st
         return st
+
+    def run_many(self, batches, previous_collisions=None, previous_min_possible_collisions=None):
+        """unroll consecutive steps in ONE replay: batches = [(x, target)] * unroll (same shapes).  Returns the list of results."""
+        if len(batches) != self.unroll:
+            raise ValueError(f"run_many needs exactly unroll = {self.unroll} batches")
+        (x0, y0) = batches[0]
+        dev = x0.device
+        empty = torch.tensor([], device=dev)
+        pc = empty if previous_collisions is None else previous_collisions.to(dev)
+        pm = empty if previous_min_possible_collisions is None else previous_min_possible_collisions.to(dev)
+        key = (tuple(x0.shape), tuple(y0.shape), tuple(pc.shape), tuple(pm.shape), bool(models.should_use_hash_function))
+        st = self._graphs.get(key)
+        if st is None:
+            st = self._build(key, x0, y0, pc, pm)
+        for sub, (bx, by) in zip([st] + st["more"], batches):
+            sub["x"].copy_(bx)
+            sub["y"].copy_(by)
+        if pc.numel():
+            st["pc"].copy_(pc)
+            st["pm"].copy_(pm)
+        st["graph"].replay()
+        return st["results"]
 
     def replay_only(self, key=None):
         """Replays the (only, or the named) captured step on the batch already in its static buffers (benchmarks)."""
@@ -349,6 +382,8 @@ class GraphedStep:
         pc = empty if previous_collisions is None else previous_collisions.to(dev)
         pm = empty if previous_min_possible_collisions is None else previous_min_possible_collisions.to(dev)
         key = (tuple(batch_x.shape), tuple(batch_target.shape), tuple(pc.shape), tuple(pm.shape), bool(models.should_use_hash_function))
+        if self.unroll != 1:
+            raise ValueError("an unrolled GraphedStep takes its batches through run_many()")
         st = self._graphs.get(key)
         if st is None:
             st = self._build(key, batch_x, batch_target, pc, pm)

@@ -377,6 +377,60 @@ def test_hipgraph_replay_of_a_step_equals_eager(golden, mode):
         models.should_use_hash_function = False
 
 
+def test_unrolled_graph_of_three_steps_equals_three_eager_steps(golden):
+    """GraphedStep(unroll=3): forward + backward + Adam of three consecutive batches in ONE replayed graph == three eager steps
+    (parameters after the third step, and the per-step outputs)."""
+    import copy
+    from collision_handling_in_instantngp_amd import models, train
+    models.should_use_hash_function = True
+    try:
+        torch.manual_seed(2)
+        net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=2 ** 14, num_levels=8, n_min=16, n_max=128,
+                                              MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
+                                              HPD_out_features=2 ** 14, feature_dim=2, topk_k=4)
+        net.return_indices = False
+        ref = copy.deepcopy(net)
+        start = {k: p.detach().clone() for k, p in net.named_parameters()}
+        X, Y, h, w = strawberry(golden)
+        batches = [(X[lo:lo + 40000].contiguous(), Y[lo:lo + 40000].contiguous()) for lo in (0, 40000, 80000)]
+        loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
+        empty = torch.tensor([], device=DEV)
+        opt_ref = train.get_optimizer(ref, 1e-2, 1e-3, 1e-3, 0.0, 0.0, 1e-6)
+        outs = []
+        for _round in range(2):
+            for xy, tgt in batches:
+                opt_ref.zero_grad(set_to_none=True)
+                rgb, probs, _i, _c = ref(xy, 1.0)
+                mse, kls, coll = loss_fn(rgb, tgt, None, probs, empty, empty)
+                train.assemble_loss(mse, kls, coll, 1, 1, 1e-3).backward()
+                opt_ref.step()
+                outs.append(rgb.detach().clone())
+        opt = train.get_optimizer(net, 1e-2, 1e-3, 1e-3, 0.0, 0.0, 1e-6)
+        gs = train.GraphedStep(net, loss_fn, opt, 1, 1, 1e-3, unroll=3)
+        got = []
+        for _round in range(2):                          # the first call captures and replays; the second only replays
+            rs = gs.run_many(batches)
+            torch.cuda.synchronize()
+            got += [r.out.clone() for r in rs]
+        # Adam's first steps turn a last-bit difference of a tiny gradient (float atomics land in a different order from run
+        # to run) into a difference of up to lr in that entry: compare outputs, and parameters in the mean against their movement
+        assert torch.equal(got[0], outs[0])
+        for i, (g_, w_) in enumerate(zip(got, outs)):
+            assert float((g_ - w_).abs().max()) <= 2e-3, i
+            assert float((g_ - w_).abs().mean()) <= 2e-5, i
+        for (k, p), (_k, q), (_k0, q0) in zip(net.named_parameters(), ref.named_parameters(), start.items()):
+            if not q.requires_grad:
+                continue
+            moved = float((q - q0).abs().mean())
+            assert float((p - q).abs().mean()) <= 0.01 * moved, k           # parameters no loss term reaches stay put in both
+        moved_any = [k for (k, q), q0 in zip(ref.named_parameters(), start.values()) if not torch.equal(q, q0)]
+        assert any("hash" in k.lower() or "table" in k.lower() or "MRHE" in k for k in moved_any) and len(moved_any) >= 7, moved_any
+        with pytest.raises(ValueError):
+            gs(*batches[0])
+    finally:
+        models.should_use_hash_function = False
+
+
 @pytest.mark.parametrize("K", [0, 3])
 def test_distinct_slot_counts_kernel_vs_torch_unique(K):
     """csrc/stats.hip (bit-map pass) == torch.unique(...).numel() per level and top-K rank, T not a multiple of 32"""
