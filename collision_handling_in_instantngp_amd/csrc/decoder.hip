@@ -955,9 +955,23 @@ static size_t bwd_smem_bytes(int in_dim, int out_dim) {
   return sizeof(float) * (main_loop > epilogue ? main_loop : epilogue);
 }
 
+#include "decoder_split.inc"
+
+// 1: in_dim 32 / 64 run on the split-bf16 kernels (decoder_split.inc); 0: everything on the fp32 matrix pipe
+static int g_decoder_split = 0;
+
 }  // namespace gngf
 
 using namespace gngf;
+
+// Switches the decoder between the fp32-MFMA kernels and the split-bf16 ones (same results to fp32 rounding); returns the
+// previous setting.  With the split kernels the hidden-layer buffer is neither written nor read.
+extern "C" int gngf_set_decoder_split_bf16(int on) {
+  const int prev = g_decoder_split;
+  g_decoder_split = on ? 1 : 0;
+  return prev;
+}
+static bool decoder_split_applies(int in_dim) { return g_decoder_split && (in_dim == 32 || in_dim == 64); }
 
 #define DISPATCH_KIN(in_dim, ...)                                         \
   if ((in_dim) <= 16) { constexpr int kKIN = 16; __VA_ARGS__; }           \
@@ -985,6 +999,19 @@ extern "C" int gngf_decoder_fwd(const float* enc, const float* W0, const float* 
   const int64_t tiles = (P + 127) / 128;
   const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);       // one persistent workgroup per CU
   const size_t smem = sizeof(float) * (size_t)raw_offsets(in_dim).total;
+  if (decoder_split_applies(in_dim)) {
+    hipStream_t s = as_stream(stream);
+    const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);     // two persistent workgroups per CU
+    const size_t smem = sizeof(float) * (size_t)((in_dim == 32 ? SplitFwd<32>::kFragWords : SplitFwd<64>::kFragWords) + SplitFwd<32>::kBiasWords + raw_offsets(in_dim).total);
+    if (in_dim == 32) {
+      if (leaky) decoder_fwd_split_kernel<32, true><<<dim3(grid), dim3(kDecThreads), smem, s>>>(enc, W0, b0, W1, b1, W2, b2, rgb, P, out_dim);
+      else decoder_fwd_split_kernel<32, false><<<dim3(grid), dim3(kDecThreads), smem, s>>>(enc, W0, b0, W1, b1, W2, b2, rgb, P, out_dim);
+    } else {
+      if (leaky) decoder_fwd_split_kernel<64, true><<<dim3(grid), dim3(kDecThreads), smem, s>>>(enc, W0, b0, W1, b1, W2, b2, rgb, P, out_dim);
+      else decoder_fwd_split_kernel<64, false><<<dim3(grid), dim3(kDecThreads), smem, s>>>(enc, W0, b0, W1, b1, W2, b2, rgb, P, out_dim);
+    }
+    GNGF_RETURN_LAUNCH();
+  }
   DISPATCH_KIN(in_dim, {
     using Kern = void (*)(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
                           float*, int64_t, int, int);

@@ -143,6 +143,11 @@ int gngf_vertex_grid_bwd_sorted(const void* tables, int feat_dtype, const int32_
  * products are accumulated in fp32 on the bf16 matrix pipe (error <= ~2e-7 sum |a_k b_k|, at or below the rounding of an
  * fp32 fma chain; 2-2.7x the fp32-MFMA rate).  Process-wide; returns the previous setting.  Default off (exact fp32 MFMA). */
 int gngf_set_gemm_split_bf16(int on);
+/* The same switch for the fused decoder (gngf_decoder_fwd / gngf_decoder_bwd) at in_dim 32 or 64: exact three-way bf16
+ * split of every operand, six cross products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  While on, the hidden-layer
+ * buffer is neither written by the forward nor read by the backward (the backward recomputes the two layers).  Process-wide;
+ * returns the previous setting. */
+int gngf_set_decoder_split_bf16(int on);
 /* ---- dense layers on the matrix cores (exact-fp32 MFMA).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.01), 3 Sigmoid.
  * nn.Linear + activation of HashProbDistribution (models.py:80-88,105-106) and of the decoder (models.py:382-392). */
 int gngf_linear_fwd(const float* X, const float* W, const float* b, float* Y, int64_t M, int N, int K, int act, void* stream);
