@@ -971,7 +971,7 @@ extern "C" int gngf_set_decoder_split_bf16(int on) {
   g_decoder_split = on ? 1 : 0;
   return prev;
 }
-static bool decoder_split_applies(int in_dim) { return g_decoder_split && (in_dim == 32 || in_dim == 64); }
+static bool decoder_split_applies(int in_dim) { return g_decoder_split && in_dim == 32; }
 
 #define DISPATCH_KIN(in_dim, ...)                                         \
   if ((in_dim) <= 16) { constexpr int kKIN = 16; __VA_ARGS__; }           \
@@ -1047,6 +1047,14 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
     if (e != hipSuccess) return (int)e;
   } else {
     GNGF_CHECK_ARG(enc && rgb && (target ? gloss != nullptr : drgb != nullptr) && W0 && b0 && W1 && b1 && W2 && denc);
+    if (decoder_split_applies(in_dim) && in_dim == 32) {
+      const size_t main_loop = SplitBwd<32>::kMainBytes, epilogue = sizeof(float) * 4 * (size_t)nslab;
+      const size_t smem = main_loop > epilogue ? main_loop : epilogue;
+      auto fn = leaky ? decoder_bwd_split_kernel<32, true> : decoder_bwd_split_kernel<32, false>;
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+      fn<<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, P, out_dim, target, gloss);
+    } else
     DISPATCH_KIN(in_dim, {
       const size_t smem = bwd_smem_bytes<kKIN>(in_dim, out_dim);
       using Kern = void (*)(const float*, const float*, const float*, const float*, const float*, const float*, const float*,

@@ -309,6 +309,51 @@ def test_decoder_saved_hidden_equals_recompute(ops, P, in_dim, leaky):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("P,leaky", [(1000, False), (128 * 300 + 77, True)])
+def test_split_bf16_decoder_kernels_are_as_accurate_as_the_fp32_ones(ops, P, leaky):
+    """gngf_set_decoder_split_bf16(1): the decoder on v_mfma_f32_32x32x16_bf16 with every operand split exactly into three
+    bf16 terms (csrc/decoder_split.inc).  Against a float64 evaluation its error must not exceed twice that of the fp32-MFMA
+    kernels (+ 1e-7 absolute on rgb); a hidden unit whose pre-activation is within rounding of 0 may switch sides, which
+    changes that pixel's gradient — hence the 99.9 % quantile for d enc and the looser bound on the summed gradients."""
+    from collision_handling_in_instantngp_amd import _lib
+    rng = np.random.default_rng(P)
+    x = (0.5 * rng.standard_normal((P, 32))).astype(np.float32)
+    dims = [32, 64, 64, 3]
+    ws = []
+    for i in range(3):
+        ws += [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32), (0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32)]
+    dy = (1e-3 * rng.standard_normal((P, 3))).astype(np.float32)
+    acts = (ops.ACT_LEAKY if leaky else ops.ACT_RELU,) * 2 + (ops.ACT_SIGMOID,)
+    x64 = torch.tensor(x, dtype=torch.float64, device=DEV, requires_grad=True)
+    p64 = [torch.tensor(w, dtype=torch.float64, device=DEV, requires_grad=True) for w in ws]
+    actf = (lambda v: torch.nn.functional.leaky_relu(v, 0.01)) if leaky else torch.relu
+    y64 = torch.sigmoid(actf(actf(x64 @ p64[0].T + p64[1]) @ p64[2].T + p64[3]) @ p64[4].T + p64[5])
+    y64.backward(torch.tensor(dy, dtype=torch.float64, device=DEV))
+    want = [y64.detach(), x64.grad] + [p.grad for p in p64]
+    errs = []
+    for split in (0, 1):
+        prev = _lib.query("gngf_set_decoder_split_bf16", split)
+        try:
+            xt = t(x).requires_grad_()
+            params = [t(w).requires_grad_() for w in ws]
+            y = ops.decoder_apply(xt, acts, params, fused=True)
+            y.backward(t(dy))
+            torch.cuda.synchronize()
+        finally:
+            _lib.query("gngf_set_decoder_split_bf16", prev)
+        got = [y.detach(), xt.grad] + [p.grad for p in params]
+        e = [float((got[0].double() - want[0]).abs().max())]
+        rel = (got[1].double() - want[1]).abs().max(1).values / want[1].abs().max()
+        e.append(float(torch.quantile(rel, 0.999)))
+        e += [float((g.double() - w).abs().max() / w.abs().max()) for g, w in zip(got[2:], want[2:])]
+        errs.append(e)
+    fp32, split = errs
+    assert split[0] <= 2 * fp32[0] + 1e-7, (fp32, split)
+    assert split[1] <= 2 * fp32[1] + 1e-7, (fp32, split)
+    for a, b in zip(fp32[2:], split[2:]):
+        assert b <= 2 * a + 2e-4, (fp32, split)
+
+
 @pytest.mark.parametrize("n", [(1, 3), (7, 3), (1000, 3), (4099, 4), (2 ** 18 + 5, 3)])
 def test_mse_kernels_vs_numpy(ops, n):
     """csrc/loss.hip: value and gradient of torch.nn.MSELoss (reference utils.py:99), incl. a non-unit upstream gradient,
