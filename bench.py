@@ -525,7 +525,7 @@ def main():
                                                           if MODES[a.mode] == "cfg2" else f"synthetic {c['image']}^2 image, L={L} F={F} T={c['T']} N {c['n_min']}->{c['n_max']}")
                                    + f", {a.mode} indexing, random-init weights, MSE loss, fwd+bwd (no optimizer)",
                        "mode": a.mode, "pixels_per_gpu": P, "parallelism": f"dp{world}",
-                       "untimed_ramp_steps_before_warmup": a.ramp_steps},
+                       "untimed_ramp_steps_before_warmup": a.ramp_steps, "launch": head["launch"]},
             "collective_ranks": collective_ranks, "rccl_ranks": (collective_ranks if (world > 1 and a.backend == "nccl") else None),
             "backend": (a.backend if world > 1 else None),
             "modes": results, "kernel_ms": {k: (v * 1e3 if isinstance(v, float) else v) for k, v in kt.items()},

@@ -4,11 +4,11 @@ the bytes of wide (16 B/lane) reads (MI355X_MICROARCH.md §HBM); WRITE_SIZE (KiB
 import json, subprocess, sys
 summ = json.loads(subprocess.check_output([sys.executable, "tools/pmc_summary.py"] + sys.argv[1:]))
 groups = {
+    "prepare(bin+vertex_fwd+clears)": ["gngf::bin_count_ride_kernel", "gngf::bin_rowscan_kernel", "gngf::bin_scan_kernel", "gngf::bin_scatter_ride_kernel<2"],
     "encode_fwd:tiled": ["gngf::tiled_fwd_kernel<2>"],
     "encode_bwd:tiled": ["gngf::tiled_bwd_kernel<2>", "gngf::gather_partials_kernel<2>"],
     "decoder_fwd": ["gngf::decoder_fwd_kernel<32"],
-    "decoder_bwd": ["gngf::decoder_bwd_kernel<32", "gngf::decoder_reduce_kernel"],
-    "vertex_fwd": ["gngf::vertex_fwd_kernel<2, true"],
+    "decoder_bwd": ["gngf::decoder_bwd_kernel<32"],
     "vertex_bwd": ["gngf::vertex_bwd_sorted_kernel<2"],
 }
 def pick(prefix, counter):          # kernel names carry their full template argument lists: match by prefix
@@ -17,7 +17,7 @@ def pick(prefix, counter):          # kernel names carry their full template arg
 # kernels whose dominant reads are 16 B per lane report exactly half (factor 2: decoder_fwd reads 128 MiB of enc and
 # FETCH_SIZE says 64.2 MiB); tiled_bwd reads its 128 MiB of d-enc rows as 8 B per lane and FETCH_SIZE already says
 # 154 MiB = rows + binned pixels (factor 1).
-fetch_factor = {"encode_bwd:tiled": 1.0}
+fetch_factor = {"encode_bwd:tiled": 1.0, "prepare(bin+vertex_fwd+clears)": 1.0, "vertex_bwd": 1.0}
 out = {}
 for name, ks in groups.items():
     f = sum(pick(k, "FETCH_SIZE") for k in ks)

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Profiles of the round (run on the GPU box through gpurun): kernel-trace statistics of the three bench modes and the two
+# PMC passes (FETCH_SIZE, WRITE_SIZE — each in its own run, with --kernel-trace only) of the headline mode.
+# Usage: bash tools/profile_round.sh r02      -> gpurun_out/prof_<tag>_*/
+set -u
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+run() { name=$1; shift; echo "== $name"; timeout -k 10 400 rocprofv3 "$@" > $OUT/prof_${TAG}_$name.log 2>&1; echo "rc $?"; }
+run frozen   --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_frozen -o p -- python3 $ROOT/bench.py --steps 300 --warmup 3 --no-extra-modes --no-cpu-baseline
+run hash     --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_hash -o p -- python3 $ROOT/bench.py --mode hash --steps 300 --warmup 3 --no-extra-modes --no-cpu-baseline
+run learning --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_learning -o p -- python3 $ROOT/bench.py --mode gngf_learning --steps 1 --warmup 1 --no-extra-modes --no-cpu-baseline
+run fetch    --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG}_pmc_fetch -o p -- python3 $ROOT/bench.py --steps 8 --warmup 1 --ramp-steps 4 --no-extra-modes --no-cpu-baseline
+run write    --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_${TAG}_pmc_write -o p -- python3 $ROOT/bench.py --steps 8 --warmup 1 --ramp-steps 4 --no-extra-modes --no-cpu-baseline
+# keep what travels back small: the per-dispatch traces of the long runs are not needed (the stats are)
+rm -f $OUT/prof_${TAG}_frozen/*kernel_trace.csv $OUT/prof_${TAG}_hash/*kernel_trace.csv
+du -sh $OUT/prof_${TAG}_* | cat
