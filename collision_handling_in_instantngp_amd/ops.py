@@ -236,6 +236,9 @@ def expand_vertex_table(xy, n_ls, vstride, NV, src_idx=None, src_val=None, want_
 HPD_Z_CACHE_BYTES = 216 << 30
 HPD_Z_CACHE_RESERVE = 40 << 30
 HPD_LAST_STATS = {}          # shape of the last chunked HPD evaluation (bench.py prices the step's GEMM FLOP with it)
+# Chunks are software-pipelined over two streams: the T-wide GEMMs (matrix-pipe bound) of one chunk run beside the streaming
+# softmax / top-K / batch-mean passes (HBM bound) of its neighbour.  False: everything in line on the current stream.
+HPD_PIPELINE = True
 
 
 # The three T-wide products of the HPD's last layer (logits, dW, dh: 3 x 2 U 128 T FLOP per training step) run on the
@@ -293,7 +296,15 @@ class HpdVertexFunction(torch.autograd.Function):
             mw = _c(mw)
             L = mw.shape[1]
             pbar = torch.zeros((L, T), dtype=_f32, device=dev)
-        scratch = None if keep_probs else torch.empty((min(rows, NV), T), dtype=_f32, device=dev)
+        pipelined = (HPD_PIPELINE and not keep_probs and NV > rows and not torch.cuda.is_current_stream_capturing())
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if pipelined else None
+        pipelined = pipelined and side is not main and side.stream_id != main.stream_id
+        # un-kept chunks alternate between two logits buffers when pipelined (the passes of chunk i read one while the GEMM
+        # of chunk i + 1 fills the other)
+        scratch = None if keep_probs else [torch.empty((min(rows, NV), T), dtype=_f32, device=dev) for _ in range(2 if pipelined else 1)]
+        scratch_free = [None] * (len(scratch) if scratch else 0)      # event after the last pass that read the buffer
+        n_scratch = 0
         # Checkpointing policy sized for 288 GB of HBM: the backward needs every chunk's logits again; the chunks that fit
         # HPD_Z_CACHE_BYTES (and leave HPD_Z_CACHE_RESERVE free on the device) keep theirs, the rest are recomputed.
         zcache, cached = {}, 0
@@ -307,7 +318,7 @@ class HpdVertexFunction(torch.autograd.Function):
         for u0 in range(0, NV, rows):
             n = min(rows, NV - u0)
             hs = HpdVertexFunction._hidden(vertex_coords(u0, n, vstride, dev), params, n_layers)
-            z = probs[u0:u0 + n] if keep_probs else scratch[:n]
+            z = probs[u0:u0 + n] if keep_probs else None
             if keep_z:
                 need = n * T * 4
                 if cached + need <= budget:
@@ -316,8 +327,26 @@ class HpdVertexFunction(torch.autograd.Function):
                         cached += need
                     except torch.OutOfMemoryError:      # another process took the memory meanwhile: recompute from here on
                         budget = 0
+            sb = None
+            if z is None:
+                sb = n_scratch % len(scratch)
+                n_scratch += 1
+                z = scratch[sb][:n]
+                if scratch_free[sb] is not None:
+                    main.wait_event(scratch_free[sb])
             with _split_gemm():
                 call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(z), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
+            if pipelined:
+                ready = torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    call("gngf_logits_topk_pbar", ptr(z), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), ptr(rowstat[u0:u0 + n]),
+                         ptr(mw[u0:u0 + n] if pbar is not None else None), L if pbar is not None else 0, ptr(pbar), n, T, K, stream_ptr())
+                    if sb is not None:
+                        scratch_free[sb] = torch.cuda.Event()
+                        scratch_free[sb].record(side)
+                continue
             if keep_probs:      # dense distribution requested (small shapes): softmax in place, p-bar by GEMM
                 call("gngf_softmax_topk", ptr(z), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), ptr(rowstat[u0:u0 + n]), n, T, K, stream_ptr())
                 if pbar is not None:
@@ -325,6 +354,8 @@ class HpdVertexFunction(torch.autograd.Function):
             else:               # streaming: the logits are only read (stats + top-K in one pass, p-bar in a second)
                 call("gngf_logits_topk_pbar", ptr(z), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), ptr(rowstat[u0:u0 + n]),
                      ptr(mw[u0:u0 + n] if pbar is not None else None), L if pbar is not None else 0, ptr(pbar), n, T, K, stream_ptr())
+        if pipelined:
+            main.wait_stream(side)
         if pbar is not None and DP_MEAN is not None:
             DP_MEAN(pbar)      # the loss is a nonlinear function of the batch mean: average BEFORE the log (SURVEY §8e ii)
         HPD_LAST_STATS.update(rows_total=int(NV), T=int(T), rows_per_chunk=int(rows), chunks=-(-NV // rows), chunks_kept=len(zcache))
@@ -353,6 +384,12 @@ class HpdVertexFunction(torch.autograd.Function):
         dz_buf = None
         if lowrank:
             scratch = torch.empty((min(rows, NV) * (1 + K),), dtype=_f32, device=dev)
+        pipelined = HPD_PIPELINE and lowrank and NV > rows and not torch.cuda.is_current_stream_capturing()
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if pipelined else None
+        pipelined = pipelined and side.stream_id != main.stream_id
+        if pipelined:
+            return HpdVertexFunction._backward_pipelined(ctx.cfg, ti, mw, rowstat, params, grads, g_tv, g_pbar, L, zcache, scratch, main, side)
         for u0 in range(0, NV, rows):
             n = min(rows, NV - u0)
             hs = HpdVertexFunction._hidden(vertex_coords(u0, n, vstride, dev), params, n_layers)
@@ -393,6 +430,64 @@ class HpdVertexFunction(torch.autograd.Function):
                 linear_bwd_weight(g, hs[i + 1], hs[i], grads[2 * i], grads[2 * i + 1], ACT_RELU)
                 if i > 0:
                     g = linear_bwd_input(g, hs[i + 1], params[2 * i], ACT_RELU)
+        return (None, None, None, None, None, None, *grads)
+
+
+    @staticmethod
+    def _backward_pipelined(cfg, ti, mw, rowstat, params, grads, g_tv, g_pbar, L, zcache, scratch, main, side):
+        """The low-rank backward with its chunks software-pipelined over two streams.  Per chunk: A (main) logits again unless
+        kept; B (side) softmax / top-K / batch-mean backward in place, HBM bound; C (main) the dW and dh GEMMs and the small
+        layers, matrix-pipe bound.  Issue order on main: A_0, A_1, C_0, A_2, C_1, ... so that C_i runs beside B_{i+1}.  Un-kept
+        chunks alternate between two logits buffers; a buffer's next A is issued on main behind the C that last read it.
+        Every tensor stays referenced until both streams have joined (the caching allocator knows only the allocating stream)."""
+        NV, vstride, K, rows, n_layers, T, _keep = cfg
+        W_last, b_last = params[-2], params[-1]
+        dev = W_last.device
+        dz_bufs, n_unkept, alive, pending = [], 0, [], None
+
+        def stage_c(dz, hs, done_b, n):
+            main.wait_event(done_b)
+            with _split_gemm():
+                linear_bwd_weight(dz, None, hs[-1], grads[-2], None, ACT_NONE)
+            g = torch.zeros((n, W_last.shape[1]), dtype=_f32, device=dev)
+            with _split_gemm():
+                gemm_acc(dz, W_last, g, n, W_last.shape[1], T, ta=False, tb=False)     # dh = dz @ W_last, split over T
+            for i in range(n_layers - 2, -1, -1):
+                linear_bwd_weight(g, hs[i + 1], hs[i], grads[2 * i], grads[2 * i + 1], ACT_RELU)
+                if i > 0:
+                    g = linear_bwd_input(g, hs[i + 1], params[2 * i], ACT_RELU)
+            alive.append(g)
+
+        for u0 in range(0, NV, rows):
+            n = min(rows, NV - u0)
+            hs = HpdVertexFunction._hidden(vertex_coords(u0, n, vstride, dev), params, n_layers)
+            dz = zcache.pop(u0, None)
+            if dz is None:                                     # A: not kept by the forward
+                if len(dz_bufs) < 2:
+                    dz_bufs.append(torch.empty((min(rows, NV), T), dtype=_f32, device=dev))
+                dz = dz_bufs[n_unkept % 2][:n]
+                n_unkept += 1
+                with _split_gemm():
+                    call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(dz), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
+            alive.extend([dz, hs])
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(side):                      # B
+                side.wait_event(ready)
+                call("gngf_softmax_bwd_lowrank", ptr(dz), ptr(rowstat[u0:u0 + n]),
+                     ptr(g_tv[u0:u0 + n] if g_tv is not None else None), ptr(ti[u0:u0 + n]),
+                     ptr(mw[u0:u0 + n] if g_pbar is not None else None), ptr(g_pbar), L if g_pbar is not None else 0,
+                     ptr(grads[-1]), ptr(scratch), n, T, K if g_tv is not None else 0, stream_ptr())
+                done_b = torch.cuda.Event()
+                done_b.record(side)
+            if pending is not None:                            # C of the previous chunk, beside this chunk's B
+                stage_c(*pending)
+            pending = (dz, hs, done_b, n)
+        if pending is not None:
+            stage_c(*pending)
+        main.wait_stream(side)
+        side.wait_stream(main)       # the helper's next use starts behind everything issued here
+        del alive[:]
         return (None, None, None, None, None, None, *grads)
 
 
