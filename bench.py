@@ -146,8 +146,12 @@ def make_batch(cfg_name, P, rank, dev):
 def build_model(mode, dev, bounds):
     import torch
     from collision_handling_in_instantngp_amd import models
+    from collision_handling_in_instantngp_amd import ops
     c = SHAPES[MODES[mode]]
     models.should_use_hash_function = is_hash(mode)
+    # fp16 tables: the gradient is handed over as the fp32 buffer it is accumulated in (what train.FusedAdam consumes), not
+    # cast to an fp16 `.grad` first (6 GiB of traffic per step at the cfg5 shape)
+    ops.FP16_TABLE_GRAD_FP32 = bool(c["half"])
     torch.manual_seed(65535)
     net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=c["T"], num_levels=c["L"], n_min=c["n_min"], n_max=c["n_max"],
                                           MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
@@ -401,6 +405,8 @@ def main():
         dt = timed(step, steps // per, -(-warmup // per), world)       # exactly `steps` steps: steps / per replays of `per` steps each
         res = results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                                "launch": launch, "shape": {k: v for k, v in SHAPES[cfg_name].items()}}
+        if SHAPES[cfg_name]["half"]:
+            res["table_gradient"] = "fp32 accumulation buffer handed over as param.grad_fp32 (ops.FP16_TABLE_GRAD_FP32), no fp16 .grad copy"
         if learning:
             st = dict(ops.HPD_LAST_STATS)
             fl, gemm = learning_flops(st)

@@ -18,7 +18,7 @@ struct AdamSegment {        // mirrored by the host packer (train.py); 64 bytes
   int64_t n;
   int64_t first_block;
   int32_t group;
-  int32_t flags;            // bit 0: param / grad are __half
+  int32_t flags;            // bit 0: param (and grad) are __half; bit 1 (with bit 0): grad is fp32 all the same
 };
 static_assert(sizeof(AdamSegment) == 64, "host packer layout");
 
@@ -68,7 +68,9 @@ adam_multi_kernel(const AdamSegment* __restrict__ segs, int nseg, const float* _
     // fp16 storage: fp16 gradient in, fp32 master weight + fp32 moments updated, fp16 parameter = round(master)
     __half* ph = static_cast<__half*>(sg.param);
     const __half* gh = static_cast<const __half*>(sg.grad);
-    const bool vec = ((reinterpret_cast<uintptr_t>(ph) | reinterpret_cast<uintptr_t>(gh)) & 7) == 0 &&
+    const float* g32 = static_cast<const float*>(sg.grad);
+    const bool gf = (sg.flags & 2) != 0;       // the fp32 buffer the table gradient was accumulated in, not an fp16 copy of it
+    const bool vec = ((reinterpret_cast<uintptr_t>(ph) | reinterpret_cast<uintptr_t>(gh)) & (gf ? 15 : 7)) == 0 &&
                      ((reinterpret_cast<uintptr_t>(sg.master) | reinterpret_cast<uintptr_t>(sg.exp_avg) |
                        reinterpret_cast<uintptr_t>(sg.exp_avg_sq)) & 15) == 0;
 #pragma unroll
@@ -79,11 +81,16 @@ adam_multi_kernel(const AdamSegment* __restrict__ segs, int nseg, const float* _
         float4 p = *reinterpret_cast<float4*>(sg.master + e);
         float4 m = *reinterpret_cast<float4*>(sg.exp_avg + e);
         float4 v = *reinterpret_cast<float4*>(sg.exp_avg_sq + e);
-        const __half2 g01 = *reinterpret_cast<const __half2*>(gh + e), g23 = *reinterpret_cast<const __half2*>(gh + e + 2);
-        adam_one(p.x, __low2float(g01) * gs, m.x, v.x, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
-        adam_one(p.y, __high2float(g01) * gs, m.y, v.y, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
-        adam_one(p.z, __low2float(g23) * gs, m.z, v.z, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
-        adam_one(p.w, __high2float(g23) * gs, m.w, v.w, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
+        float4 g;
+        if (gf) g = *reinterpret_cast<const float4*>(g32 + e);
+        else {
+          const __half2 g01 = *reinterpret_cast<const __half2*>(gh + e), g23 = *reinterpret_cast<const __half2*>(gh + e + 2);
+          g = float4{__low2float(g01), __high2float(g01), __low2float(g23), __high2float(g23)};
+        }
+        adam_one(p.x, g.x * gs, m.x, v.x, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
+        adam_one(p.y, g.y * gs, m.y, v.y, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
+        adam_one(p.z, g.z * gs, m.z, v.z, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
+        adam_one(p.w, g.w * gs, m.w, v.w, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
         *reinterpret_cast<float4*>(sg.master + e) = p;
         *reinterpret_cast<float4*>(sg.exp_avg + e) = m;
         *reinterpret_cast<float4*>(sg.exp_avg_sq + e) = v;
@@ -92,7 +99,7 @@ adam_multi_kernel(const AdamSegment* __restrict__ segs, int nseg, const float* _
       } else {
         for (int64_t q = e; q < e + 4 && q < sg.n; ++q) {
           float p = sg.master[q], m = sg.exp_avg[q], v = sg.exp_avg_sq[q];
-          adam_one(p, __half2float(gh[q]) * gs, m, v, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
+          adam_one(p, (gf ? g32[q] : __half2float(gh[q])) * gs, m, v, wd, h.beta1, h.beta2, h.eps, step_size, bc2_sqrt);
           sg.master[q] = p; sg.exp_avg[q] = m; sg.exp_avg_sq[q] = v; ph[q] = __float2half_rn(p);
         }
       }
@@ -137,7 +144,8 @@ extern "C" int gngf_adam_block_elems(void) { return kAdamBlock; }
 
 // One Adam step over `nseg` tensors.  segments: device array of 64-byte records {param, grad, exp_avg, exp_avg_sq, master,
 // n, first_block, group, flags} with first_block = running sum of ceil(n / gngf_adam_block_elems()); total_blocks = that
-// sum.  flags bit 0: param and grad are fp16 and `master` is the fp32 master copy (else master is ignored).
+// sum.  flags bit 0: param and grad are fp16 and `master` is the fp32 master copy (else master is ignored); bit 1 (with
+// bit 0): the gradient is fp32 all the same (the buffer an fp16 table's gradient was accumulated in).
 // step: device float, incremented by this call before it is used (t = 1 on the first step).  lr / weight_decay: host
 // arrays of ngroups <= GNGF_ADAM_MAX_GROUPS values.  inv_grad_scale multiplies every gradient first (1 / loss scale).
 extern "C" int gngf_adam_step(const void* segments, int nseg, int64_t total_blocks, float* step, const float* lr,

@@ -35,8 +35,28 @@ def _grad_buffer(tables):
     return torch.zeros(tables.shape, dtype=_f32, device=tables.device)
 
 
+# fp16 level tables (BASELINE config 5): the table gradient is accumulated in an fp32 (L,T,F) buffer.  torch wants `.grad` in
+# the parameter's type, so by default that buffer is cast to fp16 (6 GiB of traffic at T = 2^24, F = 4: a quarter of the
+# step).  With FP16_TABLE_GRAD_FP32 the buffer itself is handed over instead: level l's parameter gets `grad_fp32` (a view of
+# it) and no `.grad`; train.FusedAdam — which updates an fp32 master copy anyway — consumes it directly.
+FP16_TABLE_GRAD_FP32 = False
+_FP32_GRAD_SINKS = {}        # table storage pointer -> (owner module, level parameters), registered by TableViewFunction.forward
+
+
 def _grad_out(dtables, tables):
-    return dtables if tables.dtype == _f32 else dtables.to(tables.dtype)
+    if tables.dtype == _f32:
+        return dtables
+    sink = _FP32_GRAD_SINKS.get(tables.data_ptr()) if FP16_TABLE_GRAD_FP32 else None
+    if sink is None:
+        return dtables.to(tables.dtype)
+    owner, ws = sink
+    owner._grad_base = None
+    owner._grad_base_fp32 = dtables
+    for l, w in enumerate(ws):
+        if w.requires_grad:
+            w.grad = None
+            w.grad_fp32 = dtables[l]       # the gradient of the LAST backward pass (not accumulated across passes)
+    return None
 
 
 def hash_indices(xy, n_ls, T):
@@ -550,11 +570,17 @@ class TableViewFunction(torch.autograd.Function):
     def forward(ctx, base, owner, *weights):
         ctx.owner = owner
         ctx.weights = weights
+        ctx.set_materialize_grads(False)
+        if base.dtype != _f32 and FP16_TABLE_GRAD_FP32:
+            _FP32_GRAD_SINKS.clear()       # one live table buffer per process is the use case; no stale pointers
+            _FP32_GRAD_SINKS[base.data_ptr()] = (owner, weights)
         return base.detach()
 
     @staticmethod
     def backward(ctx, g):
         ws = ctx.weights
+        if g is None:                      # handed over as grad_fp32 (see _grad_out)
+            return (None, None, *([None] * len(ws)))
         if all(w.grad is None for w in ws):
             g = g.contiguous()
             for l, w in enumerate(ws):
@@ -787,7 +813,7 @@ def run_deferred_vertex_stage(exchanged=False):
     if DP_EXCHANGE is not None and not exchanged:
         DP_EXCHANGE(dG)
     _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, None, order)
-    if gout is not dtables:
+    if gout is not None and gout is not dtables:
         # fp16 table storage: the gradient autograd received is a rounded COPY of the fp32 accumulation buffer, made before
         # the vertex stage ran.  Only the staged levels are refreshed (the direct levels' slice of `gout` may already hold
         # the all-reduced gradient; their fp32 rows here are still this rank's own).

@@ -130,6 +130,9 @@ def allreduce_gradients(net, world: int, group=None, keep_tables_flag: bool = Fa
     handled = set()
     enc = getattr(net, "encoding", None)
     base = getattr(enc, "_grad_base", None) if enc is not None else None
+    if base is None and enc is not None and getattr(enc, "_grad_base_fp32", None) is not None \
+            and any(getattr(m.weight, "grad_fp32", None) is not None for m in enc._hash_tables):
+        base = enc._grad_base_fp32            # fp16 tables with ops.FP16_TABLE_GRAD_FP32: the fp32 buffer IS the gradient
     tables_done = int(ops.DP_TABLES_REDUCED)     # leading levels already reduced through dG by the encoder backward
     if not keep_tables_flag:
         ops.DP_TABLES_REDUCED = 0

@@ -99,9 +99,15 @@ class FusedAdam(torch.optim.Optimizer):
         segs = []
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
-                if p.grad is None:
+                grad = p.grad
+                g32 = getattr(p, "grad_fp32", None) if grad is None else None      # fp16 tables: the fp32 buffer itself (ops._grad_out)
+                if grad is None and g32 is None:
                     continue
-                if p.grad.is_sparse or p.dtype not in self.DTYPES or not p.is_cuda or p.grad.dtype != p.dtype:
+                if g32 is not None:
+                    if p.dtype != torch.float16 or g32.dtype != torch.float32 or g32.shape != p.shape or not p.is_cuda:
+                        raise RuntimeError("grad_fp32 is the fp32 gradient of an fp16 device parameter, same shape")
+                    grad = g32
+                elif grad.is_sparse or p.dtype not in self.DTYPES or not p.is_cuda or grad.dtype != p.dtype:
                     raise RuntimeError("FusedAdam handles dense fp32 / fp16 device parameters (gradient of the same type)")
                 half = p.dtype == torch.float16
                 st = self.state[p]
@@ -114,13 +120,20 @@ class FusedAdam(torch.optim.Optimizer):
                     prev = st.get("step", 0.0)
                     self._step = torch.full((), float(prev), dtype=torch.float32, device=p.device)
                 st["step"] = self._step          # one shared counter (torch keeps one equal copy per parameter)
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                g = grad if grad.is_contiguous() else grad.contiguous()
                 for t_ in (p, st["exp_avg"], st["exp_avg_sq"]):
                     if not t_.is_contiguous():
                         raise RuntimeError("FusedAdam needs contiguous parameters and moments")
                 segs.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                             st["master"].data_ptr() if half else 0, p.numel(), gi, int(half), g))
+                             st["master"].data_ptr() if half else 0, p.numel(), gi, int(half) | (2 if g32 is not None else 0), g))
         return segs
+
+    def zero_grad(self, set_to_none=True):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if getattr(p, "grad_fp32", None) is not None:
+                    p.grad_fp32 = None
+        return super().zero_grad(set_to_none=set_to_none)
 
     def prepare_capture(self, steps=1):
         """Sets aside the pinned staging buffers a hipGraph capture of `steps` step() calls needs (pinned memory cannot be
@@ -282,6 +295,8 @@ class GraphedStep:
         shadow = st["shadow"]
         for s_ in shadow.values():
             s_.grad = None
+            if getattr(s_, "grad_fp32", None) is not None:
+                s_.grad_fp32 = None
         # The step runs on SHADOW leaves (detached aliases of the parameters: same storage, fresh autograd identity).  An
         # autograd leaf's AccumulateGrad node is bound to the stream that was current when it was first created, and it stays
         # alive as long as any earlier graph does (a kept `loss` from an eager step on the default stream is enough): the
@@ -304,6 +319,9 @@ class GraphedStep:
         ops.join_loss_value()
         for name, p in st["named"]:
             p.grad = shadow[name].grad             # the parameters' own .grad: what the optimizer and the caller read
+            g32 = getattr(shadow[name], "grad_fp32", None)
+            if g32 is not None or getattr(p, "grad_fp32", None) is not None:
+                p.grad_fp32 = g32
         r = GraphedStep.Result()
         r.out, r.probs, r.idx, r.loss, r.mse, r.kls, r.colls = out.detach(), probs, idx, loss.detach(), mse.detach(), kls, colls
         return r

@@ -268,7 +268,8 @@ int gngf_distinct_slot_counts(const int64_t* indices, int64_t P, int L, int V, i
  *       int32_t group; int32_t flags; }
  * with first_block = running sum of ceil(n / gngf_adam_block_elems()) and total_blocks that sum over all segments.
  * flags bit 0: param and grad are fp16 (fp16 level tables, BASELINE.json config 5) and `master` is the fp32 master copy
- * the update is applied to (param = round(master)); moments are fp32 either way.  inv_grad_scale multiplies every gradient
+ * the update is applied to (param = round(master)); moments are fp32 either way; bit 1 (only with bit 0): `grad` is fp32
+ * all the same — the buffer the table gradient was accumulated in, no fp16 copy.  inv_grad_scale multiplies every gradient
  * before use (1 / loss scale of fp16 training; 1 = off).
  * step: device float holding the number of steps taken so far; the call increments it and uses the new value (bias
  * corrections in double precision), so a step is capturable in a hipGraph.  lr, weight_decay: HOST arrays of ngroups

@@ -483,13 +483,16 @@ def test_kept_logits_equal_recomputed_logits_in_the_hpd_backward(golden):
             close(other[k], outs[0][k].cpu().numpy(), 1e-4, 2e-5 * scale, k)
 
 
-def test_fp16_table_model_trains_with_fused_adam_like_the_fp32_master_model(golden):
+@pytest.mark.parametrize("fp32_grads", [False, True])
+def test_fp16_table_model_trains_with_fused_adam_like_the_fp32_master_model(golden, fp32_grads):
     """cfg5 flavour end to end (F = 4, fp16 table storage): get_optimizer returns FusedAdam, whose fp32 master copy follows
     the trajectory of an fp32 model started from the same (fp16-representable) tables; MultiResHashEncoding.forward accepts
-    the fp16 tables at the per-instance boundary."""
-    from collision_handling_in_instantngp_amd import models, train
+    the fp16 tables at the per-instance boundary.  fp32_grads: ops.FP16_TABLE_GRAD_FP32 — the table gradient reaches the
+    optimizer as the fp32 buffer it was accumulated in (`param.grad_fp32`, no `.grad`) instead of an fp16 copy."""
+    from collision_handling_in_instantngp_amd import models, train, ops
     X, Y, h, w = strawberry(golden)
     models.should_use_hash_function = True
+    ops.FP16_TABLE_GRAD_FP32 = fp32_grads
     try:
         kw = dict(input_dim=2, hash_table_size=2 ** 14, num_levels=8, n_min=16, n_max=256, MLP_hidden_layers_widths=[64, 64],
                   HPD_hidden_layers_widths=[32, 64, 128], HPD_out_features=2 ** 14, feature_dim=4, topk_k=4)
@@ -513,8 +516,18 @@ def test_fp16_table_model_trains_with_fused_adam_like_the_fp32_master_model(gold
                 rgb, _, _, _ = net(xb, 1.0)
                 loss = torch.nn.functional.mse_loss(rgb, yb)
                 (loss * sc).backward()
+                if tag == 16:
+                    w5 = net.encoding._hash_tables[5].weight
+                    if fp32_grads:
+                        assert w5.grad is None and w5.grad_fp32.dtype == torch.float32 and w5.grad_fp32.shape == w5.shape
+                        assert float(w5.grad_fp32.abs().max()) > 0
+                    else:
+                        assert w5.grad.dtype == torch.float16 and getattr(w5, "grad_fp32", None) is None
                 opt.step()
                 losses[tag].append(float(loss))
+        if fp32_grads:
+            o16.zero_grad()
+            assert n16.encoding._hash_tables[5].weight.grad_fp32 is None
         assert losses[16][-1] < losses[16][0]
         close(np.array(losses[16]), np.array(losses[32]), 2e-3, 0, "fp16-table model vs fp32 model: MSE over 5 Adam steps")
         w16 = n16.encoding._hash_tables[5].weight
@@ -531,3 +544,4 @@ def test_fp16_table_model_trains_with_fused_adam_like_the_fp32_master_model(gold
         assert torch.equal(feats, want.permute(0, 3, 1, 2))
     finally:
         models.should_use_hash_function = False
+        ops.FP16_TABLE_GRAD_FP32 = False
