@@ -409,7 +409,19 @@ class HpdVertexFunction(torch.autograd.Function):
         side = _side_stream(dev) if pipelined else None
         pipelined = pipelined and side.stream_id != main.stream_id
         if pipelined:
-            return HpdVertexFunction._backward_pipelined(ctx.cfg, ti, mw, rowstat, params, grads, g_tv, g_pbar, L, zcache, scratch, main, side)
+            # un-kept chunks alternate between TWO logits buffers; without the memory for both (e.g. several processes sharing
+            # one device) the chunks run one after the other as before
+            n_chunks = -(-NV // rows)
+            dz_bufs = []
+            try:
+                for _ in range(min(2, n_chunks - len(zcache))):
+                    dz_bufs.append(torch.empty((min(rows, NV), T), dtype=_f32, device=dev))
+            except torch.OutOfMemoryError:
+                pipelined = False
+                dz_buf = dz_bufs[0] if dz_bufs else None
+                dz_bufs = None
+        if pipelined:
+            return HpdVertexFunction._backward_pipelined(ctx.cfg, ti, mw, rowstat, params, grads, g_tv, g_pbar, L, zcache, scratch, main, side, dz_bufs)
         for u0 in range(0, NV, rows):
             n = min(rows, NV - u0)
             hs = HpdVertexFunction._hidden(vertex_coords(u0, n, vstride, dev), params, n_layers)
@@ -454,7 +466,7 @@ class HpdVertexFunction(torch.autograd.Function):
 
 
     @staticmethod
-    def _backward_pipelined(cfg, ti, mw, rowstat, params, grads, g_tv, g_pbar, L, zcache, scratch, main, side):
+    def _backward_pipelined(cfg, ti, mw, rowstat, params, grads, g_tv, g_pbar, L, zcache, scratch, main, side, dz_bufs):
         """The low-rank backward with its chunks software-pipelined over two streams.  Per chunk: A (main) logits again unless
         kept; B (side) softmax / top-K / batch-mean backward in place, HBM bound; C (main) the dW and dh GEMMs and the small
         layers, matrix-pipe bound.  Issue order on main: A_0, A_1, C_0, A_2, C_1, ... so that C_i runs beside B_{i+1}.  Un-kept
@@ -463,7 +475,7 @@ class HpdVertexFunction(torch.autograd.Function):
         NV, vstride, K, rows, n_layers, T, _keep = cfg
         W_last, b_last = params[-2], params[-1]
         dev = W_last.device
-        dz_bufs, n_unkept, alive, pending = [], 0, [], None
+        n_unkept, alive, pending = 0, [], None
 
         def stage_c(dz, hs, done_b, n):
             main.wait_event(done_b)
@@ -483,9 +495,7 @@ class HpdVertexFunction(torch.autograd.Function):
             hs = HpdVertexFunction._hidden(vertex_coords(u0, n, vstride, dev), params, n_layers)
             dz = zcache.pop(u0, None)
             if dz is None:                                     # A: not kept by the forward
-                if len(dz_bufs) < 2:
-                    dz_bufs.append(torch.empty((min(rows, NV), T), dtype=_f32, device=dev))
-                dz = dz_bufs[n_unkept % 2][:n]
+                dz = dz_bufs[n_unkept % len(dz_bufs)][:n]
                 n_unkept += 1
                 with _split_gemm():
                     call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(dz), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
