@@ -45,6 +45,7 @@ SIGNATURES = {
     "gngf_decoder_slab_floats": [_I, _I],
     "gngf_set_gemm_split_bf16": [_I],
     "gngf_set_decoder_split_bf16": [_I],
+    "gngf_set_decoder_bwd_hybrid": [_I],
     "gngf_linear_fwd": [_P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gngf_linear_bwd_input": [_P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gngf_linear_bwd_weight": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P],

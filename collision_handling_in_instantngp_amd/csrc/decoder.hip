@@ -392,6 +392,7 @@ __host__ __device__ inline int slab_size(int in_dim, int out_dim) { return slab_
 
 constexpr int kImgStride = 34;   // 8-byte aligned rows: ds_read_b64 of two consecutive pixels, conflict-free (34*i mod 64)
 constexpr int kImgFloats = 64 * kImgStride;
+#include "decoder_split.inc"
 // per-wave transposition images of the backward kernel: imgA | imgB | imgZ (dz3, 4 rows) | imgX (input rows; aliased to
 // imgB when the input is 64 wide — the four dedicated images would not fit next to the 64-wide fragments in 160 KB)
 template <int KIN> struct BwdLds {
@@ -402,7 +403,12 @@ template <int KIN> struct BwdLds {
 // EXACT: in_dim == KIN (no per-feature predicates anywhere in the loop)
 // RECOMPUTE: the hidden activations are recomputed from enc (96 more MFMAs per tile); otherwise they are read back from
 // the buffer the forward kernel saved them to (loads are free between MFMAs: 22.0 k -> ~14 k cycles per tile).
-template <int KIN, bool LEAKY, bool EXACT, bool RECOMPUTE>
+// HYB (KIN = 32, exact width, saved hidden layers): the two products with the PIXEL on the lane — dh1 = W1^T dz2 and
+// d enc = W0^T dz1, 96 of the 196 fp32 MFMAs of a tile — run on v_mfma_f32_32x32x16_bf16 with the exact three-way bf16 split of
+// decoder_split.inc (operands straight from the accumulator registers, W^T as bf16 planes in LDS): 72 MFMAs of 32 cycles
+// instead of 96 of 64, and the splitting issues underneath them.  The weight-gradient products (pixel on the k axis, fp32
+// transposition images) stay on the fp32 pipe, which keeps the kernel below the power limit of an all-bf16 one.
+template <int KIN, bool LEAKY, bool EXACT, bool RECOMPUTE, bool HYB = false>
 __global__ void __launch_bounds__(kDecThreads, 1)
 decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, const float* __restrict__ dY,
                    const float* __restrict__ W0, const float* __restrict__ b0, const float* __restrict__ W1,
@@ -421,9 +427,11 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   float* A0 = smem;                                      // forward fragments (recompute)
   float* A1 = A0 + FF::kA0;
   float* A2T = A1 + FF::kA1;                             // [t(2)][s(2)][64]   : W2[c = 2s+h][32t+i]
-  float* A1T = A2T + 2 * 2 * 64;                         // [t(2)][s2(32)][64] : W1[kmapC(s2,h)][32t+i]
-  float* A0T = A1T + 2 * 32 * 64;                        // [t(TX)][s2(32)][64]: W0[kmapC(s2,h)][32t+i]
-  float* bs = A0T + TX * 32 * 64;                        // b0 | b1
+  static_assert(!HYB || (KIN == 32 && EXACT && !RECOMPUTE), "hybrid variant: 32 input features, saved hidden layers");
+  constexpr int kA1T = HYB ? 8 * 3 * 64 * 4 : 2 * 32 * 64, kA0T = HYB ? 4 * 3 * 64 * 4 : TX * 32 * 64;
+  float* A1T = A2T + 2 * 2 * 64;                         // [t(2)][s2(32)][64] : W1[kmapC(s2,h)][32t+i]   (HYB: bf16 planes of W1^T)
+  float* A0T = A1T + kA1T;                               // [t(TX)][s2(32)][64]: W0[kmapC(s2,h)][32t+i]   (HYB: bf16 planes of W0^T)
+  float* bs = A0T + kA0T;                                // b0 | b1
   float* img = bs + 2 * kH;                              // per wave: imgA [64][34] | imgB [64][34] | imgZ [4][34] | imgX [KIN][34]
   const int nslab = slab_size(in_dim, out_dim);
 
@@ -436,6 +444,24 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     const int c = 2 * s + (lane >> 5);
     A2T[e] = raw[ro.w2 + c * 65 + 32 * t + (lane & 31)];
   }
+  if constexpr (HYB) {
+    // bf16 planes of W1^T (fragments cc * 2 + t: rows 32 t + i, k = kmapS(cc, h, j)) and W0^T (fragments cc: rows i)
+    const int ln = threadIdx.x & 63, li = ln & 31, lh = ln >> 5;
+    for (int f = threadIdx.x >> 6; f < 12; f += 4) {
+      float v[8];
+      if (f < 8) {
+        const int cc = f >> 1, t = f & 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = raw[ro.w1 + kmapS(cc, lh, j) * 65 + 32 * t + li];
+        store_planes(reinterpret_cast<u32x4*>(A1T) + f * 3 * 64 + ln, split8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]));
+      } else {
+        const int cc = f - 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = raw[ro.w0 + kmapS(cc, lh, j) * (in_dim + 1) + li];
+        store_planes(reinterpret_cast<u32x4*>(A0T) + cc * 3 * 64 + ln, split8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]));
+      }
+    }
+  } else {
   for (int e = threadIdx.x; e < 2 * 32 * 64; e += kDecThreads) {
     const int lane = e & 63, s2 = (e >> 6) & 31, t = e >> 11;
     A1T[e] = raw[ro.w1 + kmapC(s2, lane >> 5) * 65 + 32 * t + (lane & 31)];
@@ -444,6 +470,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     const int lane = e & 63, s2 = (e >> 6) & 31, t = e >> 11;
     const int j = 32 * t + (lane & 31);
     A0T[e] = j < in_dim ? raw[ro.w0 + kmapC(s2, lane >> 5) * (in_dim + 1) + j] : 0.f;
+  }
   }
   for (int e = threadIdx.x; e < 2 * kH; e += kDecThreads) bs[e] = e < kH ? raw[ro.b0 + e] : raw[ro.b1 + e - kH];
   __syncthreads();
@@ -578,8 +605,32 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   if (!RECOMPUTE) {
     hidden_load(hidden, blockIdx.x, ntiles, 0, hoff, acc1);
     hidden_load(hidden, blockIdx.x, ntiles, 1, hoff, acc2);
+    if constexpr (!HYB) {
 #pragma unroll
-    for (int s2 = 0; s2 < 32; ++s2) { ft[0][s2] = A1T[(0 * 32 + s2) * 64 + lane]; ft[1][s2] = A1T[(1 * 32 + s2) * 64 + lane]; }
+      for (int s2 = 0; s2 < 32; ++s2) { ft[0][s2] = A1T[(0 * 32 + s2) * 64 + lane]; ft[1][s2] = A1T[(1 * 32 + s2) * 64 + lane]; }
+    }
+  }
+  // HYB: h2 -> image A and h1 -> image B, for the tile whose hidden layers sit in acc2 / acc1 (64 stores; E = 0 .. 15)
+  auto store_hidden_images = [&](auto E) {
+    constexpr int e0 = 2 * E.value;
+    static_for<2>([&](auto J) {
+      constexpr int e = e0 + J.value, t = e >> 4, r = e & 15;
+      lds_store<(32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile, acc2[t][r]);
+      lds_store<kImgB + (32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile, acc1[t][r]);
+    });
+  };
+  if constexpr (HYB) static_for<16>([&](auto E) { store_hidden_images(E); });      // first tile
+  const u32x4* w1t = reinterpret_cast<const u32x4*>(A1T) + lane;      // HYB: plane p of fragment f at [(f * 3 + p) * 64]
+  const u32x4* w0t = reinterpret_cast<const u32x4*>(A0T) + lane;
+  // HYB: the W1^T planes are MFMA operands only and stay in accumulation registers for the kernel's lifetime (96 of them); the
+  // W0^T planes (48) are loaded under the dW0 run of every tile
+  Planes w1p[HYB ? 8 : 1], w0p[HYB ? 4 : 1];
+  if constexpr (HYB) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      w1p[f] = load_planes(w1t + f * 3 * 64);
+      asm volatile("" : "+a"(w1p[f].hi), "+a"(w1p[f].mid), "+a"(w1p[f].lo));
+    }
   }
   if (RECOMPUTE && kCarryF0) {
 #pragma unroll
@@ -675,6 +726,76 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     f32x16 d1[2];
     f32x2 a0p[8], a1p[8], b0p[8], b1p[8];
     float h1v[2][16];
+    if constexpr (HYB) {
+      // dh1^T = W1^T dz2^T on the bf16 pipe: k-chunk cc = registers 8 (cc & 1) .. + 7 of d2[cc >> 1] in both lane halves.
+      // A chunk is 6 cross products x 2 output tiles; it carries the LDS traffic of eight steps of the fp32 schedule
+      // (0-15 dW2 operands | 16-23 dz2 image | 24-31 dW1 operands) and the split of the next chunk.  The h2 / h1 images the
+      // operands come from were stored under the dW0 run of the PREVIOUS tile (this phase would be bound by LDS bandwidth with
+      // them: its matrix run is 2.7x shorter than on the fp32 pipe).
+      f32x2 av[16], bv[16];
+      auto lds_step = [&](auto S) {
+        constexpr int s2 = S.value;
+        if constexpr (s2 < 16) {                          // (the h2 / h1 images of this tile were stored a tile ago, see dW0)
+          av[s2] = lds_load2<kImgZ + 8 * s2>(rZ2);
+          bv[s2] = lds_load2<8 * s2>(rH2);
+        } else if constexpr (s2 < 24) {
+          static_for<4>([&](auto E) {
+            constexpr int e = 4 * (s2 - 16) + E.value, t = e >> 4, r = e & 15;
+            lds_store<(32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile, d2[t][r]);
+          });
+        } else {
+          constexpr int q = s2 - 24;
+          a0p[q] = lds_load2<(2 * q) * 4>(rOp);
+          a1p[q] = lds_load2<(32 * kImgStride + 2 * q) * 4>(rOp);
+          b0p[q] = lds_load2<kImgB + (2 * q) * 4>(rOp);
+          b1p[q] = lds_load2<kImgB + (32 * kImgStride + 2 * q) * 4>(rOp);
+        }
+      };
+      Planes zc = split8(d2[0][0], d2[0][1], d2[0][2], d2[0][3], d2[0][4], d2[0][5], d2[0][6], d2[0][7]);
+      d1[0] = 0; d1[1] = 0;
+      static_for<4>([&](auto CC) {
+        constexpr int cc = CC.value, nc = cc + 1;
+        unsigned nh[4], nm[4], nl[4];
+        const Planes& fa0 = w1p[2 * cc];
+        const Planes& fa1 = w1p[2 * cc + 1];
+        auto pair = [&](auto PP, u32x4 a0, u32x4 a1, u32x4 b) {
+          constexpr int pp = PP.value;
+          d1[0] = mfma_b(a0, b, d1[0]);
+          d1[1] = mfma_b(a1, b, d1[1]);
+          constexpr int first = 8 * cc + (pp < 1 ? 0 : pp < 4 ? pp + 1 : pp + 2), count = (pp == 0 || pp == 3) ? 2 : 1;
+          static_for<count>([&](auto J) { lds_step(std::integral_constant<int, first + J.value>{}); });
+          if constexpr (nc < 4) {
+            if constexpr (pp < 4) {                       // a quarter of the next chunk's split
+              constexpr int t = nc >> 1, r0 = 8 * (nc & 1) + 2 * pp;
+              const float a = d2[t][r0], b2 = d2[t][r0 + 1];
+              nh[pp] = pack_hi16(b2, a);
+              const float ra = trunc_residual(a), rb = trunc_residual(b2);
+              nm[pp] = pack_hi16(rb, ra);
+              nl[pp] = pack_hi16(trunc_residual(rb), trunc_residual(ra));
+            }
+          }
+          STEP_END();
+        };
+        pair(std::integral_constant<int, 0>{}, fa0.hi, fa1.hi, zc.lo);
+        pair(std::integral_constant<int, 1>{}, fa0.lo, fa1.lo, zc.hi);
+        pair(std::integral_constant<int, 2>{}, fa0.mid, fa1.mid, zc.mid);
+        pair(std::integral_constant<int, 3>{}, fa0.hi, fa1.hi, zc.mid);
+        pair(std::integral_constant<int, 4>{}, fa0.mid, fa1.mid, zc.hi);
+        pair(std::integral_constant<int, 5>{}, fa0.hi, fa1.hi, zc.hi);
+        if constexpr (nc < 4) {
+          zc.hi = u32x4{nh[0], nh[1], nh[2], nh[3]}; zc.mid = u32x4{nm[0], nm[1], nm[2], nm[3]}; zc.lo = u32x4{nl[0], nl[1], nl[2], nl[3]};
+        }
+        if constexpr (cc == 1) {                           // dW2 (see the fp32 schedule below)
+          lds_wait();
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            dW2acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].x, bv[q].x, dW2acc, 0, 0, 0);
+            dW2acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].y, bv[q].y, dW2acc, 0, 0, 0);
+          }
+          STEP_END();
+        }
+      });
+    } else {
     {
       f32x2 av[16], bv[16];
       static_for<16>([&](auto S2) {
@@ -731,6 +852,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
       STEP_END();
     });
     MFMA_DRAIN(d1[0], d1[1]);
+    }
     lds_wait();
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -754,6 +876,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     float fx[TX][32];
     static_for<8>([&](auto Q) {
       constexpr int q = Q.value;
+      if constexpr (HYB && q == 0) hidden_load(hidden, tile + gridDim.x, ntiles, 0, hoff, acc1);   // h1 is dead: the next tile's
       dW1acc[0][0] = MFMA(a0p[q].x, b0p[q].x, dW1acc[0][0]);
       dW1acc[0][1] = MFMA(a0p[q].x, b1p[q].x, dW1acc[0][1]);
       dW1acc[1][0] = MFMA(a1p[q].x, b0p[q].x, dW1acc[1][0]);
@@ -777,8 +900,10 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
           xp[0][qq] = lds_load2<kImgX + (2 * qq) * 4>(rOp);
           if constexpr (TX > 1) xp[TX - 1][qq] = lds_load2<kImgX + (32 * kImgStride + 2 * qq) * 4>(rOp);
         });
+        if constexpr (!HYB) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) fx[0][8 * (q - 4) + j] = A0T[(8 * (q - 4) + j) * 64 + lane];
+          for (int j = 0; j < 8; ++j) fx[0][8 * (q - 4) + j] = A0T[(8 * (q - 4) + j) * 64 + lane];
+        }
         if (kCarryF0 && TX > 1) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) fx[TX - 1][8 * (q - 4) + j] = A0T[((TX - 1) * 32 + 8 * (q - 4) + j) * 64 + lane];
@@ -800,7 +925,14 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
         dW0acc[0][tx] = MFMA(c0p[q].y, xp[tx][q].y, dW0acc[0][tx]);
         dW0acc[1][tx] = MFMA(c1p[q].y, xp[tx][q].y, dW0acc[1][tx]);
       }
-      if constexpr (!RECOMPUTE && q == 0) hidden_load(hidden, tile + gridDim.x, ntiles, 0, hoff, acc1);   // next tile's h1
+      if constexpr (!RECOMPUTE && !HYB && q == 0) hidden_load(hidden, tile + gridDim.x, ntiles, 0, hoff, acc1);   // next tile's h1
+      if constexpr (HYB) {
+        // the NEXT tile's h2 -> image A and h1 -> image B (both idle from here on; loaded under d1 / at the top of dW1): their
+        // 64 stores need a long fp32 run above them — under the bf16 runs of d1 or dX they cost 760 cycles per tile
+        store_hidden_images(std::integral_constant<int, 2 * q>{});
+        store_hidden_images(std::integral_constant<int, 2 * q + 1>{});
+        if constexpr (q >= 2 && q < 6) w0p[q - 2] = load_planes(w0t + (q - 2) * 3 * 64);
+      }
       if (RECOMPUTE && kCarryF0) {
 #pragma unroll
         for (int j = 0; j < 2 * S0 / 8; ++j) {
@@ -817,6 +949,31 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     STAMP(6);
     // ---- d enc^T = W0^T dz1^T ; regs 4g..4g+3 are 4 consecutive input features
     f32x16 dxv[TX];
+    if constexpr (HYB) {
+      // d enc^T = W0^T dz1^T on the bf16 pipe (k-chunks as above); the split of chunk cc + 1 issues under the products of chunk cc
+      f32x16 acc;
+      acc = 0;
+      Planes zc = split8(d1[0][0], d1[0][1], d1[0][2], d1[0][3], d1[0][4], d1[0][5], d1[0][6], d1[0][7]);
+      static_for<4>([&](auto CC) {
+        constexpr int cc = CC.value, nc = cc + 1;
+        Planes nz;
+        const Planes& fa = w0p[cc];
+        if constexpr (nc < 4) {
+          constexpr int t = nc >> 1, r0 = 8 * (nc & 1);
+          nz = split8(d1[t][r0], d1[t][r0 + 1], d1[t][r0 + 2], d1[t][r0 + 3], d1[t][r0 + 4], d1[t][r0 + 5], d1[t][r0 + 6], d1[t][r0 + 7]);
+        }
+        // six cross terms, smallest first
+        acc = mfma_b(fa.hi, zc.lo, acc);
+        acc = mfma_b(fa.lo, zc.hi, acc);
+        acc = mfma_b(fa.mid, zc.mid, acc);
+        acc = mfma_b(fa.hi, zc.mid, acc);
+        acc = mfma_b(fa.mid, zc.hi, acc);
+        acc = mfma_b(fa.hi, zc.hi, acc);
+        STEP_END();
+        if constexpr (nc < 4) zc = nz;
+      });
+      dxv[0] = acc;
+    } else {
 #pragma unroll
     for (int tx = 0; tx < TX; ++tx) {
       MFMA_VV_ZERO(dxv[tx], fx[tx][0], d1[0][0]);
@@ -832,6 +989,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     }
     if constexpr (TX > 1) MFMA_DRAIN(dxv[0], dxv[TX - 1]);
     else MFMA_DRAIN1(dxv[0]);
+    }
     STEP_END();
 #pragma unroll
     for (int tx = 0; tx < TX; ++tx)
@@ -954,8 +1112,17 @@ static size_t bwd_smem_bytes(int in_dim, int out_dim) {
   const size_t epilogue = (size_t)4 * slab;            // four per-wave regions over the dead fragment/image areas
   return sizeof(float) * (main_loop > epilogue ? main_loop : epilogue);
 }
-
-#include "decoder_split.inc"
+// the hybrid variant keeps W1^T / W0^T as bf16 planes (8 + 4 fragments of 3 KB) instead of the fp32 fragment images
+static size_t bwd_smem_bytes_hybrid(int out_dim) {
+  using FF = FwdFrags<32>;
+  const int img = 4 * BwdLds<32>::kWaveFloats, slab = slab_size(32, out_dim);
+  const size_t main_loop = (size_t)(FF::kA0 + FF::kA1 + 2 * 2 * 64 + 12 * 3 * 64 * 4 + 2 * kH + img);
+  const size_t epilogue = (size_t)4 * slab;
+  return sizeof(float) * (main_loop > epilogue ? main_loop : epilogue);
+}
+// 1 (default): gngf_decoder_bwd at in_dim == 32 with the saved hidden layers runs the hybrid kernel (dh1 and d enc on the
+// bf16 pipe with the exact three-way split, weight gradients on the fp32 pipe); 0: all products on the fp32 pipe
+static int g_decoder_bwd_hybrid = 1;
 
 // 1: in_dim 32 / 64 run on the split-bf16 kernels (decoder_split.inc); 0: everything on the fp32 matrix pipe
 static int g_decoder_split = 0;
@@ -969,6 +1136,12 @@ using namespace gngf;
 extern "C" int gngf_set_decoder_split_bf16(int on) {
   const int prev = g_decoder_split;
   g_decoder_split = on ? 1 : 0;
+  return prev;
+}
+// Switch for the hybrid backward kernel (see g_decoder_bwd_hybrid); returns the previous setting.
+extern "C" int gngf_set_decoder_bwd_hybrid(int on) {
+  const int prev = g_decoder_bwd_hybrid;
+  g_decoder_bwd_hybrid = on ? 1 : 0;
   return prev;
 }
 static bool decoder_split_applies(int in_dim) { return g_decoder_split && in_dim == 32; }
@@ -1054,6 +1227,13 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
       fn<<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, P, out_dim, target, gloss);
+    } else if (g_decoder_bwd_hybrid && in_dim == 32 && hidden) {
+      const size_t smem = bwd_smem_bytes_hybrid(out_dim);
+      auto fn = leaky ? decoder_bwd_kernel<32, true, true, false, true> : decoder_bwd_kernel<32, false, true, false, true>;
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+      fn<<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, hidden, P, in_dim, out_dim,
+                                                                 target, gloss);
     } else
     DISPATCH_KIN(in_dim, {
       const size_t smem = bwd_smem_bytes<kKIN>(in_dim, out_dim);

@@ -148,6 +148,10 @@ int gngf_set_gemm_split_bf16(int on);
  * buffer is neither written by the forward nor read by the backward (the backward recomputes the two layers).  Process-wide;
  * returns the previous setting. */
 int gngf_set_decoder_split_bf16(int on);
+/* gngf_decoder_bwd at in_dim == 32 with the saved hidden layers: 1 (default) = hybrid kernel — the two products with the pixel
+ * on the lane (dh1 = W1^T dz2, d enc = W0^T dz1) on the bf16 pipe with the exact three-way split, the weight-gradient products
+ * on the fp32 pipe; 0 = everything on the fp32 pipe.  Process-wide; returns the previous setting. */
+int gngf_set_decoder_bwd_hybrid(int on);
 /* ---- dense layers on the matrix cores (exact-fp32 MFMA).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.01), 3 Sigmoid.
  * nn.Linear + activation of HashProbDistribution (models.py:80-88,105-106) and of the decoder (models.py:382-392). */
 int gngf_linear_fwd(const float* X, const float* W, const float* b, float* Y, int64_t M, int N, int K, int act, void* stream);

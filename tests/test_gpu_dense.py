@@ -295,6 +295,8 @@ def test_decoder_saved_hidden_equals_recompute(ops, P, in_dim, leaky):
     acts = (ops.ACT_LEAKY if leaky else ops.ACT_RELU,) * 2 + (ops.ACT_SIGMOID,)
     res = []
     old = ops.DECODER_SAVE_HIDDEN
+    from collision_handling_in_instantngp_amd import _lib
+    prev_hybrid = _lib.query("gngf_set_decoder_bwd_hybrid", 0)      # all-fp32 kernels on both sides: the same arithmetic
     try:
         for save in (True, False):
             ops.DECODER_SAVE_HIDDEN = save
@@ -305,16 +307,20 @@ def test_decoder_saved_hidden_equals_recompute(ops, P, in_dim, leaky):
             res.append([y.detach().cpu().numpy(), xt.grad.cpu().numpy()] + [p.grad.cpu().numpy() for p in params])
     finally:
         ops.DECODER_SAVE_HIDDEN = old
+        _lib.query("gngf_set_decoder_bwd_hybrid", prev_hybrid)
     for a, b in zip(*res):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("variant", ["hybrid", "split"])
 @pytest.mark.parametrize("P,leaky", [(1000, False), (128 * 300 + 77, True)])
-def test_split_bf16_decoder_kernels_are_as_accurate_as_the_fp32_ones(ops, P, leaky):
-    """gngf_set_decoder_split_bf16(1): the decoder on v_mfma_f32_32x32x16_bf16 with every operand split exactly into three
-    bf16 terms (csrc/decoder_split.inc).  Against a float64 evaluation its error must not exceed twice that of the fp32-MFMA
-    kernels (+ 1e-7 absolute on rgb); a hidden unit whose pre-activation is within rounding of 0 may switch sides, which
-    changes that pixel's gradient — hence the 99.9 % quantile for d enc and the looser bound on the summed gradients."""
+def test_bf16_split_decoder_kernels_are_as_accurate_as_the_fp32_ones(ops, P, leaky, variant):
+    """The decoder products moved to v_mfma_f32_32x32x16_bf16 with every operand split exactly into three bf16 terms:
+    "hybrid" (the default backward at 32 input features: dh1 and d enc on the bf16 pipe, weight gradients on the fp32 pipe,
+    csrc/decoder.hip) and "split" (gngf_set_decoder_split_bf16(1): everything, csrc/decoder_split.inc).  Against a float64
+    evaluation the error must not exceed twice that of the all-fp32 kernels (+ 1e-7 absolute on rgb); a hidden unit whose
+    pre-activation is within rounding of 0 may switch sides, which changes that pixel's gradient — hence the 99.9 % quantile
+    for d enc and the looser bound on the summed gradients."""
     from collision_handling_in_instantngp_amd import _lib
     rng = np.random.default_rng(P)
     x = (0.5 * rng.standard_normal((P, 32))).astype(np.float32)
@@ -331,8 +337,9 @@ def test_split_bf16_decoder_kernels_are_as_accurate_as_the_fp32_ones(ops, P, lea
     y64.backward(torch.tensor(dy, dtype=torch.float64, device=DEV))
     want = [y64.detach(), x64.grad] + [p.grad for p in p64]
     errs = []
-    for split in (0, 1):
-        prev = _lib.query("gngf_set_decoder_split_bf16", split)
+    for which in ("fp32", variant):
+        prev = _lib.query("gngf_set_decoder_split_bf16", 1 if which == "split" else 0)
+        prev_h = _lib.query("gngf_set_decoder_bwd_hybrid", 1 if which == "hybrid" else 0)
         try:
             xt = t(x).requires_grad_()
             params = [t(w).requires_grad_() for w in ws]
@@ -341,6 +348,7 @@ def test_split_bf16_decoder_kernels_are_as_accurate_as_the_fp32_ones(ops, P, lea
             torch.cuda.synchronize()
         finally:
             _lib.query("gngf_set_decoder_split_bf16", prev)
+            _lib.query("gngf_set_decoder_bwd_hybrid", prev_h)
         got = [y.detach(), xt.grad] + [p.grad for p in params]
         e = [float((got[0].double() - want[0]).abs().max())]
         rel = (got[1].double() - want[1]).abs().max(1).values / want[1].abs().max()

@@ -4,6 +4,7 @@ import torch
 from collision_handling_in_instantngp_amd import ops, _lib
 from collision_handling_in_instantngp_amd._lib import call, ptr, stream_ptr
 dev = torch.device("cuda")
+_lib.query("gngf_set_decoder_bwd_hybrid", int(os.environ.get("GNGF_HYBRID", "1")))
 P, in_dim, out_dim = 2**20, 32, 3
 enc = torch.randn((P, in_dim), device=dev)
 Ws = [torch.randn((64, in_dim), device=dev) / 6, torch.zeros(64, device=dev), torch.randn((64, 64), device=dev) / 8, torch.zeros(64, device=dev),
@@ -31,9 +32,9 @@ if os.environ.get("GNGF_LIB_PATH", "").endswith("stamps.so"):
     _lib.load().gngf_debug_read_stamps.argtypes = [ctypes.c_void_p]
     torch.cuda.synchronize()
     print("rc", _lib.load().gngf_debug_read_stamps(buf))
-    names = ["load/copy", "recompute L1+L2", "img+dW2", "dh2+dact", "img+dW1", "dh1+dact", "img+dW0", "dX+store"]
-    tot = sum(buf[:8])
-    for n, v in zip(names, buf[:8]):
+    names = ["load/copy", "recompute L1+L2", "(hyb) dW2 mf4 block", "dh2+dact", "img+dW1", "dh1+dact (hyb: mask only)", "img+dW0", "dX+store", "(hyb) d1 chunks 0-1", "(hyb) d1 chunks 2-3"]
+    tot = sum(buf[:10])
+    for n, v in zip(names, buf[:10]):
         print(f"  {n:18s} {v/32:9.0f} cycles/tile  {100*v/max(tot,1):5.1f}%")
     print("  total per tile", tot / 32)
     _lib.load().gngf_debug_read_fwd_stamps.argtypes = [ctypes.c_void_p]

@@ -1,0 +1,41 @@
+"""Hybrid decoder backward (dh1 and d enc on the bf16 pipe, exact three-way split) next to the all-fp32 kernel: time, and the
+error of both against a float64 evaluation."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from collision_handling_in_instantngp_amd._lib import call, ptr, stream_ptr, query
+dev = torch.device("cuda")
+P, in_dim, out_dim = 2**20, 32, 3
+torch.manual_seed(0)
+enc = torch.randn((P, in_dim), device=dev) * 0.5
+Ws = [torch.randn((64, in_dim), device=dev) / 6, torch.randn(64, device=dev) * 0.1, torch.randn((64, 64), device=dev) / 8, torch.randn(64, device=dev) * 0.1,
+      torch.randn((out_dim, 64), device=dev) / 8, torch.randn(out_dim, device=dev) * 0.1]
+drgb = torch.randn((P, out_dim), device=dev) * 1e-6
+slabs = torch.empty((query("gngf_decoder_bwd_slabs", P) * query("gngf_decoder_slab_floats", in_dim, out_dim),), device=dev)
+hidden = torch.empty((query("gngf_decoder_hidden_floats", P),), device=dev)
+rgb = torch.empty((P, out_dim), device=dev)
+call("gngf_decoder_fwd", ptr(enc), *[ptr(w) for w in Ws], ptr(rgb), ptr(hidden), P, in_dim, out_dim, 0, stream_ptr())
+n = 2**16
+x64 = enc[:n].double().requires_grad_(True)
+W64 = [w.double() for w in Ws]
+h = torch.relu(x64 @ W64[0].T + W64[1]); h = torch.relu(h @ W64[2].T + W64[3]); y64 = torch.sigmoid(h @ W64[4].T + W64[5])
+(gx,) = torch.autograd.grad(y64, x64, drgb[:n].double())
+res = {}
+for hyb in (0, 1):
+    query("gngf_set_decoder_bwd_hybrid", hyb)
+    denc = torch.empty_like(enc); grads = [torch.empty_like(w) for w in Ws]
+    fn = lambda: call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(None), ptr(None), ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(Ws[3]), ptr(Ws[4]), ptr(denc), *[ptr(g) for g in grads], ptr(slabs), ptr(None), ptr(hidden), P, in_dim, out_dim, 0, stream_ptr())
+    for _ in range(60): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(40): fn()
+    e1.record(); torch.cuda.synchronize()
+    err = float((denc[:n].double() - gx).abs().max() / gx.abs().max())
+    print(f"hybrid={hyb}  bwd {e0.elapsed_time(e1) / 40 * 1e3:7.1f} us   max |denc - f64| / max = {err:.2e}")
+    res[hyb] = (denc, grads)
+query("gngf_set_decoder_bwd_hybrid", 1)
+a, b = res[0], res[1]
+d = (a[0] - b[0]).abs().max(1).values / a[0].abs().max()
+print("pixels whose d enc differs by > 1e-5 of the maximum:", int((d > 1e-5).sum()), "of", P, " (a hidden unit within rounding of 0 may switch sides)")
+for k, nm in enumerate(("dW0", "db0", "dW1", "db1", "dW2", "db2")):
+    print(f"  {nm}: max |fp32 - hybrid| / max = {float((a[1][k] - b[1][k]).abs().max() / a[1][k].abs().max()):.2e}")
