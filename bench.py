@@ -503,7 +503,11 @@ def main():
                 ach = fl * P / t / 1e12
                 return {"bound": "mfma", "kernel": name, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc(name),
-                        "avg_launch_ms": t * 1e3, "algorithmic_flops_per_pixel": fl, "pixels_per_launch": P}
+                        "avg_launch_ms": t * 1e3, "algorithmic_flops_per_pixel": fl, "pixels_per_launch": P,
+                        "note": "fp32-accurate arithmetic priced against the dense fp32 MFMA peak; at 32 input features the backward "
+                                "kernel runs two of its six products (96 of 196 fp32-MFMA equivalents per tile) on the bf16 pipe with an "
+                                "exact three-way split (DESIGN.md section 3, hybrid backward)" if base == "decoder_bwd" else
+                                "exact fp32 on v_mfma_f32_32x32x2_f32"}
             return None
 
         roof = roof_enc = None
