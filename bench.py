@@ -181,7 +181,7 @@ def eager_step_fn(net, mode, xy, target, world, exchange=True):
     def step():
         for p in params:
             p.grad = None
-        with net.fused_mse(target):                # as train.py's loops do: the pixel loss rides in the decoder kernels
+        with net.fused_mse(target, gloss=1.0):     # as train.py's loops do: the pixel loss rides in the decoder kernels
             rgb, probs, _idx, _c = net(xy, 1.0)
         mse, kls, coll = loss_fn(rgb, target, None if probs is None else T, probs, empty, empty)
         loss = train.assemble_loss(mse, kls, coll, 1, 1, 1e-3)    # frozen HPD / hash: the MSE term alone (no p-bar, no gradient in the rest)

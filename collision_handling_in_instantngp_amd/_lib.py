@@ -39,6 +39,7 @@ SIGNATURES = {
     "gngf_decoder_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gngf_decoder_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gngf_decoder_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "gngf_decoder_train": [_P] * 19 + [_L, _I, _I, _I, _P],
     "gngf_decoder_bwd_last_span_ns": [_P],
     "gngf_decoder_hidden_floats": [_L],
     "gngf_decoder_bwd_slabs": [_L],

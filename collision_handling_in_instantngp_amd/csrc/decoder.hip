@@ -408,13 +408,18 @@ template <int KIN> struct BwdLds {
 // decoder_split.inc (operands straight from the accumulator registers, W^T as bf16 planes in LDS): 72 MFMAs of 32 cycles
 // instead of 96 of 64, and the splitting issues underneath them.  The weight-gradient products (pixel on the k axis, fp32
 // transposition images) stay on the fp32 pipe, which keeps the kernel below the power limit of an all-bf16 one.
-template <int KIN, bool LEAKY, bool EXACT, bool RECOMPUTE, bool HYB = false>
+// TRAIN (with HYB): forward AND backward of the decoder for the training step whose loss is MSELoss(rgb, target) with a KNOWN
+// upstream gradient (gloss): the tile's hidden layers are computed here (both layers on the bf16 pipe with the exact split, as
+// decoder_fwd_split_kernel), rgb is WRITTEN to Yout, d rgb is formed from it and the target, and the backward phases follow on
+// the registers that hold h1 / h2 — the hidden layers never travel through HBM (1 GB per step at 2^20 pixels) and the forward
+// kernel's launch disappears.
+template <int KIN, bool LEAKY, bool EXACT, bool RECOMPUTE, bool HYB = false, bool TRAIN = false>
 __global__ void __launch_bounds__(kDecThreads, 1)
 decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, const float* __restrict__ dY,
                    const float* __restrict__ W0, const float* __restrict__ b0, const float* __restrict__ W1,
                    const float* __restrict__ b1, const float* __restrict__ W2, float* __restrict__ dX,
                    float* __restrict__ slabs, const float* __restrict__ hidden, int64_t P, int in_dim, int out_dim,
-                   const float* __restrict__ target, const float* __restrict__ gloss) {
+                   const float* __restrict__ target, const float* __restrict__ gloss, const float* __restrict__ b2 = nullptr) {
   using FF = FwdFrags<KIN>;
   constexpr int S0 = KIN / 2;
   constexpr int TX = (KIN + 31) / 32;                    // 32-row tiles of the input width
@@ -428,6 +433,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   float* A1 = A0 + FF::kA0;
   float* A2T = A1 + FF::kA1;                             // [t(2)][s(2)][64]   : W2[c = 2s+h][32t+i]
   static_assert(!HYB || (KIN == 32 && EXACT && !RECOMPUTE), "hybrid variant: 32 input features, saved hidden layers");
+  static_assert(!TRAIN || HYB, "the fused training kernel builds on the hybrid backward");
   constexpr int kA1T = HYB ? 8 * 3 * 64 * 4 : 2 * 32 * 64, kA0T = HYB ? 4 * 3 * 64 * 4 : TX * 32 * 64;
   float* A1T = A2T + 2 * 2 * 64;                         // [t(2)][s2(32)][64] : W1[kmapC(s2,h)][32t+i]   (HYB: bf16 planes of W1^T)
   float* A0T = A1T + kA1T;                               // [t(TX)][s2(32)][64]: W0[kmapC(s2,h)][32t+i]   (HYB: bf16 planes of W0^T)
@@ -436,8 +442,24 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   const int nslab = slab_size(in_dim, out_dim);
 
   float* raw = img;                                      // the image area is free until the main loop starts
-  stage_raw(raw, W0, b0, W1, b1, W2, nullptr, in_dim, out_dim);
+  stage_raw(raw, W0, b0, W1, b1, W2, TRAIN ? b2 : nullptr, in_dim, out_dim);
   const RawOff ro = raw_offsets(in_dim);
+  // TRAIN: the area of the fp32 recompute fragments holds the forward planes of W0 (fragments 2 c + t: rows 32 t + i,
+  // k = 16 h + 8 c + j; 12 KB) and the output layer's weights as [s2 / 4][lane][4] (8 KB)
+  u32x4* w0f = reinterpret_cast<u32x4*>(A0);
+  float* w2L = A0 + 4 * 3 * 64 * 4;
+  if constexpr (TRAIN) {
+    const int ln = threadIdx.x & 63, li = ln & 31, lh = ln >> 5;
+    {
+      const int f = threadIdx.x >> 6, c = f >> 1, t = f & 1;
+      const float* r0 = raw + ro.w0 + (32 * t + li) * (in_dim + 1) + lh * S0 + 8 * c;
+      store_planes(w0f + f * 3 * 64 + ln, split8(r0[0], r0[1], r0[2], r0[3], r0[4], r0[5], r0[6], r0[7]));
+    }
+    for (int e = threadIdx.x; e < 32 * 64; e += kDecThreads) {
+      const int s2 = e >> 6, l2 = e & 63;
+      w2L[((s2 >> 2) * 64 + l2) * 4 + (s2 & 3)] = raw[ro.w2 + (l2 & 3) * 65 + kmapC(s2, l2 >> 5)];
+    }
+  } else
   fill_fwd_frags<KIN>(A0, A1, raw, in_dim);
   for (int e = threadIdx.x; e < 2 * 2 * 64; e += kDecThreads) {
     const int lane = e & 63, s = (e >> 6) & 1, t = e >> 7;
@@ -561,7 +583,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const unsigned off = c < out_dim ? yoff + 4u * c : 0x40000000u;
-      yn[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0));
+      if constexpr (!TRAIN) yn[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0));
       dyn[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0));
     }
   };
@@ -576,7 +598,12 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   };
   fetch_x(blockIdx.x);
   fetch_y(blockIdx.x);
-  make_dz3();
+  if constexpr (!TRAIN) make_dz3();
+  float b2v[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (TRAIN) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b2v[c] = raw[ro.b2 + c];
+  }
   // biases: accumulator-file residents, the C operand of the first MFMA of each recompute chain
   f32x16 b0v[2], b1v[2];
   if (RECOMPUTE) {
@@ -602,7 +629,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   f32x16 acc1[2], acc2[2];
   float ft[2][32];
   const unsigned hoff = (unsigned)(wave * 8192 + lane * 16);
-  if (!RECOMPUTE) {
+  if (!RECOMPUTE && !TRAIN) {
     hidden_load(hidden, blockIdx.x, ntiles, 0, hoff, acc1);
     hidden_load(hidden, blockIdx.x, ntiles, 1, hoff, acc2);
     if constexpr (!HYB) {
@@ -619,7 +646,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
       lds_store<kImgB + (32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile, acc1[t][r]);
     });
   };
-  if constexpr (HYB) static_for<16>([&](auto E) { store_hidden_images(E); });      // first tile
+  if constexpr (HYB && !TRAIN) static_for<16>([&](auto E) { store_hidden_images(E); });      // first tile
   const u32x4* w1t = reinterpret_cast<const u32x4*>(A1T) + lane;      // HYB: plane p of fragment f at [(f * 3 + p) * 64]
   const u32x4* w0t = reinterpret_cast<const u32x4*>(A0T) + lane;
   // HYB: the W1^T planes are MFMA operands only and stay in accumulation registers for the kernel's lifetime (96 of them); the
@@ -631,6 +658,20 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
       w1p[f] = load_planes(w1t + f * 3 * 64);
       asm volatile("" : "+a"(w1p[f].hi), "+a"(w1p[f].mid), "+a"(w1p[f].lo));
     }
+  }
+  // TRAIN: the W1^T planes live in registers now; their LDS area takes the FORWARD planes of W1 (fragments 2 cc + t: rows
+  // 32 t + i, k = kmapS(cc, h, j)).  `raw` (the image area) is still intact: the first image store comes after the barrier.
+  u32x4* w1f = reinterpret_cast<u32x4*>(A1T);
+  if constexpr (TRAIN) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int f = threadIdx.x >> 6; f < 8; f += 4) {
+      const int cc = f >> 1, t = f & 1;
+      const float* r1 = raw + ro.w1 + (32 * t + i) * 65;
+      store_planes(w1f + f * 3 * 64 + lane, split8(r1[kmapS(cc, h, 0)], r1[kmapS(cc, h, 1)], r1[kmapS(cc, h, 2)], r1[kmapS(cc, h, 3)],
+                                                  r1[kmapS(cc, h, 4)], r1[kmapS(cc, h, 5)], r1[kmapS(cc, h, 6)], r1[kmapS(cc, h, 7)]));
+    }
+    __syncthreads();
   }
   if (RECOMPUTE && kCarryF0) {
 #pragma unroll
@@ -648,6 +689,70 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     pin_acc();
     STAMP(0);
     float f1[2][32];
+    if constexpr (TRAIN) {
+      // ---- forward of the tile on the bf16 pipe (exact three-way split): h1 = act(W0 x + b0), h2 = act(W1 h1 + b1)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 q0 = *reinterpret_cast<const f32x4*>(bs + 32 * t + 8 * g + 4 * h);
+          const f32x4 q1 = *reinterpret_cast<const f32x4*>(bs + kH + 32 * t + 8 * g + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { acc1[t][4 * g + e] = q0[e]; acc2[t][4 * g + e] = q1[e]; }
+        }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const Planes xs = split8(xr[8 * c], xr[8 * c + 1], xr[8 * c + 2], xr[8 * c + 3], xr[8 * c + 4], xr[8 * c + 5], xr[8 * c + 6], xr[8 * c + 7]);
+        mfma_split2(load_planes(w0f + (2 * c) * 3 * 64 + lane), load_planes(w0f + (2 * c + 1) * 3 * 64 + lane), xs, acc1[0], acc1[1]);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[t][r] = act_split<LEAKY>(acc1[t][r]);
+      STEP_END();
+      static_for<4>([&](auto CC) {
+        constexpr int cc = CC.value, t = cc >> 1, r0 = 8 * (cc & 1);
+        const Planes hs = split8(acc1[t][r0], acc1[t][r0 + 1], acc1[t][r0 + 2], acc1[t][r0 + 3], acc1[t][r0 + 4], acc1[t][r0 + 5],
+                                 acc1[t][r0 + 6], acc1[t][r0 + 7]);
+        mfma_split2(load_planes(w1f + (2 * cc) * 3 * 64 + lane), load_planes(w1f + (2 * cc + 1) * 3 * 64 + lane), hs, acc2[0], acc2[1]);
+        static_for<8>([&](auto E) {                        // h1 image (image B), 8 stores per chunk
+          constexpr int e = 8 * cc + E.value, tt = e >> 4, r = e & 15;
+          lds_store<kImgB + (32 * tt + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile, acc1[tt][r]);
+        });
+        STEP_END();
+      });
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[t][r] = act_split<LEAKY>(acc2[t][r]);
+      // ---- output layer on v_mfma_f32_4x4x1 (as decoder_fwd_kernel), rgb out, d rgb from it and the target
+      {
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(w2L + (g * 64 + lane) * 4);
+          o0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.x, acc2[(4 * g) >> 4][(4 * g) & 15], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.y, acc2[(4 * g + 1) >> 4][(4 * g + 1) & 15], o1, 0, 0, 0);
+          o0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.z, acc2[(4 * g + 2) >> 4][(4 * g + 2) & 15], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w, acc2[(4 * g + 3) >> 4][(4 * g + 3) & 15], o1, 0, 0, 0);
+        }
+        int64_t rem = (P - tile * 128) * out_dim * 4;
+        rem = rem > 128 * out_dim * 4 ? 128 * out_dim * 4 : rem;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Yout) + tile * 128 * out_dim, 0, (int)rem, 0x00020000);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float dc = o0[c] + o1[c];
+          const float z = dc + __shfl_xor(dc, 32, 64) + b2v[c];
+          const float y = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
+          const unsigned off = (h == 0 && c < out_dim) ? yoff + 4u * c : 0x40000000u;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs, off, 0, 0);
+          // pixels past the end of the batch read x = 0 but still produce an output: they must not produce a gradient
+          yn[c] = (c < out_dim && tile * 128 + wave * 32 + i < P) ? y : 0.f;
+        }
+      }
+      make_dz3();
+      STEP_END();
+    }
     if constexpr (RECOMPUTE) {
     if (!kCarryF0) {
 #pragma unroll
@@ -736,8 +841,23 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
       auto lds_step = [&](auto S) {
         constexpr int s2 = S.value;
         if constexpr (s2 < 16) {                          // (the h2 / h1 images of this tile were stored a tile ago, see dW0)
-          av[s2] = lds_load2<kImgZ + 8 * s2>(rZ2);
-          bv[s2] = lds_load2<8 * s2>(rH2);
+          if constexpr (TRAIN) {                           // h2 was computed in this tile: its image first, then the operands
+            if constexpr (s2 < 8) {
+              static_for<4>([&](auto E) {
+                constexpr int e = 4 * s2 + E.value, t = e >> 4, r = e & 15;
+                lds_store<(32 * t + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile, acc2[t][r]);
+              });
+            } else {
+              static_for<2>([&](auto E) {
+                constexpr int q = 2 * (s2 - 8) + E.value;
+                av[q] = lds_load2<kImgZ + 8 * q>(rZ2);
+                bv[q] = lds_load2<8 * q>(rH2);
+              });
+            }
+          } else {
+            av[s2] = lds_load2<kImgZ + 8 * s2>(rZ2);
+            bv[s2] = lds_load2<8 * s2>(rH2);
+          }
         } else if constexpr (s2 < 24) {
           static_for<4>([&](auto E) {
             constexpr int e = 4 * (s2 - 16) + E.value, t = e >> 4, r = e & 15;
@@ -864,7 +984,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
       for (int q = 1; q < 8; ++q) { s0 += a0p[q]; s1 += a1p[q]; }
       db1acc[0] += s0.x + s0.y; db1acc[1] += s1.x + s1.y;
     }
-    if (!RECOMPUTE) {                                      // h2 is dead: fetch the next tile's (needed first, at its mask)
+    if (!RECOMPUTE && !TRAIN) {                            // h2 is dead: fetch the next tile's (needed first, at its mask)
       STEP_END();
       hidden_load(hidden, tile + gridDim.x, ntiles, 1, hoff, acc2);
     }
@@ -876,7 +996,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     float fx[TX][32];
     static_for<8>([&](auto Q) {
       constexpr int q = Q.value;
-      if constexpr (HYB && q == 0) hidden_load(hidden, tile + gridDim.x, ntiles, 0, hoff, acc1);   // h1 is dead: the next tile's
+      if constexpr (HYB && !TRAIN && q == 0) hidden_load(hidden, tile + gridDim.x, ntiles, 0, hoff, acc1);   // h1 is dead: the next tile's
       dW1acc[0][0] = MFMA(a0p[q].x, b0p[q].x, dW1acc[0][0]);
       dW1acc[0][1] = MFMA(a0p[q].x, b1p[q].x, dW1acc[0][1]);
       dW1acc[1][0] = MFMA(a1p[q].x, b0p[q].x, dW1acc[1][0]);
@@ -929,8 +1049,10 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
       if constexpr (HYB) {
         // the NEXT tile's h2 -> image A and h1 -> image B (both idle from here on; loaded under d1 / at the top of dW1): their
         // 64 stores need a long fp32 run above them — under the bf16 runs of d1 or dX they cost 760 cycles per tile
-        store_hidden_images(std::integral_constant<int, 2 * q>{});
-        store_hidden_images(std::integral_constant<int, 2 * q + 1>{});
+        if constexpr (!TRAIN) {
+          store_hidden_images(std::integral_constant<int, 2 * q>{});
+          store_hidden_images(std::integral_constant<int, 2 * q + 1>{});
+        }
         if constexpr (q >= 2 && q < 6) w0p[q - 2] = load_planes(w0t + (q - 2) * 3 * 64);
       }
       if (RECOMPUTE && kCarryF0) {
@@ -1004,7 +1126,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
       for (int q = 1; q < 8; ++q) { s0 += c0p[q]; s1 += c1p[q]; }
       db0acc[0] += s0.x + s0.y; db0acc[1] += s1.x + s1.y;
     }
-    make_dz3();                                          // of tile t+1 (y, dy were requested half a tile ago)
+    if constexpr (!TRAIN) make_dz3();                    // of tile t+1 (y, dy were requested half a tile ago)
     STEP_END();
     {
       const int64_t pt = bwd_tile(tile, ntiles);
@@ -1233,12 +1355,12 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
       fn<<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, hidden, P, in_dim, out_dim,
-                                                                 target, gloss);
+                                                                 target, gloss, nullptr);
     } else
     DISPATCH_KIN(in_dim, {
       const size_t smem = bwd_smem_bytes<kKIN>(in_dim, out_dim);
       using Kern = void (*)(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
-                            const float*, float*, float*, const float*, int64_t, int, int, const float*, const float*);
+                            const float*, float*, float*, const float*, int64_t, int, int, const float*, const float*, const float*);
       const bool exact = in_dim == kKIN;
       Kern fn;
       if (hidden)
@@ -1250,11 +1372,40 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
       fn<<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, hidden, P, in_dim, out_dim,
-                                                                 target, gloss);
+                                                                 target, gloss, nullptr);
     });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
+  if (reduce_here)
+    decoder_reduce_kernel<<<dim3((unsigned)((nslab + 63) / 64)), dim3(1024), 0, s>>>(slabs, nslabs, nslab, in_dim, out_dim, dW0,
+                                                                                     db0, dW1, db1, dW2, db2, denc_absmax);
+  GNGF_RETURN_LAUNCH();
+}
+
+// Forward AND backward of the decoder for a training step whose loss is MSELoss(rgb, target) with a known upstream gradient
+// *gloss (device scalar): rgb (P,out_dim) is written, d enc and the parameter-gradient slabs as by gngf_decoder_bwd with
+// target / gloss — in ONE launch, without the hidden-layer buffer.  in_dim == 32 only (returns hipErrorInvalidValue otherwise:
+// the caller falls back to gngf_decoder_fwd + gngf_decoder_bwd).  Gradient pointers / slabs / denc_absmax as gngf_decoder_bwd.
+extern "C" int gngf_decoder_train(const float* enc, const float* target, const float* gloss, const float* W0, const float* b0,
+                                  const float* W1, const float* b1, const float* W2, const float* b2, float* rgb, float* denc,
+                                  float* dW0, float* db0, float* dW1, float* db1, float* dW2, float* db2, float* slabs,
+                                  float* denc_absmax, int64_t P, int in_dim, int out_dim, int leaky, void* stream) {
+  GNGF_CHECK_ARG(P > 0 && in_dim == 32 && out_dim > 0 && out_dim <= 4);
+  const bool reduce_here = dW0 || db0 || dW1 || db1 || dW2 || db2;
+  GNGF_CHECK_ARG(slabs && (!reduce_here || (dW0 && db0 && dW1 && db1 && dW2 && db2)));
+  GNGF_CHECK_ARG(enc && target && gloss && W0 && b0 && W1 && b1 && W2 && b2 && rgb && denc);
+  const int nslab = slab_size(in_dim, out_dim);
+  hipStream_t s = as_stream(stream);
+  const int nslabs = gngf_decoder_bwd_slabs(P);
+  const size_t smem = bwd_smem_bytes_hybrid(out_dim);
+  auto fn = leaky ? decoder_bwd_kernel<32, true, true, false, true, true> : decoder_bwd_kernel<32, false, true, false, true, true>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return (int)e;
+  fn<<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, nullptr, W0, b0, W1, b1, W2, denc, slabs, nullptr, P, in_dim, out_dim,
+                                                             target, gloss, b2);
+  e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
   if (reduce_here)
     decoder_reduce_kernel<<<dim3((unsigned)((nslab + 63) / 64)), dim3(1024), 0, s>>>(slabs, nslabs, nslab, in_dim, out_dim, dW0,
                                                                                      db0, dW1, db1, dW2, db2, denc_absmax);

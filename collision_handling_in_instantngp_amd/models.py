@@ -234,6 +234,7 @@ class GeneralNeuralGaugeFields(nn.Module):
         self.compute_pbar = True           # batch-mean distribution for the loss when probs is returned compact
         self._frozen_table = None          # cached per-vertex (idx, w, q) when the HPD is frozen
         self._fused_mse_target = None      # see fused_mse()
+        self._fused_mse_gloss = None
         self.to(device)
 
     # ------------------------------------------------------------------ helpers
@@ -252,23 +253,26 @@ class GeneralNeuralGaugeFields(nn.Module):
         n = len(self.mlp)
         hidden = ops.ACT_LEAKY if self._leaky else ops.ACT_RELU
         return ops.decoder_apply(enc, tuple([hidden] * (n - 1) + [ops.ACT_SIGMOID]), self._decoder_params(),
-                                 mse_target=self._fused_mse_target)
+                                 mse_target=self._fused_mse_target, mse_gloss=self._fused_mse_gloss)
 
-    def fused_mse(self, target):
+    def fused_mse(self, target, gloss=None):
         """Context manager: forward passes inside it also evaluate torch.nn.MSELoss()(rgb, target) in the decoder kernels and
         attach the value to the returned rgb; train.Loss (ops.mse_loss) picks it up when it is given that rgb and this very
         `target` tensor, instead of launching the loss kernels.  Results are those of the separate kernels (gradients bit
-        for bit).  The training loops of train.py use it; it is never required."""
+        for bit).  The training loops of train.py use it; it is never required.
+        gloss (number): a PROMISE that the gradient arriving at that loss value in backward() will be exactly this (the loss
+        weight l_mse when the total is l_mse * mse + ... and backward() is seeded with 1): at 32 encoder features the decoder
+        then runs its forward and backward in ONE launch (ops.DECODER_TRAIN_FUSION), results as with the two kernels."""
         import contextlib
 
         @contextlib.contextmanager
         def scope():
-            prev = self._fused_mse_target
-            self._fused_mse_target = target
+            prev = (self._fused_mse_target, self._fused_mse_gloss)
+            self._fused_mse_target, self._fused_mse_gloss = target, gloss
             try:
                 yield self
             finally:
-                self._fused_mse_target = prev
+                self._fused_mse_target, self._fused_mse_gloss = prev
         return scope()
 
     def _vertex_extent(self, x):

@@ -1082,7 +1082,27 @@ def _at_end_of_backward(fn):
         fn()
 
 
-def _decoder_fwd(ctx, enc, leaky, ws, target):
+# Training steps whose pixel loss is MSELoss(rgb, target) with a gradient known up front (the loss weight): forward and backward
+# of the decoder in ONE launch (gngf_decoder_train) — the hidden layers stay in registers, nothing is saved for the backward.
+DECODER_TRAIN_FUSION = True
+CHECK_FUSED_GLOSS = False        # tests: compare (with a device synchronisation) the gradient that arrives with the promised one
+_GLOSS_SCALARS = {}
+
+
+def _decoder_grad_buffers(ws, P, in_dim, out_dim, dev):
+    # the six parameter gradients are consecutive views of ONE buffer: the data-parallel exchange all-reduces that
+    # buffer in place (parallel.allreduce_gradients) instead of packing and unpacking a bucket
+    flat = torch.empty((sum(w.numel() for w in ws),), dtype=_f32, device=dev)
+    grads, off = [], 0
+    for w in ws:
+        grads.append(flat[off:off + w.numel()].view(w.shape))
+        off += w.numel()
+    nslabs, nslab = _lib.query("gngf_decoder_bwd_slabs", P), _lib.query("gngf_decoder_slab_floats", in_dim, out_dim)
+    slabs = torch.empty((nslabs * nslab,), dtype=_f32, device=dev)
+    return flat, grads, slabs, nslabs, nslab
+
+
+def _decoder_fwd(ctx, enc, leaky, ws, target, gloss_known=None):
     enc = _c(enc)
     ws = [_c(w) for w in ws]
     P, in_dim = enc.shape
@@ -1090,7 +1110,10 @@ def _decoder_fwd(ctx, enc, leaky, ws, target):
     dev = enc.device
     rgb = torch.empty((P, out_dim), dtype=_f32, device=dev)
     hidden = None
-    if DECODER_SAVE_HIDDEN and P > 0 and any(ctx.needs_input_grad):
+    ctx.train = None
+    train = (DECODER_TRAIN_FUSION and gloss_known is not None and target is not None and in_dim == 32 and P > 0
+             and DECODER_REDUCE_RIDES and any(ctx.needs_input_grad))
+    if DECODER_SAVE_HIDDEN and P > 0 and any(ctx.needs_input_grad) and not train:
         hidden = torch.empty((_lib.query("gngf_decoder_hidden_floats", P),), dtype=_f32, device=dev)
     if target is not None:
         if P == 0:
@@ -1098,8 +1121,21 @@ def _decoder_fwd(ctx, enc, leaky, ws, target):
         target = _c(target)
         if tuple(target.shape) != (P, out_dim) or target.dtype != _f32:
             raise ValueError(f"target {tuple(target.shape)} / {target.dtype} does not match the decoder output ({P}, {out_dim}) float32")
-    call("gngf_decoder_fwd", ptr(enc, _f32, "enc"), *[ptr(w, _f32) for w in ws], ptr(rgb), ptr(hidden), P, in_dim, out_dim, int(leaky),
-         stream_ptr())
+    if train:
+        key = (dev, float(gloss_known))
+        gl = _GLOSS_SCALARS.get(key)
+        if gl is None:
+            gl = _GLOSS_SCALARS[key] = torch.full((), float(gloss_known), dtype=_f32, device=dev)
+        target_c = _c(target)
+        denc = torch.empty_like(enc)
+        flat, grads, slabs, nslabs, nslab = _decoder_grad_buffers(ws, P, in_dim, out_dim, dev)
+        call("gngf_decoder_train", ptr(enc, _f32, "enc"), ptr(target_c, _f32, "target"), ptr(gl), *[ptr(w, _f32) for w in ws], ptr(rgb),
+             ptr(denc), *[ptr(None)] * 6, ptr(slabs), ptr(None), P, in_dim, out_dim, int(leaky), stream_ptr())
+        ctx.train = {"denc": denc, "flat": flat, "grads": grads, "slabs": slabs, "nslabs": nslabs, "nslab": nslab,
+                     "gloss": float(gloss_known)}
+    else:
+        call("gngf_decoder_fwd", ptr(enc, _f32, "enc"), *[ptr(w, _f32) for w in ws], ptr(rgb), ptr(hidden), P, in_dim, out_dim, int(leaky),
+             stream_ptr())
     mse = None
     if target is not None:
         # The loss VALUE (csrc/loss.hip::mse_fwd_kernel).  Nothing in the step's critical path reads it — the backward kernel
@@ -1126,6 +1162,21 @@ def _decoder_bwd(ctx, drgb, gloss):
     enc, rgb, target, W0, b0, W1, b1, W2, b2 = ctx.saved_tensors
     P, in_dim, out_dim, leaky = ctx.cfg
     dev = enc.device
+    tr = getattr(ctx, "train", None)
+    if tr is not None:
+        # the forward launch already ran the backward with the promised loss gradient: hand its results over
+        ctx.train = None
+        if drgb is not None or gloss is None:
+            raise RuntimeError("fused training decoder: rgb must feed the MSE loss only (use net.fused_mse(target) without gloss= otherwise)")
+        if CHECK_FUSED_GLOSS and abs(float(gloss) - tr["gloss"]) > 1e-6 * abs(tr["gloss"]):
+            raise RuntimeError(f"fused training decoder: loss gradient {float(gloss)} differs from the promised {tr['gloss']}")
+        denc, flat, grads, slabs, nslabs, nslab = tr["denc"], tr["flat"], tr["grads"], tr["slabs"], tr["nslabs"], tr["nslab"]
+        _PENDING_REDUCE.append({"slabs": slabs, "flat": flat, "gptrs": [g.data_ptr() for g in grads], "P": P, "in_dim": in_dim,
+                                "out_dim": out_dim, "device": dev, "stream": torch.cuda.current_stream(dev).cuda_stream,
+                                "stream_obj": torch.cuda.current_stream(dev)})
+        _at_end_of_backward(_flush_pending_reduces)
+        _ABSMAX_HINTS[denc.data_ptr()] = ((slabs[nslab - 1:], nslabs, nslab), denc._version)
+        return denc, grads
     if gloss is not None and drgb is not None:
         # rgb ALSO feeds something else: fold both into one explicit gradient (plain framework ops; not the training step's path)
         drgb = drgb + gloss * (2.0 / (P * out_dim)) * (rgb - target)
@@ -1136,16 +1187,8 @@ def _decoder_bwd(ctx, drgb, gloss):
     else:
         drgb = _c(drgb) if drgb is not None else torch.zeros_like(rgb)
     denc = torch.empty_like(enc)
-    # the six parameter gradients are consecutive views of ONE buffer: the data-parallel exchange all-reduces that
-    # buffer in place (parallel.allreduce_gradients) instead of packing and unpacking a bucket
     ws = (W0, b0, W1, b1, W2, b2)
-    flat = torch.empty((sum(w.numel() for w in ws),), dtype=_f32, device=dev)
-    grads, off = [], 0
-    for w in ws:
-        grads.append(flat[off:off + w.numel()].view(w.shape))
-        off += w.numel()
-    nslabs, nslab = _lib.query("gngf_decoder_bwd_slabs", P), _lib.query("gngf_decoder_slab_floats", in_dim, out_dim)
-    slabs = torch.empty((nslabs * nslab,), dtype=_f32, device=dev)
+    flat, grads, slabs, nslabs, nslab = _decoder_grad_buffers(ws, P, in_dim, out_dim, dev)
     common = (ptr(enc), ptr(rgb), ptr(None if fused else drgb, _f32, "grad"), ptr(target if fused else None), ptr(gloss if fused else None),
               ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(denc))
     if DECODER_REDUCE_RIDES and P > 0:
@@ -1191,17 +1234,18 @@ class DecoderMseFunction(torch.autograd.Function):
     inside the step for a 14 us launch saved.)"""
 
     @staticmethod
-    def forward(ctx, enc, target, leaky, W0, b0, W1, b1, W2, b2):
+    def forward(ctx, enc, target, leaky, gloss_known, W0, b0, W1, b1, W2, b2):
         ctx.set_materialize_grads(False)
-        rgb, mse = _decoder_fwd(ctx, enc, leaky, (W0, b0, W1, b1, W2, b2), target.detach())
+        rgb, mse = _decoder_fwd(ctx, enc, leaky, (W0, b0, W1, b1, W2, b2), target.detach(), gloss_known)
         return rgb, mse
 
     @staticmethod
     def backward(ctx, drgb, gloss):
         if drgb is None and gloss is None:
-            return (None,) * 9
+            ctx.train = None
+            return (None,) * 10
         denc, grads = _decoder_bwd(ctx, drgb, gloss)
-        return (denc, None, None, *grads)
+        return (denc, None, None, None, *grads)
 
 
 def decoder_fused_ok(acts, params):
@@ -1211,14 +1255,16 @@ def decoder_fused_ok(acts, params):
     return W0.shape[0] == 64 and tuple(W1.shape) == (64, 64) and W2.shape[1] == 64 and W0.shape[1] <= 64 and W2.shape[0] <= 4
 
 
-def decoder_apply(enc, acts, params, fused=None, mse_target=None):
+def decoder_apply(enc, acts, params, fused=None, mse_target=None, mse_gloss=None):
     """Decoder MLP dispatch (reference models.py:382-392,469-470): the fused kernel for the default 64/64 widths,
     the generic MFMA linear chain otherwise.  mse_target (P,out) float32: also evaluate MSELoss(rgb, mse_target) inside the
     fused kernels; the 0-dim loss is attached to the returned rgb as `rgb._gngf_fused_mse = (mse_target, loss)`."""
     if (fused is None or fused) and decoder_fused_ok(acts, params):
         if (mse_target is not None and enc.shape[0] > 0 and mse_target.is_cuda and mse_target.dtype == _f32
                 and tuple(mse_target.shape) == (enc.shape[0], params[4].shape[0])):
-            rgb, mse = DecoderMseFunction.apply(enc, mse_target, acts[0] == ACT_LEAKY, *params)
+            # mse_gloss: the gradient that WILL arrive at the loss value (a promise of the caller who owns the step, e.g. the
+            # loss weight l_mse with loss.backward() seeded with 1): forward and backward then run in one launch
+            rgb, mse = DecoderMseFunction.apply(enc, mse_target, acts[0] == ACT_LEAKY, mse_gloss, *params)
             rgb._gngf_fused_mse = (mse_target, mse)
             return rgb
         return DecoderFunction.apply(enc, acts[0] == ACT_LEAKY, *params)

@@ -307,7 +307,9 @@ class GraphedStep:
         aside = isinstance(l_mse, (int, float)) and l_mse == 1 and (models.should_use_hash_function or getattr(net, "compute_pbar", True) is False)
         ops.LOSS_VALUE_ASIDE = bool(aside)
         try:
-            with net.fused_mse(st["y"]):
+            # backward() below is seeded with 1 and the total is l_mse * mse + (terms without mse): the gradient that reaches the
+            # pixel loss IS l_mse — promised to the decoder, which then runs forward and backward in one launch
+            with net.fused_mse(st["y"], gloss=(float(l_mse) if isinstance(l_mse, (int, float)) else None)):
                 out, probs, idx, _counts = torch.func.functional_call(net, shadow, (st["x"], self.batch_percentage), {"should_calc_counts": False})
         finally:
             ops.LOSS_VALUE_ASIDE = False
@@ -454,7 +456,8 @@ def train_epoch(net, loss_fn, optimizer, x, target, w, h, l_mse, l_js_kl, l_coll
         else:
             optimizer.zero_grad()
             by = by.contiguous()
-            with (net.fused_mse(by) if hasattr(net, "fused_mse") else contextlib.nullcontext()):
+            with (net.fused_mse(by, gloss=(float(l_mse) if isinstance(l_mse, (int, float)) else None)) if hasattr(net, "fused_mse")
+                  else contextlib.nullcontext()):
                 out, probs, idx, counts = net(bx, batch_percentage, should_calc_counts=should_calc_counts)
             mse, kls, colls = loss_fn(out, by, None if probs is None else probs.shape[-1], probs,
                                       previous_collisions, previous_min_possible_collisions)

@@ -152,6 +152,16 @@ int gngf_set_decoder_split_bf16(int on);
  * on the lane (dh1 = W1^T dz2, d enc = W0^T dz1) on the bf16 pipe with the exact three-way split, the weight-gradient products
  * on the fp32 pipe; 0 = everything on the fp32 pipe.  Process-wide; returns the previous setting. */
 int gngf_set_decoder_bwd_hybrid(int on);
+/* Forward AND backward of the decoder in ONE launch for a training step whose loss is torch.nn.MSELoss()(rgb, target)
+ * (utils.py:99) with a KNOWN upstream gradient *gloss (device scalar, e.g. the loss weight l_mse of functions.py:243): rgb
+ * (P,out_dim) is written, d enc and the parameter gradients as by gngf_decoder_bwd(target, gloss).  The tile's hidden layers
+ * stay in registers between its forward and backward part (no hidden-layer buffer, no separate forward launch).  in_dim == 32
+ * only (hipErrorInvalidValue otherwise: use gngf_decoder_fwd + gngf_decoder_bwd).  Gradient pointers all NULL: the caller
+ * runs gngf_decoder_reduce on the slabs (as with gngf_decoder_bwd). */
+int gngf_decoder_train(const float* enc, const float* target, const float* gloss, const float* W0, const float* b0,
+                       const float* W1, const float* b1, const float* W2, const float* b2, float* rgb, float* denc,
+                       float* dW0, float* db0, float* dW1, float* db1, float* dW2, float* db2, float* slabs,
+                       float* denc_absmax, int64_t P, int in_dim, int out_dim, int leaky, void* stream);
 /* ---- dense layers on the matrix cores (exact-fp32 MFMA).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.01), 3 Sigmoid.
  * nn.Linear + activation of HashProbDistribution (models.py:80-88,105-106) and of the decoder (models.py:382-392). */
 int gngf_linear_fwd(const float* X, const float* W, const float* b, float* Y, int64_t M, int N, int K, int act, void* stream);

@@ -362,6 +362,62 @@ def test_bf16_split_decoder_kernels_are_as_accurate_as_the_fp32_ones(ops, P, lea
         assert b <= 2 * a + 2e-4, (fp32, split)
 
 
+@pytest.mark.parametrize("P,leaky,gl", [(1000, False, 1.0), (128 * 300 + 77, True, 0.5), (128 * 257 + 5, False, 1.0)])
+def test_fused_decoder_training_kernel_equals_forward_plus_backward(ops, P, leaky, gl):
+    """gngf_decoder_train (forward + MSE gradient + backward of the decoder in one launch, hidden layers in registers) against
+    the two-kernel path on the same inputs: rgb, the loss value, d enc and the six parameter gradients.  The forward layers of
+    the fused kernel run on the bf16 pipe (exact three-way split) instead of the fp32 pipe, so equality is to fp32 rounding;
+    a hidden unit within rounding of 0 may switch sides in a few pixels (99.9 % quantile on d enc)."""
+    from collision_handling_in_instantngp_amd import _lib
+    rng = np.random.default_rng(P)
+    x = (0.5 * rng.standard_normal((P, 32))).astype(np.float32)
+    tgt = t(rng.random((P, 3)).astype(np.float32))
+    dims = [32, 64, 64, 3]
+    ws = []
+    for i in range(3):
+        ws += [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32), (0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32)]
+    acts = (ops.ACT_LEAKY if leaky else ops.ACT_RELU,) * 2 + (ops.ACT_SIGMOID,)
+    res = {}
+    old = (ops.DECODER_TRAIN_FUSION, ops.CHECK_FUSED_GLOSS)
+    ops.CHECK_FUSED_GLOSS = True
+    try:
+        for fusion in (False, True):
+            ops.DECODER_TRAIN_FUSION = fusion
+            xt = t(x).requires_grad_()
+            params = [t(w).requires_grad_() for w in ws]
+            _lib.PROFILE = {}
+            y = ops.decoder_apply(xt, acts, params, fused=True, mse_target=tgt, mse_gloss=gl)
+            loss = ops.mse_loss(y, tgt)
+            (loss if gl == 1.0 else gl * loss).backward()
+            torch.cuda.synchronize()
+            names = set(_lib.PROFILE)
+            _lib.PROFILE = None
+            assert ("gngf_decoder_train" in names) == fusion and ("gngf_decoder_bwd" in names) == (not fusion), names
+            res[fusion] = [y.detach(), loss.detach(), xt.grad] + [p.grad for p in params]
+    finally:
+        _lib.PROFILE = None
+        ops.DECODER_TRAIN_FUSION, ops.CHECK_FUSED_GLOSS = old
+    a, b = res[False], res[True]
+    close(b[0], a[0].cpu().numpy(), 0, 5e-7, "fused training kernel: rgb vs decoder_fwd")
+    close(b[1], a[1].cpu().numpy(), 1e-6, 0, "fused training kernel: loss value")
+    rel = (a[2] - b[2]).abs().max(1).values / a[2].abs().max()
+    assert float(torch.quantile(rel, 0.999)) <= 2e-6, float(torch.quantile(rel, 0.999))
+    # (one switched hidden unit moves a summed gradient by one pixel's share of it: ~1e-4 .. 1e-3 of its maximum at these sizes)
+    for ga, gb, nm in zip(a[3:], b[3:], ("dW0", "db0", "dW1", "db1", "dW2", "db2")):
+        assert float((ga - gb).abs().max() / ga.abs().max()) <= 1e-3, nm
+        assert float((ga - gb).abs().median() / ga.abs().max()) <= 2e-6, nm        # ... and only the rows / columns of that unit
+    # a different gradient than the promised one must be noticed (CHECK_FUSED_GLOSS) rather than silently ignored
+    ops.CHECK_FUSED_GLOSS = True
+    try:
+        xt = t(x).requires_grad_()
+        params = [t(w).requires_grad_() for w in ws]
+        y = ops.decoder_apply(xt, acts, params, fused=True, mse_target=tgt, mse_gloss=gl)
+        with pytest.raises(RuntimeError):
+            (3.0 * gl * ops.mse_loss(y, tgt)).backward()
+    finally:
+        ops.CHECK_FUSED_GLOSS = old[1]
+
+
 @pytest.mark.parametrize("n", [(1, 3), (7, 3), (1000, 3), (4099, 4), (2 ** 18 + 5, 3)])
 def test_mse_kernels_vs_numpy(ops, n):
     """csrc/loss.hip: value and gradient of torch.nn.MSELoss (reference utils.py:99), incl. a non-unit upstream gradient,
