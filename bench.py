@@ -215,7 +215,7 @@ def timed(step, steps, warmup, world):
 
 ENTRY_NAMES = {"gngf_bin_pixels": "bin_pixels", "gngf_encode_tiled_prepare": "prepare(bin+vertex_fwd+clears)", "gngf_vertex_grid_fwd": "vertex_fwd", "gngf_encode_tiled_fwd": "encode_fwd:tiled",
                "gngf_encode_tiled_bwd": "encode_bwd:tiled", "gngf_vertex_grid_bwd_sorted": "vertex_bwd", "gngf_vertex_grid_bwd": "vertex_bwd",
-               "gngf_decoder_fwd": "decoder_fwd", "gngf_decoder_bwd": "decoder_bwd", "gngf_decoder_reduce": "decoder_reduce", "gngf_mse_fwd": "mse_fwd", "gngf_mse_bwd": "mse_bwd",
+               "gngf_decoder_fwd": "decoder_fwd", "gngf_decoder_bwd": "decoder_bwd", "gngf_decoder_train": "decoder_train", "gngf_decoder_reduce": "decoder_reduce", "gngf_mse_fwd": "mse_fwd", "gngf_mse_bwd": "mse_bwd",
                "gngf_encode_fwd": "encode_fwd:direct", "gngf_encode_bwd": "encode_bwd:direct"}
 
 
@@ -498,16 +498,19 @@ def main():
                         "note": "achieved/frac use the bytes this implementation must move per launch (binned pixel record + one "
                                 "enc / d-enc row per pixel); SURVEY §8(d)'s per-instance figure (zero reuse, one table gather per "
                                 "pixel-corner) is kept as algorithmic_survey_bytes: the per-vertex de-duplication removes that traffic"}
-            if base in ("decoder_fwd", "decoder_bwd"):
-                fl = dec_flops * (1 if base == "decoder_fwd" else 2)
+            if base in ("decoder_fwd", "decoder_bwd", "decoder_train"):
+                fl = dec_flops * {"decoder_fwd": 1, "decoder_bwd": 2, "decoder_train": 3}[base]
                 ach = fl * P / t / 1e12
+                notes = {"decoder_fwd": "exact fp32 on v_mfma_f32_32x32x2_f32",
+                         "decoder_bwd": "fp32-accurate arithmetic priced against the dense fp32 MFMA peak; at 32 input features the backward "
+                                        "kernel runs two of its six products on the bf16 pipe with an exact three-way split (DESIGN.md section 3)",
+                         "decoder_train": "forward + MSE gradient + backward of the decoder in ONE launch (gngf_decoder_train: the hidden layers stay "
+                                          "in registers); fp32-accurate arithmetic priced against the dense fp32 MFMA peak — the forward layers, dh1 and "
+                                          "d enc run on the bf16 pipe with an exact three-way split, the weight gradients on the fp32 pipe "
+                                          "(DESIGN.md section 3)"}
                 return {"bound": "mfma", "kernel": name, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc(name),
-                        "avg_launch_ms": t * 1e3, "algorithmic_flops_per_pixel": fl, "pixels_per_launch": P,
-                        "note": "fp32-accurate arithmetic priced against the dense fp32 MFMA peak; at 32 input features the backward "
-                                "kernel runs two of its six products (96 of 196 fp32-MFMA equivalents per tile) on the bf16 pipe with an "
-                                "exact three-way split (DESIGN.md section 3, hybrid backward)" if base == "decoder_bwd" else
-                                "exact fp32 on v_mfma_f32_32x32x2_f32"}
+                        "frac": min(1.0, ach / MFMA_F32_PEAK_TFLOPS), "traffic": pmc(name),
+                        "avg_launch_ms": t * 1e3, "algorithmic_flops_per_pixel": fl, "pixels_per_launch": P, "note": notes[base]}
             return None
 
         roof = roof_enc = None
@@ -541,10 +544,10 @@ def main():
             "modes": results, "kernel_ms": {k: (v * 1e3 if isinstance(v, float) else v) for k, v in kt.items()},
             "roofline": roof, "roofline_encoder": roof_enc, "roofline_step": roof_step,
         }
-        if roof is not None and roof.get("kernel") == "decoder_bwd" and in_graph_ms:
+        if roof is not None and roof.get("kernel") in ("decoder_bwd", "decoder_train") and in_graph_ms:
             # same kernel, timed by its own device-clock stamps inside the replayed graph (agrees with rocprofv3's average)
             roof["in_graph_launch_ms"] = in_graph_ms
-            roof["in_graph_frac"] = roof["algorithmic_flops_per_pixel"] * P / (in_graph_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS
+            roof["in_graph_frac"] = min(1.0, roof["algorithmic_flops_per_pixel"] * P / (in_graph_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.mode, a.cpu_sample)
         assert line["n_gpus"] == a.gpus

@@ -690,7 +690,10 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     STAMP(0);
     float f1[2][32];
     if constexpr (TRAIN) {
-      // ---- forward of the tile on the bf16 pipe (exact three-way split): h1 = act(W0 x + b0), h2 = act(W1 h1 + b1)
+      // ---- forward of the tile on the bf16 pipe (exact three-way split): h1 = act(W0 x + b0), h2 = act(W1 h1 + b1).
+      // Software pipeline: the planes of the next k-chunk are requested and the next chunk's operand is split while the six
+      // cross products of the current chunk (x 2 output tiles) issue; the h1 image rides under layer 2.
+      Planes pa0 = load_planes(w0f + lane), pa1 = load_planes(w0f + 3 * 64 + lane);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -700,37 +703,82 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
 #pragma unroll
           for (int e = 0; e < 4; ++e) { acc1[t][4 * g + e] = q0[e]; acc2[t][4 * g + e] = q1[e]; }
         }
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const Planes xs = split8(xr[8 * c], xr[8 * c + 1], xr[8 * c + 2], xr[8 * c + 3], xr[8 * c + 4], xr[8 * c + 5], xr[8 * c + 6], xr[8 * c + 7]);
-        mfma_split2(load_planes(w0f + (2 * c) * 3 * 64 + lane), load_planes(w0f + (2 * c + 1) * 3 * 64 + lane), xs, acc1[0], acc1[1]);
+      Planes zc = split8(xr[0], xr[1], xr[2], xr[3], xr[4], xr[5], xr[6], xr[7]);
+      // one pair of products (both output tiles) + a quarter of the next operand's split (values nv[2 q], nv[2 q + 1])
+      unsigned nh[4], nm[4], nl[4];
+      auto quarter = [&](int q, float a, float b) {
+        nh[q] = pack_hi16(b, a);
+        const float ra = trunc_residual(a), rb = trunc_residual(b);
+        nm[q] = pack_hi16(rb, ra);
+        nl[q] = pack_hi16(trunc_residual(rb), trunc_residual(ra));
+      };
+      auto take_next = [&]() {
+        zc.hi = u32x4{nh[0], nh[1], nh[2], nh[3]}; zc.mid = u32x4{nm[0], nm[1], nm[2], nm[3]}; zc.lo = u32x4{nl[0], nl[1], nl[2], nl[3]};
+      };
+      {   // layer 1, chunk 0 (carries: planes of chunk 1, split of x[8 .. 15])
+        const Planes na0 = load_planes(w0f + 2 * 3 * 64 + lane), na1 = load_planes(w0f + 3 * 3 * 64 + lane);
+        acc1[0] = mfma_b(pa0.hi, zc.lo, acc1[0]);  acc1[1] = mfma_b(pa1.hi, zc.lo, acc1[1]);  quarter(0, xr[8], xr[9]);   STEP_END();
+        acc1[0] = mfma_b(pa0.lo, zc.hi, acc1[0]);  acc1[1] = mfma_b(pa1.lo, zc.hi, acc1[1]);  quarter(1, xr[10], xr[11]); STEP_END();
+        acc1[0] = mfma_b(pa0.mid, zc.mid, acc1[0]); acc1[1] = mfma_b(pa1.mid, zc.mid, acc1[1]); quarter(2, xr[12], xr[13]); STEP_END();
+        acc1[0] = mfma_b(pa0.hi, zc.mid, acc1[0]); acc1[1] = mfma_b(pa1.hi, zc.mid, acc1[1]); quarter(3, xr[14], xr[15]); STEP_END();
+        acc1[0] = mfma_b(pa0.mid, zc.hi, acc1[0]); acc1[1] = mfma_b(pa1.mid, zc.hi, acc1[1]);
+        acc1[0] = mfma_b(pa0.hi, zc.hi, acc1[0]);  acc1[1] = mfma_b(pa1.hi, zc.hi, acc1[1]);  STEP_END();
+        take_next(); pa0 = na0; pa1 = na1;
+      }
+      {   // layer 1, chunk 1 (carries: planes of layer 2's chunk 0)
+        const Planes na0 = load_planes(w1f + lane), na1 = load_planes(w1f + 3 * 64 + lane);
+        mfma_split2(pa0, pa1, zc, acc1[0], acc1[1]);
+        STEP_END();
+        pa0 = na0; pa1 = na1;
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[t][r] = act_split<LEAKY>(acc1[t][r]);
+        for (int r = 0; r < 16; ++r) acc1[t][r] = hidden_act<LEAKY>(acc1[t][r]);      // (one instruction; its readers are VALU / LDS stores)
+      zc = split8(acc1[0][0], acc1[0][1], acc1[0][2], acc1[0][3], acc1[0][4], acc1[0][5], acc1[0][6], acc1[0][7]);
       STEP_END();
       static_for<4>([&](auto CC) {
-        constexpr int cc = CC.value, t = cc >> 1, r0 = 8 * (cc & 1);
-        const Planes hs = split8(acc1[t][r0], acc1[t][r0 + 1], acc1[t][r0 + 2], acc1[t][r0 + 3], acc1[t][r0 + 4], acc1[t][r0 + 5],
-                                 acc1[t][r0 + 6], acc1[t][r0 + 7]);
-        mfma_split2(load_planes(w1f + (2 * cc) * 3 * 64 + lane), load_planes(w1f + (2 * cc + 1) * 3 * 64 + lane), hs, acc2[0], acc2[1]);
-        static_for<8>([&](auto E) {                        // h1 image (image B), 8 stores per chunk
-          constexpr int e = 8 * cc + E.value, tt = e >> 4, r = e & 15;
-          lds_store<kImgB + (32 * tt + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile, acc1[tt][r]);
-        });
-        STEP_END();
+        constexpr int cc = CC.value, nc = cc + 1;
+        Planes na0, na1;
+        if constexpr (nc < 4) { na0 = load_planes(w1f + (2 * nc) * 3 * 64 + lane); na1 = load_planes(w1f + (2 * nc + 1) * 3 * 64 + lane); }
+        auto step = [&](auto PP, u32x4 a0, u32x4 a1, u32x4 b) {
+          constexpr int pp = PP.value;
+          acc2[0] = mfma_b(a0, b, acc2[0]);
+          acc2[1] = mfma_b(a1, b, acc2[1]);
+          if constexpr (nc < 4 && pp < 4) {
+            constexpr int t = nc >> 1, r0 = 8 * (nc & 1) + 2 * pp;
+            quarter(pp, acc1[t][r0], acc1[t][r0 + 1]);
+          }
+          if constexpr (pp < 4) {                           // h1 image (image B): 8 stores per chunk
+            static_for<2>([&](auto E) {
+              constexpr int e = 8 * cc + 2 * pp + E.value, tt = e >> 4, r = e & 15;
+              lds_store<kImgB + (32 * tt + (r & 3) + 8 * (r >> 2)) * kImgStride * 4>(wTile, acc1[tt][r]);
+            });
+          }
+          STEP_END();
+        };
+        step(std::integral_constant<int, 0>{}, pa0.hi, pa1.hi, zc.lo);
+        step(std::integral_constant<int, 1>{}, pa0.lo, pa1.lo, zc.hi);
+        step(std::integral_constant<int, 2>{}, pa0.mid, pa1.mid, zc.mid);
+        step(std::integral_constant<int, 3>{}, pa0.hi, pa1.hi, zc.mid);
+        step(std::integral_constant<int, 4>{}, pa0.mid, pa1.mid, zc.hi);
+        step(std::integral_constant<int, 5>{}, pa0.hi, pa1.hi, zc.hi);
+        if constexpr (nc < 4) { take_next(); pa0 = na0; pa1 = na1; }
       });
+      f32x4 w2v[8];                                        // output-layer weights: requested before the activation burst
+#pragma unroll
+      for (int g = 0; g < 8; ++g) w2v[g] = *reinterpret_cast<const f32x4*>(w2L + (g * 64 + lane) * 4);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[t][r] = act_split<LEAKY>(acc2[t][r]);
+        for (int r = 0; r < 16; ++r) acc2[t][r] = hidden_act<LEAKY>(acc2[t][r]);
+      STEP_END();                                          // (the 4x4 MFMAs below must not follow their operand's v_max directly)
       // ---- output layer on v_mfma_f32_4x4x1 (as decoder_fwd_kernel), rgb out, d rgb from it and the target
       {
         f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-          const f32x4 w = *reinterpret_cast<const f32x4*>(w2L + (g * 64 + lane) * 4);
+          const f32x4 w = w2v[g];
           o0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.x, acc2[(4 * g) >> 4][(4 * g) & 15], o0, 0, 0, 0);
           o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.y, acc2[(4 * g + 1) >> 4][(4 * g + 1) & 15], o1, 0, 0, 0);
           o0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.z, acc2[(4 * g + 2) >> 4][(4 * g + 2) & 15], o0, 0, 0, 0);

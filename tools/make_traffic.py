@@ -7,8 +7,7 @@ groups = {
     "prepare(bin+vertex_fwd+clears)": ["gngf::bin_count_ride_kernel", "gngf::bin_rowscan_kernel", "gngf::bin_scan_kernel", "gngf::bin_scatter_ride_kernel<2"],
     "encode_fwd:tiled": ["gngf::tiled_fwd_kernel<2>"],
     "encode_bwd:tiled": ["gngf::tiled_bwd_kernel<2>", "gngf::gather_partials_kernel<2>"],
-    "decoder_fwd": ["gngf::decoder_fwd_kernel<32"],
-    "decoder_bwd": ["gngf::decoder_bwd_kernel<32"],
+    "decoder_train": ["gngf::decoder_bwd_kernel<32, false, true, false, true, true>"],     # forward + backward in one launch
     "vertex_bwd": ["gngf::vertex_bwd_sorted_kernel<2"],
 }
 def pick(prefix, counter):          # kernel names carry their full template argument lists: match by prefix
