@@ -32,8 +32,8 @@ if os.environ.get("GNGF_LIB_PATH", "").endswith("stamps.so"):
     buf = (ctypes.c_uint64 * 16)()
     _lib.load().gngf_debug_read_stamps.argtypes = [ctypes.c_void_p]
     _lib.load().gngf_debug_read_stamps(buf)
-    names = ["load/copy", "forward (L1, L2, L3, d rgb)", "-", "dh2+dact", "img+dW1", "dh1+dact", "img+dW0", "dX+store"]
-    tot = sum(buf[:8])
-    for n, v in zip(names, buf[:8]):
+    names = ["load/copy", "forward (rest: act2, L3, sigmoid, d rgb)", "(dbg) fwd: bias, x split, L1, act1", "dh2+dact", "img+dW1", "dh1+dact", "img+dW0", "dX+store", "(dbg) fwd: split of chunk 0", "(dbg) fwd: L2 + h1 image"]
+    tot = sum(buf[:10])
+    for n, v in zip(names, buf[:10]):
         print(f"  {n:28s} {v/32:9.0f} cycles/tile  {100*v/max(tot,1):5.1f}%")
     print("  total per tile", tot / 32)
