@@ -2,6 +2,7 @@
 all arithmetic happens in the HIP kernels.  CPU tensors raise (no fallback)."""
 import ctypes as _ct
 import math as _math
+import os
 
 import torch
 
@@ -622,7 +623,10 @@ DP_MEAN = None              # data parallel: callable averaging a tensor over ra
 DP_MAX = None               # data parallel: callable max-reducing a small tensor over ranks in place (coordinate bounds)
 TILED_CHUNK = None          # max pixels per (tile, chunk) work item; None: about two average tiles' worth (see EncodePlan)
 TILED_MIN_PIXELS = 1 << 14  # below this the binning overhead is not worth it
-TILED_CELLS_PER_PIXEL = 4.0 # a level is staged while N_l^2 <= this * P (sparser levels: direct form)
+# a level is staged while N_l^2 <= this * P (sparser levels: direct form).  Measured at the cfg4 shape (2^20 px, N -> 4095):
+# 8 also stages the level with 7.6 cells per pixel — its direct backward drops 412 -> 210 us but the vertex stage and the dense
+# per-item images of that level cost more (step 1.43 -> 1.58 ms)
+TILED_CELLS_PER_PIXEL = 4.0
 TILED_LDS_LIMIT = 48 * 1024    # forward image; the backward image (64-bit accumulators) is twice this
 
 
