@@ -75,7 +75,7 @@ SIGNATURES = {
     "gngf_adam_step": [_P, _I, _L, _P, _P, _P, _I, _F, _F, _F, _F, _P],
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _RETURNS_INT64 = {"gngf_decoder_hidden_floats", "gngf_slot_bitmap_words"}
 _lib = None
 

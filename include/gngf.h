@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNGF_ABI_VERSION 5
+#define GNGF_ABI_VERSION 6
 #define GNGF_MAX_LEVELS 32
 #define GNGF_MAX_TOPK 32
 
