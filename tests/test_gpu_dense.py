@@ -362,8 +362,9 @@ def test_bf16_split_decoder_kernels_are_as_accurate_as_the_fp32_ones(ops, P, lea
         assert b <= 2 * a + 2e-4, (fp32, split)
 
 
-@pytest.mark.parametrize("P,leaky,gl", [(1000, False, 1.0), (128 * 300 + 77, True, 0.5), (128 * 257 + 5, False, 1.0)])
-def test_fused_decoder_training_kernel_equals_forward_plus_backward(ops, P, leaky, gl):
+@pytest.mark.parametrize("P,leaky,gl,out_dim", [(1000, False, 1.0, 3), (128 * 300 + 77, True, 0.5, 3), (128 * 257 + 5, False, 1.0, 3),
+                                               (3000, False, 1.0, 1)])
+def test_fused_decoder_training_kernel_equals_forward_plus_backward(ops, P, leaky, gl, out_dim):
     """gngf_decoder_train (forward + MSE gradient + backward of the decoder in one launch, hidden layers in registers) against
     the two-kernel path on the same inputs: rgb, the loss value, d enc and the six parameter gradients.  The forward layers of
     the fused kernel run on the bf16 pipe (exact three-way split) instead of the fp32 pipe, so equality is to fp32 rounding;
@@ -371,8 +372,8 @@ def test_fused_decoder_training_kernel_equals_forward_plus_backward(ops, P, leak
     from collision_handling_in_instantngp_amd import _lib
     rng = np.random.default_rng(P)
     x = (0.5 * rng.standard_normal((P, 32))).astype(np.float32)
-    tgt = t(rng.random((P, 3)).astype(np.float32))
-    dims = [32, 64, 64, 3]
+    tgt = t(rng.random((P, out_dim)).astype(np.float32))          # out_dim 1: the reference's should_bw
+    dims = [32, 64, 64, out_dim]
     ws = []
     for i in range(3):
         ws += [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32), (0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32)]
