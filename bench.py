@@ -375,8 +375,11 @@ def main():
             try:
                 if world > 1:
                     parallel.defer_vertex_stage(True)
-                # steps % 4 == 0: four steps per replayed graph (a replay costs ~9 us of launch latency whatever it holds)
-                unroll = 4 if (world == 1 and steps % 4 == 0 and warmup >= 0 and a.unroll) else 1
+                # several steps per replayed graph (a replay costs ~9 us of launch latency whatever it holds): the first of
+                # 4, 5, 6, 7, 8, 3, 2 that divides K, so that exactly K steps are timed
+                unroll = 1
+                if world == 1 and a.unroll:
+                    unroll = next((u for u in (4, 5, 6, 7, 8, 3, 2) if steps % u == 0), 1)
                 gs = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3, unroll=unroll)
                 if unroll > 1:
                     gs.run_many([(xy, target)] * unroll)
