@@ -17,7 +17,8 @@ Modes (--mode picks the headline; the others are reported in the same line under
                  the per-vertex top-K table is a function of frozen weights and is rebuilt only when they change.
   gngf_learning  cfg2, GNGF indexing with a trainable HPD: every step re-evaluates the HPD on every distinct vertex
                  (MFMA-bound: U x 128 x T contraction) and back-propagates into it.
-  hash           cfg2 shape with plain spatial-hash indexing (should_use_hash_function=True) = BASELINE.json configs[2].
+  hash           BASELINE.json configs[2]: macaw.jpg's own pixel list (508x339, tests/golden/macaw_rgb.npz) at the cfg2 table shape
+                 with plain spatial-hash indexing (should_use_hash_function=True).
   cfg4_hash      BASELINE.json configs[3] per-GPU shape: synthetic 4096^2 image, T = 2^22, N 16->4095, 2^20 px per GPU.
   cfg5_hash_fp16 BASELINE.json configs[4] per-GPU shape: synthetic 8192^2 image, F = 4, T = 2^24, fp16 tables, N 16->8191.
 """
@@ -37,10 +38,12 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
 
 SHAPES = {     # L, F, T, K, n_min, n_max, fp16 tables, image
     "cfg2": dict(L=16, F=2, T=2 ** 19, K=4, n_min=16, n_max=512, half=False, image="strawberry"),
+    "cfg3": dict(L=16, F=2, T=2 ** 19, K=4, n_min=16, n_max=512, half=False, image="macaw"),
     "cfg4": dict(L=16, F=2, T=2 ** 22, K=4, n_min=16, n_max=4096, half=False, image=4096),
     "cfg5": dict(L=16, F=4, T=2 ** 24, K=4, n_min=16, n_max=8192, half=True, image=8192),
 }
-MODES = {"gngf_frozen": "cfg2", "gngf_learning": "cfg2", "hash": "cfg2", "cfg4_hash": "cfg4", "cfg5_hash_fp16": "cfg5"}
+MODES = {"gngf_frozen": "cfg2", "gngf_learning": "cfg2", "hash": "cfg3", "cfg4_hash": "cfg4", "cfg5_hash_fp16": "cfg5"}
+XGMI_LINK_GBS = 153.0          # per link and direction (7 links per GPU)
 
 
 def is_hash(mode):
@@ -94,6 +97,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra-modes", action="store_true")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-outputs", dest="full_outputs", action="store_false",
+                    help="skip the extra timing of the step with the reference's index tensor materialised")
     ap.add_argument("--no-unroll", dest="unroll", action="store_false", help="one step per replayed graph")
     ap.add_argument("--cpu-sample", type=int, default=2 ** 20)
     ap.add_argument("--ramp-steps", type=int, default=60, help="untimed steps before the W warm-up steps (clock ramp)")
@@ -119,15 +124,15 @@ def resolve_world(a, environ=None):
 
 # ------------------------------------------------------------------------------------------------ workload
 def make_batch(cfg_name, P, rank, dev):
-    """cfg2: the 339x508 strawberry pixel list (coords = (row,col)/507, main.py:50-51), shuffled and repeated to P pixels
-    (the image has only 172 212 pixels).  cfg4 / cfg5: P pixels drawn from a synthetic S x S uniform-random RGB image
+    """cfg2 / cfg3: the strawberry / macaw pixel list (508 x 339; coords = (row,col)/507, main.py:50-51), shuffled and repeated
+    to P pixels (the images have only 172 212 pixels).  cfg4 / cfg5: P pixels drawn from a synthetic S x S uniform-random RGB image
     (coords (row, col) / (S - 1)), seed 65535 + rank."""
     import numpy as np
     import torch
     c = SHAPES[cfg_name]
     g = torch.Generator().manual_seed(65535 + rank)
-    if c["image"] == "strawberry":
-        img = np.load(os.path.join(ROOT, "tests", "golden", "strawberry_rgb.npz"))["img"]
+    if c["image"] in ("strawberry", "macaw"):
+        img = np.load(os.path.join(ROOT, "tests", "golden", c["image"] + "_rgb.npz"))["img"]
         h, w = img.shape[:2]
         sel = torch.cat([torch.randperm(h * w, generator=g) for _ in range(-(-P // (h * w)))])[:P]
         rows, cols = sel // w, sel % w
@@ -211,6 +216,48 @@ def timed(step, steps, warmup, world):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     return dt
+
+
+def measure_hbm_copy_gbs(dev):
+    """Streaming-copy bandwidth of THIS box, timed in the same run ("the builder must also report a
+    measured streaming-copy bandwidth on the box and the fraction against both"): 512 MiB device-to-device copy, read +
+    write bytes over the HIP-event time of 10 copies."""
+    import torch
+    x = torch.empty(2 ** 27, device=dev)
+    y = torch.empty_like(x)
+    for _ in range(3):
+        y.copy_(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        y.copy_(x)
+    e1.record()
+    torch.cuda.synchronize()
+    gbs = 2 * x.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del x, y
+    torch.cuda.empty_cache()
+    return gbs
+
+
+def exchange_model(net, world):
+    """Bytes one rank hands to the gradient exchange per step and the time a ring all-reduce of them takes on the xGMI links
+    (2 (n-1)/n x bytes per rank, spread over the 7 links of 153 GB/s each when n = 8, over n-1 links otherwise) — a MODEL, not
+    a measurement: it is printed next to the measured step so that the exchange's share is visible without an 8-GPU node."""
+    dp = net.dp
+    staged = dp.deferred[6].numel() * 4 if dp.deferred is not None else 0
+    enc = net.encoding
+    base = enc._grad_base if enc._grad_base is not None else enc._grad_base_fp32
+    direct = 0
+    if base is not None and dp.tables_reduced < base.shape[0]:
+        direct = base[dp.tables_reduced:].numel() * base.element_size()
+    dense = sum(p.grad.numel() * p.grad.element_size() for n_, p in net.named_parameters()
+                if p.grad is not None and "_hash_tables" not in n_)
+    total = staged + direct + dense
+    links = min(7, max(1, world - 1))
+    t = 2.0 * (world - 1) / world * total / (links * XGMI_LINK_GBS * 1e9) if world > 1 else 0.0
+    return {"vertex_grid_bytes": staged, "direct_level_table_bytes": direct, "decoder_and_hpd_bytes": dense, "exchange_bytes_per_step": total,
+            "modelled_ring_allreduce_ms": t * 1e3, "links_used": links, "link_GBs": XGMI_LINK_GBS,
+            "note": "model: ring all-reduce, 2(n-1)/n x bytes per rank over the point-to-point xGMI links; latency not included"}
 
 
 ENTRY_NAMES = {"gngf_bin_pixels": "bin_pixels", "gngf_encode_tiled_prepare": "prepare(bin+vertex_fwd+clears)", "gngf_vertex_grid_fwd": "vertex_fwd", "gngf_encode_tiled_fwd": "encode_fwd:tiled",
@@ -344,12 +391,12 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
     from collision_handling_in_instantngp_amd import ops, parallel, train
-    if world > 1:
-        parallel.enable_vertex_grid_exchange(world)
     P = a.pixels
 
     results = {}
+    broken = False
     in_graph_ms = None
+    hbm_copy = measure_hbm_copy_gbs(dev)          # this box's streaming-copy bandwidth, same run (fractions against it below)
     extra = [] if a.no_extra_modes else [m for m in ("gngf_learning", "hash", "gngf_frozen", "cfg4_hash", "cfg5_hash_fp16") if m != a.mode]
     kt, kcalls = {}, {}
     batches = {}
@@ -365,6 +412,8 @@ def main():
         if learning and head:
             steps, warmup = min(a.steps, 5), min(a.warmup, 1)
         net, models = build_model(mode, dev, bounds)
+        if world > 1:
+            parallel.enable_vertex_grid_exchange(net, world)
         loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
         step = eager_step_fn(net, mode, xy, target, world)
         launch = "eager"
@@ -374,7 +423,7 @@ def main():
             # hold no collective and replay from one hipGraph; the exchange (RCCL) and the vertex stage follow eagerly.
             try:
                 if world > 1:
-                    parallel.defer_vertex_stage(True)
+                    parallel.defer_vertex_stage(net, True)
                 # several steps per replayed graph (a replay costs ~9 us of launch latency whatever it holds): the first of
                 # 4, 5, 6, 7, 8, 3, 2 that divides K, so that exactly K steps are timed
                 unroll = 1
@@ -396,7 +445,7 @@ def main():
             except Exception as e:  # pragma: no cover
                 print(f"[bench] graph capture failed ({e!r}); running eagerly", file=sys.stderr)
                 if world > 1:
-                    parallel.defer_vertex_stage(False)
+                    parallel.defer_vertex_stage(net, False)
                 step = eager_step_fn(net, mode, xy, target, world)
         if not learning:
             # Clock ramp: the chip reaches its steady matrix-core clock only after ~15 ms of sustained work (the same kernel
@@ -408,10 +457,19 @@ def main():
         dt = timed(step, steps // per, -(-warmup // per), world)       # exactly `steps` steps: steps / per replays of `per` steps each
         res = results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                                "launch": launch, "shape": {k: v for k, v in SHAPES[cfg_name].items()}}
+        # the target's own metric: per-instance algorithmic bytes x pixels/s against the HBM peak.  For
+        # GNGF indexing that figure assumes one table gather per (pixel, corner, k); the per-vertex de-duplicated algorithm does
+        # not move those bytes, so its ratio exceeds 1 — it is printed as what it is, next to the hash modes' real fractions.
+        sb_f, sb_b = survey_bytes(mode)
+        sv = (sb_f + sb_b) * P * steps / dt / 1e9
+        res["roofline_survey"] = {"bytes_per_pixel": sb_f + sb_b, "achieved_GBs": sv, "frac_of_8TBs": sv / HBM_PEAK_GBS,
+                                  "frac_of_measured_copy": sv / hbm_copy}
+        if world > 1:
+            res["exchange"] = exchange_model(net, world)
         if SHAPES[cfg_name]["half"]:
             res["table_gradient"] = "fp32 accumulation buffer handed over as param.grad_fp32 (ops.FP16_TABLE_GRAD_FP32), no fp16 .grad copy"
         if learning:
-            st = dict(ops.HPD_LAST_STATS)
+            st = dict(net.hpd_stats)
             fl, gemm = learning_flops(st)
             res["hpd"] = st
             res["roofline"] = {"bound": "mfma", "kernel": "last HPD layer: logits / dW / dh GEMMs (128 x T per distinct vertex), fp32 MFMA",
@@ -449,6 +507,23 @@ def main():
                 del opt, gso
             except Exception as e:  # pragma: no cover
                 res["with_adam_ms_per_step"] = repr(e)
+        if world == 1 and a.graph and not learning and a.full_outputs:
+            # the same step returning the reference's index tensor as well ((P,L,4[,K]) int64, models.py:475-484): the metric's
+            # step turns it off (net.return_indices = False, build_model) — its cost is reported here, never in `value`
+            try:
+                net.return_indices = True
+                gsf = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3)
+                r = gsf(xy, target)
+                assert r.idx is not None and r.idx.shape[0] == P
+                nfull = max(4, steps // 4)
+                dtf = timed(gsf.replay_only, nfull, 2, world)
+                res["with_full_outputs_ms_per_step"] = dtf / nfull * 1e3
+                res["full_outputs_note"] = f"return_indices=True: indices {tuple(r.idx.shape)} int64 materialised every step"
+                del gsf, r
+            except Exception as e:  # pragma: no cover
+                res["with_full_outputs_ms_per_step"] = repr(e)
+            finally:
+                net.return_indices = False
         if (head or learning) and rank == 0 and world == 1:
             try:
                 k_t, k_c = kernel_times_in_step(eager_step_fn(net, mode, xy, target, world), n=(2 if learning else 20),
@@ -461,13 +536,13 @@ def main():
                     if gemm_t > 0 and "roofline" in res:
                         fl, _ = learning_flops(res["hpd"])
                         res["roofline"]["gemm_entries_ms"] = gemm_t * 1e3
-                        res["roofline"]["gemm_entries_frac"] = min(1.0, fl / gemm_t / 1e12 / MFMA_F32_PEAK_TFLOPS)
+                        res["roofline"]["gemm_entries_frac"] = fl / gemm_t / 1e12 / MFMA_F32_PEAK_TFLOPS
             except Exception as e:  # pragma: no cover
                 if head:
                     kt = {"error": repr(e)}
         models.should_use_hash_function = False
         if world > 1:
-            parallel.defer_vertex_stage(False)
+            parallel.defer_vertex_stage(net, False)
         del net, step
         torch.cuda.empty_cache()
 
@@ -495,7 +570,8 @@ def main():
                 per_px = c_fwd if fwd else c_bwd
                 ach = per_px * P / t / 1e9
                 return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": min(1.0, ach / HBM_PEAK_GBS), "traffic": pmc(name), "avg_launch_ms": t * 1e3,
+                        "frac": ach / HBM_PEAK_GBS, "frac_of_measured_copy": (ach / hbm_copy) if hbm_copy else None,
+                        "traffic": pmc(name), "avg_launch_ms": t * 1e3,
                         "compulsory_bytes_per_pixel": per_px, "pixels_per_launch": P,
                         "algorithmic_survey_bytes": (s_fwd if fwd else s_bwd) * P,
                         "note": "achieved/frac use the bytes this implementation must move per launch (binned pixel record + one "
@@ -512,7 +588,7 @@ def main():
                                           "d enc run on the bf16 pipe with an exact three-way split, the weight gradients on the fp32 pipe "
                                           "(DESIGN.md section 3)"}
                 return {"bound": "mfma", "kernel": name, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": min(1.0, ach / MFMA_F32_PEAK_TFLOPS), "traffic": pmc(name),
+                        "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc(name),
                         "avg_launch_ms": t * 1e3, "algorithmic_flops_per_pixel": fl, "pixels_per_launch": P, "note": notes[base]}
             return None
 
@@ -537,8 +613,8 @@ def main():
             "metric": "Mpixels/sec fwd+bwd at L=16,F=2,T=2^19", "value": head["mpix_s"], "unit": "Mpixel/s",
             "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"], "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{MODES[a.mode]}: " + ("strawberry.jpeg 339x508 pixel list shuffled+repeated to 2^20 px/GPU, L=16 F=2 T=2^19 K=4 N 16->512"
-                                                          if MODES[a.mode] == "cfg2" else f"synthetic {c['image']}^2 image, L={L} F={F} T={c['T']} N {c['n_min']}->{c['n_max']}")
+            "config": {"workload": f"{MODES[a.mode]}: " + (f"{c['image']} image (339x508) pixel list shuffled+repeated to 2^20 px/GPU, L=16 F=2 T=2^19 K=4 N 16->512"
+                                                          if MODES[a.mode] in ("cfg2", "cfg3") else f"synthetic {c['image']}^2 image, L={L} F={F} T={c['T']} N {c['n_min']}->{c['n_max']}")
                                    + f", {a.mode} indexing, random-init weights, MSE loss, fwd+bwd (no optimizer)",
                        "mode": a.mode, "pixels_per_gpu": P, "parallelism": f"dp{world}",
                        "untimed_ramp_steps_before_warmup": a.ramp_steps, "launch": head["launch"]},
@@ -546,18 +622,38 @@ def main():
             "backend": (a.backend if world > 1 else None),
             "modes": results, "kernel_ms": {k: (v * 1e3 if isinstance(v, float) else v) for k, v in kt.items()},
             "roofline": roof, "roofline_encoder": roof_enc, "roofline_step": roof_step,
+            "hbm_copy_measured_GBs": hbm_copy, "hbm_peak_GBs": HBM_PEAK_GBS,
+            "roofline_survey": {m: r_["roofline_survey"]["frac_of_8TBs"] for m, r_ in results.items() if "roofline_survey" in r_},
+            "roofline_survey_note": "SURVEY 8(d) algorithmic bytes/pixel x pixels/s / 8 TB/s per mode (the target's '>= 60 % of the HBM-read "
+                                    "roofline' is this number for the hash modes); per-mode detail incl. the fraction of the measured copy "
+                                    "bandwidth under modes.<mode>.roofline_survey.  GNGF modes exceed 1 by construction (see DESIGN.md section 5)",
         }
         if roof is not None and roof.get("kernel") in ("decoder_bwd", "decoder_train") and in_graph_ms:
             # same kernel, timed by its own device-clock stamps inside the replayed graph (agrees with rocprofv3's average)
             roof["in_graph_launch_ms"] = in_graph_ms
-            roof["in_graph_frac"] = min(1.0, roof["algorithmic_flops_per_pixel"] * P / (in_graph_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS)
+            roof["in_graph_frac"] = roof["algorithmic_flops_per_pixel"] * P / (in_graph_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.mode, a.cpu_sample)
         assert line["n_gpus"] == a.gpus
         print(json.dumps(line))
+        # a fraction of a peak above 1 is a broken measurement, not a result: show it (nothing is clamped) and fail the run
+        fr = {"roofline.frac": (roof or {}).get("frac"), "roofline.in_graph_frac": (roof or {}).get("in_graph_frac"),
+              "roofline_encoder.frac": (roof_enc or {}).get("frac"), "roofline_step.mfma_frac": roof_step.get("mfma_frac"),
+              "roofline_step.hbm_frac": roof_step.get("hbm_frac")}
+        for m, r_ in results.items():
+            fr[f"modes.{m}.roofline.frac"] = (r_.get("roofline") or {}).get("frac")
+            fr[f"modes.{m}.roofline.gemm_entries_frac"] = (r_.get("roofline") or {}).get("gemm_entries_frac")
+            if is_hash(m):
+                fr[f"modes.{m}.roofline_survey.frac_of_8TBs"] = r_["roofline_survey"]["frac_of_8TBs"]
+        bad = {k: v for k, v in fr.items() if isinstance(v, float) and v > 1.05}
+        if bad:
+            print(f"bench.py: fraction(s) of a hardware peak above 1.05 — the measurement is broken: {bad}", file=sys.stderr)
+            broken = True
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if broken:
+        sys.exit(4)
 
 
 if __name__ == "__main__":

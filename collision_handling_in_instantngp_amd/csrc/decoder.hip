@@ -1269,8 +1269,9 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
 __global__ void __launch_bounds__(1024)
 decoder_reduce_kernel(const float* __restrict__ slabs, int nslabs, int nslab, int in_dim, int out_dim,
                       float* __restrict__ dW0, float* __restrict__ db0, float* __restrict__ dW1, float* __restrict__ db1,
-                      float* __restrict__ dW2, float* __restrict__ db2, float* __restrict__ absmax) {
-  decoder_reduce_block(blockIdx.x, slabs, nslabs, nslab, in_dim, out_dim, dW0, db0, dW1, db1, dW2, db2, absmax);
+                      float* __restrict__ dW2, float* __restrict__ db2, float* __restrict__ absmax,
+                      const float* __restrict__ promised, const float* __restrict__ arrived) {
+  decoder_reduce_block(blockIdx.x, slabs, nslabs, nslab, in_dim, out_dim, dW0, db0, dW1, db1, dW2, db2, absmax, promised, arrived);
 }
 
 template <int KIN>
@@ -1303,10 +1304,16 @@ using namespace gngf;
 
 // Switches the decoder between the fp32-MFMA kernels and the split-bf16 ones (same results to fp32 rounding); returns the
 // previous setting.  With the split kernels the hidden-layer buffer is neither written nor read.
+// Returns -1 (and changes nothing) when the library was built without them (the default: make SPLIT=1 builds them).
 extern "C" int gngf_set_decoder_split_bf16(int on) {
+#if defined(GNGF_DECODER_SPLIT_KERNELS)
   const int prev = g_decoder_split;
   g_decoder_split = on ? 1 : 0;
   return prev;
+#else
+  (void)on;
+  return -1;
+#endif
 }
 // Switch for the hybrid backward kernel (see g_decoder_bwd_hybrid); returns the previous setting.
 extern "C" int gngf_set_decoder_bwd_hybrid(int on) {
@@ -1342,6 +1349,7 @@ extern "C" int gngf_decoder_fwd(const float* enc, const float* W0, const float* 
   const int64_t tiles = (P + 127) / 128;
   const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);       // one persistent workgroup per CU
   const size_t smem = sizeof(float) * (size_t)raw_offsets(in_dim).total;
+#if defined(GNGF_DECODER_SPLIT_KERNELS)
   if (decoder_split_applies(in_dim)) {
     hipStream_t s = as_stream(stream);
     const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);     // two persistent workgroups per CU
@@ -1355,6 +1363,7 @@ extern "C" int gngf_decoder_fwd(const float* enc, const float* W0, const float* 
     }
     GNGF_RETURN_LAUNCH();
   }
+#endif
   DISPATCH_KIN(in_dim, {
     using Kern = void (*)(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
                           float*, int64_t, int, int);
@@ -1390,6 +1399,7 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
     if (e != hipSuccess) return (int)e;
   } else {
     GNGF_CHECK_ARG(enc && rgb && (target ? gloss != nullptr : drgb != nullptr) && W0 && b0 && W1 && b1 && W2 && denc);
+#if defined(GNGF_DECODER_SPLIT_KERNELS)
     if (decoder_split_applies(in_dim) && in_dim == 32) {
       const size_t main_loop = SplitBwd<32>::kMainBytes, epilogue = sizeof(float) * 4 * (size_t)nslab;
       const size_t smem = main_loop > epilogue ? main_loop : epilogue;
@@ -1397,7 +1407,9 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
       fn<<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, P, out_dim, target, gloss);
-    } else if (g_decoder_bwd_hybrid && in_dim == 32 && hidden) {
+    } else
+#endif
+    if (g_decoder_bwd_hybrid && in_dim == 32 && hidden) {
       const size_t smem = bwd_smem_bytes_hybrid(out_dim);
       auto fn = leaky ? decoder_bwd_kernel<32, true, true, false, true> : decoder_bwd_kernel<32, false, true, false, true>;
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1427,7 +1439,7 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
   }
   if (reduce_here)
     decoder_reduce_kernel<<<dim3((unsigned)((nslab + 63) / 64)), dim3(1024), 0, s>>>(slabs, nslabs, nslab, in_dim, out_dim, dW0,
-                                                                                     db0, dW1, db1, dW2, db2, denc_absmax);
+                                                                                     db0, dW1, db1, dW2, db2, denc_absmax, nullptr, nullptr);
   GNGF_RETURN_LAUNCH();
 }
 
@@ -1456,20 +1468,24 @@ extern "C" int gngf_decoder_train(const float* enc, const float* target, const f
   if (e != hipSuccess) return (int)e;
   if (reduce_here)
     decoder_reduce_kernel<<<dim3((unsigned)((nslab + 63) / 64)), dim3(1024), 0, s>>>(slabs, nslabs, nslab, in_dim, out_dim, dW0,
-                                                                                     db0, dW1, db1, dW2, db2, denc_absmax);
+                                                                                     db0, dW1, db1, dW2, db2, denc_absmax, nullptr, nullptr);
   GNGF_RETURN_LAUNCH();
 }
 
 // Second half of gngf_decoder_bwd when it was called without gradient pointers: slabs -> the six gradients (+ max |denc|).
 // Separate so that it can run on another stream beside the encoder backward, which only needs the per-slab maxima
 // (the last word of every slab: slabs[s * gngf_decoder_slab_floats() + gngf_decoder_slab_floats() - 1]).
+// gloss_promised / gloss_arrived (device scalars, both or neither): the loss gradient gngf_decoder_train was given and the one
+// autograd delivered afterwards; if they differ (relative 1e-6) every gradient is written as NaN instead (see promise_broken).
 extern "C" int gngf_decoder_reduce(const float* slabs, float* dW0, float* db0, float* dW1, float* db1, float* dW2, float* db2,
-                                   float* denc_absmax, int64_t P, int in_dim, int out_dim, void* stream) {
+                                   float* denc_absmax, const float* gloss_promised, const float* gloss_arrived, int64_t P,
+                                   int in_dim, int out_dim, void* stream) {
   GNGF_CHECK_ARG(P >= 0 && in_dim > 0 && in_dim <= 64 && out_dim > 0 && out_dim <= 4);
-  GNGF_CHECK_ARG(slabs && dW0 && db0 && dW1 && db1 && dW2 && db2);
+  GNGF_CHECK_ARG(slabs && dW0 && db0 && dW1 && db1 && dW2 && db2 && (!gloss_promised == !gloss_arrived));
   const int nslab = slab_size(in_dim, out_dim);
   decoder_reduce_kernel<<<dim3((unsigned)((nslab + 63) / 64)), dim3(1024), 0, as_stream(stream)>>>(
-      slabs, gngf_decoder_bwd_slabs(P), nslab, in_dim, out_dim, dW0, db0, dW1, db1, dW2, db2, denc_absmax);
+      slabs, gngf_decoder_bwd_slabs(P), nslab, in_dim, out_dim, dW0, db0, dW1, db1, dW2, db2, denc_absmax, gloss_promised,
+      gloss_arrived);
   GNGF_RETURN_LAUNCH();
 }
 

@@ -294,6 +294,7 @@ struct RideAlong {
   const float* slabs;
   float *dW0, *db0, *dW1, *db1, *dW2, *db2;
   int nslabs, nslab, in_dim, out_dim, first_block;
+  const float *promised, *arrived;      // loss gradient the fused training decoder ran with / the one that arrived (gngf_common.h: promise_broken)
 };
 
 // The value of the fused pixel loss (gngf_common.h: mse_sum_block) riding on the same launch: workgroups
@@ -484,7 +485,7 @@ tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
   if (ride.slabs && (int)blockIdx.x >= ride.first_block) {
     static_assert(kTB == 1024, "decoder_reduce_block is written for 1024-thread workgroups");
     decoder_reduce_block((int)blockIdx.x - ride.first_block, ride.slabs, ride.nslabs, ride.nslab, ride.in_dim, ride.out_dim, ride.dW0,
-                         ride.db0, ride.dW1, ride.db1, ride.dW2, ride.db2, nullptr);
+                         ride.db0, ride.dW1, ride.db1, ride.dW2, ride.db2, nullptr, ride.promised, ride.arrived);
     return;
   }
   if ((int)blockIdx.x >= *n_items) return;
@@ -526,7 +527,8 @@ tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
   gmax = wmax[0];
 #pragma unroll
   for (int w = 1; w < kTB / 64; ++w) gmax = (wmax[w] > gmax || wmax[w] != wmax[w]) ? wmax[w] : gmax;
-  const bool finite = gmax < INFINITY;                     // false for inf and NaN
+  // d enc of a fused training decoder whose promised loss gradient did not arrive: the image goes out as NaN (below)
+  const bool finite = gmax < INFINITY && !promise_broken(ride.promised, ride.arrived);     // false for inf and NaN
   int eg = 0;
   if (finite && gmax > 0.f) (void)frexpf(gmax, &eg);        // gmax < 2^eg
   const int S = 61 - log2_chunk - eg;
@@ -989,10 +991,12 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
                                      int absmax_stride, float* dG, float* partials, int L, int Ls, int F, int tile_shift,
                                      int lds_bytes, int chunk, const float* ride_slabs, float* ride_dW0, float* ride_db0,
                                      float* ride_dW1, float* ride_db1, float* ride_dW2, float* ride_db2, int64_t ride_P,
-                                     int ride_in_dim, int ride_out_dim, const float* mse_pred, const float* mse_label,
+                                     int ride_in_dim, int ride_out_dim, const float* gloss_promised, const float* gloss_arrived,
+                                     const float* mse_pred, const float* mse_label,
                                      float* mse_loss, float* mse_workspace, int64_t mse_n, void* stream) {
   GNGF_CHECK_ARG(max_items >= 0 && L > 0 && Ls > 0 && Ls <= L && L <= GNGF_MAX_LEVELS && lds_bytes >= 0 && lds_bytes <= 64 * 1024);
-  RideAlong ride = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+  GNGF_CHECK_ARG(!gloss_promised == !gloss_arrived);
+  RideAlong ride = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, gloss_promised, gloss_arrived};
   int ride_blocks = 0;
   if (ride_slabs) {
     GNGF_CHECK_ARG(ride_dW0 && ride_db0 && ride_dW1 && ride_db1 && ride_dW2 && ride_db2 && ride_P >= 0 && ride_in_dim > 0 &&

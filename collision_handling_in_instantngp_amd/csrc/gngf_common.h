@@ -99,6 +99,16 @@ __device__ __forceinline__ void mse_sum_block(int blk, int nblocks, const float*
   atomicExch(counter, 0u);
 }
 
+// The fused training decoder (gngf_decoder_train) ran its backward with a PROMISED loss gradient before autograd delivered the
+// real one.  The consumers of its results (the slab reduction below, the tiled encoder backward) compare the two on the device
+// — no host synchronisation, always on — and poison what they write with NaN when the promise was broken: a wrong promise is
+// loud (NaN loss / parameters at the next step), never a silently wrong gradient.  NULL pointers: nothing was promised.
+__device__ __forceinline__ bool promise_broken(const float* __restrict__ promised, const float* __restrict__ arrived) {
+  if (!promised || !arrived) return false;
+  const float a = *promised, b = *arrived;
+  return !(fabsf(a - b) <= 1e-6f * fabsf(a));            // (NaN on either side counts as broken)
+}
+
 // Decoder backward, second half (csrc/decoder.hip): sums the per-workgroup gradient slabs
 //   dW0 [64*in_dim] | dW1 [64*64] | dW2 [out_dim*64] | db0 [64] | db1 [64] | db2 [out_dim] | max |d enc| (bit pattern)
 // into the six gradient tensors; block `blk` of 1024 threads owns elements [64 blk, 64 blk + 64) (64 elements x 16
@@ -108,8 +118,11 @@ __device__ __forceinline__ void mse_sum_block(int blk, int nblocks, const float*
 __device__ __forceinline__ void decoder_reduce_block(int blk, const float* __restrict__ slabs, int nslabs, int nslab, int in_dim,
                                                      int out_dim, float* __restrict__ dW0, float* __restrict__ db0,
                                                      float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
-                                                     float* __restrict__ db2, float* __restrict__ absmax) {
+                                                     float* __restrict__ db2, float* __restrict__ absmax,
+                                                     const float* __restrict__ promised = nullptr,
+                                                     const float* __restrict__ arrived = nullptr) {
   __shared__ float red[16][64];
+  const bool broken = promise_broken(promised, arrived);
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int e = blk * 64 + c;
   const bool is_max = e == nslab - 1;                    // last slot: max of bit patterns, not a sum
@@ -125,11 +138,12 @@ __device__ __forceinline__ void decoder_reduce_block(int blk, const float* __res
   if (is_max) {
 #pragma unroll
     for (int k = 1; k < 16; ++k) s = __float_as_uint(red[k][c]) > __float_as_uint(s) ? red[k][c] : s;
-    if (absmax) *absmax = s;
+    if (absmax) *absmax = broken ? __int_as_float(0x7fc00000) : s;
     return;
   }
 #pragma unroll
   for (int k = 1; k < 16; ++k) s += red[k][c];
+  if (broken) s = __int_as_float(0x7fc00000);
   const int o0 = 64 * in_dim, o1 = o0 + 64 * 64, o2 = o1 + out_dim * 64, o3 = o2 + 64, o4 = o3 + 64;
   if (e < o0) dW0[e] = s;
   else if (e < o1) dW1[e - o0] = s;

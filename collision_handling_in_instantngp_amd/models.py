@@ -125,6 +125,8 @@ class MultiResHashEncoding(nn.Module):
                                            for l in range(num_levels)])
         self._base = base
         self._grad_base = None          # (L,T,F) gradient buffer behind the L `.grad` views (set by backward)
+        self._grad_base_fp32 = None     # fp16 storage with the fp32 hand-over: the fp32 accumulation buffer itself
+        self.grad_fp32_handover = None  # fp16 storage: hand the fp32 gradient buffer over as param.grad_fp32 (None: ops.FP16_TABLE_GRAD_FP32)
 
     def _apply_init(self, init_func, *args):
         for i in range(self._num_levels):
@@ -148,15 +150,14 @@ class MultiResHashEncoding(nn.Module):
 
     def forward(self, hashed_indices: torch.Tensor, hashed_probs_topk: torch.Tensor, should_calc_counts: bool = False):
         """hashed_indices (P,L,4) [hash] or (P,L,4,K) [GNGF] int64; hashed_probs_topk (P,L,4,K) | None -> (P,F,L,4)."""
-        base = self.packed_tables()
-        tables = ops.TableViewFunction.apply(base, self, *[m.weight for m in self._hash_tables])
+        tables, sink = ops.table_view(self)
         if should_use_hash_function:
             if hashed_indices.dim() != 3:
                 raise ValueError("hash mode expects indices of shape (P, L, 4)")
-            return ops.MrheFunction.apply(tables, hashed_indices, None, 0)
+            return ops.MrheFunction.apply(tables, hashed_indices, None, 0, sink)
         if hashed_indices.dim() != 4:
             raise ValueError("GNGF mode expects indices of shape (P, L, 4, K)")
-        return ops.MrheFunction.apply(tables, hashed_indices, hashed_probs_topk, ops.BLEND_CODES[should_softmax_topk_features])
+        return ops.MrheFunction.apply(tables, hashed_indices, hashed_probs_topk, ops.BLEND_CODES[should_softmax_topk_features], sink)
 
 
 class VertexDistribution:
@@ -235,6 +236,10 @@ class GeneralNeuralGaugeFields(nn.Module):
         self._frozen_table = None          # cached per-vertex (idx, w, q) when the HPD is frozen
         self._fused_mse_target = None      # see fused_mse()
         self._fused_mse_gloss = None
+        self.dp = ops.DataParallel()       # data-parallel state of THIS model (parallel.enable_vertex_grid_exchange(net, ...))
+        self.hpd_stats = {}                # shape of the last chunked HPD evaluation (rows, chunks, chunks kept)
+        self.loss_value_aside = False      # the caller joins the fused loss value itself (train.GraphedStep)
+        self._last_link = None             # ops.StepLink of the most recent forward pass
         self.to(device)
 
     # ------------------------------------------------------------------ helpers
@@ -249,20 +254,29 @@ class GeneralNeuralGaugeFields(nn.Module):
             out += [seq[0].weight, seq[0].bias]
         return out
 
-    def _decode(self, enc):
+    def _decode(self, enc, link=None):
         n = len(self.mlp)
         hidden = ops.ACT_LEAKY if self._leaky else ops.ACT_RELU
         return ops.decoder_apply(enc, tuple([hidden] * (n - 1) + [ops.ACT_SIGMOID]), self._decoder_params(),
-                                 mse_target=self._fused_mse_target, mse_gloss=self._fused_mse_gloss)
+                                 mse_target=self._fused_mse_target, mse_gloss=self._fused_mse_gloss, link=link)
+
+    def join_loss_value(self):
+        """Launches the fused loss value of the last forward pass if it was deferred (loss_value_aside) and found no launch
+        to ride on."""
+        if self._last_link is not None:
+            self._last_link.join_loss_value()
 
     def fused_mse(self, target, gloss=None):
         """Context manager: forward passes inside it also evaluate torch.nn.MSELoss()(rgb, target) in the decoder kernels and
         attach the value to the returned rgb; train.Loss (ops.mse_loss) picks it up when it is given that rgb and this very
-        `target` tensor, instead of launching the loss kernels.  Results are those of the separate kernels (gradients bit
-        for bit).  The training loops of train.py use it; it is never required.
+        `target` tensor, instead of launching the loss kernels.  Without `gloss` the results are those of the separate
+        kernels (gradients bit for bit).  The training loops of train.py use it; it is never required.
         gloss (number): a PROMISE that the gradient arriving at that loss value in backward() will be exactly this (the loss
         weight l_mse when the total is l_mse * mse + ... and backward() is seeded with 1): at 32 encoder features the decoder
-        then runs its forward and backward in ONE launch (ops.DECODER_TRAIN_FUSION), results as with the two kernels."""
+        then runs its forward and backward in ONE launch (ops.DECODER_TRAIN_FUSION); its forward layers run on the bf16 pipe
+        with an exact three-way split, so results equal the two-kernel path to fp32 ROUNDING (not bit for bit; both are
+        tested against float64).  The promise is checked on the device when the gradient arrives: if it differs (relative
+        1e-6), every gradient of that backward pass is NaN — loud, never silently computed for the wrong value."""
         import contextlib
 
         @contextlib.contextmanager
@@ -280,10 +294,16 @@ class GeneralNeuralGaugeFields(nn.Module):
         if self.coord_bounds is not None:
             mx, my = self.coord_bounds
         else:
-            b = x.amax(0) if x.shape[0] > 0 else torch.zeros((2,), dtype=x.dtype, device=x.device)   # empty batch
-            if ops.DP_MAX is not None:
-                ops.DP_MAX(b)                                               # every rank must build the same vertex table
-            mx, my = b.tolist()                                             # one host sync
+            if x.shape[0] > 0:
+                b = torch.cat([x.amax(0), -x.amin(0)])
+            else:
+                b = torch.zeros((4,), dtype=x.dtype, device=x.device)       # empty batch
+            if self.dp.max_ is not None:
+                self.dp.max_(b)                                             # every rank must build the same vertex table
+            mx, my, nx, ny = b.tolist()                                     # one host sync
+            if nx > 0 or ny > 0:
+                raise ValueError("GNGF indexing builds its per-vertex table over [0, max] x [0, max]: negative coordinates "
+                                 f"(min {-nx:g}, {-ny:g}) are outside it")
         gx_hi = int(np.floor(np.float32(mx) * np.float32(self._n_max))) + 1
         gy_hi = int(np.floor(np.float32(my) * np.float32(self._n_max))) + 1
         return gx_hi + 1, (gx_hi + 1) * (gy_hi + 1)
@@ -298,7 +318,7 @@ class GeneralNeuralGaugeFields(nn.Module):
         if self._frozen_table is None or self._frozen_table[0] != key:
             vstride = self._n_max + 2
             NV = vstride * vstride
-            tv, ti, _, _ = ops.HpdVertexFunction.apply(NV, vstride, self._topk_k, None, False, HPD_CHUNK_BYTES, *params)
+            tv, ti, _, _ = ops.HpdVertexFunction.apply(NV, vstride, self._topk_k, None, False, HPD_CHUNK_BYTES, None, *params)
             w = ops.BlendFunction.apply(tv, blend_code)
             self._frozen_table = (key, tv, ti, w, vstride, NV, ops.slot_order(ti, self._n_ls_host, vstride))
         return self._frozen_table[1:]
@@ -310,18 +330,23 @@ class GeneralNeuralGaugeFields(nn.Module):
         x = x.contiguous()
         dev = x.device
         n_ls = self._n_ls_flat(dev)
-        base = self.encoding.packed_tables()
-        tables = ops.TableViewFunction.apply(base, self.encoding, *[m.weight for m in self.encoding._hash_tables])
+        tables, sink = ops.table_view(self.encoding)
         P, L, T, K = x.shape[0], self._num_levels, self._hash_table_size, self._topk_k
+        link = self._last_link = ops.StepLink(loss_value_aside=self.loss_value_aside)
+        dp = self.dp
 
         if self._hash_mode:
-            enc = ops.encode_apply(x, n_ls, self._n_ls_host, tables, None, None, 0)
-            rgb = self._decode(enc)
+            # batch-normalised coordinates (models.py:394-397) leave [0,1]^2: the direct form hashes any integer vertex
+            enc = ops.encode_apply(x, n_ls, self._n_ls_host, tables, None, None, 0, path=("direct" if should_batchnorm_data else None),
+                                   dp=dp, link=link, sink=sink)
+            rgb = self._decode(enc, link)
             idx = ops.hash_indices(x.detach(), n_ls, T) if (self.return_indices or should_calc_counts) else None
             counts = self._calc_counts_per_level(idx, x.detach(), n_ls) if should_calc_counts else []
             return rgb, None, idx, counts
 
         keep_topk = self._should_keep_topk_only
+        if should_batchnorm_data:
+            return self._forward_per_instance(x, n_ls, link, should_calc_counts)
         dense_bytes = P * L * 4 * T * 4
         want_dense = (not keep_topk) and (self.dense_probs is True or (self.dense_probs == "auto" and dense_bytes <= DENSE_OUTPUT_LIMIT_BYTES))
         extent = None
@@ -341,11 +366,11 @@ class GeneralNeuralGaugeFields(nn.Module):
             vstride, NV = extent if extent is not None else self._vertex_extent(x.detach())
             mw = ops.vertex_multiplicity_weights(x.detach(), n_ls, vstride, NV) if need_pbar else None
             tv, ti, pbar, probs_u = ops.HpdVertexFunction.apply(NV, vstride, K, mw, want_dense, HPD_CHUNK_BYTES,
-                                                                *self.HPD.flat_params())
+                                                                ops.HpdAux(dp.mean, self.hpd_stats), *self.HPD.flat_params())
             w = ops.BlendFunction.apply(tv, blend_code)
             order = None
-        enc = ops.encode_apply(x, n_ls, self._n_ls_host, tables, ti, w, vstride, order=order)
-        rgb = self._decode(enc)
+        enc = ops.encode_apply(x, n_ls, self._n_ls_host, tables, ti, w, vstride, order=order, dp=dp, link=link, sink=sink)
+        rgb = self._decode(enc, link)
 
         need_vid = want_dense or keep_topk or should_calc_counts
         need_idx = self.return_indices or should_calc_counts
@@ -361,6 +386,31 @@ class GeneralNeuralGaugeFields(nn.Module):
             to_return_probs = VertexDistribution((P, L, 4, T), pbar, tv)
         counts = self._calc_counts_per_level(idx64[..., 0], x.detach(), n_ls) if should_calc_counts else []
         return rgb, to_return_probs, idx64, counts
+
+    def _forward_per_instance(self, x, n_ls, link, should_calc_counts):
+        """GNGF indexing on coordinates outside [0,1]^2 (should_batchnorm_data, models.py:394-397: BatchNorm1d output is
+        centred on 0, so grid vertices are negative and the dense per-vertex table of the fast path does not apply): the
+        reference's own per-instance formulation on the module-boundary kernels — HPD once per DISTINCT vertex of the batch
+        (rows found with torch.unique; identical to evaluating every instance), MultiResHashEncoding.forward
+        (gngf_mrhe_fwd), _bilinear_interpolate (gngf_bilinear_fwd), decoder.  Dense (U,T) distributions: small T only."""
+        P, L, T, K = x.shape[0], self._num_levels, self._hash_table_size, self._topk_k
+        xd = x.detach()
+        scaled = xd[:, :, None] * n_ls.to(torch.float32)[None, None, :]                         # (P,2,L)   models.py:492-495
+        cube = self._voxels_helper_hypercube.to(x.device).to(torch.float32).reshape(1, 2, 1, 4)
+        grid = torch.floor(scaled)[..., None] + cube                                             # (P,2,L,4)
+        verts = grid.permute(0, 2, 3, 1).reshape(-1, 2)                                          # "p xy l v -> (p l v) xy"
+        uniq, inv = torch.unique(verts, dim=0, return_inverse=True)
+        if uniq.shape[0] * T * 4 > DENSE_OUTPUT_LIMIT_BYTES:
+            raise ValueError(f"per-instance GNGF path: {uniq.shape[0]} distinct vertices x T = {T} exceeds DENSE_OUTPUT_LIMIT_BYTES")
+        probs_u, tp_u, ti_u = self.HPD(uniq.contiguous())
+        tp = tp_u[inv].reshape(P, L, 4, K)
+        ti = ti_u[inv].reshape(P, L, 4, K)
+        feats = self.encoding(ti, tp)
+        enc = ops.BilinearFunction.apply(xd, n_ls, feats)
+        rgb = self._decode(enc, link)
+        probs = tp if self._should_keep_topk_only else probs_u[inv].reshape(P, L, 4, T)
+        counts = self._calc_counts_per_level(ti[..., 0], xd, n_ls) if should_calc_counts else []
+        return rgb, probs, ti, counts
 
     # ------------------------------------------------------------------ diagnostics (no-grad statistics, not kernels)
     @torch.no_grad()

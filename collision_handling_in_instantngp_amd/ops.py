@@ -40,23 +40,44 @@ def _grad_buffer(tables):
 # the parameter's type, so by default that buffer is cast to fp16 (6 GiB of traffic at T = 2^24, F = 4: a quarter of the
 # step).  With FP16_TABLE_GRAD_FP32 the buffer itself is handed over instead: level l's parameter gets `grad_fp32` (a view of
 # it) and no `.grad`; train.FusedAdam — which updates an fp32 master copy anyway — consumes it directly.
-FP16_TABLE_GRAD_FP32 = False
-_FP32_GRAD_SINKS = {}        # table storage pointer -> (owner module, level parameters), registered by TableViewFunction.forward
+FP16_TABLE_GRAD_FP32 = False     # default of MultiResHashEncoding.grad_fp32_handover (None there = this switch)
 
 
-def _grad_out(dtables, tables):
+def table_view(owner):
+    """(tables, sink) of an encoding module: its L level parameters as ONE (L,T,F) tensor inside the autograd graph
+    (TableViewFunction), and — fp16 storage with the fp32 hand-over on — the (owner, level parameters) pair the backward hands
+    the fp32 gradient buffer to.  The sink travels with the call (encode_apply(..., sink=) / MrheFunction) and ends up on that
+    call's autograd ctx: several models in one process do not share it."""
+    base = owner.packed_tables()
+    ws = tuple(m.weight for m in owner._hash_tables)
+    tables = TableViewFunction.apply(base, owner, *ws)
+    handover = getattr(owner, "grad_fp32_handover", None)
+    handover = FP16_TABLE_GRAD_FP32 if handover is None else handover
+    sink = (owner, ws) if (base.dtype != _f32 and handover) else None
+    return tables, sink
+
+
+def _grad_out(dtables, tables, sink=None):
     if tables.dtype == _f32:
         return dtables
-    sink = _FP32_GRAD_SINKS.get(tables.data_ptr()) if FP16_TABLE_GRAD_FP32 else None
     if sink is None:
         return dtables.to(tables.dtype)
     owner, ws = sink
     owner._grad_base = None
-    owner._grad_base_fp32 = dtables
+    fresh = all(getattr(w, "grad_fp32", None) is None for w in ws)
+    if fresh:
+        owner._grad_base_fp32 = dtables
     for l, w in enumerate(ws):
         if w.requires_grad:
             w.grad = None
-            w.grad_fp32 = dtables[l]       # the gradient of the LAST backward pass (not accumulated across passes)
+            if fresh:
+                w.grad_fp32 = dtables[l]
+            elif getattr(w, "grad_fp32", None) is None:
+                w.grad_fp32 = dtables[l].clone()
+            else:
+                w.grad_fp32.add_(dtables[l])      # a second backward pass without zero_grad: accumulated, as .grad would be
+    if not fresh:
+        owner._grad_base_fp32 = None              # the levels' gradients are no longer views of one buffer
     return None
 
 
@@ -73,7 +94,8 @@ class MrheFunction(torch.autograd.Function):
     """MultiResHashEncoding.forward (reference models.py:173-229) at the module boundary."""
 
     @staticmethod
-    def forward(ctx, tables, idx, probs, blend_code):
+    def forward(ctx, tables, idx, probs, blend_code, sink=None):
+        ctx.sink = sink
         tables, idx = _c(tables), _c(idx)
         L, T, F = tables.shape
         P = idx.shape[0]
@@ -96,7 +118,7 @@ class MrheFunction(torch.autograd.Function):
         dprobs = torch.empty_like(probs) if (K and ctx.needs_input_grad[2]) else None
         call("gngf_mrhe_bwd", *_tab(tables), ptr(idx), ptr(probs), ptr(gout, _f32, "grad"), ptr(dtables), ptr(dprobs),
              P, L, F, T, K, blend_code, stream_ptr())
-        return _grad_out(dtables, tables), None, dprobs, None
+        return _grad_out(dtables, tables, ctx.sink), None, dprobs, None, None
 
 
 class BilinearFunction(torch.autograd.Function):
@@ -256,7 +278,17 @@ def expand_vertex_table(xy, n_ls, vstride, NV, src_idx=None, src_val=None, want_
 # device memory that must remain after keeping a chunk.
 HPD_Z_CACHE_BYTES = 216 << 30
 HPD_Z_CACHE_RESERVE = 40 << 30
-HPD_LAST_STATS = {}          # shape of the last chunked HPD evaluation (bench.py prices the step's GEMM FLOP with it)
+
+
+class HpdAux:
+    """Per-call side inputs of HpdVertexFunction that are not tensors: `mean` (data parallel: callable averaging the batch-mean
+    distribution over the ranks in place, or None) and `stats` (a dict — typically the model's `hpd_stats` — that receives the
+    shape of the chunked evaluation: bench.py prices the step's GEMM FLOP with it)."""
+    __slots__ = ("mean", "stats")
+
+    def __init__(self, mean=None, stats=None):
+        self.mean, self.stats = mean, stats
+
 # Chunks are software-pipelined over two streams: the T-wide GEMMs (matrix-pipe bound) of one chunk run beside the streaming
 # softmax / top-K / batch-mean passes (HBM bound) of its neighbour.  False: everything in line on the current stream.
 HPD_PIPELINE = True
@@ -286,7 +318,7 @@ class HpdVertexFunction(torch.autograd.Function):
     """HashProbDistribution (reference models.py:45-123) evaluated ONCE PER DISTINCT VERTEX u (vid = gy*vstride+gx,
     u in [0, NV)), in row chunks so that the (rows, T) distribution never exceeds `chunk_bytes`.
 
-    apply(NV, vstride, K, mw, keep_probs, chunk_bytes, *params) ->
+    apply(NV, vstride, K, mw, keep_probs, chunk_bytes, aux, *params) ->   (aux: HpdAux or None)
         topk_val (NV,K), topk_idx (NV,K) int32, pbar (L,T) | None, probs (NV,T) | None
     pbar_l = sum_u mw[u,l] * probs[u]  is the batch-mean distribution of utils.py:138,159 (mw = multiplicity/(4P)).
     Backward recomputes each chunk (hidden layers, logits, softmax) and folds the top-K gradient and the
@@ -301,7 +333,7 @@ class HpdVertexFunction(torch.autograd.Function):
         return hs
 
     @staticmethod
-    def forward(ctx, NV, vstride, K, mw, keep_probs, chunk_bytes, *params):
+    def forward(ctx, NV, vstride, K, mw, keep_probs, chunk_bytes, aux, *params):
         params = tuple(_c(p) for p in params)
         n_layers = len(params) // 2
         W_last, b_last = params[-2], params[-1]
@@ -329,7 +361,7 @@ class HpdVertexFunction(torch.autograd.Function):
         # Checkpointing policy sized for 288 GB of HBM: the backward needs every chunk's logits again; the chunks that fit
         # HPD_Z_CACHE_BYTES (and leave HPD_Z_CACHE_RESERVE free on the device) keep theirs, the rest are recomputed.
         zcache, cached = {}, 0
-        keep_z = (not keep_probs) and HPD_Z_CACHE_BYTES > 0 and any(ctx.needs_input_grad[6:])
+        keep_z = (not keep_probs) and HPD_Z_CACHE_BYTES > 0 and any(ctx.needs_input_grad[7:])
         budget = 0
         if keep_z:
             # one query per forward: memory the driver reports free plus what torch's allocator holds in unused cached blocks
@@ -377,9 +409,10 @@ class HpdVertexFunction(torch.autograd.Function):
                      ptr(mw[u0:u0 + n] if pbar is not None else None), L if pbar is not None else 0, ptr(pbar), n, T, K, stream_ptr())
         if pipelined:
             main.wait_stream(side)
-        if pbar is not None and DP_MEAN is not None:
-            DP_MEAN(pbar)      # the loss is a nonlinear function of the batch mean: average BEFORE the log (SURVEY §8e ii)
-        HPD_LAST_STATS.update(rows_total=int(NV), T=int(T), rows_per_chunk=int(rows), chunks=-(-NV // rows), chunks_kept=len(zcache))
+        if pbar is not None and aux is not None and aux.mean is not None:
+            aux.mean(pbar)     # the loss is a nonlinear function of the batch mean: average BEFORE the log (SURVEY §8e ii)
+        if aux is not None and aux.stats is not None:
+            aux.stats.update(rows_total=int(NV), T=int(T), rows_per_chunk=int(rows), chunks=-(-NV // rows), chunks_kept=len(zcache))
         ctx.cfg = (NV, vstride, K, rows, n_layers, T, keep_probs)
         ctx.zcache = zcache
         ctx.save_for_backward(ti, mw, probs, rowstat, *params)
@@ -463,7 +496,7 @@ class HpdVertexFunction(torch.autograd.Function):
                 linear_bwd_weight(g, hs[i + 1], hs[i], grads[2 * i], grads[2 * i + 1], ACT_RELU)
                 if i > 0:
                     g = linear_bwd_input(g, hs[i + 1], params[2 * i], ACT_RELU)
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
     @staticmethod
@@ -519,7 +552,7 @@ class HpdVertexFunction(torch.autograd.Function):
         main.wait_stream(side)
         side.wait_stream(main)       # the helper's next use starts behind everything issued here
         del alive[:]
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
 class BlendFunction(torch.autograd.Function):
@@ -582,9 +615,6 @@ class TableViewFunction(torch.autograd.Function):
         ctx.owner = owner
         ctx.weights = weights
         ctx.set_materialize_grads(False)
-        if base.dtype != _f32 and FP16_TABLE_GRAD_FP32:
-            _FP32_GRAD_SINKS.clear()       # one live table buffer per process is the use case; no stale pointers
-            _FP32_GRAD_SINKS[base.data_ptr()] = (owner, weights)
         return base.detach()
 
     @staticmethod
@@ -611,16 +641,90 @@ class TableViewFunction(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------ tiled encoder
 ENCODE_PATH = "auto"        # "auto" | "direct" | "tiled"  (tests force a path; auto = tiled when it pays)
-DP_EXCHANGE = None          # data parallel: callable that sum-all-reduces + averages the vertex-grid gradient in place
-DP_TABLES_REDUCED = 0       # number of leading levels whose table gradient of the last backward came out of an exchanged dG
-# Deferred vertex stage (data parallel, index sources without a trainable weight): when True, the encoder backward stops
-# after the pixel stage and leaves (arguments of the vertex stage) in DP_DEFERRED; parallel.allreduce_gradients() all-reduces
-# dG and runs the vertex stage.  The backward pass then contains no collective, so the whole forward+backward can be
-# replayed from ONE hipGraph on every rank (bench.py does; eager launch gaps cost ~15 % of a step).
-DP_DEFER_VERTEX = False
-DP_DEFERRED = None
-DP_MEAN = None              # data parallel: callable averaging a tensor over ranks in place (batch-mean distribution p-bar)
-DP_MAX = None               # data parallel: callable max-reducing a small tensor over ranks in place (coordinate bounds)
+
+
+class DataParallel:
+    """Data-parallel state of ONE model (its `dp` attribute; parallel.enable_vertex_grid_exchange / defer_vertex_stage set it
+    up).  It travels with every call as an argument and the bookkeeping of a backward pass is written here, not into the
+    process: two models — or a training step and an evaluation pass — never see each other's.
+      exchange      callable averaging the vertex-grid gradient over the ranks in place (None: single rank)
+      mean / max_   callables averaging / max-reducing a small tensor over the ranks in place (p-bar; coordinate bounds)
+      defer_vertex  the encoder backward stops after the pixel stage and leaves the vertex stage's arguments in `deferred`;
+                    parallel.allreduce_gradients() exchanges dG and runs it.  The backward pass then holds no collective, so
+                    forward + backward replay from ONE hipGraph on every rank (eager launch gaps cost ~15 % of a step)
+      deferred      arguments of the pending vertex stage (set by the last backward pass of this model, or None)
+      tables_reduced  leading levels whose table gradient of the last backward pass came out of an exchanged dG
+      comm_stream / comm_done   set by parallel.allreduce_gradients(overlap=True): the exchange runs on its own stream"""
+
+    def __init__(self):
+        self.exchange = self.mean = self.max_ = None
+        self.defer_vertex = False
+        self.deferred = None
+        self.tables_reduced = 0
+        self.comm_stream = None
+        self.comm_done = None
+        self.world = 1
+        self.group = None
+
+    @property
+    def active(self):
+        return self.exchange is not None
+
+
+class StepLink:
+    """What the decoder of ONE forward pass hands to the encoder of the same pass when the backward pass runs (created per
+    forward by the model, passed to encode_apply and decoder_apply, kept alive by their autograd contexts):
+      pending_reduce  the decoder's slab reduction, waiting for the tiled encoder backward's launch to ride on
+      absmax          (hint, data_ptr, version) — bound on max |d enc| for the tensor with that address / version
+      loss_value      the fused pixel loss's value, deferred so that it rides on the same launch
+      promise         (promised, arrived) device scalars of the fused training decoder's loss gradient (checked on the device)
+    loss_value_aside: the caller owns the whole step and joins the loss value itself (train.GraphedStep)."""
+    __slots__ = ("pending_reduce", "absmax", "loss_value", "promise", "loss_value_aside", "__weakref__")
+
+    def __init__(self, loss_value_aside=False):
+        self.pending_reduce = self.absmax = self.loss_value = self.promise = None
+        self.loss_value_aside = bool(loss_value_aside)
+
+    def take_absmax(self, genc):
+        h, self.absmax = self.absmax, None
+        # any in-place edit (or another tensor) since invalidates the bound
+        return h[0] if (h is not None and h[1] == genc.data_ptr() and h[2] == genc._version) else None
+
+    def take_reduce(self, device):
+        r = self.pending_reduce
+        if r is not None and r["device"] == device and r["stream"] == torch.cuda.current_stream(device).cuda_stream:
+            self.pending_reduce = None
+            return r
+        return None
+
+    def take_loss_value(self, device):
+        r = self.loss_value
+        if r is not None and r["device"] == device and r["stream"] == torch.cuda.current_stream(device).cuda_stream:
+            self.loss_value = None
+            return r
+        return None
+
+    def promise_ptrs(self):
+        pr = self.promise
+        return (ptr(pr[0]), ptr(pr[1])) if pr is not None else (ptr(None), ptr(None))
+
+    def flush_reduce(self):
+        """Launches the slab reduction if nobody picked it up (no tiled encoder backward followed the decoder backward)."""
+        r, self.pending_reduce = self.pending_reduce, None
+        if r is None:
+            return
+        with torch.cuda.stream(r["stream_obj"]):      # (the Stream object itself: an ExternalStream wrapped around the default
+            # stream's raw handle is a different stream to torch — reductions launched through one came out corrupted)
+            call("gngf_decoder_reduce", ptr(r["slabs"]), *[_ct.c_void_p(a) for a in r["gptrs"]], ptr(None), *self.promise_ptrs(),
+                 r["P"], r["in_dim"], r["out_dim"], stream_ptr())
+
+    def join_loss_value(self):
+        """Launches the deferred loss value if it found no launch to ride on (end of the step)."""
+        r, self.loss_value = self.loss_value, None
+        if r is None:
+            return
+        with torch.cuda.stream(r["stream_obj"]):
+            call("gngf_mse_fwd", ptr(r["pred"]), ptr(r["label"]), ptr(r["loss"]), ptr(r["ws"]), r["pred"].numel(), stream_ptr())
 TILED_CHUNK = None          # max pixels per (tile, chunk) work item; None: about two average tiles' worth (see EncodePlan)
 TILED_MIN_PIXELS = 1 << 14  # below this the binning overhead is not worth it
 # a level is staged while N_l^2 <= this * P (sparser levels: direct form).  Measured at the cfg4 shape (2^20 px, N -> 4095):
@@ -755,17 +859,6 @@ def slot_order(vert_idx, n_ls_host=None, vstride=None):
     return torch.sort(flat, stable=True)[1].to(_i32)
 
 
-# max |d enc| handed from the fused decoder backward to the tiled encoder backward: {data_ptr: (absmax tensor, version)}
-_ABSMAX_HINTS = {}
-
-
-def _take_absmax_hint(genc):
-    h = _ABSMAX_HINTS.pop(genc.data_ptr(), None)
-    if len(_ABSMAX_HINTS) > 8:
-        _ABSMAX_HINTS.clear()
-    return h[0] if (h is not None and h[1] == genc._version) else None     # any in-place edit since invalidates the bound
-
-
 _TILE_LEVEL_OFF = {}
 
 
@@ -796,16 +889,19 @@ def tile_level_offsets(plan, device):
     return hit
 
 
-def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None):
-    """absmax: None or (tensor, count, stride) — `count` floats `stride` apart whose maximum bounds |genc|."""
+def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None, link=None):
+    """absmax: None or (tensor, count, stride) — `count` floats `stride` apart whose maximum bounds |genc|.
+    link: the StepLink of the forward pass (decoder slab reduction / loss value waiting for a launch to ride on, promise)."""
     partials = torch.empty((plan.max_items * (plan.lds_bytes // 4),), dtype=_f32, device=genc.device)
     am, am_count, am_stride = absmax if absmax is not None else (None, 0, 0)
-    ride = _take_pending_reduce(genc.device)        # a decoder slab reduction waiting for a launch to ride on
+    ride = link.take_reduce(genc.device) if link is not None else None        # a decoder slab reduction waiting for a launch to ride on
     if ride is None:
         ride_args = [ptr(None)] * 7 + [0, 0, 0]
     else:
         ride_args = [ptr(ride["slabs"])] + [_ct.c_void_p(a) for a in ride["gptrs"]] + [ride["P"], ride["in_dim"], ride["out_dim"]]
-    lv = _take_pending_loss_value(genc.device)      # ... and a loss value nobody on the critical path reads
+    # the loss gradient a fused training decoder was promised vs the one that arrived: compared inside the launch
+    ride_args += list(link.promise_ptrs()) if link is not None else [ptr(None), ptr(None)]
+    lv = link.take_loss_value(genc.device) if link is not None else None      # ... and a loss value nobody on the critical path reads
     if lv is None:
         ride_args += [ptr(None)] * 4 + [0]
     else:
@@ -816,16 +912,16 @@ def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None):
          *ride_args, stream_ptr())
 
 
-def run_deferred_vertex_stage(exchanged=False):
-    """Second half of a deferred encoder backward (see DP_DEFER_VERTEX): dG -> table gradient.  The arguments stay
-    registered (a replayed hipGraph refills the same buffers), so this can be called after every replay.
+def run_deferred_vertex_stage(dp, exchanged=False):
+    """Second half of a deferred encoder backward (DataParallel.defer_vertex): dG -> table gradient.  The arguments stay
+    registered on `dp` (a replayed hipGraph refills the same buffers), so this can be called after every replay.
     exchanged: the caller has already averaged dG over the ranks (parallel.allreduce_gradients does, together with the
     other gradients)."""
-    if DP_DEFERRED is None:
+    if dp is None or dp.deferred is None:
         return False
-    plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, order, gout = DP_DEFERRED
-    if DP_EXCHANGE is not None and not exchanged:
-        DP_EXCHANGE(dG)
+    plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, order, gout = dp.deferred
+    if dp.exchange is not None and not exchanged:
+        dp.exchange(dG)
     _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, None, order)
     if gout is not None and gout is not dtables:
         # fp16 table storage: the gradient autograd received is a rounded COPY of the fp32 accumulation buffer, made before
@@ -871,7 +967,8 @@ class EncodeFunction(torch.autograd.Function):
     EncodeDirectFunction (reference models.py:486-528, 173-229, 621-655 and their autograd backward)."""
 
     @staticmethod
-    def forward(ctx, xy, n_ls, plan, tables, vert_idx, vert_w, vstride, order=None):
+    def forward(ctx, xy, n_ls, plan, tables, vert_idx, vert_w, vstride, order=None, dp=None, link=None, sink=None):
+        ctx.dp, ctx.link, ctx.sink = dp, link, sink
         xy, tables = _c(xy), _c(tables)
         L, T, F = tables.shape
         P = xy.shape[0]
@@ -908,29 +1005,33 @@ class EncodeFunction(torch.autograd.Function):
         xy, n_ls, tables, vert_idx, vert_w, order = ctx.saved_tensors
         P, L, F, T, K, mode, vstride, NV, plan, ws = ctx.cfg
         genc = _c(genc)
-        absmax = _take_absmax_hint(genc)
+        dp, link, sink = ctx.dp, ctx.link, ctx.sink
+        absmax = link.take_absmax(genc) if link is not None else None
         # data-parallel bookkeeping describes THIS backward only: a step that takes another path (direct form, no staged
         # levels, no deferral) must not inherit the previous step's staged-level count or deferred vertex stage
-        globals()["DP_TABLES_REDUCED"] = 0
-        globals()["DP_DEFERRED"] = None
+        if dp is not None:
+            dp.tables_reduced = 0
+            dp.deferred = None
+        exchange = dp.exchange if dp is not None else None
+        NONE = (None,) * 5                                      # (order, dp, link, sink) + vstride: no gradients
         pre, ctx.pre = ctx.pre, None                            # a second backward (retain_graph) allocates fresh buffers
         dtables = pre[0] if pre else _grad_buffer(tables)
         dvw = torch.zeros_like(vert_w) if (vert_w is not None and ctx.needs_input_grad[5]) else None
         if plan.Ls > 0 and P > 0:
             dG = pre[1] if pre else torch.zeros((plan.vtot, F), dtype=_f32, device=tables.device)
-            _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax)
-            if DP_EXCHANGE is not None and DP_DEFER_VERTEX and dvw is None:
+            _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax, link)
+            if exchange is not None and dp.defer_vertex and dvw is None:
                 # the caller exchanges dG and runs the vertex stage after backward (parallel.allreduce_gradients)
                 if plan.Ls < L:
                     call("gngf_encode_bwd", ptr(xy), *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc, _f32, "grad"),
                          ptr(dtables), ptr(dvw), P, L, F, T, K, mode, vstride, NV, plan.Ls, L, stream_ptr())
-                gout = _grad_out(dtables, tables)
-                globals()["DP_DEFERRED"] = (plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, order, gout)
-                globals()["DP_TABLES_REDUCED"] = plan.Ls
-                return None, None, None, gout, None, dvw, None, None
-            if DP_EXCHANGE is not None:
-                DP_EXCHANGE(dG)                     # one small all-reduce instead of the staged levels' table gradient
-                globals()["DP_TABLES_REDUCED"] = plan.Ls
+                gout = _grad_out(dtables, tables, sink)
+                dp.deferred = (plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, order, gout)
+                dp.tables_reduced = plan.Ls
+                return (None, None, None, gout, None, dvw, *NONE)
+            if exchange is not None:
+                exchange(dG)                        # one small all-reduce instead of the staged levels' table gradient
+                dp.tables_reduced = plan.Ls
             if order is not None and dvw is not None and plan.Ls < L:
                 # the sorted kernel WRITES dvert_w; the direct levels below accumulate into the same buffer
                 dvw_t = torch.empty_like(dvw)
@@ -945,14 +1046,15 @@ class EncodeFunction(torch.autograd.Function):
                  ptr(dtables), ptr(dvw), P, L, F, T, K, mode, vstride, NV, plan.Ls, L, stream_ptr())
         if dvw_t is not None:
             dvw = dvw + dvw_t
-        return None, None, None, _grad_out(dtables, tables), None, dvw, None, None
+        return (None, None, None, _grad_out(dtables, tables, sink), None, dvw, *NONE)
 
 
-def encode_apply(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, path=None, order=None):
+def encode_apply(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, path=None, order=None, dp=None, link=None, sink=None):
     """Fused encoder dispatch: tiled form for the levels it can stage, direct form for the rest.
-    order: optional cached slot_order(vert_idx) (frozen tables)."""
+    order: optional cached slot_order(vert_idx) (frozen tables); dp: the model's DataParallel state; link: the forward
+    pass's StepLink (shared with decoder_apply); sink: see table_view()."""
     plan = EncodePlan(xy.shape[0], n_ls_host, tables.shape[2], path)
-    return EncodeFunction.apply(xy, n_ls, plan, tables, vert_idx, vert_w, vstride, order)
+    return EncodeFunction.apply(xy, n_ls, plan, tables, vert_idx, vert_w, vstride, order, dp, link, sink)
 
 
 _MSE_WORKSPACE = {}
@@ -1037,46 +1139,6 @@ DECODER_SAVE_HIDDEN = True
 # on its own when the backward pass ends.
 DECODER_REDUCE_RIDES = True
 
-_PENDING_REDUCE = []          # [{slabs, grads, P, in_dim, out_dim, device, stream}]: decoder reductions not yet launched
-# The fused decoder's loss value on the helper stream (see _decoder_fwd): only for callers that join before anything reads it
-LOSS_VALUE_ASIDE = False
-_LOSS_VALUE_PENDING = []      # [{pred, label, loss, ws, device, stream, stream_obj}]
-
-
-def _take_pending_loss_value(device):
-    cur = torch.cuda.current_stream(device).cuda_stream
-    for k, r in enumerate(_LOSS_VALUE_PENDING):
-        if r["device"] == device and r["stream"] == cur:
-            return _LOSS_VALUE_PENDING.pop(k)
-    return None
-
-
-def join_loss_value():
-    """Launches every deferred loss value that found no launch to ride on (end of the step)."""
-    while _LOSS_VALUE_PENDING:
-        r = _LOSS_VALUE_PENDING.pop()
-        with torch.cuda.stream(r["stream_obj"]):
-            call("gngf_mse_fwd", ptr(r["pred"]), ptr(r["label"]), ptr(r["loss"]), ptr(r["ws"]), r["pred"].numel(), stream_ptr())
-
-
-def _take_pending_reduce(device):
-    cur = torch.cuda.current_stream(device).cuda_stream
-    for k, r in enumerate(_PENDING_REDUCE):
-        if r["device"] == device and r["stream"] == cur:
-            return _PENDING_REDUCE.pop(k)
-    return None
-
-
-def _flush_pending_reduces():
-    """Launches every decoder slab reduction nobody picked up (no tiled encoder backward followed the decoder backward)."""
-    while _PENDING_REDUCE:
-        r = _PENDING_REDUCE.pop()
-        with torch.cuda.stream(r["stream_obj"]):      # (the Stream object itself: an ExternalStream wrapped around the default
-            # stream's raw handle is a different stream to torch — reductions launched through one came out corrupted)
-            call("gngf_decoder_reduce", ptr(r["slabs"]), *[_ct.c_void_p(a) for a in r["gptrs"]], ptr(None), r["P"], r["in_dim"],
-                 r["out_dim"], stream_ptr())
-
-
 def _at_end_of_backward(fn):
     """Runs fn when the running backward pass ends (autograd engine callback); outside a backward pass (a Function's
     backward called by hand) at once."""
@@ -1088,8 +1150,10 @@ def _at_end_of_backward(fn):
 
 # Training steps whose pixel loss is MSELoss(rgb, target) with a gradient known up front (the loss weight): forward and backward
 # of the decoder in ONE launch (gngf_decoder_train) — the hidden layers stay in registers, nothing is saved for the backward.
+# The promise is CHECKED ON THE DEVICE by the consumers of the results (csrc/gngf_common.h::promise_broken: the slab reduction
+# and the tiled encoder backward compare the promised scalar with the gradient autograd delivers, no synchronisation, always
+# on): a broken promise turns every gradient of the step into NaN instead of handing over gradients for the wrong value.
 DECODER_TRAIN_FUSION = True
-CHECK_FUSED_GLOSS = False        # tests: compare (with a device synchronisation) the gradient that arrives with the promised one
 _GLOSS_SCALARS = {}
 
 
@@ -1106,7 +1170,9 @@ def _decoder_grad_buffers(ws, P, in_dim, out_dim, dev):
     return flat, grads, slabs, nslabs, nslab
 
 
-def _decoder_fwd(ctx, enc, leaky, ws, target, gloss_known=None):
+def _decoder_fwd(ctx, enc, leaky, ws, target, gloss_known=None, link=None):
+    ctx.ws_given = tuple(ws)                      # the tensors autograd will accumulate into (see _grads_are_adopted)
+    ctx.link = link = link if link is not None else StepLink()
     enc = _c(enc)
     ws = [_c(w) for w in ws]
     P, in_dim = enc.shape
@@ -1129,6 +1195,8 @@ def _decoder_fwd(ctx, enc, leaky, ws, target, gloss_known=None):
         key = (dev, float(gloss_known))
         gl = _GLOSS_SCALARS.get(key)
         if gl is None:
+            if len(_GLOSS_SCALARS) > 64:
+                _GLOSS_SCALARS.clear()
             gl = _GLOSS_SCALARS[key] = torch.full((), float(gloss_known), dtype=_f32, device=dev)
         target_c = _c(target)
         denc = torch.empty_like(enc)
@@ -1136,23 +1204,23 @@ def _decoder_fwd(ctx, enc, leaky, ws, target, gloss_known=None):
         call("gngf_decoder_train", ptr(enc, _f32, "enc"), ptr(target_c, _f32, "target"), ptr(gl), *[ptr(w, _f32) for w in ws], ptr(rgb),
              ptr(denc), *[ptr(None)] * 6, ptr(slabs), ptr(None), P, in_dim, out_dim, int(leaky), stream_ptr())
         ctx.train = {"denc": denc, "flat": flat, "grads": grads, "slabs": slabs, "nslabs": nslabs, "nslab": nslab,
-                     "gloss": float(gloss_known)}
+                     "gloss": float(gloss_known), "promised": gl}
     else:
         call("gngf_decoder_fwd", ptr(enc, _f32, "enc"), *[ptr(w, _f32) for w in ws], ptr(rgb), ptr(hidden), P, in_dim, out_dim, int(leaky),
              stream_ptr())
     mse = None
     if target is not None:
         # The loss VALUE (csrc/loss.hip::mse_fwd_kernel).  Nothing in the step's critical path reads it — the backward kernel
-        # forms the loss gradient from rgb and the target itself — so a caller that owns the whole step (train.GraphedStep)
-        # defers it: it then rides on the tiled encoder backward's launch as extra workgroups (or is launched by
-        # join_loss_value() at the end of the step); otherwise it is launched here, in stream order.
+        # forms the loss gradient from rgb and the target itself — so a caller that owns the whole step (train.GraphedStep:
+        # link.loss_value_aside) defers it: it then rides on the tiled encoder backward's launch as extra workgroups (or is
+        # launched by link.join_loss_value() at the end of the step); otherwise it is launched here, in stream order.
         wsp = _MSE_WORKSPACE.get(dev)
         if wsp is None:
             wsp = _MSE_WORKSPACE[dev] = torch.zeros(query("gngf_mse_workspace_floats"), dtype=_f32, device=dev)
         mse = torch.empty((), dtype=_f32, device=dev)
-        if LOSS_VALUE_ASIDE:
-            _LOSS_VALUE_PENDING.append({"pred": rgb, "label": target, "loss": mse, "ws": wsp, "device": dev,
-                                        "stream": torch.cuda.current_stream(dev).cuda_stream, "stream_obj": torch.cuda.current_stream(dev)})
+        if link.loss_value_aside:
+            link.loss_value = {"pred": rgb, "label": target, "loss": mse, "ws": wsp, "device": dev,
+                               "stream": torch.cuda.current_stream(dev).cuda_stream, "stream_obj": torch.cuda.current_stream(dev)}
         else:
             call("gngf_mse_fwd", ptr(rgb), ptr(target), ptr(mse), ptr(wsp), rgb.numel(), stream_ptr())
     ctx.save_for_backward(enc, rgb, target, *ws)
@@ -1161,25 +1229,52 @@ def _decoder_fwd(ctx, enc, leaky, ws, target, gloss_known=None):
     return rgb, mse
 
 
+def _grads_are_adopted(ctx):
+    """True when autograd will ADOPT the six gradient views this backward returns (every weight's .grad is None and no tensor
+    hook reads them first): only then may the slab reduction that FILLS them be launched later in the backward pass.  With an
+    existing .grad (gradient accumulation over micro-batches, zero_grad(set_to_none=False), a second backward), AccumulateGrad
+    runs `p.grad += g` in stream order right after this node — the reduction must have been launched by then."""
+    for w in getattr(ctx, "ws_given", ()):
+        if not isinstance(w, torch.Tensor) or not w.requires_grad:
+            continue
+        if w.grad is not None or getattr(w, "_backward_hooks", None) or not w.is_leaf:
+            return False
+        if getattr(w, "_post_accumulate_grad_hooks", None):
+            return False
+    return True
+
+
+def _schedule_reduce(ctx, link, dev, slabs, flat, grads, P, in_dim, out_dim):
+    rec = {"slabs": slabs, "flat": flat, "gptrs": [g.data_ptr() for g in grads], "P": P, "in_dim": in_dim,
+           "out_dim": out_dim, "device": dev, "stream": torch.cuda.current_stream(dev).cuda_stream,
+           "stream_obj": torch.cuda.current_stream(dev)}
+    # (addresses, not the view tensors: a second reference to a gradient tensor would make autograd's AccumulateGrad
+    # CLONE it — before the reduction has filled it — instead of adopting it; `flat`, their base, keeps the memory alive)
+    link.flush_reduce()                            # (a reduction of an earlier backward through the same link: launch it now)
+    link.pending_reduce = rec
+    if _grads_are_adopted(ctx):
+        _at_end_of_backward(link.flush_reduce)     # rides on the tiled encoder backward if one follows, else launched at the end
+    else:
+        link.flush_reduce()                        # the gradients are read (accumulated into) right after this node: reduce now
+
+
 def _decoder_bwd(ctx, drgb, gloss):
     """drgb (P,out_dim) | None and gloss (0-dim) | None: gradient w.r.t. rgb and, for the fused loss, w.r.t. the MSE value."""
     enc, rgb, target, W0, b0, W1, b1, W2, b2 = ctx.saved_tensors
     P, in_dim, out_dim, leaky = ctx.cfg
     dev = enc.device
+    link = ctx.link
     tr = getattr(ctx, "train", None)
     if tr is not None:
         # the forward launch already ran the backward with the promised loss gradient: hand its results over
         ctx.train = None
         if drgb is not None or gloss is None:
             raise RuntimeError("fused training decoder: rgb must feed the MSE loss only (use net.fused_mse(target) without gloss= otherwise)")
-        if CHECK_FUSED_GLOSS and abs(float(gloss) - tr["gloss"]) > 1e-6 * abs(tr["gloss"]):
-            raise RuntimeError(f"fused training decoder: loss gradient {float(gloss)} differs from the promised {tr['gloss']}")
         denc, flat, grads, slabs, nslabs, nslab = tr["denc"], tr["flat"], tr["grads"], tr["slabs"], tr["nslabs"], tr["nslab"]
-        _PENDING_REDUCE.append({"slabs": slabs, "flat": flat, "gptrs": [g.data_ptr() for g in grads], "P": P, "in_dim": in_dim,
-                                "out_dim": out_dim, "device": dev, "stream": torch.cuda.current_stream(dev).cuda_stream,
-                                "stream_obj": torch.cuda.current_stream(dev)})
-        _at_end_of_backward(_flush_pending_reduces)
-        _ABSMAX_HINTS[denc.data_ptr()] = ((slabs[nslab - 1:], nslabs, nslab), denc._version)
+        arrived = _c(gloss.detach().to(_f32)).reshape(())
+        link.promise = (tr["promised"], arrived)   # compared on the device by whoever consumes slabs / d enc (no sync)
+        link.absmax = ((slabs[nslab - 1:], nslabs, nslab), denc.data_ptr(), denc._version)
+        _schedule_reduce(ctx, link, dev, slabs, flat, grads, P, in_dim, out_dim)
         return denc, grads
     if gloss is not None and drgb is not None:
         # rgb ALSO feeds something else: fold both into one explicit gradient (plain framework ops; not the training step's path)
@@ -1195,14 +1290,10 @@ def _decoder_bwd(ctx, drgb, gloss):
     flat, grads, slabs, nslabs, nslab = _decoder_grad_buffers(ws, P, in_dim, out_dim, dev)
     common = (ptr(enc), ptr(rgb), ptr(None if fused else drgb, _f32, "grad"), ptr(target if fused else None), ptr(gloss if fused else None),
               ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(denc))
+    link.promise = None
     if DECODER_REDUCE_RIDES and P > 0:
         call("gngf_decoder_bwd", *common, *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(ctx.hidden), P, in_dim, out_dim, leaky, stream_ptr())
-        # (addresses, not the view tensors: a second reference to a gradient tensor would make autograd's AccumulateGrad
-        # CLONE it — before the reduction has filled it — instead of adopting it; `flat`, their base, keeps the memory alive)
-        _PENDING_REDUCE.append({"slabs": slabs, "flat": flat, "gptrs": [g.data_ptr() for g in grads], "P": P, "in_dim": in_dim,
-                                "out_dim": out_dim, "device": dev, "stream": torch.cuda.current_stream(dev).cuda_stream,
-                                "stream_obj": torch.cuda.current_stream(dev)})
-        _at_end_of_backward(_flush_pending_reduces)
+        _schedule_reduce(ctx, link, dev, slabs, flat, grads, P, in_dim, out_dim)
         hint = (slabs[nslab - 1:], nslabs, nslab)         # the per-slab maxima: all the encoder backward needs from the slabs
     else:
         absmax = torch.empty((1,), dtype=_f32, device=dev)
@@ -1210,46 +1301,46 @@ def _decoder_bwd(ctx, drgb, gloss):
              stream_ptr())
         hint = (absmax, 1, 0)
     ctx.hidden = None
-    _ABSMAX_HINTS[denc.data_ptr()] = (hint, denc._version)
+    link.absmax = (hint, denc.data_ptr(), denc._version)
     return denc, grads
 
 
 class DecoderFunction(torch.autograd.Function):
     """The reference's default decoder (in -> 64 -> 64 -> out, ReLU|LeakyReLU, Sigmoid; models.py:382-392) as ONE fused
-    MFMA kernel per direction (csrc/decoder.hip).  apply(enc, leaky, W0, b0, W1, b1, W2, b2) -> rgb."""
+    MFMA kernel per direction (csrc/decoder.hip).  apply(enc, leaky, link, W0, b0, W1, b1, W2, b2) -> rgb."""
 
     @staticmethod
-    def forward(ctx, enc, leaky, W0, b0, W1, b1, W2, b2):
-        rgb, _ = _decoder_fwd(ctx, enc, leaky, (W0, b0, W1, b1, W2, b2), None)
+    def forward(ctx, enc, leaky, link, W0, b0, W1, b1, W2, b2):
+        rgb, _ = _decoder_fwd(ctx, enc, leaky, (W0, b0, W1, b1, W2, b2), None, link=link)
         return rgb
 
     @staticmethod
     def backward(ctx, drgb):
         denc, grads = _decoder_bwd(ctx, drgb, None)
-        return (denc, None, *grads)
+        return (denc, None, None, *grads)
 
 
 class DecoderMseFunction(torch.autograd.Function):
-    """Decoder + the pixel loss of the training step in the same two launches: apply(enc, target, leaky, W0 .. b2) ->
-    (rgb, mse) with mse = torch.nn.MSELoss()(rgb, target) (reference utils.py:99).  The loss gradient 2 (rgb - target) / n is
-    formed in the backward kernel's prologue (no loss-backward launch, no d rgb round trip), and the loss value — which nothing
-    on the critical path needs — is a launch that train.GraphedStep moves onto a parallel branch of the step.  Same arithmetic,
-    same bits as ops.MseFunction.  (Folding the value into the forward kernel's epilogue was tried: +25 us on that kernel
-    inside the step for a 14 us launch saved.)"""
+    """Decoder + the pixel loss of the training step in the same two launches: apply(enc, target, leaky, gloss_known, link,
+    W0 .. b2) -> (rgb, mse) with mse = torch.nn.MSELoss()(rgb, target) (reference utils.py:99).  The loss gradient
+    2 (rgb - target) / n is formed in the backward kernel's prologue (no loss-backward launch, no d rgb round trip), and the
+    loss value — which nothing on the critical path needs — is a launch that train.GraphedStep moves onto the encoder
+    backward's launch.  Same arithmetic, same bits as ops.MseFunction.  (Folding the value into the forward kernel's epilogue
+    was tried: +25 us on that kernel inside the step for a 14 us launch saved.)"""
 
     @staticmethod
-    def forward(ctx, enc, target, leaky, gloss_known, W0, b0, W1, b1, W2, b2):
+    def forward(ctx, enc, target, leaky, gloss_known, link, W0, b0, W1, b1, W2, b2):
         ctx.set_materialize_grads(False)
-        rgb, mse = _decoder_fwd(ctx, enc, leaky, (W0, b0, W1, b1, W2, b2), target.detach(), gloss_known)
+        rgb, mse = _decoder_fwd(ctx, enc, leaky, (W0, b0, W1, b1, W2, b2), target.detach(), gloss_known, link=link)
         return rgb, mse
 
     @staticmethod
     def backward(ctx, drgb, gloss):
         if drgb is None and gloss is None:
             ctx.train = None
-            return (None,) * 10
+            return (None,) * 11
         denc, grads = _decoder_bwd(ctx, drgb, gloss)
-        return (denc, None, None, None, *grads)
+        return (denc, None, None, None, None, *grads)
 
 
 def decoder_fused_ok(acts, params):
@@ -1259,19 +1350,20 @@ def decoder_fused_ok(acts, params):
     return W0.shape[0] == 64 and tuple(W1.shape) == (64, 64) and W2.shape[1] == 64 and W0.shape[1] <= 64 and W2.shape[0] <= 4
 
 
-def decoder_apply(enc, acts, params, fused=None, mse_target=None, mse_gloss=None):
+def decoder_apply(enc, acts, params, fused=None, mse_target=None, mse_gloss=None, link=None):
     """Decoder MLP dispatch (reference models.py:382-392,469-470): the fused kernel for the default 64/64 widths,
     the generic MFMA linear chain otherwise.  mse_target (P,out) float32: also evaluate MSELoss(rgb, mse_target) inside the
-    fused kernels; the 0-dim loss is attached to the returned rgb as `rgb._gngf_fused_mse = (mse_target, loss)`."""
+    fused kernels; the 0-dim loss is attached to the returned rgb as `rgb._gngf_fused_mse = (mse_target, loss)`.
+    link: the forward pass's StepLink, shared with encode_apply (None: a private one)."""
     if (fused is None or fused) and decoder_fused_ok(acts, params):
         if (mse_target is not None and enc.shape[0] > 0 and mse_target.is_cuda and mse_target.dtype == _f32
                 and tuple(mse_target.shape) == (enc.shape[0], params[4].shape[0])):
             # mse_gloss: the gradient that WILL arrive at the loss value (a promise of the caller who owns the step, e.g. the
             # loss weight l_mse with loss.backward() seeded with 1): forward and backward then run in one launch
-            rgb, mse = DecoderMseFunction.apply(enc, mse_target, acts[0] == ACT_LEAKY, mse_gloss, *params)
+            rgb, mse = DecoderMseFunction.apply(enc, mse_target, acts[0] == ACT_LEAKY, mse_gloss, link, *params)
             rgb._gngf_fused_mse = (mse_target, mse)
             return rgb
-        return DecoderFunction.apply(enc, acts[0] == ACT_LEAKY, *params)
+        return DecoderFunction.apply(enc, acts[0] == ACT_LEAKY, link, *params)
     if fused:
         raise ValueError("fused decoder needs hidden widths [64, 64], in <= 64, out <= 4")
     return MlpFunction.apply(enc, acts, *params)
@@ -1303,7 +1395,7 @@ def encode_kernels(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, genc,
                                                plan.max_items, ptr(n_ls), ptr(G), ptr(enc), L, plan.Ls, F, plan.tile_shift,
                                                plan.lds_bytes, s())
         order = slot_order(vert_idx, plan.n_ls_host[:plan.Ls], vstride) if vert_idx is not None else None
-        out["encode_bwd:tiled"] = lambda: _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, (am, 1, 0))
+        out["encode_bwd:tiled"] = lambda: _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, (am, 1, 0), None)
         out["vertex_bwd"] = lambda: _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, None, order)
     if plan.Ls < L:
         out["encode_fwd:direct"] = lambda: call("gngf_encode_fwd", ptr(xy), *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls),
@@ -1312,28 +1404,3 @@ def encode_kernels(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, genc,
                                                 ptr(genc), ptr(dtables), ptr(None), P, L, F, T, K, mode, vstride, NV, plan.Ls,
                                                 L, s())
     return out
-
-
-def decoder_kernels(enc, params, leaky, drgb):
-    """{name: zero-arg launcher} for the fused decoder kernels (bench.py per-kernel timing)."""
-    W0, b0, W1, b1, W2, b2 = [_c(p.detach()) for p in params]
-    P, in_dim = enc.shape
-    out_dim = W2.shape[0]
-    rgb = torch.empty((P, out_dim), dtype=_f32, device=enc.device)
-    denc = torch.empty_like(enc)
-    grads = [torch.empty_like(w) for w in (W0, b0, W1, b1, W2, b2)]
-    slabs = torch.empty((_lib.query("gngf_decoder_bwd_slabs", P) * _lib.query("gngf_decoder_slab_floats", in_dim, out_dim),),
-                        dtype=_f32, device=enc.device)
-
-    hidden = torch.empty((_lib.query("gngf_decoder_hidden_floats", P),), dtype=_f32, device=enc.device) if DECODER_SAVE_HIDDEN else None
-
-    def fwd():
-        call("gngf_decoder_fwd", ptr(enc), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(rgb), ptr(hidden), ptr(None), ptr(None),
-             ptr(None), P, in_dim, out_dim, int(leaky), stream_ptr())
-
-    def bwd():
-        call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(None), ptr(None), ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(denc),
-             *[ptr(g) for g in grads], ptr(slabs), ptr(None), ptr(hidden), P, in_dim, out_dim, int(leaky), stream_ptr())
-
-    fwd()
-    return {"decoder_fwd": fwd, "decoder_bwd": bwd}

@@ -26,22 +26,25 @@ def all_reduce_sum(t, group=None):
         t.copy_(h)
 
 
-def enable_vertex_grid_exchange(world: int, group=None):
-    """Exchange the dense per-level VERTEX-GRID gradient (sum_l (N_l+2)^2 * F floats: 5.7 MB at N 16->512) inside the
+def enable_vertex_grid_exchange(net, world: int, group=None):
+    """Sets up `net.dp` (ops.DataParallel: the data-parallel state of THIS model).  Exchange the dense per-level VERTEX-GRID
+    gradient (sum_l (N_l+2)^2 * F floats: 5.7 MB at N 16->512) inside the
     encoder backward instead of the (L,T,F) table gradient (64 MiB at T = 2^19) afterwards: the vertex stage
     dG -> dE is linear and identical on every rank, so reducing dG first gives the same table gradient with ~11x
     fewer bytes on the xGMI links.  Levels that run in the direct form (the finest levels of very fine grids) keep the
-    table-gradient all-reduce, restricted to their own contiguous slice of the (L,T,F) buffer."""
-    ops.DP_TABLES_REDUCED = 0          # bookkeeping of a previous configuration does not carry over
-    ops.DP_DEFERRED = None
+    table-gradient exchange, restricted to their own contiguous slice of the (L,T,F) buffer."""
+    dp = net.dp
+    dp.tables_reduced = 0              # bookkeeping of a previous configuration does not carry over
+    dp.deferred = None
+    dp.world, dp.group = int(world), group
     if world <= 1:
-        ops.DP_EXCHANGE = ops.DP_MEAN = ops.DP_MAX = None
+        dp.exchange = dp.mean = dp.max_ = None
         return
-    ops.DP_EXCHANGE = lambda t: average_tensors([t], world, group)
+    dp.exchange = lambda t: average_tensors([t], world, group)
     # GNGF with a trainable HPD: the KL/JS loss is a nonlinear function of the batch-mean distribution, so p-bar is
     # averaged over ranks in the forward (exact single-GPU equivalence), and every rank builds its per-vertex table over
     # the same vertex rectangle (max of the shards' coordinate bounds).
-    ops.DP_MEAN = ops.DP_EXCHANGE
+    dp.mean = dp.exchange
 
     def _max(t):
         if dist.get_backend(group) == "nccl" or not t.is_cuda:
@@ -50,7 +53,7 @@ def enable_vertex_grid_exchange(world: int, group=None):
             h = t.detach().cpu()
             dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
             t.copy_(h)
-    ops.DP_MAX = _max
+    dp.max_ = _max
 
 
 def shard_batch(n_items: int, rank: int, world: int):
@@ -75,15 +78,16 @@ def _flat_alias(grads):
     return torch.as_strided(g0, (off - g0.storage_offset(),), (1,), g0.storage_offset())
 
 
-def defer_vertex_stage(on: bool = True):
+def defer_vertex_stage(net, on: bool = True):
     """Keep collectives OUT of the backward pass: the encoder backward stops after the pixel stage, and
     allreduce_gradients() / finish_backward() exchange dG and run the vertex stage afterwards.  With it the whole
     forward + backward is collective-free and can be replayed from one hipGraph on every rank.  Applies to index sources
     without trainable per-vertex weights (hash, frozen HPD); a trainable HPD keeps the in-backward exchange."""
-    ops.DP_DEFER_VERTEX = bool(on)
+    dp = net.dp
+    dp.defer_vertex = bool(on)
     if not on:
-        ops.DP_DEFERRED = None
-        ops.DP_TABLES_REDUCED = 0
+        dp.deferred = None
+        dp.tables_reduced = 0
 
 
 def average_tensors(tensors, world: int, group=None):
@@ -124,7 +128,8 @@ def allreduce_gradients(net, world: int, group=None, keep_tables_flag: bool = Fa
     if world <= 1:
         return
     tensors = []
-    deferred = ops.DP_DEFERRED
+    dp = getattr(net, "dp", None)                # (a plain nn.Module without the encoder's state: dense exchange only)
+    deferred = dp.deferred if dp is not None else None
     if deferred is not None:
         tensors.append(deferred[6])              # dG of the staged levels
     handled = set()
@@ -133,9 +138,9 @@ def allreduce_gradients(net, world: int, group=None, keep_tables_flag: bool = Fa
     if base is None and enc is not None and getattr(enc, "_grad_base_fp32", None) is not None \
             and any(getattr(m.weight, "grad_fp32", None) is not None for m in enc._hash_tables):
         base = enc._grad_base_fp32            # fp16 tables with ops.FP16_TABLE_GRAD_FP32: the fp32 buffer IS the gradient
-    tables_done = int(ops.DP_TABLES_REDUCED)     # leading levels already reduced through dG by the encoder backward
-    if not keep_tables_flag:
-        ops.DP_TABLES_REDUCED = 0
+    tables_done = int(dp.tables_reduced) if dp is not None else 0     # leading levels already reduced through dG by the encoder backward
+    if dp is not None and not keep_tables_flag:
+        dp.tables_reduced = 0
     if base is not None:
         handled = {id(m.weight) for m in enc._hash_tables}
         if tables_done < base.shape[0]:
@@ -151,7 +156,7 @@ def allreduce_gradients(net, world: int, group=None, keep_tables_flag: bool = Fa
         tensors.append(flat)
     average_tensors(tensors, world, group)
     if deferred is not None:
-        ops.run_deferred_vertex_stage(exchanged=True)
+        ops.run_deferred_vertex_stage(dp, exchanged=True)
     if flat is not None and not in_place:
         off = 0
         for p in rest:

@@ -247,7 +247,22 @@ def get_optimizer(net, encoding_lr, HPD_lr, MLP_lr, encoding_weight_decay, HPD_w
         fused_kernel = on_gpu
     if fused_kernel:
         return FusedAdam(groups, betas=betas, eps=eps)
+    enc = getattr(net, "encoding", None)
+    handover = getattr(enc, "grad_fp32_handover", None)
+    handover = ops.FP16_TABLE_GRAD_FP32 if handover is None else handover
+    if handover and any(p.dtype == torch.float16 for p in groups[0]["params"]):
+        raise ValueError("fp16 level tables with the fp32 gradient hand-over (grad_fp32, no .grad) need train.FusedAdam: "
+                         "torch.optim.Adam would never see a gradient for them — pass fused_kernel=True or turn the hand-over off")
     return torch.optim.Adam(groups, betas=betas, eps=eps, **({"fused": True} if on_gpu else {}))
+
+
+def promised_gloss(loss_fn, l_mse):
+    """The gradient that will reach the pixel-loss value when the step's total is assemble_loss(...) and backward() is seeded
+    with 1: l_mse — but only when loss_fn is this package's Loss (its mse term IS MSELoss(rgb, target)) and l_mse is a plain
+    number; anything else makes no promise (the decoder then runs its two-kernel path, correct for any gradient)."""
+    if type(loss_fn) is Loss and isinstance(l_mse, (int, float)) and not isinstance(l_mse, bool):
+        return float(l_mse)
+    return None
 
 
 def assemble_loss(mse, kls, colls, l_mse, l_js_kl, l_collisions):
@@ -305,20 +320,21 @@ class GraphedStep:
         # the pixel loss is fused into the decoder: its gradient is formed inside the backward kernel, and its VALUE — which no
         # kernel of the step reads when it enters the total with weight 1 — runs on a parallel branch, joined at the end
         aside = isinstance(l_mse, (int, float)) and l_mse == 1 and (models.should_use_hash_function or getattr(net, "compute_pbar", True) is False)
-        ops.LOSS_VALUE_ASIDE = bool(aside)
+        prev_aside, net.loss_value_aside = net.loss_value_aside, bool(aside)
         try:
             # backward() below is seeded with 1 and the total is l_mse * mse + (terms without mse): the gradient that reaches the
-            # pixel loss IS l_mse — promised to the decoder, which then runs forward and backward in one launch
-            with net.fused_mse(st["y"], gloss=(float(l_mse) if isinstance(l_mse, (int, float)) else None)):
+            # pixel loss IS l_mse — promised to the decoder, which then runs forward and backward in one launch (the promise
+            # is only made for this package's own Loss: a custom loss_fn may weigh the pixel term differently)
+            with net.fused_mse(st["y"], gloss=promised_gloss(self.loss_fn, l_mse)):
                 out, probs, idx, _counts = torch.func.functional_call(net, shadow, (st["x"], self.batch_percentage), {"should_calc_counts": False})
         finally:
-            ops.LOSS_VALUE_ASIDE = False
+            net.loss_value_aside = prev_aside
         mse, kls, colls = self.loss_fn(out, st["y"], None if probs is None else probs.shape[-1], probs, st["pc"], st["pm"])
         loss = assemble_loss(mse, kls, colls, l_mse, l_js_kl, l_collisions)
         if loss is not mse:
-            ops.join_loss_value()                      # the total is computed from the value: it has to be there
+            net.join_loss_value()                      # the total is computed from the value: it has to be there
         loss.backward(gradient=st["one"].to(loss.dtype))
-        ops.join_loss_value()
+        net.join_loss_value()
         for name, p in st["named"]:
             p.grad = shadow[name].grad             # the parameters' own .grad: what the optimizer and the caller read
             g32 = getattr(shadow[name], "grad_fp32", None)
@@ -456,8 +472,7 @@ def train_epoch(net, loss_fn, optimizer, x, target, w, h, l_mse, l_js_kl, l_coll
         else:
             optimizer.zero_grad()
             by = by.contiguous()
-            with (net.fused_mse(by, gloss=(float(l_mse) if isinstance(l_mse, (int, float)) else None)) if hasattr(net, "fused_mse")
-                  else contextlib.nullcontext()):
+            with (net.fused_mse(by, gloss=promised_gloss(loss_fn, l_mse)) if hasattr(net, "fused_mse") else contextlib.nullcontext()):
                 out, probs, idx, counts = net(bx, batch_percentage, should_calc_counts=should_calc_counts)
             mse, kls, colls = loss_fn(out, by, None if probs is None else probs.shape[-1], probs,
                                       previous_collisions, previous_min_possible_collisions)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNGF_ABI_VERSION 6
+#define GNGF_ABI_VERSION 7
 #define GNGF_MAX_LEVELS 32
 #define GNGF_MAX_TOPK 32
 
@@ -124,11 +124,15 @@ int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32
                           int absmax_stride, float* dG, float* partials, int L, int Ls, int F, int tile_shift, int lds_bytes,
                           int chunk, const float* ride_slabs, float* ride_dW0, float* ride_db0, float* ride_dW1, float* ride_db1,
                           float* ride_dW2, float* ride_db2, int64_t ride_P, int ride_in_dim, int ride_out_dim,
+                          const float* gloss_promised, const float* gloss_arrived,
                           const float* mse_pred, const float* mse_label, float* mse_loss, float* mse_workspace, int64_t mse_n,
                           void* stream);
 /* ride_* (optional, ride_slabs NULL = none): the slab reduction of a preceding gngf_decoder_bwd that was called without
  * gradient pointers (= gngf_decoder_reduce(ride_slabs, ride_dW0 .. ride_db2, NULL, ride_P, ride_in_dim, ride_out_dim)) runs in
  * extra workgroups of this launch instead of a launch of its own (one dependent launch less on the step's critical path).
+ * gloss_promised / gloss_arrived (optional device scalars, both or neither): genc came out of gngf_decoder_train, which ran its
+ * backward with *gloss_promised before autograd delivered *gloss_arrived; if the two differ (relative 1e-6) every gradient
+ * this launch writes (the vertex-grid gradient and the ridden decoder gradients) is NaN — checked on the device, no sync.
  * mse_* (optional, mse_pred NULL = none): likewise gngf_mse_fwd(mse_pred, mse_label, mse_loss, mse_workspace, mse_n) — the
  * VALUE of the pixel loss, which no kernel of the step reads. */
 /* vertex stage backward for the vertex-table source in SLOT order (order (NV*K) int32 = argsort of vert_idx, flat):
@@ -198,7 +202,9 @@ int gngf_decoder_bwd(const float* enc, const float* rgb, const float* drgb, cons
   * second stream, beside the encoder backward — which only needs max |denc|: the last float of every slab is that slab's
   * maximum, i.e. genc_absmax = slabs + slab_floats - 1, absmax_count = gngf_decoder_bwd_slabs(P), absmax_stride = slab_floats). */
 int gngf_decoder_reduce(const float* slabs, float* dW0, float* db0, float* dW1, float* db1, float* dW2, float* db2,
-                        float* denc_absmax, int64_t P, int in_dim, int out_dim, void* stream);
+                        float* denc_absmax, const float* gloss_promised, const float* gloss_arrived, int64_t P, int in_dim,
+                        int out_dim, void* stream);
+/* gloss_promised / gloss_arrived: as for gngf_encode_tiled_bwd (NULL, NULL: nothing was promised). */
 int gngf_decoder_bwd_slabs(int64_t P);
 /* measurement: duration (ns, device 100 MHz clock; first workgroup start -> last workgroup end) of the most recent
  * gngf_decoder_bwd main kernel — usable when the call sits inside a replayed hipGraph, where events cannot be recorded.

@@ -302,6 +302,16 @@ def adam_step(p, g, m, v, step, lr, wd, betas=(0.9, 0.99), eps=1e-15):
     return p, m, v
 
 
+def batch_norm_train(x, weight, bias, eps=1e-5):
+    """nn.BatchNorm1d in training mode on (P,C) coordinates (models.py:340,394-397): batch mean, BIASED batch variance,
+    fp32 arithmetic as ATen's CPU kernel (mean and variance accumulated in double, normalisation in float)."""
+    x = x.astype(f32)
+    mean = x.astype(np.float64).mean(0)
+    var = x.astype(np.float64).var(0)
+    invstd = (1.0 / np.sqrt(var + eps)).astype(f32)
+    return ((x - mean.astype(f32)) * invstd * weight.astype(f32) + bias.astype(f32)).astype(f32)
+
+
 # --------------------------------------------------------------------------- a14 end-to-end (literal)
 def gngf_forward(x, n_ls, tables, dec_w, dec_b, *, hash_mode, hpd_w=None, hpd_b=None, K=4, blend=True, leaky=False):
     """GeneralNeuralGaugeFields.forward, models.py:394-484, literal per-instance formulation.

@@ -598,7 +598,89 @@ def g3b(F_, U_, M, P_):
     save("G3b_hash_large_tables", **out)
 
 
-GROUPS = {"G3b": g3b, "G11": g11, "G12": g12, "G13": g13, "G14": g14, "G10": g10, "G1": g1, "G2": g2_g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
+def g15(F_, U_, M, P_):
+    """should_keep_topk_only=True (models.py:478-484; half of the reference's grid, params.py:58-75): `probs` is the (P,L,4,K)
+    top-K tensor and the loss's distribution term runs with N = K (functions.py:226-232).  cfg1 shape, two optimisation steps."""
+    mods = (F_, U_, M)
+    img, X, Y, h, w = load_strawberry()
+    torch.manual_seed(SEED + 15)
+    perm = torch.randperm(h * w)
+    B = 4096
+    net = make_net(M, mods, hash_mode=False, T=256, L=4, n_min=8, n_max=32, K=4, keep_topk=True)
+    loss_fn = U_.Loss(delta=1, gamma=-2, epsilon=1)
+    opt = F_.get_optimizer(net, encoding_lr=1e-4, HPD_lr=1e-3, MLP_lr=1e-3,
+                           encoding_weight_decay=0, HPD_weight_decay=1e-6, MLP_weight_decay=1e-6)
+    out = {"perm": perm[: 2 * B].numpy().astype(np.int64), "hw": np.array([h, w])}
+    for k_, v_ in net.state_dict().items():
+        out["init_" + k_.replace(".", "_")] = np32(v_)
+    for step in range(2):
+        sl = perm[step * B:(step + 1) * B]
+        bx, by = X[sl], Y[sl]
+        opt.zero_grad()
+        rgb, probs, idx, counts = net(bx, 1 / 3, should_calc_counts=False)
+        assert tuple(probs.shape) == (B, 4, 4, 4)
+        mse, kls, coll = loss_fn(rgb, by, probs.shape[-1], probs, torch.tensor([]), torch.tensor([]))
+        loss = 1 * mse + ((1 * kls) + (1e-3 * coll if coll.nelement() != 0 else 1)).sum(0)
+        loss.backward()
+        s_ = f"s{step}_"
+        out[s_ + "rgb"], out[s_ + "probs"], out[s_ + "idx"] = np32(rgb), np32(probs), np32(idx)
+        out[s_ + "mse"], out[s_ + "kls"], out[s_ + "loss"] = np32(mse), np32(kls), np32(loss)
+        for k_, p_ in net.named_parameters():
+            if p_.grad is not None:
+                out[s_ + "grad_" + k_.replace(".", "_")] = np32(p_.grad)
+        opt.step()
+        for k_, p_ in net.named_parameters():
+            out[s_ + "param_" + k_.replace(".", "_")] = np32(p_)
+    save("G15_keep_topk_only", **out)
+
+
+def g16(F_, U_, M, P_):
+    """should_batchnorm_data=True (models.py:394-397; main.py:50 then feeds RAW pixel coordinates): the coordinates pass through
+    nn.BatchNorm1d in training mode, so grid vertices are centred on 0 (negative).  cfg1 shape, both index sources, one step."""
+    mods = (F_, U_, M)
+    img, X, Y, h, w = load_strawberry()
+    Xraw = X * (max(w, h) - 1)                               # main.py:50-51 skipped under should_batchnorm_data
+    torch.manual_seed(SEED + 16)
+    perm = torch.randperm(h * w)
+    B = 2048
+    rh.set_flag(mods + (P_,), "should_batchnorm_data", True)
+    try:
+        for mode in ("gngf", "hash"):
+            hash_mode = mode == "hash"
+            net = make_net(M, mods, hash_mode=hash_mode, T=256, L=4, n_min=8, n_max=32, K=4)
+            net.train()
+            loss_fn = U_.Loss(delta=1, gamma=-2, epsilon=1)
+            out = {"perm": perm[:B].numpy().astype(np.int64), "hw": np.array([h, w])}
+            for k_, v_ in net.state_dict().items():
+                out["init_" + k_.replace(".", "_")] = np32(v_)
+            bx, by = Xraw[perm[:B]], Y[perm[:B]]
+            rgb, probs, idx, counts = net(bx, 1 / 3, should_calc_counts=False)
+            mse, kls, coll = loss_fn(rgb, by, None if hash_mode else probs.shape[-1], probs,
+                                     None if hash_mode else torch.tensor([]), None if hash_mode else torch.tensor([]))
+            loss = 1 * mse
+            if not hash_mode:
+                loss = loss + ((1 * kls) + (1e-3 * coll if coll.nelement() != 0 else 1)).sum(0)
+            loss.backward()
+            out["rgb"], out["idx"], out["mse"], out["loss"] = np32(rgb), np32(idx), np32(mse), np32(loss)
+            out["idx_min_vertex"] = np.array(float(torch.floor(net._batch_norm(bx).detach() * 8).min()))
+            if not hash_mode:
+                out["kls"] = np32(kls)
+                out["pbar"] = np32(probs.sum(0).sum(1) / (probs.shape[0] * probs.shape[2]))
+                tp, _ti = torch.topk(probs, 4, dim=-1)
+                out["topk_probs"] = np32(tp)
+            for k_, p_ in net.named_parameters():
+                if p_.grad is not None:
+                    out["grad_" + k_.replace(".", "_")] = np32(p_.grad)
+            for k_, v_ in net.state_dict().items():
+                if k_.startswith("_batch_norm."):
+                    out["after_" + k_.replace(".", "_")] = np32(v_)
+            save(f"G16_batchnorm_{mode}", **out)
+    finally:
+        rh.set_flag(mods + (P_,), "should_batchnorm_data", False)
+        rh.set_flag(mods, "should_use_hash_function", False)
+
+
+GROUPS = {"G15": g15, "G16": g16, "G3b": g3b, "G11": g11, "G12": g12, "G13": g13, "G14": g14, "G10": g10, "G1": g1, "G2": g2_g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

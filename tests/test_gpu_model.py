@@ -116,6 +116,103 @@ def test_three_training_steps_match_reference(golden, mode):
         models.should_use_hash_function = False
 
 
+def _cfg1_net(models, g, **kw):
+    net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=256, num_levels=4, n_min=8, n_max=32,
+                                          MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
+                                          HPD_out_features=256, feature_dim=2, topk_k=4, **kw)
+    sd = net.state_dict()
+    net.load_state_dict({k: (t(g["init_" + k.replace(".", "_")]) if "init_" + k.replace(".", "_") in g else v) for k, v in sd.items()})
+    return net
+
+
+def test_keep_topk_only_two_steps_match_reference(golden):
+    """G15: should_keep_topk_only=True (reference models.py:478-484; half of its grid, params.py:58-75): `probs` is the
+    (P,L,4,K) top-K tensor, the loss's distribution term runs with N = K (functions.py:226-232).  Two optimisation steps
+    written by the reference itself: outputs, loss terms, every gradient, parameters after the first step."""
+    from collision_handling_in_instantngp_amd import models, train
+    g = golden("G15_keep_topk_only")
+    models.should_use_hash_function = False
+    net = _cfg1_net(models, g, should_keep_topk_only=True)
+    X, Y, h, w = strawberry(golden)
+    loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
+    opt = train.get_optimizer(net, 1e-4, 1e-3, 1e-3, 0, 1e-6, 1e-6)
+    B = 4096
+    perm = t(g["perm"])
+    empty = torch.tensor([], device=DEV)
+    for step in range(2):
+        sl = perm[step * B:(step + 1) * B]
+        opt.zero_grad()
+        rgb, probs, idx, counts = net(X[sl], 1 / 3, should_calc_counts=False)
+        assert tuple(probs.shape) == (B, 4, 4, 4) and probs.requires_grad and tuple(idx.shape) == (B, 4, 4, 4)
+        mse, kls, coll = loss_fn(rgb, Y[sl], probs.shape[-1], probs, empty, empty)
+        loss = train.assemble_loss(mse, kls, coll, 1, 1, 1e-3)
+        loss.backward()
+        s = f"s{step}_"
+        rt = [2e-5, 2e-3][step]
+        close(rgb, g[s + "rgb"], rt, 1e-6 * (1 + 50 * step), "G15 rgb")
+        same = (idx.cpu().numpy() == g[s + "idx"]).all(-1)
+        assert same.mean() > 0.995
+        close(probs.detach().cpu().numpy()[same], g[s + "probs"][same], 10 * rt, 1e-9, "G15 top-K probabilities returned as probs")
+        close(mse, g[s + "mse"], rt, 0, "G15 mse")
+        close(kls, g[s + "kls"], 10 * rt, 1e-9, "G15 JS/KL term with N = K")
+        close(loss, g[s + "loss"], rt, 0, "G15 loss")
+        if step == 0:
+            for k_, p_ in net.named_parameters():
+                gk = s + "grad_" + k_.replace(".", "_")
+                if gk in g:
+                    scale = np.abs(g[gk]).max() + 1e-30
+                    close(p_.grad, g[gk], 5e-3, 2e-4 * scale, "G15 grad " + k_)
+        opt.step()
+
+
+@pytest.mark.parametrize("mode", ["hash", "gngf"])
+def test_batchnorm_coordinates_match_reference(golden, mode):
+    """G16: should_batchnorm_data=True (reference models.py:394-397; main.py:50 then feeds RAW pixel coordinates): nn.BatchNorm1d
+    in training mode centres the coordinates on 0, so grid vertices are negative.  Hash: the direct-form kernels hash any
+    integer vertex (indices bit-exact).  GNGF: the per-instance formulation on the module-boundary kernels."""
+    from collision_handling_in_instantngp_amd import models, train
+    g = golden(f"G16_batchnorm_{mode}")
+    models.should_use_hash_function = mode == "hash"
+    models.should_batchnorm_data = True
+    try:
+        net = _cfg1_net(models, g)
+        net.train()
+        img = golden("strawberry_rgb")["img"]
+        h, w = img.shape[:2]
+        rows, cols = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+        Xraw = torch.tensor(np.stack([rows, cols], -1).reshape(-1, 2)).float().to(DEV)          # main.py:50 skipped
+        Y = torch.tensor(img.reshape(-1, 3) / 255).float().to(DEV)
+        sl = t(g["perm"])
+        rgb, probs, idx, _ = net(Xraw[sl], 1 / 3)
+        empty = torch.tensor([], device=DEV)
+        mse, kls, coll = train.Loss(delta=1, gamma=-2, epsilon=1)(rgb, Y[sl], None if probs is None else probs.shape[-1], probs, empty, empty)
+        loss = train.assemble_loss(mse, kls, coll, 1, 1, 1e-3)
+        loss.backward()
+        close(rgb, g["rgb"], 2e-5, 2e-6, f"G16 batchnorm {mode} rgb")
+        close(mse, g["mse"], 2e-5, 0, f"G16 batchnorm {mode} mse")
+        close(loss, g["loss"], 2e-5, 0, f"G16 batchnorm {mode} loss")
+        if mode == "hash":
+            assert np.array_equal(idx.cpu().numpy(), g["idx"])                                  # negative vertices hashed bit-exactly
+        else:
+            assert (idx.cpu().numpy() == g["idx"]).mean() > 0.995
+            assert tuple(probs.shape) == (2048, 4, 4, 256)
+            close(kls, g["kls"], 2e-4, 1e-9, "G16 batchnorm gngf JS/KL")
+            close(probs.sum(0).sum(1) / (probs.shape[0] * probs.shape[2]), g["pbar"], 1e-4, 1e-9, "G16 batchnorm gngf p-bar")
+        for k_, p_ in net.named_parameters():
+            gk = "grad_" + k_.replace(".", "_")
+            if gk in g:
+                scale = np.abs(g[gk]).max() + 1e-30
+                close(p_.grad, g[gk], 5e-3, 2e-4 * scale, f"G16 batchnorm {mode} grad " + k_)
+            else:
+                assert p_.grad is None or float(p_.grad.abs().max()) == 0.0, k_                # BatchNorm's affine parameters: no gradient path
+        for k_, v_ in net.state_dict().items():
+            if k_.startswith("_batch_norm.") and v_.dtype.is_floating_point:
+                close(v_, g["after_" + k_.replace(".", "_")], 1e-5, 1e-6, "G16 " + k_)           # running statistics updated as the reference's
+    finally:
+        models.should_batchnorm_data = False
+        models.should_use_hash_function = False
+
+
 def test_state_dict_keys_and_shapes_match_reference_contract(golden):
     net, g, models, train = build(golden, "gngf")
     keys = set(net.state_dict().keys())
@@ -545,3 +642,76 @@ def test_fp16_table_model_trains_with_fused_adam_like_the_fp32_master_model(gold
     finally:
         models.should_use_hash_function = False
         ops.FP16_TABLE_GRAD_FP32 = False
+
+
+def test_three_models_interleaved_do_not_share_state(golden):
+    """Every piece of per-step state lives on the model / the autograd context (ops.DataParallel, ops.StepLink, the fp32
+    gradient sink), not in the process: three live models — fp32 tables, fp16 tables with the fp32 gradient hand-over, and one
+    with a deferred vertex stage (data parallel) — run their forward and backward passes INTERLEAVED, each inside
+    fused_mse(target, gloss=1.0) (decoder slab reduction riding on the encoder backward), and every model's gradients equal the
+    ones it produces alone."""
+    from collision_handling_in_instantngp_amd import models, ops, train
+    models.should_use_hash_function = True
+    try:
+        gen = torch.Generator().manual_seed(3)
+        P = 2 ** 15
+        xs = [torch.rand((P, 2), generator=gen).to(DEV) for _ in range(3)]
+        ys = [torch.rand((P, 3), generator=gen).to(DEV) for _ in range(3)]
+
+        def make(kind):
+            torch.manual_seed(11)
+            net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=2 ** 14, num_levels=16, n_min=16, n_max=256,
+                                                  MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
+                                                  HPD_out_features=2 ** 14, feature_dim=2, topk_k=4,
+                                                  table_dtype=(torch.float16 if kind == "fp16" else torch.float32))
+            net.return_indices = False
+            if kind == "fp16":
+                with torch.no_grad():
+                    for m in net.encoding._hash_tables:
+                        m.weight.mul_(100.0)
+                net.encoding.grad_fp32_handover = True
+            if kind == "deferred":
+                net.dp.exchange = lambda tns: None            # a world of one: the exchange leaves dG as it is
+                net.dp.defer_vertex = True
+            return net
+
+        def fwd(net, k):
+            with net.fused_mse(ys[k], gloss=1.0):
+                rgb, *_ = net(xs[k], 1.0)
+            return ops.mse_loss(rgb, ys[k])
+
+        def finish(net, kind):
+            if kind == "deferred":
+                assert net.dp.deferred is not None and net.dp.tables_reduced == 16
+                assert ops.run_deferred_vertex_stage(net.dp)
+            else:
+                assert net.dp.deferred is None
+            torch.cuda.synchronize()
+            out = {}
+            for n_, p_ in net.named_parameters():
+                gr = p_.grad if p_.grad is not None else getattr(p_, "grad_fp32", None)
+                if gr is not None:
+                    out[n_] = gr.detach().float().clone()
+            return out
+
+        kinds = ("fp32", "fp16", "deferred")
+        alone = []
+        for k, kind in enumerate(kinds):
+            net = make(kind)
+            fwd(net, k).backward()
+            alone.append(finish(net, kind))
+            del net
+        nets = [make(kind) for kind in kinds]
+        losses = [fwd(net, k) for k, net in enumerate(nets)]          # three forward passes in flight
+        for k in (2, 0, 1):                                           # backward passes in another order
+            losses[k].backward()
+        for k, kind in enumerate(kinds):
+            got = finish(nets[k], kind)
+            assert set(got) == set(alone[k]) and len(got) >= 16 + 6, (kind, sorted(got))
+            assert (kind == "fp16") == (nets[k].encoding._hash_tables[0].weight.grad is None)      # handed over as grad_fp32
+            for n_ in got:
+                scale = float(alone[k][n_].abs().max())
+                assert scale > 0, (kind, n_)
+                close(got[n_], alone[k][n_].cpu().numpy(), 0, 1e-5 * scale, f"interleaved == alone ({kind}: {n_})")
+    finally:
+        models.should_use_hash_function = False

@@ -80,16 +80,16 @@ def _worker(rank, world, port, mode, ret):
         loss_of(xy, tgt).backward()
         ref = _grads(net)
         net.zero_grad()
-    parallel.enable_vertex_grid_exchange(world)
+    parallel.enable_vertex_grid_exchange(net, world)
     defer = mode.endswith("_deferred")
-    parallel.defer_vertex_stage(defer)
+    parallel.defer_vertex_stage(net, defer)
     lo, hi = parallel.shard_batch(P, rank, world)
     loss_of(xy[lo:hi], tgt[lo:hi]).backward()
-    reduced_flag = ops.DP_TABLES_REDUCED
+    reduced_flag = net.dp.tables_reduced
     if defer:
-        assert ops.DP_DEFERRED is not None, "the vertex stage was not deferred"
+        assert net.dp.deferred is not None, "the vertex stage was not deferred"
     parallel.allreduce_gradients(net, world)
-    parallel.defer_vertex_stage(False)
+    parallel.defer_vertex_stage(net, False)
     got = _grads(net)
     ok = True
     if rank == 0:
@@ -100,7 +100,7 @@ def _worker(rank, world, port, mode, ret):
             ok &= bool(np.abs(got[k].astype(np.float64) - ref[k].astype(np.float64)).max() <= tol * scale)
     with open(os.path.join(ret, f"rank{rank}.json"), "w") as fh:      # (a Manager would fork this GPU-initialised process)
         json.dump([bool(ok), int(reduced_flag)], fh)
-    parallel.enable_vertex_grid_exchange(1)
+    parallel.enable_vertex_grid_exchange(net, 1)
     models.should_use_hash_function = False
     dist.destroy_process_group()
 

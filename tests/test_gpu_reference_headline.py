@@ -50,8 +50,13 @@ def headline_net(models, T=2 ** 19, L=16, Fd=2, K=4, **kw):
                                            HPD_out_features=T, feature_dim=Fd, topk_k=K, **kw)
 
 
-def test_gngf_headline_shape_matches_reference_T19(golden):
-    from collision_handling_in_instantngp_amd import models, ops, train
+@pytest.mark.parametrize("fused_train", [False, True])
+def test_gngf_headline_shape_matches_reference_T19(golden, fused_train):
+    """fused_train: the same step inside net.fused_mse(target, gloss=1.0), i.e. through gngf_decoder_train (forward + MSE
+    gradient + backward of the decoder in ONE launch — the kernel bench.py times): the reference's own gradients check it
+    (models.py:469-470, utils.py:99)."""
+    import contextlib
+    from collision_handling_in_instantngp_amd import models, ops, train, _lib
     g = golden("G12_gngf_T19_reference")
     L, T, Fd, K = 16, 2 ** 19, 2, 4
     models.should_use_hash_function = False
@@ -73,12 +78,21 @@ def test_gngf_headline_shape_matches_reference_T19(golden):
     x = X[sel]
     loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
     net.zero_grad()
-    rgb, probs, idx, counts = net(x, 1.0, should_calc_counts=False)
-    assert isinstance(probs, models.VertexDistribution) and tuple(probs.shape) == (8, L, 4, T)
-    empty = torch.tensor([], device=DEV)
-    mse, kls, coll = loss_fn(rgb, Y[sel], probs.shape[-1], probs, empty, empty)
-    loss = train.assemble_loss(mse, kls, coll, 1, 1, 1e-3)
-    loss.backward()
+    ysel = Y[sel].contiguous()
+    _lib.PROFILE = {}
+    try:
+        with (net.fused_mse(ysel, gloss=1.0) if fused_train else contextlib.nullcontext()):
+            rgb, probs, idx, counts = net(x, 1.0, should_calc_counts=False)
+        assert isinstance(probs, models.VertexDistribution) and tuple(probs.shape) == (8, L, 4, T)
+        empty = torch.tensor([], device=DEV)
+        mse, kls, coll = loss_fn(rgb, ysel, probs.shape[-1], probs, empty, empty)
+        loss = train.assemble_loss(mse, kls, coll, 1, 1, 1e-3)
+        loss.backward()
+        torch.cuda.synchronize()
+        names = set(_lib.PROFILE)
+    finally:
+        _lib.PROFILE = None
+    assert ("gngf_decoder_train" in names) == fused_train and ("gngf_decoder_bwd" in names) == (not fused_train), names
 
     # --- top-K membership per (pixel, level, corner): equal as a set unless the reference's own K-th / (K+1)-th gap is a tie
     ref_idx, ref_tp, nxt = g["topk_idx"].astype(np.int64), g["topk_probs"], g["next_prob"]
@@ -244,9 +258,12 @@ def test_hwp_constructor_path_frozen_hpd_matches_reference_and_caches_its_table(
     assert torch.equal(idx_d, idx_a) and torch.equal(rgb_d, rgb_a)
 
 
-def test_macaw_hash_step_at_headline_shape_matches_reference(golden):
-    """BASELINE configs[2]: macaw.jpg, plain spatial hash, L=16 F=2 T=2^19 — one forward + MSE + backward on 4096 of its pixels."""
-    from collision_handling_in_instantngp_amd import models, train
+@pytest.mark.parametrize("fused_train", [False, True])
+def test_macaw_hash_step_at_headline_shape_matches_reference(golden, fused_train):
+    """BASELINE configs[2]: macaw.jpg, plain spatial hash, L=16 F=2 T=2^19 — one forward + MSE + backward on 4096 of its pixels.
+    fused_train: inside net.fused_mse(target, gloss=1.0) — the decoder's forward, loss gradient and backward in one launch."""
+    import contextlib
+    from collision_handling_in_instantngp_amd import models, train, _lib
     g = golden("G14_macaw_hash")
     img = golden("macaw_rgb")["img"]
     assert tuple(g["hw"]) == img.shape[:2]
@@ -266,9 +283,18 @@ def test_macaw_hash_step_at_headline_shape_matches_reference(golden):
         X, Y, h, w = image_xy(img)
         sel = t(g["sel"])
         net.zero_grad()
-        rgb, probs, idx, _ = net(X[sel], 1.0)
-        mse, _, _ = train.Loss(delta=1, gamma=-2, epsilon=1)(rgb, Y[sel], None, None, None, None)
-        mse.backward()
+        ysel = Y[sel].contiguous()
+        _lib.PROFILE = {}
+        try:
+            with (net.fused_mse(ysel, gloss=1.0) if fused_train else contextlib.nullcontext()):
+                rgb, probs, idx, _ = net(X[sel], 1.0)
+            mse, _, _ = train.Loss(delta=1, gamma=-2, epsilon=1)(rgb, ysel, None, None, None, None)
+            mse.backward()
+            torch.cuda.synchronize()
+            names = set(_lib.PROFILE)
+        finally:
+            _lib.PROFILE = None
+        assert ("gngf_decoder_train" in names) == fused_train, names
         ic = idx.cpu()
         chk = np.array([int(ic.sum()), int((ic * torch.arange(1, 4097)[:, None, None]).sum() % (2 ** 61 - 1))], dtype=np.int64)
         assert np.array_equal(chk, g["idx_checksum"])                            # index work: bit-exact

@@ -165,3 +165,60 @@ def test_adam_matches_reference_step(golden):
         close(p1, g["s0_param_" + name], 1e-5, 1e-9)
         p2, m, v = orc.adam_step(p1, g["s1_grad_" + name], m, v, 2, lr, wd)
         close(p2, g["s1_param_" + name], 1e-5, 1e-9)
+
+
+def _strawberry_xy(golden, g, raw=False):
+    img = golden("strawberry_rgb")["img"]
+    h, w = (int(v) for v in g["hw"])
+    rows, cols = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    X = np.stack([rows, cols], -1).reshape(-1, 2).astype(np.float32)
+    if not raw:
+        X = (X / np.float32(max(w, h) - 1)).astype(np.float32)
+    Y = (img.reshape(-1, 3) / 255).astype(np.float32)
+    return X, Y
+
+
+def test_g15_keep_topk_only(golden):
+    """should_keep_topk_only=True (reference models.py:478-484, functions.py:226-232): probs IS the (P,L,4,K) top-K tensor
+    and the distribution term of the loss runs with N = K."""
+    g = golden("G15_keep_topk_only")
+    X, Y = _strawberry_xy(golden, g)
+    sl = g["perm"][:4096]
+    tables, (dw, db) = _state(g, "init_")
+    hw, hb = _mlp_params(g, "init_HPD_module_list_", 4)
+    out = orc.gngf_forward(X[sl], orc.level_resolutions(8, 32, 4), tables, dw, db, hash_mode=False, K=4, hpd_w=hw, hpd_b=hb)
+    close(out["rgb"], g["s0_rgb"], 1e-5, 1e-6)
+    assert g["s0_probs"].shape == (4096, 4, 4, 4)
+    same = (out["idx"] == g["s0_idx"]).all(-1)
+    assert same.mean() > 0.999
+    close(out["topk_probs"][same], g["s0_probs"][same], 1e-5, 1e-9)
+    mse, kls = orc.loss_forward(out["rgb"], Y[sl], out["topk_probs"], gamma=-2, epsilon=1)      # N = K
+    close(mse, g["s0_mse"], 1e-5, 0)
+    close(kls, g["s0_kls"], 1e-4, 1e-9)
+    close(mse + (kls + 1).sum(), g["s0_loss"], 1e-5, 0)
+
+
+@pytest.mark.parametrize("mode", ["hash", "gngf"])
+def test_g16_batchnorm_coordinates(golden, mode):
+    """should_batchnorm_data=True (reference models.py:394-397 with main.py:50 feeding raw pixel coordinates): BatchNorm1d in
+    training mode centres the coordinates on 0, so the grid has NEGATIVE vertices (hashed / fed to the HPD as they are)."""
+    g = golden(f"G16_batchnorm_{mode}")
+    X, Y = _strawberry_xy(golden, g, raw=True)
+    sl = g["perm"]
+    x = orc.batch_norm_train(X[sl], g["init__batch_norm_weight"], g["init__batch_norm_bias"])
+    assert float(np.floor(x * 8).min()) == float(g["idx_min_vertex"]) < 0
+    tables, (dw, db) = _state(g, "init_")
+    kw = {}
+    if mode == "gngf":
+        kw["hpd_w"], kw["hpd_b"] = _mlp_params(g, "init_HPD_module_list_", 4)
+    out = orc.gngf_forward(x, orc.level_resolutions(8, 32, 4), tables, dw, db, hash_mode=(mode == "hash"), K=4, **kw)
+    close(out["rgb"], g["rgb"], 1e-5, 1e-6)
+    if mode == "hash":
+        assert np.array_equal(out["idx"], g["idx"])
+    else:
+        assert (out["idx"] == g["idx"]).mean() > 0.999
+        close(out["topk_probs"], g["topk_probs"], 1e-4, 1e-9)
+    mse, kls = orc.loss_forward(out["rgb"], Y[sl], out["probs"], gamma=-2, epsilon=1)
+    close(mse, g["mse"], 1e-5, 0)
+    if mode == "gngf":
+        close(kls, g["kls"], 1e-4, 1e-9)

@@ -13,9 +13,9 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 dev = torch.device("cuda", 0)
 xy, target, bounds = bench.make_batch("cfg2", 2 ** 20, 0, dev)
 world = 2          # pretend: the exchange code runs, the group really has one rank
-parallel.enable_vertex_grid_exchange(world)
-parallel.defer_vertex_stage(True)
 net, models = bench.build_model("gngf_frozen", dev, bounds)
+parallel.enable_vertex_grid_exchange(net, world)
+parallel.defer_vertex_stage(net, True)
 loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
 gs = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3)
 gs(xy, target)
@@ -29,13 +29,13 @@ def both():
     replay(); parallel.allreduce_gradients(net, world, keep_tables_flag=True)
 for _ in range(20): both()
 print(f"graph replay + RCCL exchange: {timeit(both):.3f} ms/step at 2^20 px; table grad norm {float(net.encoding._grad_base.norm()):.3e}")
-dG = ops.DP_DEFERRED[6]
+dG = net.dp.deferred[6]
 print(f"replay only            {timeit(replay):.3f} ms")
 print(f"all_reduce(dG {dG.numel() * 4 / 1e6:.1f} MB)  {timeit(lambda: dist.all_reduce(dG)):.3f} ms")
-print(f"deferred vertex stage  {timeit(ops.run_deferred_vertex_stage):.3f} ms")
+print(f"deferred vertex stage  {timeit(lambda: ops.run_deferred_vertex_stage(net.dp)):.3f} ms")
 flat = parallel._flat_alias([p.grad for p in net.mlp.parameters()])
 print(f"all_reduce(flat {flat.numel()} floats) {timeit(lambda: dist.all_reduce(flat)):.3f} ms")
 print(f"allreduce_gradients    {timeit(lambda: parallel.allreduce_gradients(net, world, keep_tables_flag=True)):.3f} ms")
-parallel.defer_vertex_stage(False)
-parallel.enable_vertex_grid_exchange(1)
+parallel.defer_vertex_stage(net, False)
+parallel.enable_vertex_grid_exchange(net, 1)
 dist.destroy_process_group()
