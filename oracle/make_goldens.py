@@ -662,7 +662,8 @@ def g16(F_, U_, M, P_):
                 loss = loss + ((1 * kls) + (1e-3 * coll if coll.nelement() != 0 else 1)).sum(0)
             loss.backward()
             out["rgb"], out["idx"], out["mse"], out["loss"] = np32(rgb), np32(idx), np32(mse), np32(loss)
-            out["idx_min_vertex"] = np.array(float(torch.floor(net._batch_norm(bx).detach() * 8).min()))
+            xb = (bx - bx.mean(0)) / torch.sqrt(bx.var(0, unbiased=False) + 1e-5)      # (not through the module: no second statistics update)
+            out["idx_min_vertex"] = np.array(float(torch.floor(xb * 8).min()))
             if not hash_mode:
                 out["kls"] = np32(kls)
                 out["pbar"] = np32(probs.sum(0).sum(1) / (probs.shape[0] * probs.shape[2]))
