@@ -32,14 +32,16 @@ SIGNATURES = {
                                   _P, _L, _P],
     "gngf_vertex_grid_fwd": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L, _P],
     "gngf_vertex_grid_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L, _P],
-    "gngf_encode_tiled_fwd": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gngf_encode_tiled_fwd": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gngf_set_tiled_interleaved": [_I],
+    "gngf_debug_il_stamps": [_P],
     "gngf_encode_tiled_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I,
                               _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P],
     "gngf_vertex_grid_bwd_sorted": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _L, _P],
     "gngf_decoder_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gngf_decoder_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gngf_decoder_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
-    "gngf_decoder_train": [_P] * 19 + [_L, _I, _I, _I, _P],
+    "gngf_decoder_train": [_P] * 20 + [_L, _L, _I, _I, _I, _P],
     "gngf_decoder_bwd_last_span_ns": [_P],
     "gngf_decoder_hidden_floats": [_L],
     "gngf_decoder_bwd_slabs": [_L],
@@ -75,7 +77,7 @@ SIGNATURES = {
     "gngf_adam_step": [_P, _I, _L, _P, _P, _P, _I, _F, _F, _F, _F, _P],
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _RETURNS_INT64 = {"gngf_decoder_hidden_floats", "gngf_slot_bitmap_words"}
 _lib = None
 

@@ -419,7 +419,8 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
                    const float* __restrict__ W0, const float* __restrict__ b0, const float* __restrict__ W1,
                    const float* __restrict__ b1, const float* __restrict__ W2, float* __restrict__ dX,
                    float* __restrict__ slabs, const float* __restrict__ hidden, int64_t P, int in_dim, int out_dim,
-                   const float* __restrict__ target, const float* __restrict__ gloss, const float* __restrict__ b2 = nullptr) {
+                   const float* __restrict__ target, const float* __restrict__ gloss, const float* __restrict__ b2 = nullptr,
+                   float4* __restrict__ zero_fill = nullptr, int64_t zero_vecs = 0) {
   using FF = FwdFrags<KIN>;
   constexpr int S0 = KIN / 2;
   constexpr int TX = (KIN + 31) / 32;                    // 32-row tiles of the input width
@@ -538,6 +539,21 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
     asm volatile("" : "+a"(dW2acc));
   };
   const int64_t ntiles = (P + 127) / 128;
+  // TRAIN: a buffer the REST of the step needs zero-filled (the table gradient the encoder backward accumulates into: 64 MiB at
+  // T = 2^19) is cleared from here — a few 16-byte stores per lane and tile between the MFMAs, where memory instructions cost
+  // no issue time and the HBM is idle — instead of in rider workgroups of the binning launch (8 us of the step's critical path).
+  // Workgroup b owns vectors [b per, (b + 1) per); every tile of its loop clears zper vectors per thread.
+  int64_t zlo = 0, zhi = 0;
+  int zper = 0;
+  if constexpr (TRAIN) {
+    if (zero_fill && zero_vecs > 0) {
+      const int64_t per = (zero_vecs + gridDim.x - 1) / gridDim.x;
+      zlo = (int64_t)blockIdx.x * per + threadIdx.x;
+      zhi = (int64_t)(blockIdx.x + 1) * per < zero_vecs ? (int64_t)(blockIdx.x + 1) * per : zero_vecs;
+      const int64_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+      zper = (int)((per + (int64_t)kDecThreads * my_tiles - 1) / ((int64_t)kDecThreads * my_tiles));
+    }
+  }
   // Rows are fetched / stored through per-tile buffer descriptors (as in the forward kernel): lanes past the end of
   // the batch read zeros (so dz3 = 0 and they contribute nothing anywhere) and their stores are dropped — no masks.
   const unsigned xoff = (unsigned)(((wave * 32 + i) * in_dim + (EXACT ? h * S0 : 0)) * 4);
@@ -1200,6 +1216,10 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
           }
         }
     }
+    if constexpr (TRAIN) {
+      for (int z = 0; z < zper; ++z, zlo += kDecThreads)
+        if (zlo < zhi) zero_fill[zlo] = float4{0.f, 0.f, 0.f, 0.f};
+    }
     pin_acc();
     STEP_END();
     STAMP(7);
@@ -1415,12 +1435,13 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
       fn<<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, hidden, P, in_dim, out_dim,
-                                                                 target, gloss, nullptr);
+                                                                 target, gloss, nullptr, nullptr, 0);
     } else
     DISPATCH_KIN(in_dim, {
       const size_t smem = bwd_smem_bytes<kKIN>(in_dim, out_dim);
       using Kern = void (*)(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
-                            const float*, float*, float*, const float*, int64_t, int, int, const float*, const float*, const float*);
+                            const float*, float*, float*, const float*, int64_t, int, int, const float*, const float*, const float*,
+                            float4*, int64_t);
       const bool exact = in_dim == kKIN;
       Kern fn;
       if (hidden)
@@ -1432,7 +1453,7 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
       fn<<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, hidden, P, in_dim, out_dim,
-                                                                 target, gloss, nullptr);
+                                                                 target, gloss, nullptr, nullptr, 0);
     });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -1447,11 +1468,15 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
 // *gloss (device scalar): rgb (P,out_dim) is written, d enc and the parameter-gradient slabs as by gngf_decoder_bwd with
 // target / gloss — in ONE launch, without the hidden-layer buffer.  in_dim == 32 only (returns hipErrorInvalidValue otherwise:
 // the caller falls back to gngf_decoder_fwd + gngf_decoder_bwd).  Gradient pointers / slabs / denc_absmax as gngf_decoder_bwd.
+// zero_fill (optional; zero_floats floats, a multiple of 4, 16-byte aligned): cleared by the kernel on the way (see above) —
+// complete when the launch is, i.e. before anything later on the stream.
 extern "C" int gngf_decoder_train(const float* enc, const float* target, const float* gloss, const float* W0, const float* b0,
                                   const float* W1, const float* b1, const float* W2, const float* b2, float* rgb, float* denc,
                                   float* dW0, float* db0, float* dW1, float* db1, float* dW2, float* db2, float* slabs,
-                                  float* denc_absmax, int64_t P, int in_dim, int out_dim, int leaky, void* stream) {
+                                  float* denc_absmax, float* zero_fill, int64_t zero_floats, int64_t P, int in_dim, int out_dim,
+                                  int leaky, void* stream) {
   GNGF_CHECK_ARG(P > 0 && in_dim == 32 && out_dim > 0 && out_dim <= 4);
+  GNGF_CHECK_ARG(!zero_fill || (zero_floats >= 0 && (zero_floats & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_fill) & 15) == 0));
   const bool reduce_here = dW0 || db0 || dW1 || db1 || dW2 || db2;
   GNGF_CHECK_ARG(slabs && (!reduce_here || (dW0 && db0 && dW1 && db1 && dW2 && db2)));
   GNGF_CHECK_ARG(enc && target && gloss && W0 && b0 && W1 && b1 && W2 && b2 && rgb && denc);
@@ -1463,7 +1488,8 @@ extern "C" int gngf_decoder_train(const float* enc, const float* target, const f
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return (int)e;
   fn<<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, nullptr, W0, b0, W1, b1, W2, denc, slabs, nullptr, P, in_dim, out_dim,
-                                                             target, gloss, b2);
+                                                             target, gloss, b2, reinterpret_cast<float4*>(zero_fill),
+                                                             zero_fill ? zero_floats / 4 : 0);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   if (reduce_here)

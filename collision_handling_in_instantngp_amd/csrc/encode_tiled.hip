@@ -122,7 +122,11 @@ bin_scan_kernel(const int32_t* __restrict__ tot, int tile_shift, int chunk, int3
       ioff += nit;
     }
   }
-  if (tid == kBinThreads - 1) { tile_off[ntiles] = off; tile_item_base[ntiles] = ioff; *n_items = ioff; }
+  if (tid == kBinThreads - 1) {
+    tile_off[ntiles] = off; tile_item_base[ntiles] = ioff;
+    n_items[0] = ioff;
+    n_items[1] = n_items[2] = n_items[3] = 0;     // work / exit counters of the persistent interleaved kernels (il_claim, il_done)
+  }
 }
 
 // K3: scatter (x, y, original index) into tile order.  Same pixel->block partition as K1.
@@ -222,6 +226,20 @@ vertex_fwd_kernel(const TT* __restrict__ tables, const int32_t* __restrict__ ver
   vertex_fwd_lane<F, VT, TT>(tables, vert_idx, vert_w, G, nullptr, T, K, vstride, NV, pow2, l, gw, i, level_offset(n_ls, l));
 }
 
+// rider block `vb` of the vertex stage forward: one (level, vertex) per thread, flat over the level grids
+template <int F, bool VT, typename TT>
+__device__ __forceinline__ void vertex_ride_block(int vb, const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx,
+                                                  const float* __restrict__ vert_w, const int32_t* __restrict__ n_ls, float* __restrict__ G,
+                                                  float* __restrict__ dG_zero, int Ls, int64_t T, int K, int vstride, int64_t NV, bool pow2,
+                                                  int64_t vtot) {
+  const int64_t e = (int64_t)vb * kBinThreads + threadIdx.x;
+  if (e >= vtot) return;
+  int l = 0, gw = n_ls[0] + 2;
+  int64_t goff = 0;
+  while (l + 1 < Ls && e >= goff + (int64_t)gw * gw) { goff += (int64_t)gw * gw; ++l; gw = n_ls[l] + 2; }
+  vertex_fwd_lane<F, VT, TT>(tables, vert_idx, vert_w, G, dG_zero, T, K, vstride, NV, pow2, l, gw, (int)(e - goff), goff);
+}
+
 // K3 with the VERTEX STAGE FORWARD riding on the launch: workgroups [NB, NB + ceil(vtot / 1024)) evaluate one (level, vertex)
 // per thread (flat over the level grids) — work that does not depend on the binned pixels and used to be a launch on a
 // helper stream.  Measured: parallel branches of a replayed hipGraph run on different hardware queues, and every
@@ -240,24 +258,39 @@ bin_scatter_ride_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_bl
     bin_scatter_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, tile_off, sorted, cursor);
     return;
   }
-  const int64_t e = (int64_t)((int)blockIdx.x - NB) * kBinThreads + threadIdx.x;
-  if (e >= vtot) return;
-  int l = 0, gw = n_ls[0] + 2;
-  int64_t goff = 0;
-  while (l + 1 < Ls && e >= goff + (int64_t)gw * gw) { goff += (int64_t)gw * gw; ++l; gw = n_ls[l] + 2; }
-  vertex_fwd_lane<F, VT, TT>(tables, vert_idx, vert_w, G, dG_zero, T, K, vstride, NV, pow2, l, gw, (int)(e - goff), goff);
+  vertex_ride_block<F, VT, TT>((int)blockIdx.x - NB, tables, vert_idx, vert_w, n_ls, G, dG_zero, Ls, T, K, vstride, NV, pow2, vtot);
+}
+
+// K1 with the vertex stage forward riding on it (the count keeps half of the CUs busy for ~8 us): used when the launch does
+// not carry the 64 MiB gradient clear (the fused training decoder clears that buffer between its MFMAs) — the scatter launch
+// then runs alone.
+template <int F, bool VT, typename TT>
+__global__ void __launch_bounds__(kBinThreads)
+bin_count_vride_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB,
+                       int32_t* __restrict__ blockhist, const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx,
+                       const float* __restrict__ vert_w, const int32_t* __restrict__ n_ls, float* __restrict__ G,
+                       float* __restrict__ dG_zero, int Ls, int64_t T, int K, int vstride, int64_t NV, bool pow2, int64_t vtot) {
+  extern __shared__ int hist[];
+  if ((int)blockIdx.x < NB) {
+    bin_count_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, hist);
+    return;
+  }
+  vertex_ride_block<F, VT, TT>((int)blockIdx.x - NB, tables, vert_idx, vert_w, n_ls, G, dG_zero, Ls, T, K, vstride, NV, pow2, vtot);
 }
 
 template <int F, bool VT, typename TT>
 __global__ void __launch_bounds__(256)
 vertex_bwd_kernel(const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
                   const int32_t* __restrict__ n_ls, const float* __restrict__ dG, float* __restrict__ dtables,
-                  float* __restrict__ dvert_w, int64_t T, int K, int vstride, int64_t NV, bool pow2) {
-  const int l = blockIdx.y;
-  const int gw = n_ls[l] + 2;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= gw * gw) return;
-  const float* gp = dG + (level_offset(n_ls, l) + i) * F;
+                  float* __restrict__ dvert_w, int Ls, int64_t T, int K, int vstride, int64_t NV, bool pow2) {
+  // flat over the level grids (see gather_partials_kernel): blockIdx.y is not used
+  int l = 0, gw = n_ls[0] + 2;
+  int64_t goff = 0;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  while (l + 1 < Ls && e >= goff + (int64_t)gw * gw) { goff += (int64_t)gw * gw; ++l; gw = n_ls[l] + 2; }
+  if (e - goff >= (int64_t)gw * gw) return;
+  const int i = (int)(e - goff);
+  const float* gp = dG + (goff + i) * F;
   float g[F];
   bool any = false;
 #pragma unroll
@@ -587,8 +620,474 @@ tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
     part[i] = finite ? (float)((double)(long long)acc64[i] * inv) : __int_as_float(0x7fc00000);
 }
 
+// ---------------------------------------------------------------------------------------------- pixel stage, LEVEL-INTERLEAVED images
+// Round 3.  The kernels above place the sub-grids of the staged levels back to back in LDS; with one lane per (pixel, level)
+// the 16 level-lanes of a pixel then hit 16 unrelated LDS columns per instruction: 70 % (forward) / 72 % (backward) of the
+// kernels' LDS cycles were bank conflicts (PMC, profiles/r02_pmc_sq_counters.json).  For F = 2 and <= 16 staged levels the
+// images below are INTERLEAVED BY LEVEL instead: vertex i of level l lives in row i, column l of a [rows][16] array of 8-byte
+// slots (forward: the vertex's two fp32 features; backward: one 64-bit fixed-point accumulator per feature, rows 2 i and
+// 2 i + 1).  A 16-lane group — the 16 levels of one pixel — then touches 16 DIFFERENT 8-byte columns whatever the cells are:
+// the write / atomic path (banked in 16-lane groups over 128 bytes, MI355X_MICROARCH.md section LDS) is conflict-free by
+// construction, and the forward's ds_read_b64 (32-lane groups over 256 bytes) sees at most a 2-way conflict.
+// Cost: the image is as tall as the finest level for every column (46 KB forward, 92 KB backward at N = 512 and 32 x 32
+// tiles instead of 10 / 20 KB), so one 1024-thread workgroup per CU.  Same items, same partial-image format, same results.
+constexpr int kIL = 16;             // columns = levels per interleaved row
+
+// worst-case vertex count of one level's sub-grid in a tile (setup_tile: wx, wy <= (n >> tile_shift) + 3)
+static int interleaved_rows(const int32_t* n_ls_host, int Ls, int tile_shift) {
+  int m = 0;
+  for (int l = 0; l < Ls; ++l) { const int w = (n_ls_host[l] >> tile_shift) + 3; m = w * w > m ? w * w : m; }
+  return m;
+}
+
+// private accumulator copies of a level with `rows_l` rows in a column of `rows2` rows: 4, 2 or 1
+__device__ __forceinline__ int il_copies(int rows_l, int rows2) {
+  return rows_l * 4 <= rows2 ? 4 : (rows_l * 2 <= rows2 ? 2 : 1);
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// diagnostic: per-phase cycle totals of workgroup 0 of the interleaved backward kernel (s_memtime; tools/perf_tiled_il.py)
+__device__ unsigned long long g_il_stamps[8];
+#define IL_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+    g_il_stamps[k] += t_ - il_t; il_t = t_; } } while (0)      // pairs of fp32: the compiler maps their arithmetic to v_pk_*_f32
+
+// Per-item geometry of the interleaved kernels, filled by the first 16 lanes of the workgroup (one level each; the prefix
+// sums meet in shuffles — setup_tile's serial walk over the levels cost ~0.5 us per item) and read by everybody after one
+// barrier.  `next`: the item the workgroup takes after this one (persistent workgroups, see il_next_item).
+struct ILMeta {
+  int n[kIL], cx[kIL], cy[kIL], wx[kIL], wy[kIL], loff[kIL], copies[kIL];
+  int64_t goff[kIL];
+  int nls[kIL];                 // the level resolutions (the same for every item: read from global memory once per workgroup)
+  int used, rows_used;
+};
+
+__device__ __forceinline__ void il_setup(ILMeta& m, int Ls, int tx, int ty, int tile_shift, int rows2) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    int n = 0, cx = 0, cy = 0, wx = 0, wy = 0;
+    if (tid < Ls) {
+      n = m.nls[tid];
+      cx = (tx * n) >> tile_shift; cy = (ty * n) >> tile_shift;
+      int hx = (((tx + 1) * n) >> tile_shift) + 1, hy = (((ty + 1) * n) >> tile_shift) + 1;
+      hx = hx > n + 1 ? n + 1 : hx;
+      hy = hy > n + 1 ? n + 1 : hy;
+      wx = hx - cx + 1; wy = hy - cy + 1;
+    }
+    const int sz = wx * wy * 2;                           // floats of the level in the compact image (F = 2)
+    const int64_t g2 = tid < Ls ? (int64_t)(n + 2) * (n + 2) : 0;
+    int lo = sz;                                          // inclusive prefix sums over the 16 level lanes
+    int64_t go = g2;
+#pragma unroll
+    for (int o = 1; o < kIL; o <<= 1) {
+      const int ul = __shfl_up(lo, o, 64);
+      const int64_t ug = __shfl_up(go, o, 64);
+      if ((tid & 15) >= o) { lo += ul; go += ug; }
+    }
+    const int copies = rows2 > 0 ? il_copies(sz, rows2) : 1;
+    int tall = sz * copies, tot = __shfl(lo, kIL - 1, 64);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { const int t2 = __shfl_xor(tall, o, 64); tall = t2 > tall ? t2 : tall; }
+    if (tid < kIL) {
+      m.n[tid] = n; m.cx[tid] = cx; m.cy[tid] = cy; m.wx[tid] = wx; m.wy[tid] = wy;
+      m.loff[tid] = lo - sz; m.goff[tid] = go - g2; m.copies[tid] = copies;
+    }
+    if (tid == 0) { m.used = tot; m.rows_used = tall; }
+  }
+}
+
+// Persistent workgroups: workgroup b of `nwork` takes items b, b + nwork, ... (the items are about equally heavy: at most
+// `chunk` pixels of one tile each); the next item's record is requested before the current item is processed.  (Claiming
+// items through a global counter was tried: the atomic's round trip sat in front of every item's first barrier.)
+
+template <bool L16, int PIPE>
+__global__ void __launch_bounds__(kTBF)
+tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ items, const int32_t* __restrict__ n_items,
+                    int32_t* __restrict__ counter, const int32_t* __restrict__ n_ls, const float* __restrict__ G,
+                    float* __restrict__ enc, int L, int Ls, int tile_shift, int nwork) {
+  constexpr int F = 2;
+  extern __shared__ float2 img_raw[];             // [rows][kIL]: (feature 0, feature 1) of vertex `row` of level `column`
+  v2f* img = reinterpret_cast<v2f*>(img_raw);
+  __shared__ ILMeta m;
+  const int tid = threadIdx.x;
+  const int nit = *n_items;
+  const int TSm = (1 << tile_shift) - 1;
+  constexpr int ppp = kTBF / kIL;                 // pixels per pass: lane = 16 * pixel + level
+  const int lp = tid >> 4, l = tid & 15;
+  const int LF = L16 ? 32 : L * F, LF2 = LF / 2;
+  const v2f* G2 = reinterpret_cast<const v2f*>(G);
+  if (tid < kIL) m.nls[tid] = tid < Ls ? n_ls[tid] : 0;
+  int4 it_next = items[(int)blockIdx.x < nit ? (int)blockIdx.x : 0];
+  for (int item = blockIdx.x; item < nit; item += nwork) {
+    const int4 it = it_next;
+    it_next = items[item + nwork < nit ? item + nwork : item];
+    __syncthreads();                              // (the previous item's image is no longer read; m.nls is there)
+    il_setup(m, Ls, it.z & TSm, it.z >> tile_shift, tile_shift, 0);
+    __syncthreads();
+    {
+      // Staging: one vertex per thread and level, ALL the loads issued before the first LDS store (a load-store loop per level
+      // exposes one memory round trip per level: 16 per item).  The row of a vertex comes from a float reciprocal —
+      // (i + 0.5) / wx is at least 0.5 / wx away from an integer, far more than fp32 rounding moves it.
+      // Flattened over (level, vertex) — element e of the compact image — three elements per thread and pass, their loads in
+      // flight together; the level of e by a 4-step binary search over the compact starts (m.loff / 2, non-decreasing).
+      const int used_v = m.used / F;
+      auto locate = [&](int e, int& lv, int& i, unsigned& off) {
+        int q = (e >= (m.loff[8] >> 1) && 8 < Ls) ? 8 : 0;
+        if (q + 4 < Ls && e >= (m.loff[q + 4] >> 1)) q += 4;
+        if (q + 2 < Ls && e >= (m.loff[q + 2] >> 1)) q += 2;
+        if (q + 1 < Ls && e >= (m.loff[q + 1] >> 1)) q += 1;
+        lv = q;
+        i = e - (m.loff[q] >> 1);
+        const int wx = m.wx[q];
+        const int iy = (int)(((float)i + 0.5f) * (1.0f / (float)wx)), ix = i - iy * wx;
+        off = (unsigned)((int)m.goff[q] + (m.cy[q] + iy) * (m.n[q] + 2) + m.cx[q] + ix);
+      };
+      for (int base = 0; base < used_v; base += 3 * kTBF) {
+        int lv[3], iv[3];
+        unsigned off[3];
+        v2f val[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int e = base + k * kTBF + tid;
+          locate(e < used_v ? e : used_v - 1, lv[k], iv[k], off[k]);
+          val[k] = G2[off[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (base + k * kTBF + tid < used_v) img[iv[k] * kIL + lv[k]] = val[k];
+      }
+    }
+    __syncthreads();
+    if (l < Ls) {
+      const int n = m.n[l], cx = m.cx[l], cy = m.cy[l], wx = m.wx[l], wy = m.wy[l], gw = n + 2;
+      const float* Gl = G + m.goff[l] * F;
+      const v2f* col = img + l;                   // this level's column
+      v2f* enc_l = reinterpret_cast<v2f*>(enc) + l;
+      const float fn = (float)n;
+      const float4* rec = sorted + it.x;
+      const int last = it.y - 1;
+      auto fetch = [&](int j) { return rec[j < last ? j : last]; };
+      // one pixel outside the fast path (a pixel outside its tile's staged sub-grid: never for coordinates in [0,1]^2)
+      auto slow = [&](const float4 sv, int j) {
+        if (j > last) return;
+        const Cell cc = make_cell(sv.x, sv.y, n);
+        const int lx = cc.gx - cx, ly = cc.gy - cy;
+        float vv[4][F];
+        if (lx >= 0 && ly >= 0 && lx + 1 < wx && ly + 1 < wy) {
+          const v2f* a = col + (ly * wx + lx) * kIL;
+          const v2f* b = a + wx * kIL;
+          vv[0][0] = a[0].x; vv[0][1] = a[0].y; vv[1][0] = a[kIL].x; vv[1][1] = a[kIL].y;
+          vv[2][0] = b[0].x; vv[2][1] = b[0].y; vv[3][0] = b[kIL].x; vv[3][1] = b[kIL].y;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            int vx = cc.gx + (q & 1), vy = cc.gy + (q >> 1);
+            vx = vx < 0 ? 0 : (vx > n + 1 ? n + 1 : vx);
+            vy = vy < 0 ? 0 : (vy > n + 1 ? n + 1 : vy);
+#pragma unroll
+            for (int f = 0; f < F; ++f) vv[q][f] = Gl[((int64_t)vy * gw + vx) * F + f];
+          }
+        }
+        float* o = enc + (int64_t)__float_as_int(sv.z) * LF + l * F;
+#pragma unroll
+        for (int f = 0; f < F; ++f) o[f] = ((vv[0][f] * cc.c[0] + vv[1][f] * cc.c[1]) + vv[2][f] * cc.c[2]) + vv[3][f] * cc.c[3];
+      };
+      // Four pixels per trip: their 16 LDS reads are in flight together, and a wave-uniform vote keeps the common case — every
+      // pixel inside its staged sub-grid — free of per-lane branches.  Pairs of fp32 (coordinates, the two features) go through
+      // packed instructions: same separately rounded operations as make_cell / the reference, half the instructions.
+      constexpr int U = PIPE == 2 ? 2 : 4;          // (variant 3 of gngf_set_tiled_interleaved: two pixels per trip, fewer registers)
+      float4 nx[U];
+      if constexpr (false) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) nx[u] = fetch(lp + u * ppp);
+      }
+      for (int j0 = lp; j0 <= last; j0 += U * ppp) {
+        float4 sv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) sv[u] = fetch(j0 + u * ppp);
+        if constexpr (false) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) nx[u] = fetch(j0 + (U + u) * ppp);
+        }
+        float c[U][4];
+        int v[U];
+        bool inside = true;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const v2f sxy = (v2f){sv[u].x, sv[u].y} * fn;
+          const v2f a = __builtin_elementwise_floor(sxy);
+          const v2f d = a + 1.0f;
+          const v2f w0 = d - sxy, w1 = sxy - a;
+          c[u][0] = w0.x * w0.y; c[u][1] = w1.x * w0.y; c[u][2] = w0.x * w1.y; c[u][3] = w1.x * w1.y;
+          const int lx = (int)a.x - cx, ly = (int)a.y - cy;
+          inside = inside && ((unsigned)lx < (unsigned)(wx - 1)) && ((unsigned)ly < (unsigned)(wy - 1));
+          v[u] = ly * wx + lx;
+        }
+        if (__ballot(!inside) == 0ull) {
+          v2f a0[U], a1[U], b0[U], b1[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const v2f* a = col + v[u] * kIL;
+            const v2f* b = a + wx * kIL;
+            a0[u] = a[0]; a1[u] = a[kIL]; b0[u] = b[0]; b1[u] = b[kIL];
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const v2f r = ((a0[u] * c[u][0] + a1[u] * c[u][1]) + b0[u] * c[u][2]) + b1[u] * c[u][3];
+            if (j0 + u * ppp <= last) enc_l[(int64_t)__float_as_int(sv[u].z) * LF2] = r;
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u) slow(sv[u], j0 + u * ppp);
+        }
+      }
+    }
+  }
+}
+
+// Backward with the level-interleaved accumulator image acc[rows][16] (row 2 i + f = feature f of vertex i, column = level):
+// the eight ds_add_u64 of a (pixel, level) lane go to base + {0, 128, 256, 384} bytes of two row pairs — immediate offsets —
+// and every 16-lane group (one pixel, 16 levels) hits 16 distinct columns.  The four pixels of a wave-instruction still meet on
+// the SAME address whenever they share a cell — the rule at the coarse levels, where a tile covers a handful of cells, and an
+// LDS atomic serialises on equal addresses (tools/micro/lds_atomic64_patterns.cpp) — so a level whose sub-grid is small
+// enough keeps up to four private copies of its accumulators stacked in its column (copy = pixel slot of the lane; the column
+// is as tall as the finest level anyway, so the copies are free) and the store pass adds them up as integers.
+// Fixed point, scale, store pass and riders exactly as tiled_bwd_kernel: the partial image leaves bit-identical, in the same
+// compact (level-after-level) format, so gather_partials is shared.  Workgroups [0, nwork) are persistent (il_claim).
+template <bool L16, int PIPE>
+__global__ void __launch_bounds__(kTB)
+tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ items, const int32_t* __restrict__ n_items,
+                    int32_t* __restrict__ counter, const int32_t* __restrict__ n_ls, const float* __restrict__ genc,
+                    float* __restrict__ dG, float* __restrict__ partials, const float* __restrict__ gmax_hint, int hint_count,
+                    int hint_stride, int L, int Ls, int tile_shift, int lds_floats, int rows2, int log2_chunk, int nwork,
+                    RideAlong ride, MseRide mride) {
+  constexpr int F = 2;
+  extern __shared__ unsigned long long accil[];   // [rows2][kIL], then the compact fp32 image of the store pass
+  __shared__ ILMeta m;
+  __shared__ float wmax[kTB / 64];
+  if (mride.pred && (int)blockIdx.x >= mride.first_block) {
+    mse_sum_block((int)blockIdx.x - mride.first_block, mride.nblocks, mride.pred, mride.label, mride.loss, mride.acc, mride.counter,
+                  mride.n);
+    return;
+  }
+  if (ride.slabs && (int)blockIdx.x >= ride.first_block) {
+    decoder_reduce_block((int)blockIdx.x - ride.first_block, ride.slabs, ride.nslabs, ride.nslab, ride.in_dim, ride.out_dim, ride.dW0,
+                         ride.db0, ride.dW1, ride.db1, ride.dW2, ride.db2, nullptr, ride.promised, ride.arrived);
+    return;
+  }
+  const int tid = threadIdx.x;
+  const int nit = *n_items;
+  const int TSm = (1 << tile_shift) - 1;
+  constexpr int ppp = kTB / kIL;
+  const int lp = tid >> 4, l = tid & 15;
+  const bool lane_on = l < Ls;
+  const int LF = L16 ? 32 : L * F, LF2 = LF / 2;
+  const v2f* genc_l = reinterpret_cast<const v2f*>(genc) + l;
+  float* cimg = reinterpret_cast<float*>(accil + (size_t)rows2 * kIL);
+  const bool broken = promise_broken(ride.promised, ride.arrived);
+  // the bound on |genc| handed over by its producer (one value per decoder slab): the same for every item
+  float hint = 0.f;
+  if (gmax_hint) {
+    for (int q = tid; q < hint_count; q += kTB) { const float a = gmax_hint[(int64_t)q * hint_stride]; hint = (a > hint || a != a) ? a : hint; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float ov = __shfl_xor(hint, o, 64); hint = (ov > hint || ov != ov) ? ov : hint; }
+    if ((tid & 63) == 0) wmax[tid >> 6] = hint;
+    __syncthreads();
+    hint = wmax[0];
+#pragma unroll
+    for (int w = 1; w < kTB / 64; ++w) hint = (wmax[w] > hint || wmax[w] != wmax[w]) ? wmax[w] : hint;
+  }
+  if (tid < kIL) m.nls[tid] = tid < Ls ? n_ls[tid] : 0;
+  unsigned long long il_t = __builtin_readcyclecounter();
+  int4 it_next = items[(int)blockIdx.x < nit ? (int)blockIdx.x : 0];
+  for (int item = blockIdx.x; item < nit; item += nwork) {
+    const int4 it = it_next;
+    it_next = items[item + nwork < nit ? item + nwork : item];
+    __syncthreads();                              // the previous item's compact image has left; m.nls is there
+    IL_STAMP(0);
+    il_setup(m, Ls, it.z & TSm, it.z >> tile_shift, tile_shift, rows2);
+    __syncthreads();
+    IL_STAMP(1);
+    const int used = m.used, rows_used = m.rows_used;
+    {
+      ulonglong2* z = reinterpret_cast<ulonglong2*>(accil);
+      const ulonglong2 zero = {0ull, 0ull};
+      for (int i = tid; i < rows_used * (kIL / 2); i += kTB) z[i] = zero;
+    }
+    const float4* rec = sorted + it.x;
+    const int last = it.y - 1;
+    auto fetch = [&](int j) { return rec[j < last ? j : last]; };
+    auto grad_of = [&](const float4 sv) { return genc_l[(int64_t)__float_as_int(sv.z) * LF2]; };
+    constexpr int U = 4;
+    // pass 1: largest |gradient| over the item's pixels — skipped when the producer of genc handed over a bound
+    float gmax = hint;
+    if (!gmax_hint) {
+      gmax = 0.f;
+      if (lane_on)
+        for (int j0 = lp; j0 <= last; j0 += U * ppp) {
+          v2f gv[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) gv[u] = grad_of(fetch(j0 + u * ppp));
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const float a = fabsf(gv[u].x), b = fabsf(gv[u].y);
+            gmax = (a > gmax || a != a) ? a : gmax;
+            gmax = (b > gmax || b != b) ? b : gmax;                    // NaN sticks
+          }
+        }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const float ov = __shfl_xor(gmax, o, 64); gmax = (ov > gmax || ov != ov) ? ov : gmax; }
+      if ((tid & 63) == 0) wmax[tid >> 6] = gmax;
+      __syncthreads();
+      gmax = wmax[0];
+#pragma unroll
+      for (int w = 1; w < kTB / 64; ++w) gmax = (wmax[w] > gmax || wmax[w] != wmax[w]) ? wmax[w] : gmax;
+    }
+    __syncthreads();                              // the image is zero (and wmax is free again)
+    IL_STAMP(2);
+    const bool finite = gmax < INFINITY && !broken;        // false for inf and NaN
+    int eg = 0;
+    if (finite && gmax > 0.f) (void)frexpf(gmax, &eg);       // gmax < 2^eg
+    const int S = 61 - log2_chunk - eg;
+    if (lane_on && finite) {
+      const int n = m.n[l], cx = m.cx[l], cy = m.cy[l], wx = m.wx[l], wy = m.wy[l], gw = n + 2;
+      float* dGl = dG + m.goff[l] * F;
+      const int rows_l = wx * wy * F;
+      unsigned long long* col = accil + l + ((lp & (m.copies[l] - 1)) * rows_l) * kIL;
+      const float fn = (float)n;
+      const float scale = ldexpf(1.0f, S - 32);   // (a power of two: scaling by it is exact, as ldexp)
+      auto stage = [&](const float4 sv, const v2f gv, int j) {
+        if (j > last) return;
+        const v2f sxy = (v2f){sv.x, sv.y} * fn;   // make_cell, on pairs: every operation separately rounded as in the reference
+        const v2f a = __builtin_elementwise_floor(sxy);
+        const v2f d = a + 1.0f;
+        const v2f w0 = d - sxy, w1 = sxy - a;
+        const float c0 = w0.x * w0.y, c1 = w1.x * w0.y, c2 = w0.x * w1.y, c3 = w1.x * w1.y;
+        const int gx = (int)a.x, gy = (int)a.y;
+        const int lx = gx - cx, ly = gy - cy;
+        if (((unsigned)lx < (unsigned)(wx - 1)) && ((unsigned)ly < (unsigned)(wy - 1))) {
+          unsigned long long* pa = col + (ly * wx + lx) * (F * kIL);
+          unsigned long long* pb = pa + wx * (F * kIL);
+          const v2f g = gv * scale;
+          const v2f t0 = g * c0, t1 = g * c1, t2 = g * c2, t3 = g * c3;      // the terms g*c: one fp32 multiply each, as the reference's
+          atomicAdd(pa, (unsigned long long)to_fixed_scaled(t0.x));
+          atomicAdd(pa + kIL, (unsigned long long)to_fixed_scaled(t0.y));
+          atomicAdd(pa + 2 * kIL, (unsigned long long)to_fixed_scaled(t1.x));
+          atomicAdd(pa + 3 * kIL, (unsigned long long)to_fixed_scaled(t1.y));
+          atomicAdd(pb, (unsigned long long)to_fixed_scaled(t2.x));
+          atomicAdd(pb + kIL, (unsigned long long)to_fixed_scaled(t2.y));
+          atomicAdd(pb + 2 * kIL, (unsigned long long)to_fixed_scaled(t3.x));
+          atomicAdd(pb + 3 * kIL, (unsigned long long)to_fixed_scaled(t3.y));
+        } else {                                   // outside the staged sub-grid (never for in-domain coordinates): global
+          const float cq[4] = {c0, c1, c2, c3};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            int vx = gx + (q & 1), vy = gy + (q >> 1);
+            vx = vx < 0 ? 0 : (vx > n + 1 ? n + 1 : vx);
+            vy = vy < 0 ? 0 : (vy > n + 1 ? n + 1 : vy);
+            atomicAdd(dGl + ((int64_t)vy * gw + vx) * F, gv.x * cq[q]);
+            atomicAdd(dGl + ((int64_t)vy * gw + vx) * F + 1, gv.y * cq[q]);
+          }
+        }
+      };
+      // fast path of one pixel, no branches: every lane is inside its staged sub-grid (voted per trip) and a pixel past the end
+      // of the item arrives with a zero gradient (it adds zeros to the cell of the item's last pixel)
+      auto fast = [&](const v2f a, const v2f w0, const v2f w1, const int v, const v2f gv) {
+        const float c0 = w0.x * w0.y, c1 = w1.x * w0.y, c2 = w0.x * w1.y, c3 = w1.x * w1.y;
+        unsigned long long* pa = col + v * (F * kIL);
+        unsigned long long* pb = pa + wx * (F * kIL);
+        const v2f g = gv * scale;
+        const v2f t0 = g * c0, t1 = g * c1, t2 = g * c2, t3 = g * c3;
+        atomicAdd(pa, (unsigned long long)to_fixed_scaled(t0.x));
+        atomicAdd(pa + kIL, (unsigned long long)to_fixed_scaled(t0.y));
+        atomicAdd(pa + 2 * kIL, (unsigned long long)to_fixed_scaled(t1.x));
+        atomicAdd(pa + 3 * kIL, (unsigned long long)to_fixed_scaled(t1.y));
+        atomicAdd(pb, (unsigned long long)to_fixed_scaled(t2.x));
+        atomicAdd(pb + kIL, (unsigned long long)to_fixed_scaled(t2.y));
+        atomicAdd(pb + 2 * kIL, (unsigned long long)to_fixed_scaled(t3.x));
+        atomicAdd(pb + 3 * kIL, (unsigned long long)to_fixed_scaled(t3.y));
+      };
+      // four pixels per trip, loads issued together; PIPE == 2: the records of trip t + 2 and the gradient rows of trip t + 1
+      // are requested before trip t computes
+      float4 n1[U], n2[U];
+      v2f gn[U];
+      if constexpr (PIPE == 2) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) { n1[u] = fetch(lp + u * ppp); n2[u] = fetch(lp + (U + u) * ppp); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) gn[u] = grad_of(n1[u]);
+      }
+      for (int j0 = lp; j0 <= last; j0 += U * ppp) {
+        float4 sv[U];
+        v2f gv[U];
+        if constexpr (PIPE == 2) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) { sv[u] = n1[u]; gv[u] = gn[u]; n1[u] = n2[u]; }
+#pragma unroll
+          for (int u = 0; u < U; ++u) { gn[u] = grad_of(n1[u]); n2[u] = fetch(j0 + (2 * U + u) * ppp); }
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u) sv[u] = fetch(j0 + u * ppp);
+#pragma unroll
+          for (int u = 0; u < U; ++u) gv[u] = grad_of(sv[u]);
+        }
+        v2f fa[U], fw0[U], fw1[U];
+        int fv[U];
+        bool inside = true;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const v2f sxy = (v2f){sv[u].x, sv[u].y} * fn;     // make_cell, on pairs: every operation separately rounded as in the reference
+          fa[u] = __builtin_elementwise_floor(sxy);
+          const v2f d = fa[u] + 1.0f;
+          fw0[u] = d - sxy; fw1[u] = sxy - fa[u];
+          const int lx = (int)fa[u].x - cx, ly = (int)fa[u].y - cy;
+          inside = inside && ((unsigned)lx < (unsigned)(wx - 1)) && ((unsigned)ly < (unsigned)(wy - 1));
+          fv[u] = ly * wx + lx;
+          if (j0 + u * ppp > last) gv[u] = (v2f){0.f, 0.f};
+        }
+        if (__ballot(!inside) == 0ull) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) fast(fa[u], fw0[u], fw1[u], fv[u], gv[u]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u) stage(sv[u], gv[u], j0 + u * ppp);
+        }
+      }
+    }
+    IL_STAMP(3);
+    __syncthreads();
+    IL_STAMP(4);
+    // Store pass.  The lanes keep their (pixel slot, level) roles: lane (r, l) converts rows r, r + 64, ... of column l — 16
+    // consecutive lanes read 16 different columns, no bank conflicts — and drops the fp32 value into a COMPACT image (levels
+    // back to back, the format tiled_bwd_kernel writes and gather_partials reads) behind the accumulators; that image then
+    // leaves with coalesced 16-byte stores.
+    const double inv = finite ? ldexp(1.0, -S) : 0.0;
+    if (lane_on) {
+      const int rows_l = m.wx[l] * m.wy[l] * F, copies = m.copies[l], lo = m.loff[l];
+      for (int i = lp; i < rows_l; i += ppp) {
+        unsigned long long sum = accil[i * kIL + l];
+        for (int c = 1; c < copies; ++c) sum += accil[(c * rows_l + i) * kIL + l];      // integer adds: any order, same bits
+        cimg[lo + i] = finite ? (float)((double)(long long)sum * inv) : __int_as_float(0x7fc00000);
+      }
+    }
+    __syncthreads();
+    float* part = partials + (int64_t)item * lds_floats;
+    if (((lds_floats | used) & 3) == 0) {
+      const float4* c4 = reinterpret_cast<const float4*>(cimg);
+      float4* p4 = reinterpret_cast<float4*>(part);
+      for (int e = tid; e < used / 4; e += kTB) p4[e] = c4[e];
+    } else {
+      for (int e = tid; e < used; e += kTB) part[e] = cimg[e];
+    }
+    IL_STAMP(5);
+    if (blockIdx.x == 0 && tid == 0) { g_il_stamps[6] += 1; g_il_stamps[7] += (unsigned long long)it.y; }
+  }
+}
+
 // Gather pass: dG[(l, gx, gy)] += sum over the items whose tile sub-grid contains the vertex.
-// grid = (ceil(maxverts/256), Ls).  Re-derives each covering tile's LDS layout (same rule as setup_tile).
+// grid = ceil(vtot / 256): one thread per (level, vertex), FLAT over the level grids (a (vertices of the finest level, Ls)
+// grid launched 16.5 k workgroups at N = 512 of which 2.8 k had work: the empty ones cost more dispatch time than the kernel's
+// memory round trips).  Re-derives each covering tile's LDS layout (same rule as setup_tile).
 template <int F>
 __global__ void __launch_bounds__(256)
 gather_partials_kernel(const float* __restrict__ partials, const int32_t* __restrict__ tile_item_base,
@@ -597,10 +1096,18 @@ gather_partials_kernel(const float* __restrict__ partials, const int32_t* __rest
   __shared__ int s_n[GNGF_MAX_LEVELS];
   if (threadIdx.x < Ls) s_n[threadIdx.x] = n_ls[threadIdx.x];
   __syncthreads();
-  const int l = blockIdx.y;
+  int l = 0;
+  int64_t goff = 0;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (;;) {
+    const int64_t g2 = (int64_t)(s_n[l] + 2) * (s_n[l] + 2);
+    if (e < goff + g2 || l + 1 >= Ls) break;
+    goff += g2;
+    ++l;
+  }
   const int n = s_n[l], gw = n + 2;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= gw * gw) return;
+  if (e - goff >= (int64_t)gw * gw) return;
+  const int i = (int)(e - goff);
   const int gy = i / gw, gx = i - gy * gw;
   const int TS = 1 << tile_shift;
   // tiles whose [cx, hx] range can contain gx:  cx(t) = (t*n)>>s <= gx   and   hx(t) = min(((t+1)*n>>s)+1, n+1) >= gx
@@ -686,8 +1193,6 @@ gather_partials_kernel(const float* __restrict__ partials, const int32_t* __rest
         for (int it = it0; it < it1; ++it) add_item(it, o);
       }
   }
-  int64_t goff = 0;
-  for (int j = 0; j < l; ++j) goff += (int64_t)(s_n[j] + 2) * (s_n[j] + 2);
   float* d = dG + (goff + i) * F;
 #pragma unroll
   for (int f = 0; f < F; ++f) d[f] += acc[f];      // += : the out-of-sub-grid fallback may already have added (atomically, earlier kernel)
@@ -851,7 +1356,7 @@ using namespace gngf;
 
 // Bins P pixels into 4^tile_shift spatial tiles.  NB = number of binning blocks (<= 512), chunk = max pixels per
 // work item.  Outputs: sorted (P float4 = x, y, bits(original index), 0), items (max_items int4 = start, count,
-// tile, items of that tile; max_items >= ceil(P/chunk) + 4^tile_shift), n_items (1), tile_off and tile_item_base
+// tile, items of that tile; max_items >= ceil(P/chunk) + 4^tile_shift), n_items (4: the count + three work counters), tile_off and tile_item_base
 // (4^tile_shift + 1 each: exclusive prefixes of pixels / items per tile), blockhist (4^tile_shift * (NB + 1) scratch).
 extern "C" int gngf_bin_pixels(const float* xy, int64_t P, int tile_shift, int NB, int chunk, int32_t* blockhist,
                                int32_t* tile_off, int32_t* tile_item_base, int32_t* items, int32_t* n_items, float* sorted,
@@ -900,9 +1405,27 @@ extern "C" int gngf_encode_tiled_prepare(const float* xy, int64_t P, int tile_sh
   const float2* xy2 = reinterpret_cast<const float2*>(xy);
   const int64_t nvec = zero_fill ? zero_floats / 4 : 0;
   const int zblocks = nvec > 0 ? (int)(ceil_div(nvec, 4096) < 1024 ? ceil_div(nvec, 4096) : 1024) : 0;
+  int32_t* tot = blockhist + (int64_t)ntiles * NB;
+  if (zblocks == 0) {
+    // no gradient clear on this launch: the vertex riders move to the COUNT launch and the scatter launch runs alone
+    if (mode == GNGF_MODE_HASH) {
+      DISPATCH_TT(feat_dtype, DISPATCH_F(F, (bin_count_vride_kernel<kF, false, TT><<<dim3((unsigned)(NB + vblocks)), dim3(kBinThreads), smem, s>>>(
+                                  xy2, P, per_block, tile_shift, NB, blockhist, static_cast<const TT*>(tables), nullptr, nullptr, n_ls, G,
+                                  dG_zero, Ls, T, 0, 0, 0, pow2, vtot))));
+    } else {
+      DISPATCH_TT(feat_dtype, DISPATCH_F(F, (bin_count_vride_kernel<kF, true, TT><<<dim3((unsigned)(NB + vblocks)), dim3(kBinThreads), smem, s>>>(
+                                  xy2, P, per_block, tile_shift, NB, blockhist, static_cast<const TT*>(tables), vert_idx, vert_w, n_ls, G,
+                                  dG_zero, Ls, T, K, vstride, NV, pow2, vtot))));
+    }
+    bin_rowscan_kernel<<<dim3((unsigned)ceil_div(ntiles, 4)), dim3(256), 0, s>>>(blockhist, NB, ntiles, tot);
+    bin_scan_kernel<<<dim3(1), dim3(kBinThreads), 0, s>>>(tot, tile_shift, chunk, tile_off, tile_item_base,
+                                                           reinterpret_cast<int4*>(items), n_items);
+    bin_scatter_kernel<<<dim3(NB), dim3(kBinThreads), smem, s>>>(xy2, P, per_block, tile_shift, NB, blockhist, tile_off,
+                                                                 reinterpret_cast<float4*>(sorted));
+    GNGF_RETURN_LAUNCH();
+  }
   bin_count_ride_kernel<<<dim3((unsigned)(NB + zblocks)), dim3(kBinThreads), smem, s>>>(xy2, P, per_block, tile_shift, NB, blockhist,
                                                                                        reinterpret_cast<float4*>(zero_fill), nvec, zblocks);
-  int32_t* tot = blockhist + (int64_t)ntiles * NB;
   bin_rowscan_kernel<<<dim3((unsigned)ceil_div(ntiles, 4)), dim3(256), 0, s>>>(blockhist, NB, ntiles, tot);
   bin_scan_kernel<<<dim3(1), dim3(kBinThreads), 0, s>>>(tot, tile_shift, chunk, tile_off, tile_item_base,
                                                          reinterpret_cast<int4*>(items), n_items);
@@ -950,15 +1473,16 @@ extern "C" int gngf_vertex_grid_bwd(const void* tables, int feat_dtype, const in
                                     int64_t T, int K, int mode, int vstride, int64_t NV, void* stream) {
   GNGF_CHECK_ARG(Ls > 0 && Ls <= GNGF_MAX_LEVELS && T > 0 && tables && n_ls && n_ls_host && dG && dtables);
   GNGF_CHECK_ARG(mode == GNGF_MODE_HASH || (vert_idx && vert_w && K > 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0));
-  const int side = max_grid_side(n_ls_host, Ls);
-  dim3 grid((unsigned)ceil_div((int64_t)side * side, 256), (unsigned)Ls), block(256);
+  int64_t vtot = 0;
+  for (int l = 0; l < Ls; ++l) vtot += (int64_t)(n_ls_host[l] + 2) * (n_ls_host[l] + 2);
+  dim3 grid((unsigned)ceil_div(vtot, 256)), block(256);
   const bool pow2 = (T & (T - 1)) == 0;
   if (mode == GNGF_MODE_HASH) {
     DISPATCH_TT(feat_dtype, DISPATCH_F(F, (vertex_bwd_kernel<kF, false, TT><<<grid, block, 0, as_stream(stream)>>>(
-                                static_cast<const TT*>(tables), nullptr, nullptr, n_ls, dG, dtables, nullptr, T, 0, 0, 0, pow2))));
+                                static_cast<const TT*>(tables), nullptr, nullptr, n_ls, dG, dtables, nullptr, Ls, T, 0, 0, 0, pow2))));
   } else {
     DISPATCH_TT(feat_dtype, DISPATCH_F(F, (vertex_bwd_kernel<kF, true, TT><<<grid, block, 0, as_stream(stream)>>>(
-                                static_cast<const TT*>(tables), vert_idx, vert_w, n_ls, dG, dtables, dvert_w, T, K, vstride, NV,
+                                static_cast<const TT*>(tables), vert_idx, vert_w, n_ls, dG, dtables, dvert_w, Ls, T, K, vstride, NV,
                                 pow2))));
   }
   GNGF_RETURN_LAUNCH();
@@ -966,12 +1490,71 @@ extern "C" int gngf_vertex_grid_bwd(const void* tables, int feat_dtype, const in
 
 // Pixel stage.  enc / genc are (P, L*F) rows; levels [0, Ls) are produced / consumed here (the remaining levels, if any,
 // by the direct form).  lds_bytes = dynamic LDS for the per-tile sub-grids (levels that do not fit fall back to global).
+// diagnostic: reads and clears the phase stamps of tiled_bwd_il_kernel's workgroup 0 (8 x uint64: cycles before the item's
+// first barrier, setup, zero + hint, main loop (thread 0), wait for the others, store pass; items; pixels)
+extern "C" int gngf_debug_il_stamps(unsigned long long* host8) {
+  hipError_t e = hipMemcpyFromSymbol(host8, HIP_SYMBOL(gngf::g_il_stamps), 8 * sizeof(unsigned long long));
+  if (e != hipSuccess) return (int)e;
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(gngf::g_il_stamps), z, sizeof(z));
+}
+
+static int compute_units() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+
+// 1 (default): F = 2 with <= 16 staged levels runs the level-interleaved kernels (tiled_fwd_il_kernel / tiled_bwd_il_kernel);
+// 0: the back-to-back layout for every shape.  Returns the previous setting (measurement / tests).
+static int g_tiled_interleaved = 1;
+extern "C" int gngf_set_tiled_interleaved(int on) {
+  const int prev = g_tiled_interleaved;
+  g_tiled_interleaved = on < 0 ? 0 : (on > 3 ? 3 : on);      // (2, 3: experimental load-pipelining variants of the same kernels)
+  return prev;
+}
+
+// the interleaved kernels apply: two features, at most 16 staged levels, every level's sub-grid fits the compact image
+// (lds_floats, the host plan's worst case) and the interleaved image fits the LDS
+static bool interleaved_applies(const int32_t* n_ls_host, int Ls, int F, int tile_shift, int lds_floats, bool backward) {
+  if (!g_tiled_interleaved || F != 2 || Ls > kIL || !n_ls_host) return false;
+  int64_t compact = 0;
+  for (int l = 0; l < Ls; ++l) { const int64_t w = (n_ls_host[l] >> tile_shift) + 3; compact += w * w * F; }
+  if (compact > lds_floats) return false;
+  const int64_t bytes = (int64_t)interleaved_rows(n_ls_host, Ls, tile_shift) * kIL * 8 * (backward ? 2 : 1) + (backward ? lds_floats * 4 : 0);
+  return bytes <= 150 * 1024;
+}
+
 extern "C" int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
-                                     const int32_t* n_ls, const float* G, float* enc, int L, int Ls, int F, int tile_shift,
-                                     int lds_bytes, void* stream) {
+                                     const int32_t* n_ls, const int32_t* n_ls_host, const float* G, float* enc, int L, int Ls,
+                                     int F, int tile_shift, int lds_bytes, void* stream) {
   GNGF_CHECK_ARG(max_items >= 0 && L > 0 && Ls > 0 && Ls <= L && L <= GNGF_MAX_LEVELS && lds_bytes >= 0 && lds_bytes <= 128 * 1024);
   if (max_items == 0) return 0;
   GNGF_CHECK_ARG(sorted && items && n_items && n_ls && G && enc);
+  if (interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, false)) {
+    const size_t smem = (size_t)interleaved_rows(n_ls_host, Ls, tile_shift) * kIL * 8;
+    const int pv = g_tiled_interleaved;
+    auto fn = (L == 16) ? (pv == 3 ? tiled_fwd_il_kernel<true, 2> : tiled_fwd_il_kernel<true, 0>) : tiled_fwd_il_kernel<false, 0>;
+    if (smem > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+    }
+    // persistent workgroups: as many as fit the chip at once (LDS-bound), sharing the items through a counter
+    const int per_cu = (int)((150 * 1024) / (smem + 2048)) < 1 ? 1 : (int)((150 * 1024) / (smem + 2048));
+    (void)per_cu;
+    const int nwork = max_items;                   // forward: one item per workgroup (two to three workgroups share a CU)
+    fn<<<dim3((unsigned)nwork), dim3(kTBF), smem, as_stream(stream)>>>(
+        reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, const_cast<int32_t*>(n_items) + 1, n_ls, G,
+        enc, L, Ls, tile_shift, nwork);
+    GNGF_RETURN_LAUNCH();
+  }
   DISPATCH_F(F, {
     if (lds_bytes > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiled_fwd_kernel<kF>),
@@ -1022,7 +1605,29 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
   while ((1 << log2_chunk) < chunk) ++log2_chunk;
   if (max_items == 0 && ride_blocks == 0) return 0;
   GNGF_CHECK_ARG(max_items == 0 || (sorted && items && n_items && tile_item_base && n_ls && n_ls_host && genc && dG && partials));
-  const int side = max_items > 0 ? max_grid_side(n_ls_host, Ls) : 0;
+  int64_t vtot_h = 0;
+  if (max_items > 0)
+    for (int l = 0; l < Ls; ++l) vtot_h += (int64_t)(n_ls_host[l] + 2) * (n_ls_host[l] + 2);
+  if (max_items > 0 && interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, true)) {
+    const int rows2 = 2 * interleaved_rows(n_ls_host, Ls, tile_shift);
+    const size_t smem = (size_t)rows2 * kIL * 8 + (size_t)lds_bytes;          // accumulators + the compact fp32 image of the store pass
+    const int pv = g_tiled_interleaved;
+    auto fn = (L == 16) ? (pv == 3 ? tiled_bwd_il_kernel<true, 2> : tiled_bwd_il_kernel<true, 0>) : tiled_bwd_il_kernel<false, 0>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    const int per_cu = (int)((150 * 1024) / (smem + 2048)) < 1 ? 1 : (int)((150 * 1024) / (smem + 2048));
+    const int fit = compute_units() * (per_cu > 2 ? 2 : per_cu);
+    const int nwork = max_items < fit ? max_items : fit;
+    ride.first_block = nwork;                      // the riders follow the persistent workgroups
+    if (mse_pred) mride.first_block = nwork + (ride_slabs ? (ride.nslab + 63) / 64 : 0);
+    fn<<<dim3((unsigned)(nwork + ride_blocks)), dim3(kTB), smem, as_stream(stream)>>>(
+        reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, const_cast<int32_t*>(n_items) + 2, n_ls,
+        genc, dG, partials, genc_absmax, absmax_count, absmax_stride, L, Ls, tile_shift, lds_bytes / 4, rows2, log2_chunk, nwork, ride,
+        mride);
+    gather_partials_kernel<2><<<dim3((unsigned)ceil_div(vtot_h, 256)), dim3(256), 0, as_stream(stream)>>>(
+        partials, tile_item_base, tile_level_off, n_ls, dG, Ls, tile_shift, lds_bytes / 4);
+    GNGF_RETURN_LAUNCH();
+  }
   DISPATCH_F(F, {
     if (2 * lds_bytes > 48 * 1024) {       // 64-bit accumulators: twice the forward image
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiled_bwd_kernel<kF>),
@@ -1033,7 +1638,7 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
         reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, n_ls, genc, dG, partials,
         genc_absmax, absmax_count, absmax_stride, L, Ls, tile_shift, lds_bytes / 4, log2_chunk, ride, mride);
     if (max_items > 0)
-      gather_partials_kernel<kF><<<dim3((unsigned)ceil_div((int64_t)side * side, 256), (unsigned)Ls), dim3(256), 0,
+      gather_partials_kernel<kF><<<dim3((unsigned)ceil_div(vtot_h, 256)), dim3(256), 0,
                                    as_stream(stream)>>>(partials, tile_item_base, tile_level_off, n_ls, dG, Ls, tile_shift,
                                                         lds_bytes / 4);
   });

@@ -332,7 +332,11 @@ class GeneralNeuralGaugeFields(nn.Module):
         n_ls = self._n_ls_flat(dev)
         tables, sink = ops.table_view(self.encoding)
         P, L, T, K = x.shape[0], self._num_levels, self._hash_table_size, self._topk_k
-        link = self._last_link = ops.StepLink(loss_value_aside=self.loss_value_aside)
+        # (the fused training decoder — 32 encoder features, a promised loss gradient — clears the table-gradient buffer itself)
+        train_fused = (self._fused_mse_gloss is not None and self._fused_mse_target is not None and ops.DECODER_TRAIN_FUSION
+                       and ops.DECODER_REDUCE_RIDES and L * self._feature_dim == 32 and P > 0
+                       and ops.decoder_fused_ok((ops.ACT_RELU, ops.ACT_RELU, ops.ACT_SIGMOID), self._decoder_params()))
+        link = self._last_link = ops.StepLink(loss_value_aside=self.loss_value_aside, defer_zero=train_fused)
         dp = self.dp
 
         if self._hash_mode:

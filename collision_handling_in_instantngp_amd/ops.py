@@ -679,11 +679,16 @@ class StepLink:
       loss_value      the fused pixel loss's value, deferred so that it rides on the same launch
       promise         (promised, arrived) device scalars of the fused training decoder's loss gradient (checked on the device)
     loss_value_aside: the caller owns the whole step and joins the loss value itself (train.GraphedStep)."""
-    __slots__ = ("pending_reduce", "absmax", "loss_value", "promise", "loss_value_aside", "__weakref__")
+    __slots__ = ("pending_reduce", "absmax", "loss_value", "promise", "loss_value_aside", "defer_zero", "zero_request", "__weakref__")
 
-    def __init__(self, loss_value_aside=False):
+    def __init__(self, loss_value_aside=False, defer_zero=False):
         self.pending_reduce = self.absmax = self.loss_value = self.promise = None
         self.loss_value_aside = bool(loss_value_aside)
+        # defer_zero: the caller expects the fused training decoder to follow the encoder in this forward pass: the encoder then
+        # does NOT clear its table-gradient buffer in rider workgroups of the binning launch but leaves it here (zero_request);
+        # gngf_decoder_train clears it between its MFMAs.  If nobody took it, the encoder backward clears it itself.
+        self.defer_zero = bool(defer_zero)
+        self.zero_request = None
 
     def take_absmax(self, genc):
         h, self.absmax = self.absmax, None
@@ -732,6 +737,7 @@ TILED_MIN_PIXELS = 1 << 14  # below this the binning overhead is not worth it
 # per-item images of that level cost more (step 1.43 -> 1.58 ms)
 TILED_CELLS_PER_PIXEL = 4.0
 TILED_LDS_LIMIT = 48 * 1024    # forward image; the backward image (64-bit accumulators) is twice this
+TILED_TILE_SHIFT_BIAS = 0      # +1: four times as many (smaller) spatial tiles as "<= 16 cells of the finest staged level per tile side"
 
 
 class EncodePlan:
@@ -757,7 +763,7 @@ class EncodePlan:
         if Ls == 0:
             return
         nmax = max(self.n_ls_host[:Ls])
-        shift = max(0, min(6, int(_math.ceil(_math.log2(max(nmax / 16.0, 1.0))))))
+        shift = max(0, min(6, int(_math.ceil(_math.log2(max(nmax / 16.0, 1.0)))) + TILED_TILE_SHIFT_BIAS))
         while True:
             TS = 1 << shift
             lds = sum((n // TS + 3) ** 2 for n in self.n_ls_host[:Ls]) * F * 4
@@ -800,7 +806,7 @@ class TiledWorkspace:
         self.tile_off = torch.empty((plan.ntiles + 1,), dtype=_i32, device=dev)
         self.tile_item_base = torch.empty((plan.ntiles + 1,), dtype=_i32, device=dev)
         self.items = torch.empty((plan.max_items, 4), dtype=_i32, device=dev)
-        self.n_items = torch.empty((1,), dtype=_i32, device=dev)
+        self.n_items = torch.empty((4,), dtype=_i32, device=dev)      # [0] items; [1..3] counters of the persistent pixel-stage kernels
         self.sorted = torch.empty((max(P, 1), 4), dtype=_f32, device=dev)
         if vertex is None:
             call("gngf_bin_pixels", ptr(xy, _f32, "xy"), P, plan.tile_shift, plan.NB, plan.chunk, ptr(self.blockhist),
@@ -987,10 +993,13 @@ class EncodeFunction(torch.autograd.Function):
             if ctx.needs_input_grad[3]:
                 pre = [torch.empty(tables.shape, dtype=_f32, device=tables.device), torch.empty((plan.vtot, F), dtype=_f32, device=tables.device)]
                 tile_level_offsets(plan, tables.device)        # cached; built here so that no backward (or graph capture) uploads it
+            defer = pre is not None and link is not None and link.defer_zero and pre[0].numel() % 4 == 0
+            if defer:
+                link.zero_request = pre[0]
             ws = TiledWorkspace(plan, xy, vertex=(tables, vert_idx, vert_w, n_ls, vstride, G),
-                                zero_dG=pre[1] if pre else None, zero=pre[0] if pre else None)
-            call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), ptr(G),
-                 ptr(enc), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, stream_ptr())
+                                zero_dG=pre[1] if pre else None, zero=(pre[0] if (pre and not defer) else None))
+            call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), plan.n_ls_c,
+                 ptr(G), ptr(enc), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, stream_ptr())
         if plan.Ls < L:
             call("gngf_encode_fwd", ptr(xy, _f32, "xy"), *_tab(tables), ptr(vert_idx, _i32, "vert_idx"),
                  ptr(vert_w, _f32, "vert_w"), ptr(n_ls, _i32, "n_ls"), ptr(enc), P, L, F, T, K, mode, vstride, NV, plan.Ls, L,
@@ -1015,6 +1024,9 @@ class EncodeFunction(torch.autograd.Function):
         exchange = dp.exchange if dp is not None else None
         NONE = (None,) * 5                                      # (order, dp, link, sink) + vstride: no gradients
         pre, ctx.pre = ctx.pre, None                            # a second backward (retain_graph) allocates fresh buffers
+        if pre and link is not None and link.zero_request is pre[0]:
+            link.zero_request = None                            # the decoder that was to clear the buffer did not run: clear it here
+            pre[0].zero_()
         dtables = pre[0] if pre else _grad_buffer(tables)
         dvw = torch.zeros_like(vert_w) if (vert_w is not None and ctx.needs_input_grad[5]) else None
         if plan.Ls > 0 and P > 0:
@@ -1201,8 +1213,10 @@ def _decoder_fwd(ctx, enc, leaky, ws, target, gloss_known=None, link=None):
         target_c = _c(target)
         denc = torch.empty_like(enc)
         flat, grads, slabs, nslabs, nslab = _decoder_grad_buffers(ws, P, in_dim, out_dim, dev)
+        zr, link.zero_request = link.zero_request, None        # the encoder's table-gradient buffer: cleared by this launch
         call("gngf_decoder_train", ptr(enc, _f32, "enc"), ptr(target_c, _f32, "target"), ptr(gl), *[ptr(w, _f32) for w in ws], ptr(rgb),
-             ptr(denc), *[ptr(None)] * 6, ptr(slabs), ptr(None), P, in_dim, out_dim, int(leaky), stream_ptr())
+             ptr(denc), *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(zr), 0 if zr is None else zr.numel(), P, in_dim, out_dim,
+             int(leaky), stream_ptr())
         ctx.train = {"denc": denc, "flat": flat, "grads": grads, "slabs": slabs, "nslabs": nslabs, "nslab": nslab,
                      "gloss": float(gloss_known), "promised": gl}
     else:
@@ -1392,8 +1406,8 @@ def encode_kernels(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, genc,
         out["bin_pixels"] = lambda: TiledWorkspace(plan, xy)
         out["vertex_fwd"] = lambda: _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G)
         out["encode_fwd:tiled"] = lambda: call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items),
-                                               plan.max_items, ptr(n_ls), ptr(G), ptr(enc), L, plan.Ls, F, plan.tile_shift,
-                                               plan.lds_bytes, s())
+                                               plan.max_items, ptr(n_ls), plan.n_ls_c, ptr(G), ptr(enc), L, plan.Ls, F,
+                                               plan.tile_shift, plan.lds_bytes, s())
         order = slot_order(vert_idx, plan.n_ls_host[:plan.Ls], vstride) if vert_idx is not None else None
         out["encode_bwd:tiled"] = lambda: _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, (am, 1, 0), None)
         out["vertex_bwd"] = lambda: _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, None, order)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNGF_ABI_VERSION 7
+#define GNGF_ABI_VERSION 8
 #define GNGF_MAX_LEVELS 32
 #define GNGF_MAX_TOPK 32
 
@@ -79,7 +79,8 @@ int gngf_encode_bwd(const float* xy, const void* tables, int feat_dtype, const i
 /* ---- a5..a12 fused, "tiled" form: vertex stage + spatially binned, LDS-privatised pixel stage.
  * gngf_bin_pixels: bins P pixels into 4^tile_shift tiles of [0,1]^2.  NB binning blocks (<= 512); `chunk` = max pixels
  *   per work item.  Outputs: sorted (P,4) fp32 = x, y, bits(original index), 0;  items (max_items,4) int32 = start, count,
- *   tile, items-of-tile with max_items >= ceil(P/chunk) + 4^tile_shift;  n_items (1);  tile_off and tile_item_base
+ *   tile, items-of-tile with max_items >= ceil(P/chunk) + 4^tile_shift;  n_items (4 int32: [0] = number of items, [1..3] = work counters of the persistent pixel-stage kernels, zeroed here and put
+ *   back to zero by those kernels when they finish);  tile_off and tile_item_base
  *   (4^tile_shift + 1 each: exclusive prefixes of pixels / items per tile);  blockhist: scratch of 4^tile_shift * (NB + 1)
  *   int32. */
 int gngf_bin_pixels(const float* xy, int64_t P, int tile_shift, int NB, int chunk, int32_t* blockhist, int32_t* tile_off,
@@ -116,8 +117,16 @@ int gngf_vertex_grid_bwd(const void* tables, int feat_dtype, const int32_t* vert
  * [t * Ls + l], -1 when the level does not fit (levels are laid out back to back in ascending order, a level that
  * would exceed lds_bytes is skipped); NULL: the gather pass re-derives it per vertex. */
 int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
-                          const int32_t* n_ls, const float* G, float* enc, int L, int Ls, int F, int tile_shift, int lds_bytes,
-                          void* stream);
+                          const int32_t* n_ls, const int32_t* n_ls_host, const float* G, float* enc, int L, int Ls, int F,
+                          int tile_shift, int lds_bytes, void* stream);
+/* n_ls_host (host copy of n_ls; may be NULL): lets the launcher size the LEVEL-INTERLEAVED LDS images (F = 2, <= 16 staged
+ * levels: vertex i of level l in row i, column l of 8-byte slots, so that the 16 level-lanes of a pixel never share an LDS
+ * column); NULL, or gngf_set_tiled_interleaved(0): the back-to-back layout.  Results do not depend on the layout. */
+int gngf_set_tiled_interleaved(int on);       /* returns the previous setting (default 1) */
+/* diagnostic: per-phase cycle totals of workgroup 0 of the interleaved backward kernel since the last call (read and cleared;
+ * synchronises): [0] tail wait, [1] setup, [2] clear + bound, [3] main loop, [4] wait for the other waves, [5] store pass,
+ * [6] items, [7] pixels */
+int gngf_debug_il_stamps(unsigned long long* host8);
 int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
                           const int32_t* tile_item_base, const int32_t* tile_level_off, const int32_t* n_ls,
                           const int32_t* n_ls_host, const float* genc, const float* genc_absmax, int absmax_count,
@@ -165,7 +174,11 @@ int gngf_set_decoder_bwd_hybrid(int on);
 int gngf_decoder_train(const float* enc, const float* target, const float* gloss, const float* W0, const float* b0,
                        const float* W1, const float* b1, const float* W2, const float* b2, float* rgb, float* denc,
                        float* dW0, float* db0, float* dW1, float* db1, float* dW2, float* db2, float* slabs,
-                       float* denc_absmax, int64_t P, int in_dim, int out_dim, int leaky, void* stream);
+                       float* denc_absmax, float* zero_fill, int64_t zero_floats, int64_t P, int in_dim, int out_dim, int leaky,
+                       void* stream);
+/* zero_fill (optional): zero_floats floats (a multiple of 4, 16-byte aligned) cleared by this launch on the way — the table
+ * gradient the encoder backward will accumulate into; the stores issue between the kernel's MFMAs (no issue time, idle HBM)
+ * instead of in rider workgroups of gngf_encode_tiled_prepare. */
 /* ---- dense layers on the matrix cores (exact-fp32 MFMA).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.01), 3 Sigmoid.
  * nn.Linear + activation of HashProbDistribution (models.py:80-88,105-106) and of the decoder (models.py:382-392). */
 int gngf_linear_fwd(const float* X, const float* W, const float* b, float* Y, int64_t M, int N, int K, int act, void* stream);

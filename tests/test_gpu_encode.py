@@ -215,7 +215,7 @@ def test_binning_is_a_permutation_grouped_by_tile(ops):
     TS = 1 << plan.tile_shift
     tile = np.minimum((srt[:, 1] * TS).astype(np.int64), TS - 1) * TS + np.minimum((srt[:, 0] * TS).astype(np.int64), TS - 1)
     assert np.all(np.diff(tile) >= 0)                                      # sorted by tile
-    n_items = int(ws.n_items.item())
+    n_items = int(ws.n_items[0].item())                                     # ([1..3]: work counters of the persistent kernels)
     items = ws.items.cpu().numpy()[:n_items]
     assert items[:, 1].sum() == P and items[:, 1].max() <= plan.chunk and items[:, 1].min() > 0
     for s_, c_, t_, _ in items[:: max(1, n_items // 50)]:
@@ -335,3 +335,59 @@ def test_mrhe_boundary_fp16_tables_cfg5_feature_width_vs_oracle(ops, K):
     close(tt.grad.float(), dt, 1e-3, 1e-3 * float(np.abs(dt).max()))
     if K:
         close(tp.grad, dp, 1e-4, 1e-6)
+
+
+@pytest.mark.parametrize("P,n_max,L,coords", [(2 ** 17 + 77, 512, 16, "unit"), (40001, 256, 12, "strip"), (2 ** 15, 512, 16, "outside"),
+                                             (5000, 64, 3, "unit")])
+def test_level_interleaved_pixel_stage_equals_back_to_back_layout(ops, P, n_max, L, coords):
+    """The level-interleaved LDS images (csrc/encode_tiled.hip: tiled_fwd_il_kernel / tiled_bwd_il_kernel; F = 2, <= 16 staged
+    levels) against the back-to-back layout on the same binned pixels: the forward rows and the vertex-grid gradient are
+    BIT-IDENTICAL (same fp32 expressions; the backward sums exact 64-bit fixed-point terms, and integer adds commute — the
+    private accumulator copies of the coarse levels included).  Ragged sizes, a 12-level table, pixels confined to a strip (many
+    empty tiles, many pixels per cell) and coordinates outside [0,1]^2 (the global fall-back path)."""
+    from collision_handling_in_instantngp_amd import _lib
+    rng = np.random.default_rng(P)
+    xy = rng.random((P, 2), dtype=np.float32)
+    if coords == "strip":
+        xy[:, 1] = 0.31 + 0.02 * xy[:, 1]
+    if coords == "outside":
+        xy[::7] = xy[::7] * 1.5 - 0.25                                  # a seventh of the pixels partly outside the unit square
+    xy_t = t(xy)
+    n_ls = orc.level_resolutions(16, n_max, L)
+    n_host = [int(n) for n in n_ls]
+    n_t = t(n_ls, torch.int32)
+    Fd = 2
+    tables = t((rng.random((L, 4096, Fd), dtype=np.float32) - 0.5) * 2e-1)
+    genc = t((rng.standard_normal((P, L * Fd)) * np.exp(rng.standard_normal((P, 1)) * 3)).astype(np.float32))      # wide dynamic range
+    plan = ops.EncodePlan(P, n_host, Fd, "tiled")
+    assert plan.Ls >= min(L, 12)              # (levels finer than 4 P cells are left to the direct form: not this test's subject)
+    res = {}
+    prev = _lib.query("gngf_set_tiled_interleaved", 1)
+    try:
+        # ONE binning for both variants: the order of a tile's pixels comes out of LDS atomics, and a tile with more than `chunk`
+        # pixels is cut into work items along that order — two binnings give different (equally valid) partial sums
+        G = torch.empty((plan.vtot, Fd), dtype=torch.float32, device=DEV)
+        ws = ops.TiledWorkspace(plan, xy_t, vertex=(tables, None, None, n_t, 0, G))
+        for variant in (0, 1):
+            _lib.query("gngf_set_tiled_interleaved", variant)
+            enc = torch.full((P, L * Fd), float("nan"), dtype=torch.float32, device=DEV)
+            ops.call("gngf_encode_tiled_fwd", ops.ptr(ws.sorted), ops.ptr(ws.items), ops.ptr(ws.n_items), plan.max_items, ops.ptr(n_t),
+                     plan.n_ls_c, ops.ptr(G), ops.ptr(enc), L, plan.Ls, Fd, plan.tile_shift, plan.lds_bytes, ops.stream_ptr())
+            dG = torch.zeros((plan.vtot, Fd), dtype=torch.float32, device=DEV)
+            ops._pixel_bwd(plan, ws, n_t, genc, dG, L, Fd, None, None)
+            torch.cuda.synchronize()
+            res[variant] = (enc[:, :plan.Ls * Fd].clone(), dG.clone())
+    finally:
+        _lib.query("gngf_set_tiled_interleaved", prev)
+    assert bool(torch.isfinite(res[0][0]).all())
+    assert torch.equal(res[0][0], res[1][0]), "forward rows differ between the LDS layouts"
+    if coords == "outside":        # out-of-sub-grid pixels add to dG with global FLOAT atomics in both kernels: order-dependent rounding
+        close(res[1][1], res[0][1].cpu().numpy(), 1e-5, 1e-6 * float(res[0][1].abs().max()), "interleaved vs back-to-back dG (with out-of-domain pixels)")
+    else:
+        assert torch.equal(res[0][1], res[1][1]), "vertex-grid gradients differ between the LDS layouts"
+    # ... and against the oracle (forward rows of a sample of pixels)
+    sel = rng.choice(P, size=min(P, 2000), replace=False)
+    want = orc.gngf_forward(xy[sel], n_ls, tables.cpu().numpy(), [np.zeros((64, L * Fd), np.float32), np.zeros((64, 64), np.float32), np.zeros((3, 64), np.float32)],
+                            [np.zeros(64, np.float32), np.zeros(64, np.float32), np.zeros(3, np.float32)], hash_mode=True)["enc"]
+    if coords != "outside":
+        close(res[1][0][t(sel)], want[:, :plan.Ls * Fd], 1e-5, 1e-7, "interleaved forward rows vs oracle")
