@@ -435,10 +435,13 @@ def main():
                 else:
                     gs(xy, target)                      # captures; the batch stays in the static buffers
                 if world > 1:
+                    # the exchange (RCCL) and the deferred vertex stage go to the model's communication stream; the next
+                    # replay waits for them on the device (it overwrites the exchanged buffers from its first kernel on)
                     def step(gs=gs, net=net):
+                        parallel.wait_for_gradients(net)
                         gs.replay_only()
-                        parallel.allreduce_gradients(net, world, keep_tables_flag=True)
-                    launch = "hipGraph + eager exchange"
+                        parallel.allreduce_gradients(net, world, keep_tables_flag=True, overlap=True)
+                    launch = "hipGraph + exchange on a communication stream"
                 else:
                     step = gs.replay_only
                     launch = "hipGraph" if unroll == 1 else f"hipGraph ({unroll} steps per replay)"

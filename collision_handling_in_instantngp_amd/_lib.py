@@ -28,15 +28,15 @@ SIGNATURES = {
     "gngf_encode_fwd": [_P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _L, _I, _I, _P],
     "gngf_encode_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _L, _I, _I, _P],
     "gngf_bin_pixels": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
-    "gngf_encode_tiled_prepare": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L,
-                                  _P, _L, _P],
+    "gngf_encode_tiled_prepare": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _I, _L,
+                                  _P, _L, _P, _P],
     "gngf_vertex_grid_fwd": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L, _P],
     "gngf_vertex_grid_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L, _P],
     "gngf_encode_tiled_fwd": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gngf_set_tiled_interleaved": [_I],
     "gngf_debug_il_stamps": [_P],
     "gngf_encode_tiled_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I,
-                              _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P],
+                              _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _I, _P],
     "gngf_vertex_grid_bwd_sorted": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _L, _P],
     "gngf_decoder_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gngf_decoder_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],

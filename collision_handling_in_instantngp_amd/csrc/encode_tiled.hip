@@ -42,7 +42,7 @@ __device__ __forceinline__ int tile_of(float x, float y, int tile_shift) {
 // ---------------------------------------------------------------------------------------------- binning
 // K1: per-block histogram over a contiguous pixel range -> blockhist[tile][block]
 __device__ __forceinline__ void bin_count_body(int blk, const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift,
-                                               int NB, int32_t* __restrict__ blockhist, int* hist) {
+                                               int NB, int32_t* __restrict__ blockhist, int* hist, int32_t* __restrict__ tot_atomic = nullptr) {
   const int ntiles = 1 << (2 * tile_shift);
   for (int i = threadIdx.x; i < ntiles; i += kBinThreads) hist[i] = 0;
   __syncthreads();
@@ -53,7 +53,11 @@ __device__ __forceinline__ void bin_count_body(int blk, const float2* __restrict
     atomicAdd(&hist[tile_of(c.x, c.y, tile_shift)], 1);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < ntiles; i += kBinThreads) blockhist[(int64_t)i * NB + blk] = hist[i];
+  for (int i = threadIdx.x; i < ntiles; i += kBinThreads) {
+    const int c = hist[i];
+    blockhist[(int64_t)i * NB + blk] = c;
+    if (tot_atomic && c) atomicAdd(tot_atomic + i, c);      // two-launch binning: the tile totals meet in global atomics (bin_scatter2_kernel)
+  }
 }
 
 __global__ void __launch_bounds__(kBinThreads)
@@ -152,6 +156,87 @@ bin_scatter_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, 
   bin_scatter_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, tile_off, sorted, cursor);
 }
 
+// TWO-LAUNCH BINNING (count -> scatter): the row scan and the tile scan — two launches of ~5 us each inside a replayed step, all
+// of it launch latency — fold into the scatter launch.  The count blocks add their histograms to per-tile totals with global
+// atomics (`pws`: a PERSISTENT zero-initialised workspace [totals ntiles | cursors ntiles | ticket]); every scatter block
+// scans the totals itself (1024 tiles: one per thread), reserves its pixels' places in each tile with one atomic on the tile's
+// cursor (the order of the blocks inside a tile is whatever the atomics make it — as the order of pixels inside a block
+// already is), block 0 also writes the tables the pixel stage reads, and the LAST block out (ticket) puts the workspace back to
+// zero for the next call.  No block ever waits for another block.
+__global__ void __launch_bounds__(kBinThreads)
+bin_scatter2_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB, int chunk,
+                    const int32_t* __restrict__ blockhist, int32_t* __restrict__ pws, int32_t* __restrict__ tile_off,
+                    int32_t* __restrict__ tile_item_base, int4* __restrict__ items, int32_t* __restrict__ n_items,
+                    float4* __restrict__ sorted) {
+  extern __shared__ int cursor[];                 // [ntiles]
+  __shared__ int wsum[kBinThreads / 64], wsum2[kBinThreads / 64];
+  __shared__ int s_last;
+  const int ntiles = 1 << (2 * tile_shift);
+  int32_t* tot = pws;
+  int32_t* gcur = pws + ntiles;
+  int32_t* ticket = pws + 2 * ntiles;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = blockIdx.x;
+  const int per = (ntiles + kBinThreads - 1) / kBinThreads;      // consecutive tiles per thread
+  // exclusive scans over tiles of (pixels, items), as bin_scan_kernel
+  int mytot = 0, myit = 0;
+  for (int q = 0; q < per; ++q) {
+    const int t = tid * per + q;
+    if (t < ntiles) { const int c = tot[t]; mytot += c; myit += (c + chunk - 1) / chunk; }
+  }
+  int a = mytot, n2 = myit;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int ua = __shfl_up(a, o, 64), un = __shfl_up(n2, o, 64);
+    if (lane >= o) { a += ua; n2 += un; }
+  }
+  if (lane == 63) { wsum[wave] = a; wsum2[wave] = n2; }
+  __syncthreads();
+  int off = a - mytot, ioff = n2 - myit;
+  for (int w = 0; w < wave; ++w) { off += wsum[w]; ioff += wsum2[w]; }
+  for (int q = 0; q < per; ++q) {
+    const int t = tid * per + q;
+    if (t < ntiles) {
+      const int total = tot[t];
+      const int nit = (total + chunk - 1) / chunk;
+      // this block's first place in tile t: behind the blocks that reserved before it
+      const int mine = blockhist[(int64_t)t * NB + blk];
+      cursor[t] = off + (mine ? atomicAdd(gcur + t, mine) : 0);
+      if (blk == 0) {
+        tile_off[t] = off;
+        tile_item_base[t] = ioff;
+        for (int jj = 0; jj < nit; ++jj) {
+          const int cnt = (total - jj * chunk) < chunk ? (total - jj * chunk) : chunk;
+          items[ioff + jj] = make_int4(off + jj * chunk, cnt, t, nit);
+        }
+      }
+      off += total;
+      ioff += nit;
+    }
+  }
+  if (blk == 0 && tid == kBinThreads - 1) {
+    tile_off[ntiles] = off; tile_item_base[ntiles] = ioff;
+    n_items[0] = ioff;
+    n_items[1] = n_items[2] = n_items[3] = 0;
+  }
+  __syncthreads();
+  const int64_t lo = (int64_t)blk * per_block;
+  const int64_t hi = lo + per_block < P ? lo + per_block : P;
+  for (int64_t p = lo + tid; p < hi; p += kBinThreads) {
+    const float2 c = xy[p];
+    const int pos = atomicAdd(&cursor[tile_of(c.x, c.y, tile_shift)], 1);
+    sorted[pos] = make_float4(c.x, c.y, __int_as_float((int)p), 0.f);
+  }
+  // last block out clears the workspace (every block has finished reading the totals and reserving on the cursors by then)
+  __syncthreads();
+  if (tid == 0) s_last = atomicAdd(ticket, 1) == NB - 1;
+  __syncthreads();
+  if (s_last) {
+    for (int t = tid; t < ntiles; t += kBinThreads) { tot[t] = 0; gcur[t] = 0; }
+    if (tid == 0) *ticket = 0;
+  }
+}
+
 // K1 with a ZERO-FILL riding on the launch: workgroups [NB, NB + zblocks) clear `zero` (nvec float4) instead — the gradient
 // buffer the backward pass will accumulate into (64 MiB at T = 2^19).  The count keeps 128 of the 256 CUs busy for ~8 us;
 // the fill runs on the others, instead of being a launch (or a stream) of its own.
@@ -183,7 +268,8 @@ __device__ __forceinline__ int64_t level_offset(const int32_t* n_ls, int l) {
 template <int F, bool VT, typename TT>
 __device__ __forceinline__ void vertex_fwd_lane(const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx,
                                                 const float* __restrict__ vert_w, float* __restrict__ G, float* __restrict__ dG_zero,
-                                                int64_t T, int K, int vstride, int64_t NV, bool pow2, int l, int gw, int i, int64_t goff) {
+                                                int64_t T, int K, int vstride, int64_t NV, bool pow2, int l, int gw, int i, int64_t goff,
+                                                int zero_words = 1) {
   const int gy = i / gw, gx = i - gy * gw;
   const TT* tab = tables + (int64_t)l * T * F;
   float acc[F];
@@ -208,9 +294,8 @@ __device__ __forceinline__ void vertex_fwd_lane(const TT* __restrict__ tables, c
 #pragma unroll
   for (int f = 0; f < F; ++f) o[f] = acc[f];
   if (dG_zero) {                                  // the vertex-grid gradient of the coming backward pass starts from zero
-    float* z = dG_zero + (goff + i) * F;
-#pragma unroll
-    for (int f = 0; f < F; ++f) z[f] = 0.f;
+    float* z = dG_zero + (goff + i) * F * zero_words;          // (zero_words = 2: the 64-bit fixed-point form, see tiled_bwd_il_kernel)
+    for (int f = 0; f < F * zero_words; ++f) z[f] = 0.f;
   }
 }
 
@@ -231,13 +316,17 @@ template <int F, bool VT, typename TT>
 __device__ __forceinline__ void vertex_ride_block(int vb, const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx,
                                                   const float* __restrict__ vert_w, const int32_t* __restrict__ n_ls, float* __restrict__ G,
                                                   float* __restrict__ dG_zero, int Ls, int64_t T, int K, int vstride, int64_t NV, bool pow2,
-                                                  int64_t vtot) {
+                                                  int64_t vtot, int zero_words) {
   const int64_t e = (int64_t)vb * kBinThreads + threadIdx.x;
   if (e >= vtot) return;
+  if (e == 0 && dG_zero && zero_words == 2) {     // the two 64-bit words behind the fixed-point grid: scale and poison flag
+    float* t = dG_zero + vtot * F * 2;
+    t[0] = t[1] = t[2] = t[3] = 0.f;
+  }
   int l = 0, gw = n_ls[0] + 2;
   int64_t goff = 0;
   while (l + 1 < Ls && e >= goff + (int64_t)gw * gw) { goff += (int64_t)gw * gw; ++l; gw = n_ls[l] + 2; }
-  vertex_fwd_lane<F, VT, TT>(tables, vert_idx, vert_w, G, dG_zero, T, K, vstride, NV, pow2, l, gw, (int)(e - goff), goff);
+  vertex_fwd_lane<F, VT, TT>(tables, vert_idx, vert_w, G, dG_zero, T, K, vstride, NV, pow2, l, gw, (int)(e - goff), goff, zero_words);
 }
 
 // K3 with the VERTEX STAGE FORWARD riding on the launch: workgroups [NB, NB + ceil(vtot / 1024)) evaluate one (level, vertex)
@@ -252,13 +341,14 @@ bin_scatter_ride_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_bl
                         const int32_t* __restrict__ blockhist, const int32_t* __restrict__ tile_off, float4* __restrict__ sorted,
                         const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx,
                         const float* __restrict__ vert_w, const int32_t* __restrict__ n_ls, float* __restrict__ G,
-                        float* __restrict__ dG_zero, int Ls, int64_t T, int K, int vstride, int64_t NV, bool pow2, int64_t vtot) {
+                        float* __restrict__ dG_zero, int Ls, int64_t T, int K, int vstride, int64_t NV, bool pow2, int64_t vtot,
+                        int zero_words) {
   extern __shared__ int cursor[];
   if ((int)blockIdx.x < NB) {
     bin_scatter_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, tile_off, sorted, cursor);
     return;
   }
-  vertex_ride_block<F, VT, TT>((int)blockIdx.x - NB, tables, vert_idx, vert_w, n_ls, G, dG_zero, Ls, T, K, vstride, NV, pow2, vtot);
+  vertex_ride_block<F, VT, TT>((int)blockIdx.x - NB, tables, vert_idx, vert_w, n_ls, G, dG_zero, Ls, T, K, vstride, NV, pow2, vtot, zero_words);
 }
 
 // K1 with the vertex stage forward riding on it (the count keeps half of the CUs busy for ~8 us): used when the launch does
@@ -269,13 +359,14 @@ __global__ void __launch_bounds__(kBinThreads)
 bin_count_vride_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB,
                        int32_t* __restrict__ blockhist, const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx,
                        const float* __restrict__ vert_w, const int32_t* __restrict__ n_ls, float* __restrict__ G,
-                       float* __restrict__ dG_zero, int Ls, int64_t T, int K, int vstride, int64_t NV, bool pow2, int64_t vtot) {
+                       float* __restrict__ dG_zero, int Ls, int64_t T, int K, int vstride, int64_t NV, bool pow2, int64_t vtot,
+                       int zero_words, int32_t* __restrict__ tot_atomic) {
   extern __shared__ int hist[];
   if ((int)blockIdx.x < NB) {
-    bin_count_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, hist);
+    bin_count_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, hist, tot_atomic);
     return;
   }
-  vertex_ride_block<F, VT, TT>((int)blockIdx.x - NB, tables, vert_idx, vert_w, n_ls, G, dG_zero, Ls, T, K, vstride, NV, pow2, vtot);
+  vertex_ride_block<F, VT, TT>((int)blockIdx.x - NB, tables, vert_idx, vert_w, n_ls, G, dG_zero, Ls, T, K, vstride, NV, pow2, vtot, zero_words);
 }
 
 template <int F, bool VT, typename TT>
@@ -700,7 +791,7 @@ __device__ __forceinline__ void il_setup(ILMeta& m, int Ls, int tx, int ty, int 
 // `chunk` pixels of one tile each); the next item's record is requested before the current item is processed.  (Claiming
 // items through a global counter was tried: the atomic's round trip sat in front of every item's first barrier.)
 
-template <bool L16, int PIPE>
+template <bool L16, int U>
 __global__ void __launch_bounds__(kTBF)
 tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ items, const int32_t* __restrict__ n_items,
                     int32_t* __restrict__ counter, const int32_t* __restrict__ n_ls, const float* __restrict__ G,
@@ -792,23 +883,14 @@ tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
 #pragma unroll
         for (int f = 0; f < F; ++f) o[f] = ((vv[0][f] * cc.c[0] + vv[1][f] * cc.c[1]) + vv[2][f] * cc.c[2]) + vv[3][f] * cc.c[3];
       };
-      // Four pixels per trip: their 16 LDS reads are in flight together, and a wave-uniform vote keeps the common case — every
+      // U pixels per trip: their 4 U LDS reads are in flight together, and a wave-uniform vote keeps the common case — every
       // pixel inside its staged sub-grid — free of per-lane branches.  Pairs of fp32 (coordinates, the two features) go through
       // packed instructions: same separately rounded operations as make_cell / the reference, half the instructions.
-      constexpr int U = PIPE == 2 ? 2 : 4;          // (variant 3 of gngf_set_tiled_interleaved: two pixels per trip, fewer registers)
-      float4 nx[U];
-      if constexpr (false) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) nx[u] = fetch(lp + u * ppp);
-      }
+      // (U = 2: 72 VGPRs, three workgroups per CU: 33 us at 2^20 pixels; U = 4: 92 VGPRs, two workgroups: 35 us.)
       for (int j0 = lp; j0 <= last; j0 += U * ppp) {
         float4 sv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) sv[u] = fetch(j0 + u * ppp);
-        if constexpr (false) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) nx[u] = fetch(j0 + (U + u) * ppp);
-        }
         float c[U][4];
         int v[U];
         bool inside = true;
@@ -853,14 +935,19 @@ tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
 // enough keeps up to four private copies of its accumulators stacked in its column (copy = pixel slot of the lane; the column
 // is as tall as the finest level anyway, so the copies are free) and the store pass adds them up as integers.
 // Fixed point, scale, store pass and riders exactly as tiled_bwd_kernel: the partial image leaves bit-identical, in the same
-// compact (level-after-level) format, so gather_partials is shared.  Workgroups [0, nwork) are persistent (il_claim).
-template <bool L16, int PIPE>
+// compact (level-after-level) format, so gather_partials is shared.  Workgroups [0, nwork) are persistent.
+// dG64 (needs the bound on |genc| handed over by its producer — ONE scale for the whole launch; log2_chunk then bounds the
+// pixels of the whole batch, not of an item): the store pass adds the item's 64-bit sums straight into a fixed-point vertex
+// grid with global integer atomics (fire and forget: they drain while other workgroups compute) — no partial images, no gather
+// pass; the sums are exact and order-free, so the vertex-grid gradient is bitwise reproducible.  dG64[vtot * F] = the scale S,
+// dG64[vtot * F + 1] != 0: poisoned (non-finite gradient or broken promise) — read by the kernels that turn dG64 into fp32.
+template <bool L16>
 __global__ void __launch_bounds__(kTB)
 tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ items, const int32_t* __restrict__ n_items,
                     int32_t* __restrict__ counter, const int32_t* __restrict__ n_ls, const float* __restrict__ genc,
                     float* __restrict__ dG, float* __restrict__ partials, const float* __restrict__ gmax_hint, int hint_count,
                     int hint_stride, int L, int Ls, int tile_shift, int lds_floats, int rows2, int log2_chunk, int nwork,
-                    RideAlong ride, MseRide mride) {
+                    RideAlong ride, MseRide mride, unsigned long long* __restrict__ dG64) {
   constexpr int F = 2;
   extern __shared__ unsigned long long accil[];   // [rows2][kIL], then the compact fp32 image of the store pass
   __shared__ ILMeta m;
@@ -949,6 +1036,11 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
     int eg = 0;
     if (finite && gmax > 0.f) (void)frexpf(gmax, &eg);       // gmax < 2^eg
     const int S = 61 - log2_chunk - eg;
+    if (dG64 && tid == 0) {
+      const int64_t vt = m.goff[Ls - 1] + (int64_t)(m.n[Ls - 1] + 2) * (m.n[Ls - 1] + 2);
+      if (blockIdx.x == 0 && item == (int)blockIdx.x) dG64[vt * F] = (unsigned long long)(long long)S;
+      if (!finite) dG64[vt * F + 1] = 1ull;
+    }
     if (lane_on && finite) {
       const int n = m.n[l], cx = m.cx[l], cy = m.cy[l], wx = m.wx[l], wy = m.wy[l], gw = n + 2;
       float* dGl = dG + m.goff[l] * F;
@@ -985,8 +1077,14 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
             int vx = gx + (q & 1), vy = gy + (q >> 1);
             vx = vx < 0 ? 0 : (vx > n + 1 ? n + 1 : vx);
             vy = vy < 0 ? 0 : (vy > n + 1 ? n + 1 : vy);
-            atomicAdd(dGl + ((int64_t)vy * gw + vx) * F, gv.x * cq[q]);
-            atomicAdd(dGl + ((int64_t)vy * gw + vx) * F + 1, gv.y * cq[q]);
+            if (dG64) {
+              unsigned long long* d = dG64 + (m.goff[l] + (int64_t)vy * gw + vx) * F;
+              atomicAdd(d, (unsigned long long)to_fixed_scaled((gv.x * scale) * cq[q]));
+              atomicAdd(d + 1, (unsigned long long)to_fixed_scaled((gv.y * scale) * cq[q]));
+            } else {
+              atomicAdd(dGl + ((int64_t)vy * gw + vx) * F, gv.x * cq[q]);
+              atomicAdd(dGl + ((int64_t)vy * gw + vx) * F + 1, gv.y * cq[q]);
+            }
           }
         }
       };
@@ -1007,30 +1105,16 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
         atomicAdd(pb + 2 * kIL, (unsigned long long)to_fixed_scaled(t3.x));
         atomicAdd(pb + 3 * kIL, (unsigned long long)to_fixed_scaled(t3.y));
       };
-      // four pixels per trip, loads issued together; PIPE == 2: the records of trip t + 2 and the gradient rows of trip t + 1
-      // are requested before trip t computes
-      float4 n1[U], n2[U];
-      v2f gn[U];
-      if constexpr (PIPE == 2) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) { n1[u] = fetch(lp + u * ppp); n2[u] = fetch(lp + (U + u) * ppp); }
-#pragma unroll
-        for (int u = 0; u < U; ++u) gn[u] = grad_of(n1[u]);
-      }
+      // four pixels per trip, loads issued together.  (Requesting the records two trips and the gradient rows one trip ahead
+      // made the first wave finish earlier and the item no sooner: the phase is bound by VALU issue plus the LDS atomic unit,
+      // 7.6 cycles per conflict-free ds_add_u64, not by memory latency.)
       for (int j0 = lp; j0 <= last; j0 += U * ppp) {
         float4 sv[U];
         v2f gv[U];
-        if constexpr (PIPE == 2) {
 #pragma unroll
-          for (int u = 0; u < U; ++u) { sv[u] = n1[u]; gv[u] = gn[u]; n1[u] = n2[u]; }
+        for (int u = 0; u < U; ++u) sv[u] = fetch(j0 + u * ppp);
 #pragma unroll
-          for (int u = 0; u < U; ++u) { gn[u] = grad_of(n1[u]); n2[u] = fetch(j0 + (2 * U + u) * ppp); }
-        } else {
-#pragma unroll
-          for (int u = 0; u < U; ++u) sv[u] = fetch(j0 + u * ppp);
-#pragma unroll
-          for (int u = 0; u < U; ++u) gv[u] = grad_of(sv[u]);
-        }
+        for (int u = 0; u < U; ++u) gv[u] = grad_of(sv[u]);
         v2f fa[U], fw0[U], fw1[U];
         int fv[U];
         bool inside = true;
@@ -1061,6 +1145,26 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
     // consecutive lanes read 16 different columns, no bank conflicts — and drops the fp32 value into a COMPACT image (levels
     // back to back, the format tiled_bwd_kernel writes and gather_partials reads) behind the accumulators; that image then
     // leaves with coalesced 16-byte stores.
+    if (dG64) {
+      // straight into the fixed-point vertex grid: row i of column l = feature i & 1 of vertex i >> 1 of the sub-grid
+      if (lane_on && finite) {
+        const int wx = m.wx[l], rows_l = wx * m.wy[l] * F, copies = m.copies[l], gw = m.n[l] + 2;
+        unsigned long long* base = dG64 + (m.goff[l] + (int64_t)m.cy[l] * gw + m.cx[l]) * F;
+        const float rw = 1.0f / (float)wx;
+        for (int i = lp; i < rows_l; i += ppp) {
+          unsigned long long sum = accil[i * kIL + l];
+          for (int c = 1; c < copies; ++c) sum += accil[(c * rows_l + i) * kIL + l];
+          if (sum != 0ull) {
+            const int v = i >> 1;
+            const int iy = (int)(((float)v + 0.5f) * rw), ix = v - iy * wx;
+            atomicAdd(base + ((int64_t)iy * gw + ix) * F + (i & 1), sum);
+          }
+        }
+      }
+      IL_STAMP(5);
+      if (blockIdx.x == 0 && tid == 0) { g_il_stamps[6] += 1; g_il_stamps[7] += (unsigned long long)it.y; }
+      continue;
+    }
     const double inv = finite ? ldexp(1.0, -S) : 0.0;
     if (lane_on) {
       const int rows_l = m.wx[l] * m.wy[l] * F, copies = m.copies[l], lo = m.loff[l];
@@ -1088,11 +1192,49 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
 // grid = ceil(vtot / 256): one thread per (level, vertex), FLAT over the level grids (a (vertices of the finest level, Ls)
 // grid launched 16.5 k workgroups at N = 512 of which 2.8 k had work: the empty ones cost more dispatch time than the kernel's
 // memory round trips).  Re-derives each covering tile's LDS layout (same rule as setup_tile).
+// dG64 (fixed point, scale at [nvals], poison flag at [nvals + 1]) -> dG (fp32): what the data-parallel exchange and the
+// slot-ordered vertex backward read
+__global__ void __launch_bounds__(256)
+dg64_to_float_kernel(const unsigned long long* __restrict__ dG64, float* __restrict__ dG, int64_t nvals) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= nvals) return;
+  const int S = (int)(long long)dG64[nvals];
+  const bool poisoned = dG64[nvals + 1] != 0ull;
+  dG[e] = poisoned ? __int_as_float(0x7fc00000) : (float)((double)(long long)dG64[e] * ldexp(1.0, -S));
+}
+
+// dG64 -> table gradient, spatial-hash index source (= vertex_bwd_kernel<F, false> reading the fixed-point grid)
 template <int F>
+__global__ void __launch_bounds__(256)
+vertex_bwd_hash64_kernel(const unsigned long long* __restrict__ dG64, const int32_t* __restrict__ n_ls, float* __restrict__ dtables,
+                         int Ls, int64_t T, bool pow2, int64_t vtot) {
+  int l = 0, gw = n_ls[0] + 2;
+  int64_t goff = 0;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  while (l + 1 < Ls && e >= goff + (int64_t)gw * gw) { goff += (int64_t)gw * gw; ++l; gw = n_ls[l] + 2; }
+  if (e - goff >= (int64_t)gw * gw) return;
+  const int i = (int)(e - goff);
+  const int gy = i / gw, gx = i - gy * gw;
+  const int S = (int)(long long)dG64[vtot * F];
+  const bool poisoned = dG64[vtot * F + 1] != 0ull;
+  float* r = dtables + ((int64_t)l * T + spatial_hash(gx, gy, T, pow2)) * F;
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+    const long long v = (long long)dG64[e * F + f];
+    if (poisoned) atomicAdd(r + f, __int_as_float(0x7fc00000));
+    else if (v != 0) atomicAdd(r + f, (float)((double)v * ldexp(1.0, -S)));
+  }
+}
+
+// HASHFUSE: the vertex stage backward of the spatial-hash index source rides along — the summed gradient of vertex (l, gx, gy)
+// goes straight to row hash(gx, gy) of the level's table gradient (float atomics, as vertex_bwd_kernel) and dG is not written:
+// one launch and one round trip of the vertex-grid gradient less (single rank only: a data-parallel exchange needs dG).
+template <int F, bool HASHFUSE = false>
 __global__ void __launch_bounds__(256)
 gather_partials_kernel(const float* __restrict__ partials, const int32_t* __restrict__ tile_item_base,
                        const int32_t* __restrict__ tile_level_off, const int32_t* __restrict__ n_ls, float* __restrict__ dG,
-                       int Ls, int tile_shift, int lds_floats) {
+                       int Ls, int tile_shift, int lds_floats, float* __restrict__ dtables = nullptr, int64_t T = 0,
+                       bool pow2 = false) {
   __shared__ int s_n[GNGF_MAX_LEVELS];
   if (threadIdx.x < Ls) s_n[threadIdx.x] = n_ls[threadIdx.x];
   __syncthreads();
@@ -1194,8 +1336,17 @@ gather_partials_kernel(const float* __restrict__ partials, const int32_t* __rest
       }
   }
   float* d = dG + (goff + i) * F;
+  if constexpr (HASHFUSE) {
+    float* r = dtables + ((int64_t)l * T + spatial_hash(gx, gy, T, pow2)) * F;
 #pragma unroll
-  for (int f = 0; f < F; ++f) d[f] += acc[f];      // += : the out-of-sub-grid fallback may already have added (atomically, earlier kernel)
+    for (int f = 0; f < F; ++f) {
+      const float g = acc[f] + d[f];                 // (d: what the out-of-sub-grid fallback added, normally 0)
+      if (g != 0.f) atomicAdd(r + f, g);
+    }
+  } else {
+#pragma unroll
+    for (int f = 0; f < F; ++f) d[f] += acc[f];      // += : the out-of-sub-grid fallback may already have added (atomically, earlier kernel)
+  }
 }
 
 // DPP lane movement (row_shr:n = 0x110+n inside 16-lane rows, row_bcast:15 = 0x142, row_bcast:31 = 0x143); lanes without a
@@ -1387,8 +1538,9 @@ extern "C" int gngf_encode_tiled_prepare(const float* xy, int64_t P, int tile_sh
                                          int32_t* tile_off, int32_t* tile_item_base, int32_t* items, int32_t* n_items,
                                          float* sorted, const void* tables, int feat_dtype, const int32_t* vert_idx,
                                          const float* vert_w, const int32_t* n_ls, const int32_t* n_ls_host, float* G,
-                                         float* dG_zero, int Ls, int F, int64_t T, int K, int mode, int vstride, int64_t NV,
-                                         float* zero_fill, int64_t zero_floats, void* stream) {
+                                         float* dG_zero, int dG_zero_words, int Ls, int F, int64_t T, int K, int mode, int vstride,
+                                         int64_t NV, float* zero_fill, int64_t zero_floats, int32_t* persistent_ws, void* stream) {
+  GNGF_CHECK_ARG(dG_zero_words == 1 || dG_zero_words == 2);
   GNGF_CHECK_ARG(P >= 0 && P < (1ll << 31) && tile_shift >= 0 && tile_shift <= 6 && NB > 0 && NB <= kBinMaxBlocks && chunk > 0);
   GNGF_CHECK_ARG(xy && blockhist && tile_off && tile_item_base && items && n_items && sorted);
   GNGF_CHECK_ARG(Ls > 0 && Ls <= GNGF_MAX_LEVELS && T > 0 && tables && n_ls && n_ls_host && G);
@@ -1411,11 +1563,17 @@ extern "C" int gngf_encode_tiled_prepare(const float* xy, int64_t P, int tile_sh
     if (mode == GNGF_MODE_HASH) {
       DISPATCH_TT(feat_dtype, DISPATCH_F(F, (bin_count_vride_kernel<kF, false, TT><<<dim3((unsigned)(NB + vblocks)), dim3(kBinThreads), smem, s>>>(
                                   xy2, P, per_block, tile_shift, NB, blockhist, static_cast<const TT*>(tables), nullptr, nullptr, n_ls, G,
-                                  dG_zero, Ls, T, 0, 0, 0, pow2, vtot))));
+                                  dG_zero, Ls, T, 0, 0, 0, pow2, vtot, dG_zero_words, persistent_ws))));
     } else {
       DISPATCH_TT(feat_dtype, DISPATCH_F(F, (bin_count_vride_kernel<kF, true, TT><<<dim3((unsigned)(NB + vblocks)), dim3(kBinThreads), smem, s>>>(
                                   xy2, P, per_block, tile_shift, NB, blockhist, static_cast<const TT*>(tables), vert_idx, vert_w, n_ls, G,
-                                  dG_zero, Ls, T, K, vstride, NV, pow2, vtot))));
+                                  dG_zero, Ls, T, K, vstride, NV, pow2, vtot, dG_zero_words, persistent_ws))));
+    }
+    if (persistent_ws) {       // count -> scatter: the scans ride inside the scatter launch (bin_scatter2_kernel)
+      bin_scatter2_kernel<<<dim3(NB), dim3(kBinThreads), smem, s>>>(xy2, P, per_block, tile_shift, NB, chunk, blockhist, persistent_ws,
+                                                                   tile_off, tile_item_base, reinterpret_cast<int4*>(items), n_items,
+                                                                   reinterpret_cast<float4*>(sorted));
+      GNGF_RETURN_LAUNCH();
     }
     bin_rowscan_kernel<<<dim3((unsigned)ceil_div(ntiles, 4)), dim3(256), 0, s>>>(blockhist, NB, ntiles, tot);
     bin_scan_kernel<<<dim3(1), dim3(kBinThreads), 0, s>>>(tot, tile_shift, chunk, tile_off, tile_item_base,
@@ -1433,11 +1591,11 @@ extern "C" int gngf_encode_tiled_prepare(const float* xy, int64_t P, int tile_sh
   if (mode == GNGF_MODE_HASH) {
     DISPATCH_TT(feat_dtype, DISPATCH_F(F, (bin_scatter_ride_kernel<kF, false, TT><<<dim3((unsigned)(NB + vblocks)), dim3(kBinThreads), smem, s>>>(
                                 xy2, P, per_block, tile_shift, NB, blockhist, tile_off, sorted4, static_cast<const TT*>(tables), nullptr,
-                                nullptr, n_ls, G, dG_zero, Ls, T, 0, 0, 0, pow2, vtot))));
+                                nullptr, n_ls, G, dG_zero, Ls, T, 0, 0, 0, pow2, vtot, dG_zero_words))));
   } else {
     DISPATCH_TT(feat_dtype, DISPATCH_F(F, (bin_scatter_ride_kernel<kF, true, TT><<<dim3((unsigned)(NB + vblocks)), dim3(kBinThreads), smem, s>>>(
                                 xy2, P, per_block, tile_shift, NB, blockhist, tile_off, sorted4, static_cast<const TT*>(tables), vert_idx,
-                                vert_w, n_ls, G, dG_zero, Ls, T, K, vstride, NV, pow2, vtot))));
+                                vert_w, n_ls, G, dG_zero, Ls, T, K, vstride, NV, pow2, vtot, dG_zero_words))));
   }
   GNGF_RETURN_LAUNCH();
 }
@@ -1517,7 +1675,7 @@ static int compute_units() {
 static int g_tiled_interleaved = 1;
 extern "C" int gngf_set_tiled_interleaved(int on) {
   const int prev = g_tiled_interleaved;
-  g_tiled_interleaved = on < 0 ? 0 : (on > 3 ? 3 : on);      // (2, 3: experimental load-pipelining variants of the same kernels)
+  g_tiled_interleaved = on < 0 ? 0 : (on > 3 ? 3 : on);      // (3: the forward kernel with four pixels per trip instead of two)
   return prev;
 }
 
@@ -1541,7 +1699,7 @@ extern "C" int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, 
   if (interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, false)) {
     const size_t smem = (size_t)interleaved_rows(n_ls_host, Ls, tile_shift) * kIL * 8;
     const int pv = g_tiled_interleaved;
-    auto fn = (L == 16) ? (pv == 3 ? tiled_fwd_il_kernel<true, 2> : tiled_fwd_il_kernel<true, 0>) : tiled_fwd_il_kernel<false, 0>;
+    auto fn = (L == 16) ? (pv == 3 ? tiled_fwd_il_kernel<true, 4> : tiled_fwd_il_kernel<true, 2>) : tiled_fwd_il_kernel<false, 2>;
     if (smem > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
@@ -1576,7 +1734,10 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
                                      float* ride_dW1, float* ride_db1, float* ride_dW2, float* ride_db2, int64_t ride_P,
                                      int ride_in_dim, int ride_out_dim, const float* gloss_promised, const float* gloss_arrived,
                                      const float* mse_pred, const float* mse_label,
-                                     float* mse_loss, float* mse_workspace, int64_t mse_n, void* stream) {
+                                     float* mse_loss, float* mse_workspace, int64_t mse_n, float* hash_dtables, int64_t hash_T,
+                                     void* dG64, int log2_pixels, void* stream) {
+  GNGF_CHECK_ARG(!hash_dtables || hash_T > 0);
+  const bool hpow2 = hash_dtables && (hash_T & (hash_T - 1)) == 0;
   GNGF_CHECK_ARG(max_items >= 0 && L > 0 && Ls > 0 && Ls <= L && L <= GNGF_MAX_LEVELS && lds_bytes >= 0 && lds_bytes <= 64 * 1024);
   GNGF_CHECK_ARG(!gloss_promised == !gloss_arrived);
   RideAlong ride = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, gloss_promised, gloss_arrived};
@@ -1612,7 +1773,8 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
     const int rows2 = 2 * interleaved_rows(n_ls_host, Ls, tile_shift);
     const size_t smem = (size_t)rows2 * kIL * 8 + (size_t)lds_bytes;          // accumulators + the compact fp32 image of the store pass
     const int pv = g_tiled_interleaved;
-    auto fn = (L == 16) ? (pv == 3 ? tiled_bwd_il_kernel<true, 2> : tiled_bwd_il_kernel<true, 0>) : tiled_bwd_il_kernel<false, 0>;
+    (void)pv;
+    auto fn = (L == 16) ? tiled_bwd_il_kernel<true> : tiled_bwd_il_kernel<false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     const int per_cu = (int)((150 * 1024) / (smem + 2048)) < 1 ? 1 : (int)((150 * 1024) / (smem + 2048));
@@ -1620,12 +1782,26 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
     const int nwork = max_items < fit ? max_items : fit;
     ride.first_block = nwork;                      // the riders follow the persistent workgroups
     if (mse_pred) mride.first_block = nwork + (ride_slabs ? (ride.nslab + 63) / 64 : 0);
+    // one scale for the launch (a bound on |genc| from its producer) -> the items add their sums into a fixed-point vertex grid
+    unsigned long long* g64 = (genc_absmax && dG64 && log2_pixels > 0 && log2_pixels <= 40) ? static_cast<unsigned long long*>(dG64) : nullptr;
     fn<<<dim3((unsigned)(nwork + ride_blocks)), dim3(kTB), smem, as_stream(stream)>>>(
         reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, const_cast<int32_t*>(n_items) + 2, n_ls,
-        genc, dG, partials, genc_absmax, absmax_count, absmax_stride, L, Ls, tile_shift, lds_bytes / 4, rows2, log2_chunk, nwork, ride,
-        mride);
-    gather_partials_kernel<2><<<dim3((unsigned)ceil_div(vtot_h, 256)), dim3(256), 0, as_stream(stream)>>>(
-        partials, tile_item_base, tile_level_off, n_ls, dG, Ls, tile_shift, lds_bytes / 4);
+        genc, dG, partials, genc_absmax, absmax_count, absmax_stride, L, Ls, tile_shift, lds_bytes / 4, rows2,
+        g64 ? log2_pixels : log2_chunk, nwork, ride, mride, g64);
+    if (g64) {
+      if (hash_dtables)
+        vertex_bwd_hash64_kernel<2><<<dim3((unsigned)ceil_div(vtot_h, 256)), dim3(256), 0, as_stream(stream)>>>(
+            g64, n_ls, hash_dtables, Ls, hash_T, hpow2, vtot_h);
+      else
+        dg64_to_float_kernel<<<dim3((unsigned)ceil_div(vtot_h * 2, 256)), dim3(256), 0, as_stream(stream)>>>(g64, dG, vtot_h * 2);
+      GNGF_RETURN_LAUNCH();
+    }
+    if (hash_dtables)
+      gather_partials_kernel<2, true><<<dim3((unsigned)ceil_div(vtot_h, 256)), dim3(256), 0, as_stream(stream)>>>(
+          partials, tile_item_base, tile_level_off, n_ls, dG, Ls, tile_shift, lds_bytes / 4, hash_dtables, hash_T, hpow2);
+    else
+      gather_partials_kernel<2><<<dim3((unsigned)ceil_div(vtot_h, 256)), dim3(256), 0, as_stream(stream)>>>(
+          partials, tile_item_base, tile_level_off, n_ls, dG, Ls, tile_shift, lds_bytes / 4);
     GNGF_RETURN_LAUNCH();
   }
   DISPATCH_F(F, {
@@ -1637,10 +1813,15 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
     tiled_bwd_kernel<kF><<<dim3((unsigned)(max_items + ride_blocks)), dim3(kTB), (size_t)2 * lds_bytes, as_stream(stream)>>>(
         reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, n_ls, genc, dG, partials,
         genc_absmax, absmax_count, absmax_stride, L, Ls, tile_shift, lds_bytes / 4, log2_chunk, ride, mride);
-    if (max_items > 0)
-      gather_partials_kernel<kF><<<dim3((unsigned)ceil_div(vtot_h, 256)), dim3(256), 0,
-                                   as_stream(stream)>>>(partials, tile_item_base, tile_level_off, n_ls, dG, Ls, tile_shift,
-                                                        lds_bytes / 4);
+    if (max_items > 0) {
+      if (hash_dtables)
+        gather_partials_kernel<kF, true><<<dim3((unsigned)ceil_div(vtot_h, 256)), dim3(256), 0, as_stream(stream)>>>(
+            partials, tile_item_base, tile_level_off, n_ls, dG, Ls, tile_shift, lds_bytes / 4, hash_dtables, hash_T, hpow2);
+      else
+        gather_partials_kernel<kF><<<dim3((unsigned)ceil_div(vtot_h, 256)), dim3(256), 0,
+                                     as_stream(stream)>>>(partials, tile_item_base, tile_level_off, n_ls, dG, Ls, tile_shift,
+                                                          lds_bytes / 4);
+    }
   });
   GNGF_RETURN_LAUNCH();
 }

@@ -663,6 +663,7 @@ class DataParallel:
         self.tables_reduced = 0
         self.comm_stream = None
         self.comm_done = None
+        self.bin_ws = {}                # persistent counters of the two-launch binning (ops._bin_workspace)
         self.world = 1
         self.group = None
 
@@ -794,10 +795,30 @@ class EncodePlan:
         self.n_ls_c = (_ct.c_int32 * L)(*self.n_ls_host)
 
 
+TWO_LAUNCH_BINNING = True     # count -> scatter (the scans ride inside the scatter launch) when the launch carries no gradient clear
+_BIN_WORKSPACES = {}
+
+
+def _bin_workspace(dev, ntiles, owner=None):
+    """Persistent zero-initialised counters of the two-launch binning (tile totals, tile cursors, a ticket).  The kernels put
+    them back to zero themselves, so one buffer serves every step — including every replay of a captured step (it is allocated
+    at warm-up, outside the capture).  It belongs to ONE sequence of steps: `owner` is the model's DataParallel object (one per
+    model: two models stepping concurrently on two streams do not share counters); calls without an owner (the op used on its
+    own) share one buffer per device and tiling and must not overlap in time."""
+    store = owner.bin_ws if owner is not None else _BIN_WORKSPACES
+    key = (dev.type, dev.index, int(ntiles))
+    w = store.get(key)
+    if w is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None                     # first use inside a capture: the four-launch binning (no allocation + memset in the graph)
+        w = store[key] = torch.zeros((2 * int(ntiles) + 1,), dtype=_i32, device=dev)
+    return w
+
+
 class TiledWorkspace:
     """Device buffers of one forward/backward pair (binning result is shared by both)."""
 
-    def __init__(self, plan, xy, vertex=None, zero_dG=None, zero=None):
+    def __init__(self, plan, xy, vertex=None, zero_dG=None, zero=None, zero_dG_words=1, owner=None):
         """vertex = (tables, vert_idx, vert_w, n_ls, vstride, G): also run the vertex stage forward into G (riding on the binning
         launches); zero_dG (same shape as G) and zero (any fp32 buffer, typically the table gradient): cleared on the way."""
         dev = xy.device
@@ -821,9 +842,10 @@ class TiledWorkspace:
                 zero = None
             call("gngf_encode_tiled_prepare", ptr(xy, _f32, "xy"), P, plan.tile_shift, plan.NB, plan.chunk, ptr(self.blockhist),
                  ptr(self.tile_off), ptr(self.tile_item_base), ptr(self.items), ptr(self.n_items), ptr(self.sorted),
-                 *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), plan.n_ls_c, ptr(G), ptr(zero_dG), plan.Ls, F, T,
+                 *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), plan.n_ls_c, ptr(G), ptr(zero_dG), int(zero_dG_words), plan.Ls, F, T,
                  0 if vert_idx is None else vert_idx.shape[1], mode, vstride, 0 if vert_idx is None else vert_idx.shape[0],
-                 ptr(zero), 0 if zero is None else zero.numel(), stream_ptr())
+                 ptr(zero), 0 if zero is None else zero.numel(), ptr(_bin_workspace(dev, plan.ntiles, owner) if TWO_LAUNCH_BINNING else None),
+                 stream_ptr())
 
 
 def _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G):
@@ -895,7 +917,13 @@ def tile_level_offsets(plan, device):
     return hit
 
 
-def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None, link=None):
+HASH_VERTEX_FUSION = True    # hash indexing, single rank: the vertex stage backward rides on the gather pass of the pixel stage
+
+
+DG64 = True                  # F = 2, <= 16 staged levels, bounded |genc|: 64-bit fixed-point vertex grid fed by global integer atomics
+
+
+def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None, link=None, hash_fuse=None, dG64=None):
     """absmax: None or (tensor, count, stride) — `count` floats `stride` apart whose maximum bounds |genc|.
     link: the StepLink of the forward pass (decoder slab reduction / loss value waiting for a launch to ride on, promise)."""
     partials = torch.empty((plan.max_items * (plan.lds_bytes // 4),), dtype=_f32, device=genc.device)
@@ -912,6 +940,10 @@ def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None, link=None):
         ride_args += [ptr(None)] * 4 + [0]
     else:
         ride_args += [ptr(lv["pred"]), ptr(lv["label"]), ptr(lv["loss"]), ptr(lv["ws"]), lv["pred"].numel()]
+    # hash_fuse = (dtables (L,T,F) fp32, T): the gather pass scatters into the table gradient itself (no vertex-stage launch)
+    ride_args += [ptr(hash_fuse[0], _f32, "dtables"), int(hash_fuse[1])] if hash_fuse is not None else [ptr(None), 0]
+    # dG64: zeroed (vtot * F + 2) int64 grid; log2_pixels bounds the number of terms any vertex can receive
+    ride_args += [ptr(dG64, _i64, "dG64"), max(1, int(plan.P - 1).bit_length())] if dG64 is not None else [ptr(None), 0]
     call("gngf_encode_tiled_bwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(ws.tile_item_base),
          ptr(tile_level_offsets(plan, genc.device)), ptr(n_ls), plan.n_ls_c, ptr(genc, _f32, "grad"), ptr(am),
          int(am_count), int(am_stride), ptr(dG), ptr(partials), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, plan.chunk,
@@ -990,14 +1022,21 @@ class EncodeFunction(torch.autograd.Function):
             # binning, vertex stage and the clears of the backward's gradient buffers: ONE chain of four launches (the vertex
             # stage and the clears ride on the binning kernels as extra workgroups: ops.TiledWorkspace)
             G = torch.empty((plan.vtot, F), dtype=_f32, device=tables.device)
+            use64 = False
             if ctx.needs_input_grad[3]:
-                pre = [torch.empty(tables.shape, dtype=_f32, device=tables.device), torch.empty((plan.vtot, F), dtype=_f32, device=tables.device)]
+                # F = 2, <= 16 staged levels (the level-interleaved kernels): the pixel stage of the backward adds its exact
+                # fixed-point sums straight into a 64-bit vertex grid (cleared here; + scale and poison words), no gather pass
+                use64 = DG64 and F == 2 and plan.Ls <= 16
+                dgrid = (torch.empty((plan.vtot * F + 2,), dtype=_i64, device=tables.device) if use64
+                         else torch.empty((plan.vtot, F), dtype=_f32, device=tables.device))
+                pre = [torch.empty(tables.shape, dtype=_f32, device=tables.device), dgrid]
                 tile_level_offsets(plan, tables.device)        # cached; built here so that no backward (or graph capture) uploads it
             defer = pre is not None and link is not None and link.defer_zero and pre[0].numel() % 4 == 0
             if defer:
                 link.zero_request = pre[0]
             ws = TiledWorkspace(plan, xy, vertex=(tables, vert_idx, vert_w, n_ls, vstride, G),
-                                zero_dG=pre[1] if pre else None, zero=(pre[0] if (pre and not defer) else None))
+                                zero_dG=(pre[1].view(_f32) if use64 else pre[1]) if pre else None,
+                                zero=(pre[0] if (pre and not defer) else None), zero_dG_words=(2 if use64 else 1), owner=dp)
             call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), plan.n_ls_c,
                  ptr(G), ptr(enc), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, stream_ptr())
         if plan.Ls < L:
@@ -1030,9 +1069,14 @@ class EncodeFunction(torch.autograd.Function):
         dtables = pre[0] if pre else _grad_buffer(tables)
         dvw = torch.zeros_like(vert_w) if (vert_w is not None and ctx.needs_input_grad[5]) else None
         if plan.Ls > 0 and P > 0:
-            dG = pre[1] if pre else torch.zeros((plan.vtot, F), dtype=_f32, device=tables.device)
-            _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax, link)
-            if exchange is not None and dp.defer_vertex and dvw is None:
+            dG64 = pre[1] if (pre and pre[1].dtype == _i64) else None
+            if dG64 is not None and absmax is None:            # no bound on |genc| from its producer: the per-item scales need the fp32 path
+                dG64 = None
+            dG = (pre[1] if (pre and pre[1].dtype == _f32) else
+                  (torch.empty if dG64 is not None else torch.zeros)((plan.vtot, F), dtype=_f32, device=tables.device))
+            fuse = (dtables, T) if (HASH_VERTEX_FUSION and vert_idx is None and exchange is None) else None
+            _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax, link, fuse, dG64)
+            if fuse is None and exchange is not None and dp.defer_vertex and dvw is None:
                 # the caller exchanges dG and runs the vertex stage after backward (parallel.allreduce_gradients)
                 if plan.Ls < L:
                     call("gngf_encode_bwd", ptr(xy), *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc, _f32, "grad"),
@@ -1044,7 +1088,9 @@ class EncodeFunction(torch.autograd.Function):
             if exchange is not None:
                 exchange(dG)                        # one small all-reduce instead of the staged levels' table gradient
                 dp.tables_reduced = plan.Ls
-            if order is not None and dvw is not None and plan.Ls < L:
+            if fuse is not None:
+                dvw_t = None                        # (hash source: the vertex stage rode on the gather pass)
+            elif order is not None and dvw is not None and plan.Ls < L:
                 # the sorted kernel WRITES dvert_w; the direct levels below accumulate into the same buffer
                 dvw_t = torch.empty_like(dvw)
                 _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw_t, order)
@@ -1410,6 +1456,13 @@ def encode_kernels(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, genc,
                                                plan.tile_shift, plan.lds_bytes, s())
         order = slot_order(vert_idx, plan.n_ls_host[:plan.Ls], vstride) if vert_idx is not None else None
         out["encode_bwd:tiled"] = lambda: _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, (am, 1, 0), None)
+        if F == 2 and plan.Ls <= 16:
+            dG64 = torch.zeros((plan.vtot * F + 2,), dtype=_i64, device=xy.device)
+
+            def bwd64():
+                dG64.zero_()                    # (the training step clears it in rider workgroups of the binning launch)
+                _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, (am, 1, 0), None, None, dG64)
+            out["encode_bwd:tiled+dG64"] = bwd64
         out["vertex_bwd"] = lambda: _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, None, order)
     if plan.Ls < L:
         out["encode_fwd:direct"] = lambda: call("gngf_encode_fwd", ptr(xy), *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls),

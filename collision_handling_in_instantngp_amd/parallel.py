@@ -120,13 +120,43 @@ def average_tensors(tensors, world: int, group=None):
         t.mul_(1.0 / world)
 
 
-def allreduce_gradients(net, world: int, group=None, keep_tables_flag: bool = False):
+def wait_for_gradients(net):
+    """Makes the current stream wait for an exchange started with allreduce_gradients(..., overlap=True): call it before
+    anything reads the gradients (optimizer.step()) or overwrites the exchanged buffers (the next backward pass; for a step
+    replayed from a hipGraph, the next replay).  No-op when nothing is in flight.  The host does not block."""
+    dp = getattr(net, "dp", None)
+    if dp is not None and dp.comm_done is not None:
+        torch.cuda.current_stream().wait_event(dp.comm_done)
+        dp.comm_done = None
+
+
+def allreduce_gradients(net, world: int, group=None, keep_tables_flag: bool = False, overlap: bool = False):
     """All gradient traffic of one step, as one coalesced exchange: the deferred vertex-grid gradient (if the encoder
     backward left one, see defer_vertex_stage), the table-gradient slice of the direct-form levels, and every other
     gradient as one flat buffer; the deferred vertex stage runs behind it.  keep_tables_flag: the step is replayed from
-    a hipGraph, so the staged-level count recorded at capture time stays valid for every replay."""
+    a hipGraph, so the staged-level count recorded at capture time stays valid for every replay.
+    overlap: the exchange and the deferred vertex stage are issued on the model's own communication stream (behind everything
+    already on the current stream) and the call returns at once: whatever the caller launches next that does not touch the
+    gradients — the next batch's host-side preparation, its upload, its binning (ops.TiledWorkspace on the next coordinates) —
+    runs beside the RCCL transfer; wait_for_gradients(net) joins.  (The next step's forward itself cannot run ahead: it reads
+    the weights the optimizer is about to update with these gradients.)"""
     if world <= 1:
         return
+    if overlap and torch.cuda.is_available():
+        dp = getattr(net, "dp", None)
+        if dp is not None:
+            wait_for_gradients(net)                  # (an earlier exchange nobody joined)
+            if dp.comm_stream is None:
+                dp.comm_stream = torch.cuda.Stream()
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(dp.comm_stream):
+                dp.comm_stream.wait_event(ready)
+                allreduce_gradients(net, world, group, keep_tables_flag, overlap=False)
+                done = torch.cuda.Event()
+                done.record()
+            dp.comm_done = done
+            return
     tensors = []
     dp = getattr(net, "dp", None)                # (a plain nn.Module without the encoder's state: dense exchange only)
     deferred = dp.deferred if dp is not None else None

@@ -93,8 +93,14 @@ int gngf_bin_pixels(const float* xy, int64_t P, int tile_shift, int NB, int chun
 int gngf_encode_tiled_prepare(const float* xy, int64_t P, int tile_shift, int NB, int chunk, int32_t* blockhist,
                               int32_t* tile_off, int32_t* tile_item_base, int32_t* items, int32_t* n_items, float* sorted,
                               const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w,
-                              const int32_t* n_ls, const int32_t* n_ls_host, float* G, float* dG_zero, int Ls, int F, int64_t T,
-                              int K, int mode, int vstride, int64_t NV, float* zero_fill, int64_t zero_floats, void* stream);
+                              const int32_t* n_ls, const int32_t* n_ls_host, float* G, float* dG_zero, int dG_zero_words, int Ls,
+                              int F, int64_t T, int K, int mode, int vstride, int64_t NV, float* zero_fill, int64_t zero_floats,
+                              int32_t* persistent_ws, void* stream);
+/* persistent_ws (optional): (2 * 4^tile_shift + 1) int32, ZERO before its first use and owned by one stream — with it (and
+ * without zero_fill) the binning is TWO launches instead of four: the tile totals meet in global atomics, every scatter
+ * workgroup scans them itself, and the last one out puts the workspace back to zero. */
+/* dG_zero_words: 1 = dG_zero is the fp32 vertex-grid gradient (vtot * F floats); 2 = it is the 64-bit fixed-point form of
+ * gngf_encode_tiled_bwd's dG64 ((vtot * F + 2) 64-bit words, the two trailing words cleared as well). */
 /* vertex stage: G[(goff_l + gy*(N_l+2) + gx)*F + f] for levels [0, Ls), goff_l = sum_{j<l} (N_j+2)^2.
  * n_ls_host mirrors n_ls on the host (grid sizing only). */
 int gngf_vertex_grid_fwd(const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w, const int32_t* n_ls,
@@ -135,13 +141,21 @@ int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32
                           float* ride_dW2, float* ride_db2, int64_t ride_P, int ride_in_dim, int ride_out_dim,
                           const float* gloss_promised, const float* gloss_arrived,
                           const float* mse_pred, const float* mse_label, float* mse_loss, float* mse_workspace, int64_t mse_n,
-                          void* stream);
+                          float* hash_dtables, int64_t hash_T, void* dG64, int log2_pixels, void* stream);
 /* ride_* (optional, ride_slabs NULL = none): the slab reduction of a preceding gngf_decoder_bwd that was called without
  * gradient pointers (= gngf_decoder_reduce(ride_slabs, ride_dW0 .. ride_db2, NULL, ride_P, ride_in_dim, ride_out_dim)) runs in
  * extra workgroups of this launch instead of a launch of its own (one dependent launch less on the step's critical path).
  * gloss_promised / gloss_arrived (optional device scalars, both or neither): genc came out of gngf_decoder_train, which ran its
  * backward with *gloss_promised before autograd delivered *gloss_arrived; if the two differ (relative 1e-6) every gradient
  * this launch writes (the vertex-grid gradient and the ridden decoder gradients) is NaN — checked on the device, no sync.
+ * hash_dtables (optional; (L, hash_T, F) fp32 gradient buffer): spatial-hash index source on a single rank — the gather pass
+ * adds every vertex's gradient straight to row _fast_hash(gx, gy) of the level's table gradient (= gngf_vertex_grid_bwd in hash
+ * mode for levels [0, Ls)) and leaves dG unwritten: one launch and one round trip of dG less.
+ * dG64 (optional; (vtot * F + 2) 64-bit words, ZERO on entry — gngf_encode_tiled_prepare clears it with dG_zero_words = 2) with
+ * log2_pixels >= ceil(log2(P)) and a bound on |genc| (genc_absmax): the work items add their exact 64-bit fixed-point sums
+ * straight into this vertex grid with global integer atomics (no partial images, no gather pass; bitwise reproducible), and
+ * the launch ends with the conversion to dG (fp32) or — with hash_dtables — with the hash-source vertex stage reading dG64.
+ * Used by the interleaved kernels (F = 2, <= 16 staged levels); ignored otherwise.
  * mse_* (optional, mse_pred NULL = none): likewise gngf_mse_fwd(mse_pred, mse_label, mse_loss, mse_workspace, mse_n) — the
  * VALUE of the pixel loss, which no kernel of the step reads. */
 /* vertex stage backward for the vertex-table source in SLOT order (order (NV*K) int32 = argsort of vert_idx, flat):

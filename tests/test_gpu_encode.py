@@ -391,3 +391,57 @@ def test_level_interleaved_pixel_stage_equals_back_to_back_layout(ops, P, n_max,
                             [np.zeros(64, np.float32), np.zeros(64, np.float32), np.zeros(3, np.float32)], hash_mode=True)["enc"]
     if coords != "outside":
         close(res[1][0][t(sel)], want[:, :plan.Ls * Fd], 1e-5, 1e-7, "interleaved forward rows vs oracle")
+
+
+@pytest.mark.parametrize("P,coords", [(2 ** 17 + 77, "unit"), (60001, "strip"), (2 ** 15, "outside")])
+def test_fixed_point_vertex_grid_is_exact_and_order_free(ops, P, coords):
+    """dG64 path of the pixel-stage backward (F = 2, <= 16 staged levels, a bound on |genc| from its producer): the work items
+    add their exact 64-bit fixed-point sums into ONE fixed-point vertex grid with global integer atomics.  (1) Two DIFFERENT
+    binnings of the same pixels (the order inside a tile, hence the cut into work items, comes out of LDS atomics) give the
+    BIT-IDENTICAL vertex-grid gradient — integer sums do not depend on order or grouping; (2) it equals the partial-image +
+    gather path to fp32 rounding; (3) the table gradient of the hash source formed straight from the fixed-point grid equals
+    vertex_grid_bwd on the fp32 grid; (4) a NaN bound poisons everything."""
+    rng = np.random.default_rng(P + 1)
+    xy = rng.random((P, 2), dtype=np.float32)
+    if coords == "strip":
+        xy[:, 1] = 0.31 + 0.02 * xy[:, 1]
+    if coords == "outside":
+        xy[::7] = xy[::7] * 1.5 - 0.25
+    xy_t = t(xy)
+    L, Fd, T = 16, 2, 4096
+    n_ls = orc.level_resolutions(16, 256, L)
+    n_host = [int(n) for n in n_ls]
+    n_t = t(n_ls, torch.int32)
+    tables = t((rng.random((L, T, Fd), dtype=np.float32) - 0.5) * 2e-1)
+    genc = t((rng.standard_normal((P, L * Fd)) * np.exp(rng.standard_normal((P, 1)) * 3)).astype(np.float32))
+    am = genc.abs().max().reshape(1)
+    plan = ops.EncodePlan(P, n_host, Fd, "tiled")
+    assert plan.Ls == L
+    grids = []
+    for rep in range(2):
+        G = torch.empty((plan.vtot, Fd), dtype=torch.float32, device=DEV)
+        ws = ops.TiledWorkspace(plan, xy_t, vertex=(tables, None, None, n_t, 0, G))      # a fresh binning each time
+        dG64 = torch.zeros((plan.vtot * Fd + 2,), dtype=torch.int64, device=DEV)
+        dG = torch.full((plan.vtot, Fd), float("nan"), dtype=torch.float32, device=DEV)
+        ops._pixel_bwd(plan, ws, n_t, genc, dG, L, Fd, (am, 1, 0), None, None, dG64)
+        torch.cuda.synchronize()
+        grids.append((dG.clone(), dG64[:-2].clone()))
+    assert bool(torch.isfinite(grids[0][0]).all())
+    assert torch.equal(grids[0][1], grids[1][1]), "the fixed-point sums depend on the binning"
+    assert torch.equal(grids[0][0], grids[1][0])
+    # (2) the partial-image + gather path on the last workspace
+    dG_ref = torch.zeros((plan.vtot, Fd), dtype=torch.float32, device=DEV)
+    ops._pixel_bwd(plan, ws, n_t, genc, dG_ref, L, Fd, (am, 1, 0), None)
+    close(grids[0][0], dG_ref.cpu().numpy(), 2e-6, 1e-6 * float(dG_ref.abs().max()), "fixed-point vertex grid vs partial images + gather")
+    # (3) hash source: table gradient straight from the fixed-point grid
+    dt_a = torch.zeros((L, T, Fd), dtype=torch.float32, device=DEV)
+    dG64 = torch.zeros((plan.vtot * Fd + 2,), dtype=torch.int64, device=DEV)
+    ops._pixel_bwd(plan, ws, n_t, genc, torch.empty_like(dG_ref), L, Fd, (am, 1, 0), None, (dt_a, T), dG64)
+    dt_b = torch.zeros_like(dt_a)
+    ops._vertex_bwd(plan, tables, None, None, n_t, 0, grids[0][0], dt_b, None)
+    close(dt_a, dt_b.cpu().numpy(), 1e-5, 1e-6 * float(dt_b.abs().max()), "hash table gradient from the fixed-point grid")
+    # (4) poison
+    dG64 = torch.zeros((plan.vtot * Fd + 2,), dtype=torch.int64, device=DEV)
+    dG = torch.zeros((plan.vtot, Fd), dtype=torch.float32, device=DEV)
+    ops._pixel_bwd(plan, ws, n_t, genc, dG, L, Fd, (torch.full((1,), float("nan"), device=DEV), 1, 0), None, None, dG64)
+    assert bool(torch.isnan(dG).all())

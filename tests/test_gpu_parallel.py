@@ -26,7 +26,7 @@ def _grads(net):
 
 
 def _make(models, mode):
-    mode = mode.replace("_deferred", "")
+    mode = mode.replace("_overlap", "").replace("_deferred", "")
     half = mode.endswith("_fp16")
     mode = mode.replace("_fp16", "")
     models.should_use_hash_function = (mode.startswith("hash"))
@@ -81,14 +81,20 @@ def _worker(rank, world, port, mode, ret):
         ref = _grads(net)
         net.zero_grad()
     parallel.enable_vertex_grid_exchange(net, world)
-    defer = mode.endswith("_deferred")
+    overlap = mode.endswith("_overlap")          # exchange + deferred vertex stage on the model's communication stream
+    defer = mode.replace("_overlap", "").endswith("_deferred")
     parallel.defer_vertex_stage(net, defer)
     lo, hi = parallel.shard_batch(P, rank, world)
     loss_of(xy[lo:hi], tgt[lo:hi]).backward()
     reduced_flag = net.dp.tables_reduced
     if defer:
         assert net.dp.deferred is not None, "the vertex stage was not deferred"
-    parallel.allreduce_gradients(net, world)
+    parallel.allreduce_gradients(net, world, overlap=overlap)
+    if overlap:
+        assert net.dp.comm_done is not None and net.dp.comm_stream is not None
+        torch.ones(8, device=dev).sum()                   # (work on the main stream beside the exchange)
+        parallel.wait_for_gradients(net)
+        assert net.dp.comm_done is None
     parallel.defer_vertex_stage(net, False)
     got = _grads(net)
     ok = True
@@ -107,7 +113,8 @@ def _worker(rank, world, port, mode, ret):
 
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("mode", ["hash", "gngf_frozen", "gngf_learning", "hash_partial", "hash_deferred", "gngf_frozen_deferred",
-                                  "hash_partial_deferred", "hash_partial_fp16_deferred", "hash_fp16_deferred", "hash_partial_fp16"])
+                                  "hash_partial_deferred", "hash_partial_fp16_deferred", "hash_fp16_deferred", "hash_partial_fp16",
+                                  "hash_deferred_overlap", "gngf_frozen_deferred_overlap", "hash_partial_overlap"])
 def test_two_rank_sharded_step_equals_single_rank(mode, tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), mode, str(tmp_path)), nprocs=2, join=True)
     ret = {r: json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)}

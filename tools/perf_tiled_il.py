@@ -18,7 +18,7 @@ for variant, bias in ((0, 0), (1, 0), (3, 0), (0, 0), (1, 0), (3, 0)):
     _lib.query("gngf_set_tiled_interleaved", variant)
     ks = ops.encode_kernels(xy, n_ls, n_host, tables, None, None, 0, genc)
     out = []
-    for name in ("encode_fwd:tiled", "encode_bwd:tiled", "prepare", "vertex_bwd"):
+    for name in ("encode_fwd:tiled", "encode_bwd:tiled", "encode_bwd:tiled+dG64", "prepare", "vertex_bwd"):
         fn = ks[name]
         for _ in range(5): fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
