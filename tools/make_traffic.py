@@ -1,14 +1,18 @@
 """profiles/traffic.json from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs):
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 — FETCH_SIZE is in KiB and on gfx950 reports exactly half of
 the bytes of wide (16 B/lane) reads (MI355X_MICROARCH.md §HBM); WRITE_SIZE (KiB) is exact for 16 B/lane stores."""
-import json, subprocess, sys
+import json, os, subprocess, sys
 summ = json.loads(subprocess.check_output([sys.executable, "tools/pmc_summary.py"] + sys.argv[1:]))
-groups = {
-    "prepare(bin+vertex_fwd+clears)": ["gngf::bin_count_ride_kernel", "gngf::bin_rowscan_kernel", "gngf::bin_scan_kernel", "gngf::bin_scatter_ride_kernel<2"],
-    "encode_fwd:tiled": ["gngf::tiled_fwd_kernel<2>"],
-    "encode_bwd:tiled": ["gngf::tiled_bwd_kernel<2>", "gngf::gather_partials_kernel<2>"],
+groups = {     # round 3 kernel names (the round-2 names stay listed: general shapes still run those kernels)
+    "prepare(bin+vertex_fwd+clears)": ["gngf::bin_count_ride_kernel", "gngf::bin_count_vride_kernel", "gngf::bin_rowscan_kernel", "gngf::bin_scan_kernel",
+                                       "gngf::bin_scatter_ride_kernel<2", "gngf::bin_scatter_kernel", "gngf::bin_scatter2_kernel"],
+    "encode_fwd:tiled": ["gngf::tiled_fwd_kernel<2>", "gngf::tiled_fwd_il_kernel"],
+    "encode_bwd:tiled": ["gngf::tiled_bwd_kernel<2>", "gngf::gather_partials_kernel<2", "gngf::tiled_bwd_il_kernel", "gngf::dg64_to_float_kernel",
+                         "gngf::vertex_bwd_hash64_kernel"],
     "decoder_train": ["gngf::decoder_bwd_kernel<32, false, true, false, true, true>"],     # forward + backward in one launch
-    "vertex_bwd": ["gngf::vertex_bwd_sorted_kernel<2"],
+    "vertex_bwd": ["gngf::vertex_bwd_sorted_kernel<2", "gngf::vertex_bwd_kernel<2"],
+    "encode_fwd:direct": ["gngf::encode_fwd_kernel"],
+    "encode_bwd:direct": ["gngf::encode_bwd_kernel"],
 }
 def pick(prefix, counter):          # kernel names carry their full template argument lists: match by prefix
     return sum(v.get(counter, 0.0) for k, v in summ.items() if k.startswith(prefix))
@@ -25,5 +29,5 @@ for name, ks in groups.items():
         ff = fetch_factor.get(name, 2.0)
         out[name] = {"hbm_bytes_per_launch": (ff * f + w) * 1024, "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB": w, "fetch_factor": ff,
                      "note": "bytes = (fetch_factor*FETCH_SIZE + WRITE_SIZE)*1024; gfx950 FETCH_SIZE counts wide (16 B/lane) reads at half"}
-json.dump(out, open("profiles/traffic.json", "w"), indent=1)
+json.dump(out, open(os.environ.get("GNGF_TRAFFIC_OUT", "profiles/traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
