@@ -527,8 +527,13 @@ def main():
                 res["with_full_outputs_ms_per_step"] = repr(e)
             finally:
                 net.return_indices = False
-        if (head or learning) and rank == 0 and world == 1:
+        if (head and not learning) or (learning and world == 1):
+            # per-kernel launch times inside eagerly launched steps (the `roofline` objects).  At N > 1 EVERY rank runs them — the
+            # eager step holds the gradient exchange, and collectives must stay matched — and rank 0 reports its own.
             try:
+                if world > 1:
+                    parallel.wait_for_gradients(net)
+                    parallel.defer_vertex_stage(net, False)
                 k_t, k_c = kernel_times_in_step(eager_step_fn(net, mode, xy, target, world), n=(2 if learning else 20),
                                                 warm=(0 if learning else 3))
                 if head:
