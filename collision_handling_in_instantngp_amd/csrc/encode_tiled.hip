@@ -27,7 +27,10 @@ namespace gngf {
 #endif
 constexpr int kTBF = GNGF_TBF;  // pixel-stage workgroup, forward
 constexpr int kTB = GNGF_TBB;   // pixel-stage workgroup, backward
-constexpr int kBinThreads = 1024;
+#ifndef GNGF_BIN_THREADS
+#define GNGF_BIN_THREADS 1024
+#endif
+constexpr int kBinThreads = GNGF_BIN_THREADS;
 
 __device__ __forceinline__ int g_max0(int v) { return v < 0 ? 0 : v; }
 

@@ -789,12 +789,14 @@ class EncodePlan:
         else:
             want = 2 * max(1, -(-P // self.ntiles))
             self.chunk = min(4096, max(1024, 1 << (want - 1).bit_length()))
-        self.NB = max(1, min(128, -(-P // 8192)))        # more binning workgroups do not help (measured: tools/perf_bin.py)
+        self.NB = max(1, min(BIN_BLOCKS_MAX, -(-P // BIN_PIXELS_PER_BLOCK)))        # more binning workgroups do not help (measured: tools/perf_bin.py)
         self.max_items = -(-P // self.chunk) + self.ntiles
         self.vtot = sum((n + 2) ** 2 for n in self.n_ls_host[:Ls])
         self.n_ls_c = (_ct.c_int32 * L)(*self.n_ls_host)
 
 
+BIN_BLOCKS_MAX = 128            # binning workgroups: more do not help (measured: tools/perf_bin.py, tools/perf_overlap.py)
+BIN_PIXELS_PER_BLOCK = 8192
 TWO_LAUNCH_BINNING = True     # count -> scatter (the scans ride inside the scatter launch) when the launch carries no gradient clear
 _BIN_WORKSPACES = {}
 

@@ -7,10 +7,20 @@
 //   pattern 3  level-interleaved, 32 columns: slot = row * 32 + 16 * (pixel & 1) + level
 //   pattern 4  as 2, but the 4 pixels of a wave share the row for levels < 6 (coarse levels: same cell => same address)
 //   pattern 5  as 3, same sharing
-// build: hipcc -O3 --offload-arch=gfx950 tools/micro/lds_atomic64_patterns.cpp -o tools/micro/lds_atomic64_patterns
+// -DF32 measures ds_add_f32 on 4-byte slots of the same patterns instead (would fp32 LDS atomics be cheaper than the fixed-point ones?)
+// measured (MI355X): ds_add_u64 7.6 (lane-linear) / 10.1 (interleaved) / 15.1 (interleaved, shared coarse cells) cycles per
+// wave instruction; ds_add_f32 193 cycles in EVERY pattern (3 cycles per lane: the LDS float atomic is serialised) -- 25 x slower.
+// build: hipcc -O3 [-DF32 -munsafe-fp-atomics] --offload-arch=gfx950 tools/micro/lds_atomic64_patterns.cpp -o tools/micro/lds_atomic64_patterns
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#ifdef F32
+typedef float slot_t;
+#define ADDNAME "ds_add_f32"
+#else
+typedef unsigned long long slot_t;
+#define ADDNAME "ds_add_u64"
+#endif
 
 constexpr int kSlots = 16384;      // 128 KB of 8-byte slots
 
@@ -31,14 +41,18 @@ __device__ __forceinline__ int slot_of(unsigned& r, int lane, int it) {
 
 template <int PAT>
 __global__ void __launch_bounds__(1024) k_add(float* out, int iters) {
-  extern __shared__ unsigned long long lds[];
+  extern __shared__ slot_t lds[];
   for (int i = threadIdx.x; i < kSlots; i += blockDim.x) lds[i] = 0;
   __syncthreads();
   unsigned r = threadIdx.x * 2654435761u + blockIdx.x;
   const int lane = threadIdx.x & 63;
   for (int it = 0; it < iters; ++it) {
     const int a = slot_of<PAT>(r, lane, it);
+    #ifdef F32
+    __hip_atomic_fetch_add(&lds[a], __uint_as_float((r & 0x007fffffu) | 0x3f800000u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
     atomicAdd(&lds[a], (unsigned long long)(r | 1));
+#endif
   }
   __syncthreads();
   if (threadIdx.x == 0) out[blockIdx.x] = (float)(lds[0] + lds[1]);
@@ -46,12 +60,12 @@ __global__ void __launch_bounds__(1024) k_add(float* out, int iters) {
 
 template <int PAT>
 __global__ void __launch_bounds__(1024) k_read(float* out, int iters) {
-  extern __shared__ unsigned long long lds[];
+  extern __shared__ slot_t lds[];
   for (int i = threadIdx.x; i < kSlots; i += blockDim.x) lds[i] = i;
   __syncthreads();
   unsigned r = threadIdx.x * 2654435761u + blockIdx.x;
   const int lane = threadIdx.x & 63;
-  unsigned long long acc = 0;
+  slot_t acc = 0;
   for (int it = 0; it < iters; it += 4) {
     int a[4];
 #pragma unroll
@@ -59,15 +73,15 @@ __global__ void __launch_bounds__(1024) k_read(float* out, int iters) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc += lds[a[u]];
   }
-  if (acc == 0x1234567ull) out[blockIdx.x] = 1.f;
+  if (acc == (slot_t)0x1234567) out[blockIdx.x] = 1.f;
 }
 
 template <int PAT> void run(const char* name) {
   float* out;
   hipMalloc(&out, 4096 * 4);
   const int iters = 8192, blocks = 256;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k_add<PAT>), hipFuncAttributeMaxDynamicSharedMemorySize, kSlots * 8);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k_read<PAT>), hipFuncAttributeMaxDynamicSharedMemorySize, kSlots * 8);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k_add<PAT>), hipFuncAttributeMaxDynamicSharedMemorySize, kSlots * sizeof(slot_t));
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k_read<PAT>), hipFuncAttributeMaxDynamicSharedMemorySize, kSlots * sizeof(slot_t));
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
@@ -75,8 +89,8 @@ template <int PAT> void run(const char* name) {
   for (int which = 0; which < 2; ++which) {
     for (int rep = 0; rep < 2; ++rep) {
       hipEventRecord(e0);
-      if (which == 0) k_add<PAT><<<blocks, 1024, kSlots * 8>>>(out, iters);
-      else k_read<PAT><<<blocks, 1024, kSlots * 8>>>(out, iters);
+      if (which == 0) k_add<PAT><<<blocks, 1024, kSlots * sizeof(slot_t)>>>(out, iters);
+      else k_read<PAT><<<blocks, 1024, kSlots * sizeof(slot_t)>>>(out, iters);
       hipEventRecord(e1);
       hipEventSynchronize(e1);
       hipEventElapsedTime(&ms[which], e0, e1);
@@ -84,7 +98,7 @@ template <int PAT> void run(const char* name) {
   }
   // per CU: 16 waves x iters wave-instructions
   const double winstr = 16.0 * iters;
-  printf("%-44s ds_add_u64 %7.2f cycles/wave-instr   ds_read_b64 %7.2f (incl. ~6 VALU of address generation per instr, 16 waves/CU)\n", name,
+  printf("%-44s " ADDNAME " %7.2f cycles/wave-instr   ds_read_b64 %7.2f (incl. ~6 VALU of address generation per instr, 16 waves/CU)\n", name,
          ms[0] * 1e-3 * 2.4e9 / winstr, ms[1] * 1e-3 * 2.4e9 / winstr);
   hipFree(out);
 }
