@@ -20,7 +20,7 @@ def two():
     call("gngf_decoder_fwd", ptr(enc), *[ptr(w) for w in Ws], ptr(rgb), ptr(hidden), P, in_dim, out_dim, 0, stream_ptr())
     call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(None), ptr(target), ptr(one), ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(Ws[3]), ptr(Ws[4]), ptr(denc), *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(hidden), P, in_dim, out_dim, 0, stream_ptr())
 def fused():
-    call("gngf_decoder_train", ptr(enc), ptr(target), ptr(one), *[ptr(w) for w in Ws], ptr(rgb), ptr(denc), *[ptr(None)] * 6, ptr(slabs), ptr(None), P, in_dim, out_dim, 0, stream_ptr())
+    call("gngf_decoder_train", ptr(enc), ptr(target), ptr(one), *[ptr(w) for w in Ws], ptr(rgb), ptr(denc), *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(None), 0, P, in_dim, out_dim, 0, stream_ptr())
 for name, fn in (("decoder_fwd + decoder_bwd", two), ("decoder_train", fused)):
     for _ in range(60): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
