@@ -100,6 +100,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-full-outputs", dest="full_outputs", action="store_false",
                     help="skip the extra timing of the step with the reference's index tensor materialised")
     ap.add_argument("--no-unroll", dest="unroll", action="store_false", help="one step per replayed graph")
+    ap.add_argument("--unrolls", type=lambda v: tuple(int(x) for x in v.split(",")), default=(4, 5, 6, 7, 8, 3, 2),
+                    help="steps per replayed graph: the first of these that divides --steps")
     ap.add_argument("--cpu-sample", type=int, default=2 ** 20)
     ap.add_argument("--ramp-steps", type=int, default=60, help="untimed steps before the W warm-up steps (clock ramp)")
     ap.add_argument("--backend", default="nccl", help="rehearsal only: 'gloo' runs the N>1 code path with ranks sharing one GPU")
@@ -408,7 +410,8 @@ def main():
             batches[cfg_name] = make_batch(cfg_name, P, rank, dev)
         xy, target, bounds = batches[cfg_name]
         learning = mode == "gngf_learning"
-        steps, warmup = (a.steps, a.warmup) if head else ((2, 1) if learning else (max(5, a.steps // 2), 2))
+        # (the other single-kernel-chain modes: as many steps as the headline — 10 steps of 0.4 ms are a 4 ms window, ±1 % of noise)
+        steps, warmup = (a.steps, a.warmup) if head else ((2, 1) if learning else (max(5, a.steps), max(2, a.warmup)))
         if learning and head:
             steps, warmup = min(a.steps, 5), min(a.warmup, 1)
         net, models = build_model(mode, dev, bounds)
@@ -428,7 +431,7 @@ def main():
                 # 4, 5, 6, 7, 8, 3, 2 that divides K, so that exactly K steps are timed
                 unroll = 1
                 if world == 1 and a.unroll:
-                    unroll = next((u for u in (4, 5, 6, 7, 8, 3, 2) if steps % u == 0), 1)
+                    unroll = next((u for u in a.unrolls if steps % u == 0), 1)
                 gs = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3, unroll=unroll)
                 if unroll > 1:
                     gs.run_many([(xy, target)] * unroll)
