@@ -589,6 +589,19 @@ __device__ __forceinline__ long long to_fixed_scaled(float u) {
   return ((long long)hi << 32) + (long long)(unsigned long long)lo;
 }
 
+// The same in TWO instructions (level-interleaved kernel): the product g * c of two fp32 values is exact in double precision, and
+// one double-precision fma with the constant 1.5 * 2^52 leaves RNE(g * c) — g already scaled by 2^S — as a two's-complement integer
+// in the low 52 bits of the result; subtracting the constant's bit pattern (its low word is zero: one 32-bit add) yields the 64-bit
+// fixed-point term.  Needs |g * c| < 2^51 (S leaves that room).  The term is the exactly rounded product instead of the fp32-rounded
+// one the reference forms: closer to the real sum, and — like it — independent of the order of the additions.
+#ifndef GNGF_FIXED_FMA
+#define GNGF_FIXED_FMA 1
+#endif
+__device__ __forceinline__ unsigned long long to_fixed_fma(double g, double c) {
+  const double r = __builtin_fma(g, c, 6755399441055744.0);
+  return (unsigned long long)__double_as_longlong(r) - 0x4338000000000000ull;
+}
+
 // Backward pixel stage.  gfx950's LDS float atomic (ds_add_f32) retires ~3 cycles PER LANE (193 cycles per
 // wave-instruction, measured: tools/micro/lds_atomic.cpp) while ds_add_u64 takes 7-12 cycles per wave-instruction,
 // so the privatised sub-grids accumulate in 64-bit FIXED POINT: every term g*c (one fp32 multiply, as in the
@@ -658,7 +671,8 @@ tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
   const bool finite = gmax < INFINITY && !promise_broken(ride.promised, ride.arrived);     // false for inf and NaN
   int eg = 0;
   if (finite && gmax > 0.f) (void)frexpf(gmax, &eg);        // gmax < 2^eg
-  const int S = 61 - log2_chunk - eg;
+  int S = (GNGF_FIXED_FMA ? 60 : 61) - log2_chunk - eg;        // (fma form: every term below 2^51)
+  S = S > 126 ? 126 : S;                                         // 2^S stays an fp32 number for any gradient magnitude
   if (lp < ppp && finite) {
     const int n = m.n[l], cx = m.cx[l], cy = m.cy[l], wx = m.wx[l], wy = m.wy[l], gw = m.gw[l];
     unsigned long long* sub = acc64 + m.loff[l];
@@ -686,11 +700,19 @@ tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
           unsigned long long* b = a + wx * F;
 #pragma unroll
           for (int f = 0; f < F; ++f) {
+#if GNGF_FIXED_FMA
+            const double gd = (double)ldexpf(g[f], S);
+            atomicAdd(a + f, to_fixed_fma(gd, (double)c.c[0]));
+            atomicAdd(a + F + f, to_fixed_fma(gd, (double)c.c[1]));
+            atomicAdd(b + f, to_fixed_fma(gd, (double)c.c[2]));
+            atomicAdd(b + F + f, to_fixed_fma(gd, (double)c.c[3]));
+#else
             const float gs = ldexpf(g[f], S - 32);
             atomicAdd(a + f, (unsigned long long)to_fixed_scaled(gs * c.c[0]));
             atomicAdd(a + F + f, (unsigned long long)to_fixed_scaled(gs * c.c[1]));
             atomicAdd(b + f, (unsigned long long)to_fixed_scaled(gs * c.c[2]));
             atomicAdd(b + F + f, (unsigned long long)to_fixed_scaled(gs * c.c[3]));
+#endif
           }
         } else {
 #pragma unroll
@@ -1038,7 +1060,8 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
     const bool finite = gmax < INFINITY && !broken;        // false for inf and NaN
     int eg = 0;
     if (finite && gmax > 0.f) (void)frexpf(gmax, &eg);       // gmax < 2^eg
-    const int S = 61 - log2_chunk - eg;
+    int S = (GNGF_FIXED_FMA ? 60 : 61) - log2_chunk - eg;              // (fma form: every term below 2^51)
+    S = S > 126 ? 126 : S;                                               // 2^S stays an fp32 number for any gradient magnitude
     if (dG64 && tid == 0) {
       const int64_t vt = m.goff[Ls - 1] + (int64_t)(m.n[Ls - 1] + 2) * (m.n[Ls - 1] + 2);
       if (blockIdx.x == 0 && item == (int)blockIdx.x) dG64[vt * F] = (unsigned long long)(long long)S;
@@ -1050,7 +1073,39 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
       const int rows_l = wx * wy * F;
       unsigned long long* col = accil + l + ((lp & (m.copies[l] - 1)) * rows_l) * kIL;
       const float fn = (float)n;
-      const float scale = ldexpf(1.0f, S - 32);   // (a power of two: scaling by it is exact, as ldexp)
+      const float scale = ldexpf(1.0f, GNGF_FIXED_FMA ? S : S - 32);   // (a power of two: scaling by it is exact, as ldexp)
+      // one fixed-point term g * c (g scaled by 2^S), the same value on every path a pixel can take
+      auto term = [&](float g, float c) -> unsigned long long {
+#if GNGF_FIXED_FMA
+        return to_fixed_fma((double)g, (double)c);
+#else
+        return (unsigned long long)to_fixed_scaled(g * c);
+#endif
+      };
+      // the eight terms of one (pixel, level): corners (a, a + 1) of row pa and of row pb, two features each
+      auto add8 = [&](unsigned long long* pa, unsigned long long* pb, const v2f g, float c0, float c1, float c2, float c3) {
+#if GNGF_FIXED_FMA
+        const double gx = (double)g.x, gy = (double)g.y, d0 = (double)c0, d1 = (double)c1, d2 = (double)c2, d3 = (double)c3;
+        atomicAdd(pa, to_fixed_fma(gx, d0));
+        atomicAdd(pa + kIL, to_fixed_fma(gy, d0));
+        atomicAdd(pa + 2 * kIL, to_fixed_fma(gx, d1));
+        atomicAdd(pa + 3 * kIL, to_fixed_fma(gy, d1));
+        atomicAdd(pb, to_fixed_fma(gx, d2));
+        atomicAdd(pb + kIL, to_fixed_fma(gy, d2));
+        atomicAdd(pb + 2 * kIL, to_fixed_fma(gx, d3));
+        atomicAdd(pb + 3 * kIL, to_fixed_fma(gy, d3));
+#else
+        const v2f t0 = g * c0, t1 = g * c1, t2 = g * c2, t3 = g * c3;      // the terms g*c: one fp32 multiply each, as the reference's
+        atomicAdd(pa, (unsigned long long)to_fixed_scaled(t0.x));
+        atomicAdd(pa + kIL, (unsigned long long)to_fixed_scaled(t0.y));
+        atomicAdd(pa + 2 * kIL, (unsigned long long)to_fixed_scaled(t1.x));
+        atomicAdd(pa + 3 * kIL, (unsigned long long)to_fixed_scaled(t1.y));
+        atomicAdd(pb, (unsigned long long)to_fixed_scaled(t2.x));
+        atomicAdd(pb + kIL, (unsigned long long)to_fixed_scaled(t2.y));
+        atomicAdd(pb + 2 * kIL, (unsigned long long)to_fixed_scaled(t3.x));
+        atomicAdd(pb + 3 * kIL, (unsigned long long)to_fixed_scaled(t3.y));
+#endif
+      };
       auto stage = [&](const float4 sv, const v2f gv, int j) {
         if (j > last) return;
         const v2f sxy = (v2f){sv.x, sv.y} * fn;   // make_cell, on pairs: every operation separately rounded as in the reference
@@ -1064,15 +1119,7 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
           unsigned long long* pa = col + (ly * wx + lx) * (F * kIL);
           unsigned long long* pb = pa + wx * (F * kIL);
           const v2f g = gv * scale;
-          const v2f t0 = g * c0, t1 = g * c1, t2 = g * c2, t3 = g * c3;      // the terms g*c: one fp32 multiply each, as the reference's
-          atomicAdd(pa, (unsigned long long)to_fixed_scaled(t0.x));
-          atomicAdd(pa + kIL, (unsigned long long)to_fixed_scaled(t0.y));
-          atomicAdd(pa + 2 * kIL, (unsigned long long)to_fixed_scaled(t1.x));
-          atomicAdd(pa + 3 * kIL, (unsigned long long)to_fixed_scaled(t1.y));
-          atomicAdd(pb, (unsigned long long)to_fixed_scaled(t2.x));
-          atomicAdd(pb + kIL, (unsigned long long)to_fixed_scaled(t2.y));
-          atomicAdd(pb + 2 * kIL, (unsigned long long)to_fixed_scaled(t3.x));
-          atomicAdd(pb + 3 * kIL, (unsigned long long)to_fixed_scaled(t3.y));
+          add8(pa, pb, g, c0, c1, c2, c3);
         } else {                                   // outside the staged sub-grid (never for in-domain coordinates): global
           const float cq[4] = {c0, c1, c2, c3};
 #pragma unroll
@@ -1082,8 +1129,8 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
             vy = vy < 0 ? 0 : (vy > n + 1 ? n + 1 : vy);
             if (dG64) {
               unsigned long long* d = dG64 + (m.goff[l] + (int64_t)vy * gw + vx) * F;
-              atomicAdd(d, (unsigned long long)to_fixed_scaled((gv.x * scale) * cq[q]));
-              atomicAdd(d + 1, (unsigned long long)to_fixed_scaled((gv.y * scale) * cq[q]));
+              atomicAdd(d, term(gv.x * scale, cq[q]));
+              atomicAdd(d + 1, term(gv.y * scale, cq[q]));
             } else {
               atomicAdd(dGl + ((int64_t)vy * gw + vx) * F, gv.x * cq[q]);
               atomicAdd(dGl + ((int64_t)vy * gw + vx) * F + 1, gv.y * cq[q]);
@@ -1097,16 +1144,7 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
         const float c0 = w0.x * w0.y, c1 = w1.x * w0.y, c2 = w0.x * w1.y, c3 = w1.x * w1.y;
         unsigned long long* pa = col + v * (F * kIL);
         unsigned long long* pb = pa + wx * (F * kIL);
-        const v2f g = gv * scale;
-        const v2f t0 = g * c0, t1 = g * c1, t2 = g * c2, t3 = g * c3;
-        atomicAdd(pa, (unsigned long long)to_fixed_scaled(t0.x));
-        atomicAdd(pa + kIL, (unsigned long long)to_fixed_scaled(t0.y));
-        atomicAdd(pa + 2 * kIL, (unsigned long long)to_fixed_scaled(t1.x));
-        atomicAdd(pa + 3 * kIL, (unsigned long long)to_fixed_scaled(t1.y));
-        atomicAdd(pb, (unsigned long long)to_fixed_scaled(t2.x));
-        atomicAdd(pb + kIL, (unsigned long long)to_fixed_scaled(t2.y));
-        atomicAdd(pb + 2 * kIL, (unsigned long long)to_fixed_scaled(t3.x));
-        atomicAdd(pb + 3 * kIL, (unsigned long long)to_fixed_scaled(t3.y));
+        add8(pa, pb, gv * scale, c0, c1, c2, c3);
       };
       // four pixels per trip, loads issued together.  (Requesting the records two trips and the gradient rows one trip ahead
       // made the first wave finish earlier and the item no sooner: the phase is bound by VALU issue plus the LDS atomic unit,
