@@ -1149,11 +1149,14 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
       // four pixels per trip, loads issued together.  (Requesting the records two trips and the gradient rows one trip ahead
       // made the first wave finish earlier and the item no sooner: the phase is bound by VALU issue plus the LDS atomic unit,
       // 7.6 cycles per conflict-free ds_add_u64, not by memory latency.)
-      for (int j0 = lp; j0 <= last; j0 += U * ppp) {
+      // TAIL = false: all four pixels of the trip exist (no clamped record index, no zeroed gradient: the phase is bound by
+      // VALU issue, four instructions per pixel matter); the one trip that runs past the item's end is peeled off below
+      auto trip = [&](const int j0, auto TAIL) {
+        constexpr bool tail = decltype(TAIL)::value;
         float4 sv[U];
         v2f gv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) sv[u] = fetch(j0 + u * ppp);
+        for (int u = 0; u < U; ++u) sv[u] = tail ? fetch(j0 + u * ppp) : rec[j0 + u * ppp];
 #pragma unroll
         for (int u = 0; u < U; ++u) gv[u] = grad_of(sv[u]);
         v2f fa[U], fw0[U], fw1[U];
@@ -1168,7 +1171,7 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
           const int lx = (int)fa[u].x - cx, ly = (int)fa[u].y - cy;
           inside = inside && ((unsigned)lx < (unsigned)(wx - 1)) && ((unsigned)ly < (unsigned)(wy - 1));
           fv[u] = ly * wx + lx;
-          if (j0 + u * ppp > last) gv[u] = (v2f){0.f, 0.f};
+          if (tail && j0 + u * ppp > last) gv[u] = (v2f){0.f, 0.f};
         }
         if (__ballot(!inside) == 0ull) {
 #pragma unroll
@@ -1177,7 +1180,10 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
 #pragma unroll
           for (int u = 0; u < U; ++u) stage(sv[u], gv[u], j0 + u * ppp);
         }
-      }
+      };
+      int j0 = lp;
+      for (; j0 + (U - 1) * ppp <= last; j0 += U * ppp) trip(j0, std::false_type{});
+      if (j0 <= last) trip(j0, std::true_type{});
     }
     IL_STAMP(3);
     __syncthreads();
