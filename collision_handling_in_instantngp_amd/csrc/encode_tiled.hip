@@ -1417,12 +1417,15 @@ template <int CTRL, int ROWMASK> __device__ __forceinline__ int dppi(int x) {
 // adjacent lanes — are combined with a wave-level segmented scan before the one atomic per (wave, run).
 // dvert_w needs no atomics at all: every entry is owned by exactly one lane.
 constexpr int kVB = 512;           // vertex_bwd_sorted workgroup: 8 waves share one atomic per (run, level); measured 1024: 35 us, 512: 26, 256: 27
-template <int F, typename TT>
+// FROM64: the vertex-grid gradient is read as the 64-bit fixed-point grid the pixel stage accumulated (dG64: vtot * F words,
+// then the scale S and the poison flag) and converted on the fly — the launch of dg64_to_float_kernel and one round trip of the
+// grid less.
+template <int F, typename TT, bool FROM64>
 __global__ void __launch_bounds__(kVB)
 vertex_bwd_sorted_kernel(const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
                          const int32_t* __restrict__ order, const int32_t* __restrict__ n_ls, const float* __restrict__ dG,
                          float* __restrict__ dtables, float* __restrict__ dvert_w, int Ls, int64_t T, int K, int vstride,
-                         int64_t NE) {
+                         int64_t NE, const unsigned long long* __restrict__ dG64, int64_t vtot) {
   constexpr int NW = kVB / 64;
   __shared__ int s_n[GNGF_MAX_LEVELS];
   __shared__ int64_t s_goff[GNGF_MAX_LEVELS];
@@ -1459,6 +1462,12 @@ vertex_bwd_sorted_kernel(const TT* __restrict__ tables, const int32_t* __restric
   const bool p1 = dppi<0x111, 0xF>(rid) == rid, p2 = dppi<0x112, 0xF>(rid) == rid, p4 = dppi<0x114, 0xF>(rid) == rid,
              p8 = dppi<0x118, 0xF>(rid) == rid, pA = dppi<0x142, 0xA>(rid) == rid, pB = dppi<0x143, 0xC>(rid) == rid;
   float dw_acc = 0.f;
+  double inv64 = 0.0;
+  bool poisoned = false;
+  if constexpr (FROM64) {
+    inv64 = ldexp(1.0, -(int)(long long)dG64[vtot * F]);
+    poisoned = dG64[vtot * F + 1] != 0ull;
+  }
   int lstart = lmin;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { const int ov = __shfl_xor(lstart, o, 64); lstart = ov < lstart ? ov : lstart; }
@@ -1483,7 +1492,16 @@ vertex_bwd_sorted_kernel(const TT* __restrict__ tables, const int32_t* __restric
     float v[F];
     float dot = 0.f;
     if (in) {
-      const float* g = dG + (s_goff[l] + (int64_t)gy * (n + 2) + gx) * F;
+      const int64_t gi = (s_goff[l] + (int64_t)gy * (n + 2) + gx) * F;
+      float g[F];
+      if constexpr (FROM64) {
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+          g[f] = poisoned ? __int_as_float(0x7fc00000) : (float)((double)(long long)dG64[gi + f] * inv64);      // as dg64_to_float_kernel
+      } else {
+#pragma unroll
+        for (int f = 0; f < F; ++f) g[f] = dG[gi + f];
+      }
       if (dvert_w) {                       // the table row is only needed for d w (trainable HPD)
         const TT* r = tables + ((int64_t)l * T + slot) * F;
 #pragma unroll
@@ -1820,7 +1838,10 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
   int log2_chunk = 0;
   while ((1 << log2_chunk) < chunk) ++log2_chunk;
   if (max_items == 0 && ride_blocks == 0) return 0;
-  GNGF_CHECK_ARG(max_items == 0 || (sorted && items && n_items && tile_item_base && n_ls && n_ls_host && genc && dG && partials));
+  GNGF_CHECK_ARG(max_items == 0 || (sorted && items && n_items && tile_item_base && n_ls && n_ls_host && genc && partials));
+  // dG may be NULL only when the launch is going to fill dG64 and nothing else (the caller reads the fixed-point grid itself)
+  GNGF_CHECK_ARG(max_items == 0 || dG || (genc_absmax && dG64 && log2_pixels > 0 && log2_pixels <= 40 && !hash_dtables &&
+                                          interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, true)));
   int64_t vtot_h = 0;
   if (max_items > 0)
     for (int l = 0; l < Ls; ++l) vtot_h += (int64_t)(n_ls_host[l] + 2) * (n_ls_host[l] + 2);
@@ -1847,7 +1868,7 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
       if (hash_dtables)
         vertex_bwd_hash64_kernel<2><<<dim3((unsigned)ceil_div(vtot_h, 256)), dim3(256), 0, as_stream(stream)>>>(
             g64, n_ls, hash_dtables, Ls, hash_T, hpow2, vtot_h);
-      else
+      else if (dG)        // (dG NULL: the caller's vertex stage reads the fixed-point grid itself — gngf_vertex_grid_bwd_sorted(dG64))
         dg64_to_float_kernel<<<dim3((unsigned)ceil_div(vtot_h * 2, 256)), dim3(256), 0, as_stream(stream)>>>(g64, dG, vtot_h * 2);
       GNGF_RETURN_LAUNCH();
     }
@@ -1884,15 +1905,22 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
 // Vertex stage backward, vertex-table source, slot-ordered and contention-free (see vertex_bwd_sorted_kernel).
 // order (NV*K) int32 = argsort of vert_idx viewed flat.  dtables accumulated; dvert_w (NV,K) WRITTEN (may be NULL).
 extern "C" int gngf_vertex_grid_bwd_sorted(const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w,
-                                           const int32_t* order, const int32_t* n_ls, const float* dG, float* dtables,
-                                           float* dvert_w, int Ls, int F, int64_t T, int K, int vstride, int64_t NV,
-                                           void* stream) {
+                                           const int32_t* order, const int32_t* n_ls, const float* dG, const void* dG64,
+                                           int64_t vtot, float* dtables, float* dvert_w, int Ls, int F, int64_t T, int K,
+                                           int vstride, int64_t NV, void* stream) {
   GNGF_CHECK_ARG(Ls > 0 && Ls <= GNGF_MAX_LEVELS && T > 0 && K > 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0);
-  GNGF_CHECK_ARG(tables && vert_idx && vert_w && order && n_ls && dG && dtables && NV * K < (1ll << 31));
+  GNGF_CHECK_ARG(tables && vert_idx && vert_w && order && n_ls && (dG || (dG64 && vtot > 0)) && dtables && NV * K < (1ll << 31));
   const int64_t NE = NV * K;
-  DISPATCH_TT(feat_dtype, DISPATCH_F(F, (vertex_bwd_sorted_kernel<kF, TT><<<dim3((unsigned)ceil_div(NE, kVB)), dim3(kVB), 0,
-                                                                          as_stream(stream)>>>(
+  if (dG64) {
+    DISPATCH_TT(feat_dtype, DISPATCH_F(F, (vertex_bwd_sorted_kernel<kF, TT, true><<<dim3((unsigned)ceil_div(NE, kVB)), dim3(kVB), 0,
+                                                                                  as_stream(stream)>>>(
+                                static_cast<const TT*>(tables), vert_idx, vert_w, order, n_ls, nullptr, dtables, dvert_w, Ls, T, K,
+                                vstride, NE, static_cast<const unsigned long long*>(dG64), vtot))));
+    GNGF_RETURN_LAUNCH();
+  }
+  DISPATCH_TT(feat_dtype, DISPATCH_F(F, (vertex_bwd_sorted_kernel<kF, TT, false><<<dim3((unsigned)ceil_div(NE, kVB)), dim3(kVB), 0,
+                                                                                 as_stream(stream)>>>(
                               static_cast<const TT*>(tables), vert_idx, vert_w, order, n_ls, dG, dtables, dvert_w, Ls, T, K,
-                              vstride, NE))));
+                              vstride, NE, nullptr, 0))));
   GNGF_RETURN_LAUNCH();
 }

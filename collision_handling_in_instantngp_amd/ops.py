@@ -923,6 +923,7 @@ HASH_VERTEX_FUSION = True    # hash indexing, single rank: the vertex stage back
 
 
 DG64 = True                  # F = 2, <= 16 staged levels, bounded |genc|: 64-bit fixed-point vertex grid fed by global integer atomics
+VERTEX_READS_DG64 = True     # ... and the slot-ordered vertex backward converts it on the fly (False: dg64_to_float first)
 
 
 def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None, link=None, hash_fuse=None, dG64=None):
@@ -971,12 +972,16 @@ def run_deferred_vertex_stage(dp, exchanged=False):
     return True
 
 
-def _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw, order=None):
+def _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw, order=None, dG64=None):
+    """dG64: the fixed-point vertex grid of _pixel_bwd(..., dG=None, dG64=...) read directly (slot-ordered form only)."""
     L, T, F = tables.shape
     if vert_idx is not None and order is not None:
         call("gngf_vertex_grid_bwd_sorted", *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(order, _i32, "order"), ptr(n_ls), ptr(dG),
-             ptr(dtables), ptr(dvw), plan.Ls, F, T, vert_idx.shape[1], vstride, vert_idx.shape[0], stream_ptr())
+             ptr(dG64, _i64, "dG64"), plan.vtot, ptr(dtables), ptr(dvw), plan.Ls, F, T, vert_idx.shape[1], vstride, vert_idx.shape[0],
+             stream_ptr())
         return
+    if dG64 is not None:
+        raise ValueError("the fixed-point vertex grid is read by the slot-ordered vertex backward only")
     mode = MODE_HASH if vert_idx is None else MODE_VERTEX_TABLE
     call("gngf_vertex_grid_bwd", *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), plan.n_ls_c, ptr(dG), ptr(dtables), ptr(dvw),
          plan.Ls, F, T, 0 if vert_idx is None else vert_idx.shape[1], mode, vstride,
@@ -1074,9 +1079,13 @@ class EncodeFunction(torch.autograd.Function):
             dG64 = pre[1] if (pre and pre[1].dtype == _i64) else None
             if dG64 is not None and absmax is None:            # no bound on |genc| from its producer: the per-item scales need the fp32 path
                 dG64 = None
-            dG = (pre[1] if (pre and pre[1].dtype == _f32) else
-                  (torch.empty if dG64 is not None else torch.zeros)((plan.vtot, F), dtype=_f32, device=tables.device))
             fuse = (dtables, T) if (HASH_VERTEX_FUSION and vert_idx is None and exchange is None) else None
+            # vertex-table source in slot order, single rank, no d w: the vertex stage reads the fixed-point grid itself (no
+            # fp32 copy of the vertex-grid gradient, no conversion launch)
+            direct64 = (dG64 is not None and VERTEX_READS_DG64 and vert_idx is not None and order is not None and exchange is None
+                        and dvw is None)
+            dG = None if direct64 else (pre[1] if (pre and pre[1].dtype == _f32) else
+                                        (torch.empty if dG64 is not None else torch.zeros)((plan.vtot, F), dtype=_f32, device=tables.device))
             _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax, link, fuse, dG64)
             if fuse is None and exchange is not None and dp.defer_vertex and dvw is None:
                 # the caller exchanges dG and runs the vertex stage after backward (parallel.allreduce_gradients)
@@ -1098,7 +1107,7 @@ class EncodeFunction(torch.autograd.Function):
                 _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw_t, order)
             else:
                 dvw_t = None
-                _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw, order)
+                _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw, order, dG64 if direct64 else None)
         else:
             dvw_t = None
         if plan.Ls < L:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNGF_ABI_VERSION 8
+#define GNGF_ABI_VERSION 9
 #define GNGF_MAX_LEVELS 32
 #define GNGF_MAX_TOPK 32
 
@@ -160,10 +160,12 @@ int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32
  * VALUE of the pixel loss, which no kernel of the step reads. */
 /* vertex stage backward for the vertex-table source in SLOT order (order (NV*K) int32 = argsort of vert_idx, flat):
  * contention-free for any slot distribution (wave-level segmented reduction, one atomic per (wave, slot run));
- * dtables accumulated, dvert_w (NV,K) written without atomics (NULL when not needed). */
+ * dtables accumulated, dvert_w (NV,K) written without atomics (NULL when not needed).
+ * dG64 (optional, with vtot = sum_l (N_l+2)^2; dG may then be NULL): read the vertex-grid gradient from the 64-bit fixed-point grid
+ * gngf_encode_tiled_bwd filled (called with dG = NULL, which skips its conversion to fp32) — one launch less. */
 int gngf_vertex_grid_bwd_sorted(const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w, const int32_t* order,
-                                const int32_t* n_ls, const float* dG, float* dtables, float* dvert_w, int Ls, int F, int64_t T,
-                                int K, int vstride, int64_t NV, void* stream);
+                                const int32_t* n_ls, const float* dG, const void* dG64, int64_t vtot, float* dtables, float* dvert_w,
+                                int Ls, int F, int64_t T, int K, int vstride, int64_t NV, void* stream);
 
 /* Large aligned GEMMs (full 128 x 128 tiles, contraction a multiple of 32) of the dense-layer entry points run on the
  * split-bf16 kernel while this is on: every fp32 operand is split exactly into three bf16 terms and six of the nine cross

@@ -440,8 +440,25 @@ def test_fixed_point_vertex_grid_is_exact_and_order_free(ops, P, coords):
     dt_b = torch.zeros_like(dt_a)
     ops._vertex_bwd(plan, tables, None, None, n_t, 0, grids[0][0], dt_b, None)
     close(dt_a, dt_b.cpu().numpy(), 1e-5, 1e-6 * float(dt_b.abs().max()), "hash table gradient from the fixed-point grid")
+    # (3b) vertex-table source in slot order: the vertex stage reading the fixed-point grid itself (no fp32 grid at all)
+    vstride = max(n_host) + 2
+    NV, K = vstride * vstride, 3
+    vi = t(rng.integers(0, T, size=(NV, K)).astype(np.int32), torch.int32)
+    vw = t(rng.random((NV, K), dtype=np.float32))
+    order = ops.slot_order(vi, n_host, vstride)
+    dG64 = torch.zeros((plan.vtot * Fd + 2,), dtype=torch.int64, device=DEV)
+    ops._pixel_bwd(plan, ws, n_t, genc, None, L, Fd, (am, 1, 0), None, None, dG64)          # dG = None: no conversion launch
+    assert torch.equal(dG64[:-2], grids[0][1])
+    dt_c, dt_d = torch.zeros((L, T, Fd), dtype=torch.float32, device=DEV), torch.zeros((L, T, Fd), dtype=torch.float32, device=DEV)
+    ops._vertex_bwd(plan, tables, vi, vw, n_t, vstride, None, dt_c, None, order, dG64)
+    ops._vertex_bwd(plan, tables, vi, vw, n_t, vstride, grids[0][0], dt_d, None, order)
+    close(dt_c, dt_d.cpu().numpy(), 2e-6, 1e-6 * float(dt_d.abs().max()), "slot-ordered vertex backward on the fixed-point grid")
     # (4) poison
     dG64 = torch.zeros((plan.vtot * Fd + 2,), dtype=torch.int64, device=DEV)
     dG = torch.zeros((plan.vtot, Fd), dtype=torch.float32, device=DEV)
     ops._pixel_bwd(plan, ws, n_t, genc, dG, L, Fd, (torch.full((1,), float("nan"), device=DEV), 1, 0), None, None, dG64)
     assert bool(torch.isnan(dG).all())
+    dt_e = torch.zeros((L, T, Fd), dtype=torch.float32, device=DEV)
+    ops._vertex_bwd(plan, tables, vi, vw, n_t, vstride, None, dt_e, None, order, dG64)
+    touched = dt_d != 0
+    assert bool(torch.isnan(dt_e[touched]).all()) and bool(touched.any())
