@@ -31,6 +31,7 @@ constexpr int kTB = GNGF_TBB;   // pixel-stage workgroup, backward
 #define GNGF_BIN_THREADS 1024
 #endif
 constexpr int kBinThreads = GNGF_BIN_THREADS;
+constexpr int kBinU = 8;          // pixels per thread and trip in the binning kernels
 
 __device__ __forceinline__ int g_max0(int v) { return v < 0 ? 0 : v; }
 
@@ -51,9 +52,15 @@ __device__ __forceinline__ void bin_count_body(int blk, const float2* __restrict
   __syncthreads();
   const int64_t lo = (int64_t)blk * per_block;
   const int64_t hi = lo + per_block < P ? lo + per_block : P;
-  for (int64_t p = lo + threadIdx.x; p < hi; p += kBinThreads) {
-    const float2 c = xy[p];
-    atomicAdd(&hist[tile_of(c.x, c.y, tile_shift)], 1);
+  // kBinU pixels per thread and trip, loads issued together: one pixel per trip made the block's time the SUM of eight memory
+  // round trips (one workgroup per CU: there is nobody else to hide them)
+  for (int64_t p0 = lo + threadIdx.x; p0 < hi; p0 += (int64_t)kBinU * kBinThreads) {
+    float2 c[kBinU];
+#pragma unroll
+    for (int u = 0; u < kBinU; ++u) { const int64_t p = p0 + (int64_t)u * kBinThreads; c[u] = xy[p < hi ? p : hi - 1]; }
+#pragma unroll
+    for (int u = 0; u < kBinU; ++u)
+      if (p0 + (int64_t)u * kBinThreads < hi) atomicAdd(&hist[tile_of(c[u].x, c[u].y, tile_shift)], 1);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < ntiles; i += kBinThreads) {
@@ -145,10 +152,17 @@ __device__ __forceinline__ void bin_scatter_body(int blk, const float2* __restri
   __syncthreads();
   const int64_t lo = (int64_t)blk * per_block;
   const int64_t hi = lo + per_block < P ? lo + per_block : P;
-  for (int64_t p = lo + threadIdx.x; p < hi; p += kBinThreads) {
-    const float2 c = xy[p];
-    const int pos = atomicAdd(&cursor[tile_of(c.x, c.y, tile_shift)], 1);
-    sorted[pos] = make_float4(c.x, c.y, __int_as_float((int)p), 0.f);
+  for (int64_t p0 = lo + threadIdx.x; p0 < hi; p0 += (int64_t)kBinU * kBinThreads) {
+    float2 c[kBinU];
+    int pos[kBinU];
+#pragma unroll
+    for (int u = 0; u < kBinU; ++u) { const int64_t p = p0 + (int64_t)u * kBinThreads; c[u] = xy[p < hi ? p : hi - 1]; }
+#pragma unroll
+    for (int u = 0; u < kBinU; ++u)
+      pos[u] = (p0 + (int64_t)u * kBinThreads < hi) ? atomicAdd(&cursor[tile_of(c[u].x, c[u].y, tile_shift)], 1) : -1;
+#pragma unroll
+    for (int u = 0; u < kBinU; ++u)
+      if (pos[u] >= 0) sorted[pos[u]] = make_float4(c[u].x, c[u].y, __int_as_float((int)(p0 + (int64_t)u * kBinThreads)), 0.f);
   }
 }
 
@@ -225,10 +239,17 @@ bin_scatter2_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block,
   __syncthreads();
   const int64_t lo = (int64_t)blk * per_block;
   const int64_t hi = lo + per_block < P ? lo + per_block : P;
-  for (int64_t p = lo + tid; p < hi; p += kBinThreads) {
-    const float2 c = xy[p];
-    const int pos = atomicAdd(&cursor[tile_of(c.x, c.y, tile_shift)], 1);
-    sorted[pos] = make_float4(c.x, c.y, __int_as_float((int)p), 0.f);
+  for (int64_t p0 = lo + tid; p0 < hi; p0 += (int64_t)kBinU * kBinThreads) {     // (loads together: see bin_count_body)
+    float2 c[kBinU];
+    int pos[kBinU];
+#pragma unroll
+    for (int u = 0; u < kBinU; ++u) { const int64_t p = p0 + (int64_t)u * kBinThreads; c[u] = xy[p < hi ? p : hi - 1]; }
+#pragma unroll
+    for (int u = 0; u < kBinU; ++u)
+      pos[u] = (p0 + (int64_t)u * kBinThreads < hi) ? atomicAdd(&cursor[tile_of(c[u].x, c[u].y, tile_shift)], 1) : -1;
+#pragma unroll
+    for (int u = 0; u < kBinU; ++u)
+      if (pos[u] >= 0) sorted[pos[u]] = make_float4(c[u].x, c[u].y, __int_as_float((int)(p0 + (int64_t)u * kBinThreads)), 0.f);
   }
   // last block out clears the workspace (every block has finished reading the totals and reserving on the cursors by then)
   __syncthreads();
