@@ -692,7 +692,8 @@ tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
   const bool finite = gmax < INFINITY && !promise_broken(ride.promised, ride.arrived);     // false for inf and NaN
   int eg = 0;
   if (finite && gmax > 0.f) (void)frexpf(gmax, &eg);        // gmax < 2^eg
-  int S = (GNGF_FIXED_FMA ? 60 : 61) - log2_chunk - eg;        // (fma form: every term below 2^51)
+  // fma form: every term must stay below 2^51 — |g| 2^S < 2^(60 - log2_chunk), so a bound of fewer than 2^10 terms counts as 2^10
+  int S = GNGF_FIXED_FMA ? 60 - (log2_chunk < 10 ? 10 : log2_chunk) - eg : 61 - log2_chunk - eg;
   S = S > 126 ? 126 : S;                                         // 2^S stays an fp32 number for any gradient magnitude
   if (lp < ppp && finite) {
     const int n = m.n[l], cx = m.cx[l], cy = m.cy[l], wx = m.wx[l], wy = m.wy[l], gw = m.gw[l];
@@ -1081,7 +1082,8 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
     const bool finite = gmax < INFINITY && !broken;        // false for inf and NaN
     int eg = 0;
     if (finite && gmax > 0.f) (void)frexpf(gmax, &eg);       // gmax < 2^eg
-    int S = (GNGF_FIXED_FMA ? 60 : 61) - log2_chunk - eg;              // (fma form: every term below 2^51)
+    // fma form: every term must stay below 2^51 — |g| 2^S < 2^(60 - log2_chunk), so a bound of fewer than 2^10 terms counts as 2^10
+    int S = GNGF_FIXED_FMA ? 60 - (log2_chunk < 10 ? 10 : log2_chunk) - eg : 61 - log2_chunk - eg;
     S = S > 126 ? 126 : S;                                               // 2^S stays an fp32 number for any gradient magnitude
     if (dG64 && tid == 0) {
       const int64_t vt = m.goff[Ls - 1] + (int64_t)(m.n[Ls - 1] + 2) * (m.n[Ls - 1] + 2);
