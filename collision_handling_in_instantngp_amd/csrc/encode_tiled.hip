@@ -934,10 +934,13 @@ tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
       // pixel inside its staged sub-grid — free of per-lane branches.  Pairs of fp32 (coordinates, the two features) go through
       // packed instructions: same separately rounded operations as make_cell / the reference, half the instructions.
       // (U = 2: 72 VGPRs, three workgroups per CU: 33 us at 2^20 pixels; U = 4: 92 VGPRs, two workgroups: 35 us.)
-      for (int j0 = lp; j0 <= last; j0 += U * ppp) {
+      // (TAIL = false: every pixel of the trip exists — no clamped record index, no predicated store; the one trip that runs
+      // past the item's end is peeled off below)
+      auto trip = [&](const int j0, auto TAIL) {
+        constexpr bool tail = decltype(TAIL)::value;
         float4 sv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) sv[u] = fetch(j0 + u * ppp);
+        for (int u = 0; u < U; ++u) sv[u] = tail ? fetch(j0 + u * ppp) : rec[j0 + u * ppp];
         float c[U][4];
         int v[U];
         bool inside = true;
@@ -963,13 +966,16 @@ tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const v2f r = ((a0[u] * c[u][0] + a1[u] * c[u][1]) + b0[u] * c[u][2]) + b1[u] * c[u][3];
-            if (j0 + u * ppp <= last) enc_l[(int64_t)__float_as_int(sv[u].z) * LF2] = r;
+            if (!tail || j0 + u * ppp <= last) enc_l[(int64_t)__float_as_int(sv[u].z) * LF2] = r;
           }
         } else {
 #pragma unroll
           for (int u = 0; u < U; ++u) slow(sv[u], j0 + u * ppp);
         }
-      }
+      };
+      int j0 = lp;
+      for (; j0 + (U - 1) * ppp <= last; j0 += U * ppp) trip(j0, std::false_type{});
+      if (j0 <= last) trip(j0, std::true_type{});
     }
   }
 }
