@@ -878,7 +878,7 @@ tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
         i = e - (m.loff[q] >> 1);
         const int wx = m.wx[q];
         const int iy = (int)(((float)i + 0.5f) * (1.0f / (float)wx)), ix = i - iy * wx;
-        off = (unsigned)((int)m.goff[q] + (m.cy[q] + iy) * (m.n[q] + 2) + m.cx[q] + ix);
+        off = (unsigned)((int)m.goff[q] + __mul24(m.cy[q] + iy, m.n[q] + 2) + m.cx[q] + ix);
       };
       for (int base = 0; base < used_v; base += 3 * kTBF) {
         int lv[3], iv[3];
@@ -953,7 +953,7 @@ tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
           c[u][0] = w0.x * w0.y; c[u][1] = w1.x * w0.y; c[u][2] = w0.x * w1.y; c[u][3] = w1.x * w1.y;
           const int lx = (int)a.x - cx, ly = (int)a.y - cy;
           inside = inside && ((unsigned)lx < (unsigned)(wx - 1)) && ((unsigned)ly < (unsigned)(wy - 1));
-          v[u] = ly * wx + lx;
+          v[u] = __mul24(ly, wx) + lx;                      // (24-bit multiply: the plain product became a quarter-rate v_mad_u64_u32)
         }
         if (__ballot(!inside) == 0ull) {
           v2f a0[U], a1[U], b0[U], b1[U];
@@ -1199,7 +1199,7 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
           fw0[u] = d - sxy; fw1[u] = sxy - fa[u];
           const int lx = (int)fa[u].x - cx, ly = (int)fa[u].y - cy;
           inside = inside && ((unsigned)lx < (unsigned)(wx - 1)) && ((unsigned)ly < (unsigned)(wy - 1));
-          fv[u] = ly * wx + lx;
+          fv[u] = __mul24(ly, wx) + lx;                     // (24-bit multiply: the plain product became a quarter-rate v_mad_u64_u32)
           if (tail && j0 + u * ppp > last) gv[u] = (v2f){0.f, 0.f};
         }
         if (__ballot(!inside) == 0ull) {
@@ -1239,7 +1239,7 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
           if (sum != 0ull) {
             const int v = i >> 1;
             const int iy = (int)(((float)v + 0.5f) * (1.0f / (float)wx)), ix = v - iy * wx;
-            atomicAdd(dG64 + (m.goff[q] + (int64_t)(m.cy[q] + iy) * gw + m.cx[q] + ix) * F + (i & 1), sum);
+            atomicAdd(dG64 + (m.goff[q] + (int64_t)(__mul24(m.cy[q] + iy, gw) + m.cx[q] + ix)) * F + (i & 1), sum);
           }
         }
       }
