@@ -97,6 +97,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra-modes", action="store_true")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B measurements: set a module-level switch of collision_handling_in_instantngp_amd.ops (e.g. DECODER_CLEARS_DG64=0)")
     ap.add_argument("--no-full-outputs", dest="full_outputs", action="store_false",
                     help="skip the extra timing of the step with the reference's index tensor materialised")
     ap.add_argument("--no-unroll", dest="unroll", action="store_false", help="one step per replayed graph")
@@ -393,6 +395,11 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
     from collision_handling_in_instantngp_amd import ops, parallel, train
+    for kv in a.set:
+        name, _, val = kv.partition("=")
+        if not hasattr(ops, name):
+            raise SystemExit(f"bench.py --set: ops has no switch {name!r}")
+        setattr(ops, name, type(getattr(ops, name))(int(val)) if isinstance(getattr(ops, name), (bool, int)) else val)
     P = a.pixels
 
     results = {}
