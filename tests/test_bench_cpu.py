@@ -43,3 +43,11 @@ def test_bare_gpus_n_starts_n_rank_processes(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "127.0.0.1" in cmd
     assert cmd[-6:] == ["--gpus", "2", "--backend", "gloo", "--steps", "3"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_ab_switches_and_unroll_list_parse():
+    """--set NAME=VALUE (same-box A/B of ops switches) and --unrolls a,b,c (steps per replayed graph)"""
+    import bench
+    a = bench.parse_args(["--set", "DG64=0", "--set", "HASH_VERTEX_FUSION=1", "--unrolls", "10,4,2"])
+    assert a.set == ["DG64=0", "HASH_VERTEX_FUSION=1"] and a.unrolls == (10, 4, 2)
+    assert bench.parse_args([]).set == [] and 4 in bench.parse_args([]).unrolls
