@@ -410,159 +410,172 @@ def main():
     kt, kcalls = {}, {}
     batches = {}
     for mode in [a.mode] + extra:
-        head = mode == a.mode
-        cfg_name = MODES[mode]
-        if cfg_name not in batches:
-            batches.clear()
-            batches[cfg_name] = make_batch(cfg_name, P, rank, dev)
-        xy, target, bounds = batches[cfg_name]
-        learning = mode == "gngf_learning"
-        # (the other single-kernel-chain modes: as many steps as the headline — 10 steps of 0.4 ms are a 4 ms window, ±1 % of noise)
-        steps, warmup = (a.steps, a.warmup) if head else ((2, 1) if learning else (max(5, a.steps), max(2, a.warmup)))
-        if learning and head:
-            steps, warmup = min(a.steps, 5), min(a.warmup, 1)
-        net, models = build_model(mode, dev, bounds)
-        if world > 1:
-            parallel.enable_vertex_grid_exchange(net, world)
-        loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
-        step = eager_step_fn(net, mode, xy, target, world)
-        launch = "eager"
-        unroll = 1
-        if a.graph and not learning:
-            # world > 1: the vertex stage of the encoder backward is deferred behind the dG exchange, so forward + backward
-            # hold no collective and replay from one hipGraph; the exchange (RCCL) and the vertex stage follow eagerly.
-            try:
-                if world > 1:
-                    parallel.defer_vertex_stage(net, True)
-                # several steps per replayed graph (a replay costs ~9 us of launch latency whatever it holds): the first of
-                # 4, 5, 6, 7, 8, 3, 2 that divides K, so that exactly K steps are timed
-                unroll = 1
-                if world == 1 and a.unroll:
-                    unroll = next((u for u in a.unrolls if steps % u == 0), 1)
-                gs = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3, unroll=unroll)
-                if unroll > 1:
-                    gs.run_many([(xy, target)] * unroll)
-                else:
-                    gs(xy, target)                      # captures; the batch stays in the static buffers
-                if world > 1:
-                    # the exchange (RCCL) and the deferred vertex stage go to the model's communication stream; the next
-                    # replay waits for them on the device (it overwrites the exchanged buffers from its first kernel on)
-                    def step(gs=gs, net=net):
+        # an extra mode that fails on this box (out of memory at the 4 GiB shape, say) must not cost the headline line: at
+        # N = 1 it is recorded as an error and the run goes on; the headline mode, and every mode at N > 1 (collectives
+        # must stay matched across ranks), fail loudly
+        try:
+            head = mode == a.mode
+            cfg_name = MODES[mode]
+            if cfg_name not in batches:
+                batches.clear()
+                batches[cfg_name] = make_batch(cfg_name, P, rank, dev)
+            xy, target, bounds = batches[cfg_name]
+            learning = mode == "gngf_learning"
+            # (the other single-kernel-chain modes: as many steps as the headline — 10 steps of 0.4 ms are a 4 ms window, ±1 % of noise)
+            steps, warmup = (a.steps, a.warmup) if head else ((2, 1) if learning else (max(5, a.steps), max(2, a.warmup)))
+            if learning and head:
+                steps, warmup = min(a.steps, 5), min(a.warmup, 1)
+            net, models = build_model(mode, dev, bounds)
+            if world > 1:
+                parallel.enable_vertex_grid_exchange(net, world)
+            loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
+            step = eager_step_fn(net, mode, xy, target, world)
+            launch = "eager"
+            unroll = 1
+            if a.graph and not learning:
+                # world > 1: the vertex stage of the encoder backward is deferred behind the dG exchange, so forward + backward
+                # hold no collective and replay from one hipGraph; the exchange (RCCL) and the vertex stage follow eagerly.
+                try:
+                    if world > 1:
+                        parallel.defer_vertex_stage(net, True)
+                    # several steps per replayed graph (a replay costs ~9 us of launch latency whatever it holds): the first of
+                    # 4, 5, 6, 7, 8, 3, 2 that divides K, so that exactly K steps are timed
+                    unroll = 1
+                    if world == 1 and a.unroll:
+                        unroll = next((u for u in a.unrolls if steps % u == 0), 1)
+                    gs = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3, unroll=unroll)
+                    if unroll > 1:
+                        gs.run_many([(xy, target)] * unroll)
+                    else:
+                        gs(xy, target)                      # captures; the batch stays in the static buffers
+                    if world > 1:
+                        # the exchange (RCCL) and the deferred vertex stage go to the model's communication stream; the next
+                        # replay waits for them on the device (it overwrites the exchanged buffers from its first kernel on)
+                        def step(gs=gs, net=net):
+                            parallel.wait_for_gradients(net)
+                            gs.replay_only()
+                            parallel.allreduce_gradients(net, world, keep_tables_flag=True, overlap=True)
+                        launch = "hipGraph + exchange on a communication stream"
+                    else:
+                        step = gs.replay_only
+                        launch = "hipGraph" if unroll == 1 else f"hipGraph ({unroll} steps per replay)"
+                except Exception as e:  # pragma: no cover
+                    print(f"[bench] graph capture failed ({e!r}); running eagerly", file=sys.stderr)
+                    if world > 1:
+                        parallel.defer_vertex_stage(net, False)
+                    step = eager_step_fn(net, mode, xy, target, world)
+            if not learning:
+                # Clock ramp: the chip reaches its steady matrix-core clock only after ~15 ms of sustained work (the same kernel
+                # is ~10 % slower before; tools/perf_decoder_warm.py), and W warm-up steps of 0.6 ms do not get there.  Untimed
+                # steps first (every rank runs the same number, so collectives stay matched), then the W + K of the contract.
+                for _ in range(a.ramp_steps // (unroll if launch.startswith("hipGraph (") else 1)):
+                    step()
+            per = unroll if (a.graph and not learning and launch.startswith("hipGraph (")) else 1
+            dt = timed(step, steps // per, -(-warmup // per), world)       # exactly `steps` steps: steps / per replays of `per` steps each
+            res = results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+                                   "launch": launch, "shape": {k: v for k, v in SHAPES[cfg_name].items()}}
+            # the target's own metric: per-instance algorithmic bytes x pixels/s against the HBM peak.  For
+            # GNGF indexing that figure assumes one table gather per (pixel, corner, k); the per-vertex de-duplicated algorithm does
+            # not move those bytes, so its ratio exceeds 1 — it is printed as what it is, next to the hash modes' real fractions.
+            sb_f, sb_b = survey_bytes(mode)
+            sv = (sb_f + sb_b) * P * steps / dt / 1e9
+            res["roofline_survey"] = {"bytes_per_pixel": sb_f + sb_b, "achieved_GBs": sv, "frac_of_8TBs": sv / HBM_PEAK_GBS,
+                                      "frac_of_measured_copy": sv / hbm_copy}
+            if world > 1:
+                res["exchange"] = exchange_model(net, world)
+            if SHAPES[cfg_name]["half"]:
+                res["table_gradient"] = "fp32 accumulation buffer handed over as param.grad_fp32 (ops.FP16_TABLE_GRAD_FP32), no fp16 .grad copy"
+            if learning:
+                st = dict(net.hpd_stats)
+                fl, gemm = learning_flops(st)
+                res["hpd"] = st
+                res["roofline"] = {"bound": "mfma", "kernel": "last HPD layer: logits / dW / dh GEMMs (128 x T per distinct vertex), fp32 MFMA",
+                                   "achieved": fl / (dt / steps) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": fl / (dt / steps) / 1e12 / MFMA_F32_PEAK_TFLOPS, "flop_per_step": fl, "traffic": None,
+                                   "note": "whole-step time against the FLOP of the three GEMMs (+ recomputed logits chunks)"}
+            if head and launch.startswith("hipGraph"):
+                # decoder_bwd's duration INSIDE the replayed graph, from the device clock the kernel stamps (events cannot be
+                # recorded in a replayed hipGraph here): one sample per burst of replays.  Every rank runs it: at world > 1 a step
+                # carries the gradient exchange, and collectives must stay matched across ranks.
+                try:
+                    import ctypes
+                    from collision_handling_in_instantngp_amd import _lib
+                    spans = []
+                    for _ in range(10):
+                        for _ in range(8):
+                            step()
+                        torch.cuda.synchronize()
+                        ns = ctypes.c_double(0.0)
+                        _lib.call("gngf_decoder_bwd_last_span_ns", ctypes.byref(ns))
+                        spans.append(ns.value)
+                    spans.sort()
+                    in_graph_ms = spans[len(spans) // 2] * 1e-6
+                except Exception as e:  # pragma: no cover
+                    in_graph_ms = None
+                    print(f"[bench] in-graph span unavailable ({e!r})", file=sys.stderr)
+            if head and world == 1 and a.graph and not learning:
+                # the same step with the optimizer in the graph (get_optimizer's Adam as one launch): reported, not the metric
+                try:
+                    opt = train.get_optimizer(net, 1e-2, 1e-3, 1e-3, 0.0, 0.0, 1e-6)
+                    gso = train.GraphedStep(net, loss_fn, opt, 1, 1, 1e-3)
+                    gso(xy, target)
+                    dto = timed(gso.replay_only, steps, warmup, world)
+                    res["with_adam_ms_per_step"] = dto / steps * 1e3
+                    del opt, gso
+                except Exception as e:  # pragma: no cover
+                    res["with_adam_ms_per_step"] = repr(e)
+            if world == 1 and a.graph and not learning and a.full_outputs:
+                # the same step returning the reference's index tensor as well ((P,L,4[,K]) int64, models.py:475-484): the metric's
+                # step turns it off (net.return_indices = False, build_model) — its cost is reported here, never in `value`
+                try:
+                    net.return_indices = True
+                    gsf = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3)
+                    r = gsf(xy, target)
+                    assert r.idx is not None and r.idx.shape[0] == P
+                    nfull = max(4, steps // 4)
+                    dtf = timed(gsf.replay_only, nfull, 2, world)
+                    res["with_full_outputs_ms_per_step"] = dtf / nfull * 1e3
+                    res["full_outputs_note"] = f"return_indices=True: indices {tuple(r.idx.shape)} int64 materialised every step"
+                    del gsf, r
+                except Exception as e:  # pragma: no cover
+                    res["with_full_outputs_ms_per_step"] = repr(e)
+                finally:
+                    net.return_indices = False
+            if (head and not learning) or (learning and world == 1):
+                # per-kernel launch times inside eagerly launched steps (the `roofline` objects).  At N > 1 EVERY rank runs them — the
+                # eager step holds the gradient exchange, and collectives must stay matched — and rank 0 reports its own.
+                try:
+                    if world > 1:
                         parallel.wait_for_gradients(net)
-                        gs.replay_only()
-                        parallel.allreduce_gradients(net, world, keep_tables_flag=True, overlap=True)
-                    launch = "hipGraph + exchange on a communication stream"
-                else:
-                    step = gs.replay_only
-                    launch = "hipGraph" if unroll == 1 else f"hipGraph ({unroll} steps per replay)"
-            except Exception as e:  # pragma: no cover
-                print(f"[bench] graph capture failed ({e!r}); running eagerly", file=sys.stderr)
-                if world > 1:
-                    parallel.defer_vertex_stage(net, False)
-                step = eager_step_fn(net, mode, xy, target, world)
-        if not learning:
-            # Clock ramp: the chip reaches its steady matrix-core clock only after ~15 ms of sustained work (the same kernel
-            # is ~10 % slower before; tools/perf_decoder_warm.py), and W warm-up steps of 0.6 ms do not get there.  Untimed
-            # steps first (every rank runs the same number, so collectives stay matched), then the W + K of the contract.
-            for _ in range(a.ramp_steps // (unroll if launch.startswith("hipGraph (") else 1)):
-                step()
-        per = unroll if (a.graph and not learning and launch.startswith("hipGraph (")) else 1
-        dt = timed(step, steps // per, -(-warmup // per), world)       # exactly `steps` steps: steps / per replays of `per` steps each
-        res = results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
-                               "launch": launch, "shape": {k: v for k, v in SHAPES[cfg_name].items()}}
-        # the target's own metric: per-instance algorithmic bytes x pixels/s against the HBM peak.  For
-        # GNGF indexing that figure assumes one table gather per (pixel, corner, k); the per-vertex de-duplicated algorithm does
-        # not move those bytes, so its ratio exceeds 1 — it is printed as what it is, next to the hash modes' real fractions.
-        sb_f, sb_b = survey_bytes(mode)
-        sv = (sb_f + sb_b) * P * steps / dt / 1e9
-        res["roofline_survey"] = {"bytes_per_pixel": sb_f + sb_b, "achieved_GBs": sv, "frac_of_8TBs": sv / HBM_PEAK_GBS,
-                                  "frac_of_measured_copy": sv / hbm_copy}
-        if world > 1:
-            res["exchange"] = exchange_model(net, world)
-        if SHAPES[cfg_name]["half"]:
-            res["table_gradient"] = "fp32 accumulation buffer handed over as param.grad_fp32 (ops.FP16_TABLE_GRAD_FP32), no fp16 .grad copy"
-        if learning:
-            st = dict(net.hpd_stats)
-            fl, gemm = learning_flops(st)
-            res["hpd"] = st
-            res["roofline"] = {"bound": "mfma", "kernel": "last HPD layer: logits / dW / dh GEMMs (128 x T per distinct vertex), fp32 MFMA",
-                               "achieved": fl / (dt / steps) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": fl / (dt / steps) / 1e12 / MFMA_F32_PEAK_TFLOPS, "flop_per_step": fl, "traffic": None,
-                               "note": "whole-step time against the FLOP of the three GEMMs (+ recomputed logits chunks)"}
-        if head and launch.startswith("hipGraph"):
-            # decoder_bwd's duration INSIDE the replayed graph, from the device clock the kernel stamps (events cannot be
-            # recorded in a replayed hipGraph here): one sample per burst of replays.  Every rank runs it: at world > 1 a step
-            # carries the gradient exchange, and collectives must stay matched across ranks.
-            try:
-                import ctypes
-                from collision_handling_in_instantngp_amd import _lib
-                spans = []
-                for _ in range(10):
-                    for _ in range(8):
-                        step()
-                    torch.cuda.synchronize()
-                    ns = ctypes.c_double(0.0)
-                    _lib.call("gngf_decoder_bwd_last_span_ns", ctypes.byref(ns))
-                    spans.append(ns.value)
-                spans.sort()
-                in_graph_ms = spans[len(spans) // 2] * 1e-6
-            except Exception as e:  # pragma: no cover
-                in_graph_ms = None
-                print(f"[bench] in-graph span unavailable ({e!r})", file=sys.stderr)
-        if head and world == 1 and a.graph and not learning:
-            # the same step with the optimizer in the graph (get_optimizer's Adam as one launch): reported, not the metric
-            try:
-                opt = train.get_optimizer(net, 1e-2, 1e-3, 1e-3, 0.0, 0.0, 1e-6)
-                gso = train.GraphedStep(net, loss_fn, opt, 1, 1, 1e-3)
-                gso(xy, target)
-                dto = timed(gso.replay_only, steps, warmup, world)
-                res["with_adam_ms_per_step"] = dto / steps * 1e3
-                del opt, gso
-            except Exception as e:  # pragma: no cover
-                res["with_adam_ms_per_step"] = repr(e)
-        if world == 1 and a.graph and not learning and a.full_outputs:
-            # the same step returning the reference's index tensor as well ((P,L,4[,K]) int64, models.py:475-484): the metric's
-            # step turns it off (net.return_indices = False, build_model) — its cost is reported here, never in `value`
-            try:
-                net.return_indices = True
-                gsf = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3)
-                r = gsf(xy, target)
-                assert r.idx is not None and r.idx.shape[0] == P
-                nfull = max(4, steps // 4)
-                dtf = timed(gsf.replay_only, nfull, 2, world)
-                res["with_full_outputs_ms_per_step"] = dtf / nfull * 1e3
-                res["full_outputs_note"] = f"return_indices=True: indices {tuple(r.idx.shape)} int64 materialised every step"
-                del gsf, r
-            except Exception as e:  # pragma: no cover
-                res["with_full_outputs_ms_per_step"] = repr(e)
-            finally:
-                net.return_indices = False
-        if (head and not learning) or (learning and world == 1):
-            # per-kernel launch times inside eagerly launched steps (the `roofline` objects).  At N > 1 EVERY rank runs them — the
-            # eager step holds the gradient exchange, and collectives must stay matched — and rank 0 reports its own.
-            try:
-                if world > 1:
-                    parallel.wait_for_gradients(net)
-                    parallel.defer_vertex_stage(net, False)
-                k_t, k_c = kernel_times_in_step(eager_step_fn(net, mode, xy, target, world), n=(2 if learning else 20),
-                                                warm=(0 if learning else 3))
-                if head:
-                    kt, kcalls = k_t, k_c
-                if learning:
-                    res["entry_ms"] = {k: v * 1e3 for k, v in sorted(k_t.items(), key=lambda kv: -kv[1])[:12]}
-                    gemm_t = sum(v for k, v in k_t.items() if k in ("gngf_linear_fwd", "gngf_gemm_acc", "gngf_linear_bwd_weight", "gngf_hpd_last_bwd"))
-                    if gemm_t > 0 and "roofline" in res:
-                        fl, _ = learning_flops(res["hpd"])
-                        res["roofline"]["gemm_entries_ms"] = gemm_t * 1e3
-                        res["roofline"]["gemm_entries_frac"] = fl / gemm_t / 1e12 / MFMA_F32_PEAK_TFLOPS
-            except Exception as e:  # pragma: no cover
-                if head:
-                    kt = {"error": repr(e)}
-        models.should_use_hash_function = False
-        if world > 1:
-            parallel.defer_vertex_stage(net, False)
-        del net, step
-        torch.cuda.empty_cache()
+                        parallel.defer_vertex_stage(net, False)
+                    k_t, k_c = kernel_times_in_step(eager_step_fn(net, mode, xy, target, world), n=(2 if learning else 20),
+                                                    warm=(0 if learning else 3))
+                    if head:
+                        kt, kcalls = k_t, k_c
+                    if learning:
+                        res["entry_ms"] = {k: v * 1e3 for k, v in sorted(k_t.items(), key=lambda kv: -kv[1])[:12]}
+                        gemm_t = sum(v for k, v in k_t.items() if k in ("gngf_linear_fwd", "gngf_gemm_acc", "gngf_linear_bwd_weight", "gngf_hpd_last_bwd"))
+                        if gemm_t > 0 and "roofline" in res:
+                            fl, _ = learning_flops(res["hpd"])
+                            res["roofline"]["gemm_entries_ms"] = gemm_t * 1e3
+                            res["roofline"]["gemm_entries_frac"] = fl / gemm_t / 1e12 / MFMA_F32_PEAK_TFLOPS
+                except Exception as e:  # pragma: no cover
+                    if head:
+                        kt = {"error": repr(e)}
+            models.should_use_hash_function = False
+            if world > 1:
+                parallel.defer_vertex_stage(net, False)
+            del net, step
+            torch.cuda.empty_cache()
+        except Exception as e:
+            if mode == a.mode or world > 1:
+                raise
+            print(f"[bench] mode {mode} failed: {e!r}", file=sys.stderr)
+            results[mode] = {"error": repr(e)}
+            models_mod = sys.modules.get("collision_handling_in_instantngp_amd.models")
+            if models_mod is not None:
+                models_mod.should_use_hash_function = False
+            torch.cuda.empty_cache()
 
     if rank == 0:
         head = results[a.mode]
@@ -661,7 +674,7 @@ def main():
         for m, r_ in results.items():
             fr[f"modes.{m}.roofline.frac"] = (r_.get("roofline") or {}).get("frac")
             fr[f"modes.{m}.roofline.gemm_entries_frac"] = (r_.get("roofline") or {}).get("gemm_entries_frac")
-            if is_hash(m):
+            if is_hash(m) and "roofline_survey" in r_:
                 fr[f"modes.{m}.roofline_survey.frac_of_8TBs"] = r_["roofline_survey"]["frac_of_8TBs"]
         bad = {k: v for k, v in fr.items() if isinstance(v, float) and v > 1.05}
         if bad:
