@@ -190,6 +190,8 @@ def eager_step_fn(net, mode, xy, target, world, exchange=True):
     def step():
         for p in params:
             p.grad = None
+            if getattr(p, "grad_fp32", None) is not None:      # fp16 tables: the fp32 hand-over buffer is the gradient (ops._grad_out)
+                p.grad_fp32 = None
         with net.fused_mse(target, gloss=1.0):     # as train.py's loops do: the pixel loss rides in the decoder kernels
             rgb, probs, _idx, _c = net(xy, 1.0)
         mse, kls, coll = loss_fn(rgb, target, None if probs is None else T, probs, empty, empty)

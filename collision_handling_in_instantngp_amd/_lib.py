@@ -34,6 +34,7 @@ SIGNATURES = {
     "gngf_vertex_grid_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L, _P],
     "gngf_encode_tiled_fwd": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gngf_set_tiled_interleaved": [_I],
+    "gngf_tiled_interleaved_applies": [_P, _I, _I, _I, _I, _I],
     "gngf_debug_il_stamps": [_P],
     "gngf_encode_tiled_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I,
                               _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _I, _P],
@@ -77,7 +78,7 @@ SIGNATURES = {
     "gngf_adam_step": [_P, _I, _L, _P, _P, _P, _I, _F, _F, _F, _F, _P],
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _RETURNS_INT64 = {"gngf_decoder_hidden_floats", "gngf_slot_bitmap_words"}
 _lib = None
 

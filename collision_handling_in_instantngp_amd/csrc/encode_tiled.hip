@@ -785,10 +785,19 @@ __device__ __forceinline__ int il_copies(int rows_l, int rows2) {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// diagnostic: per-phase cycle totals of workgroup 0 of the interleaved backward kernel (s_memtime; tools/perf_tiled_il.py)
+// diagnostic (-DGNGF_STAMPS builds only, as csrc/decoder.hip): per-phase cycle totals of workgroup 0 of the interleaved backward
+// kernel (tools/perf_tiled_il.py).  The production build carries no stamps and no read-modify-writes of this array.
+#ifdef GNGF_STAMPS
 __device__ unsigned long long g_il_stamps[8];
+#define IL_STAMP_INIT() unsigned long long il_t = __builtin_readcyclecounter()
 #define IL_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
-    g_il_stamps[k] += t_ - il_t; il_t = t_; } } while (0)      // pairs of fp32: the compiler maps their arithmetic to v_pk_*_f32
+    g_il_stamps[k] += t_ - il_t; il_t = t_; } } while (0)
+#define IL_STAMP_ITEM(px) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_il_stamps[6] += 1; g_il_stamps[7] += (unsigned long long)(px); } } while (0)
+#else
+#define IL_STAMP_INIT() do {} while (0)
+#define IL_STAMP(k) do {} while (0)
+#define IL_STAMP_ITEM(px) do {} while (0)
+#endif
 
 // Per-item geometry of the interleaved kernels, filled by the first 16 lanes of the workgroup (one level each; the prefix
 // sums meet in shuffles — setup_tile's serial walk over the levels cost ~0.5 us per item) and read by everybody after one
@@ -1038,7 +1047,7 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
     for (int w = 1; w < kTB / 64; ++w) hint = (wmax[w] > hint || wmax[w] != wmax[w]) ? wmax[w] : hint;
   }
   if (tid < kIL) m.nls[tid] = tid < Ls ? n_ls[tid] : 0;
-  unsigned long long il_t = __builtin_readcyclecounter();
+  IL_STAMP_INIT();
   int4 it_next = items[(int)blockIdx.x < nit ? (int)blockIdx.x : 0];
   for (int item = blockIdx.x; item < nit; item += nwork) {
     const int4 it = it_next;
@@ -1244,7 +1253,7 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
         }
       }
       IL_STAMP(5);
-      if (blockIdx.x == 0 && tid == 0) { g_il_stamps[6] += 1; g_il_stamps[7] += (unsigned long long)it.y; }
+      IL_STAMP_ITEM(it.y);
       continue;
     }
     const double inv = finite ? ldexp(1.0, -S) : 0.0;
@@ -1266,7 +1275,7 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
       for (int e = tid; e < used; e += kTB) part[e] = cimg[e];
     }
     IL_STAMP(5);
-    if (blockIdx.x == 0 && tid == 0) { g_il_stamps[6] += 1; g_il_stamps[7] += (unsigned long long)it.y; }
+    IL_STAMP_ITEM(it.y);
   }
 }
 
@@ -1751,10 +1760,15 @@ extern "C" int gngf_vertex_grid_bwd(const void* tables, int feat_dtype, const in
 // diagnostic: reads and clears the phase stamps of tiled_bwd_il_kernel's workgroup 0 (8 x uint64: cycles before the item's
 // first barrier, setup, zero + hint, main loop (thread 0), wait for the others, store pass; items; pixels)
 extern "C" int gngf_debug_il_stamps(unsigned long long* host8) {
+#ifdef GNGF_STAMPS
   hipError_t e = hipMemcpyFromSymbol(host8, HIP_SYMBOL(gngf::g_il_stamps), 8 * sizeof(unsigned long long));
   if (e != hipSuccess) return (int)e;
   unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(gngf::g_il_stamps), z, sizeof(z));
+#else
+  (void)host8;
+  return (int)hipErrorNotSupported;          // the production build carries no stamps: build with HIPFLAGS += -DGNGF_STAMPS
+#endif
 }
 
 static int compute_units() {
@@ -1790,6 +1804,13 @@ static bool interleaved_applies(const int32_t* n_ls_host, int Ls, int F, int til
   // conflicts it removes — measured at the 4096^2 shape, finest staged level N = 1955: 139 KB forward image, 106 us vs 88 us)
   const int64_t bytes = (int64_t)interleaved_rows(n_ls_host, Ls, tile_shift) * kIL * 8 * (backward ? 2 : 1) + (backward ? lds_floats * 4 : 0);
   return bytes <= (backward ? 112 : 72) * 1024;
+}
+
+// The launcher's own decision, for callers that size / initialise buffers differently for the two kernel families (the
+// fixed-point vertex grid dG64 is only filled by the interleaved backward): 1 = the level-interleaved kernel will run.
+extern "C" int gngf_tiled_interleaved_applies(const int32_t* n_ls_host, int Ls, int F, int tile_shift, int lds_bytes, int backward) {
+  if (!n_ls_host || Ls <= 0 || Ls > GNGF_MAX_LEVELS || tile_shift < 0 || tile_shift > 6 || lds_bytes < 0) return 0;
+  return interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, backward != 0) ? 1 : 0;
 }
 
 extern "C" int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
@@ -1871,6 +1892,10 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
   // dG may be NULL only when the launch is going to fill dG64 and nothing else (the caller reads the fixed-point grid itself)
   GNGF_CHECK_ARG(max_items == 0 || dG || (genc_absmax && dG64 && log2_pixels > 0 && log2_pixels <= 40 && !hash_dtables &&
                                           interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, true)));
+  // a fixed-point grid (with the bound that makes it usable) is only ever filled by the interleaved kernel: a caller that
+  // passes one for a shape the generic kernels take has sized / initialised dG for the wrong path (it would read an
+  // uninitialised dG) — rejected instead of computed (callers ask gngf_tiled_interleaved_applies first)
+  GNGF_CHECK_ARG(max_items == 0 || !(dG64 && genc_absmax) || interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, true));
   int64_t vtot_h = 0;
   if (max_items > 0)
     for (int l = 0; l < Ls; ++l) vtot_h += (int64_t)(n_ls_host[l] + 2) * (n_ls_host[l] + 2);

@@ -132,6 +132,15 @@ class MultiResHashEncoding(nn.Module):
         for i in range(self._num_levels):
             init_func(self._hash_tables[i].weight, *args)
 
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        """nn.Module.zero_grad, plus the fp32 hand-over gradients of fp16 tables (`param.grad_fp32`, ops._grad_out): a loop that
+        clears gradients through the module (net.zero_grad()) must not let them pile up across steps."""
+        for m in self._hash_tables:
+            if getattr(m.weight, "grad_fp32", None) is not None:
+                m.weight.grad_fp32 = None
+        self._grad_base_fp32 = None
+        super().zero_grad(set_to_none=set_to_none)
+
     def packed_tables(self) -> torch.Tensor:
         """The contiguous (L,T,F) storage behind the L parameters; re-packs (keeping the Parameter objects,
         hence optimizer state) if something — .to(), .cuda(), load with assign — split the storage."""

@@ -794,6 +794,15 @@ class EncodePlan:
         self.vtot = sum((n + 2) ** 2 for n in self.n_ls_host[:Ls])
         self.n_ls_c = (_ct.c_int32 * L)(*self.n_ls_host)
 
+    def interleaved(self, backward):
+        """True when the launcher will run the level-interleaved pixel-stage kernel for this plan (the library's own decision —
+        gngf_tiled_interleaved_applies: F = 2, <= 16 staged levels, the image fits the LDS, the process switch is on).  Only
+        the interleaved BACKWARD fills the fixed-point vertex grid, so the buffers of a backward pass are chosen with it."""
+        if self.Ls == 0:
+            return False
+        return bool(query("gngf_tiled_interleaved_applies", self.n_ls_c, self.Ls, self.F, self.tile_shift, self.lds_bytes,
+                          int(bool(backward))))
+
 
 BIN_BLOCKS_MAX = 128            # binning workgroups: more do not help (measured: tools/perf_bin.py, tools/perf_overlap.py)
 BIN_PIXELS_PER_BLOCK = 8192
@@ -812,9 +821,19 @@ def _bin_workspace(dev, ntiles, owner=None):
     w = store.get(key)
     if w is None:
         if torch.cuda.is_current_stream_capturing():
-            return None                     # first use inside a capture: the four-launch binning (no allocation + memset in the graph)
+            # first use inside a capture: the four-launch binning (no allocation + memset in the graph) — correct, ~10 us slower
+            # per step for the life of that graph; one eager step before capturing (train.GraphedStep warms up) avoids it
+            import warnings
+            warnings.warn("gngf: the two-launch binning's counters were first needed inside a hipGraph capture; this graph uses "
+                          "the four-launch binning (run one eager step of the model before capturing)", RuntimeWarning, stacklevel=3)
+            return None
         w = store[key] = torch.zeros((2 * int(ntiles) + 1,), dtype=_i32, device=dev)
     return w
+
+
+def _drop_bin_workspace(dev, ntiles, owner=None):
+    store = owner.bin_ws if owner is not None else _BIN_WORKSPACES
+    store.pop((dev.type, dev.index, int(ntiles)), None)
 
 
 class TiledWorkspace:
@@ -842,12 +861,18 @@ class TiledWorkspace:
             if zero is not None and (zero.numel() % 4 or zero.data_ptr() % 16 or zero.dtype != _f32):
                 zero.zero_()
                 zero = None
-            call("gngf_encode_tiled_prepare", ptr(xy, _f32, "xy"), P, plan.tile_shift, plan.NB, plan.chunk, ptr(self.blockhist),
-                 ptr(self.tile_off), ptr(self.tile_item_base), ptr(self.items), ptr(self.n_items), ptr(self.sorted),
-                 *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), plan.n_ls_c, ptr(G), ptr(zero_dG), int(zero_dG_words), plan.Ls, F, T,
-                 0 if vert_idx is None else vert_idx.shape[1], mode, vstride, 0 if vert_idx is None else vert_idx.shape[0],
-                 ptr(zero), 0 if zero is None else zero.numel(), ptr(_bin_workspace(dev, plan.ntiles, owner) if TWO_LAUNCH_BINNING else None),
-                 stream_ptr())
+            try:
+                call("gngf_encode_tiled_prepare", ptr(xy, _f32, "xy"), P, plan.tile_shift, plan.NB, plan.chunk, ptr(self.blockhist),
+                     ptr(self.tile_off), ptr(self.tile_item_base), ptr(self.items), ptr(self.n_items), ptr(self.sorted),
+                     *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), plan.n_ls_c, ptr(G), ptr(zero_dG), int(zero_dG_words), plan.Ls, F, T,
+                     0 if vert_idx is None else vert_idx.shape[1], mode, vstride, 0 if vert_idx is None else vert_idx.shape[0],
+                     ptr(zero), 0 if zero is None else zero.numel(), ptr(_bin_workspace(dev, plan.ntiles, owner) if TWO_LAUNCH_BINNING else None),
+                     stream_ptr())
+            except Exception:
+                # the count launch may have run without the scatter launch that puts the persistent counters back to zero: the
+                # next step gets a fresh (zeroed) workspace instead of binning with dirty totals
+                _drop_bin_workspace(dev, plan.ntiles, owner)
+                raise
 
 
 def _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G):
@@ -926,9 +951,16 @@ DG64 = True                  # F = 2, <= 16 staged levels, bounded |genc|: 64-bi
 VERTEX_READS_DG64 = True     # ... and the slot-ordered vertex backward converts it on the fly (False: dg64_to_float first)
 
 
+PIXEL_BWD_TRACE = None       # tests: a list that receives one record per pixel-stage backward launch (which chain ran)
+
+
 def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None, link=None, hash_fuse=None, dG64=None):
     """absmax: None or (tensor, count, stride) — `count` floats `stride` apart whose maximum bounds |genc|.
     link: the StepLink of the forward pass (decoder slab reduction / loss value waiting for a launch to ride on, promise)."""
+    if PIXEL_BWD_TRACE is not None:
+        PIXEL_BWD_TRACE.append({"P": plan.P, "Ls": plan.Ls, "bound": absmax is not None, "dG64": dG64 is not None and absmax is not None,
+                                "hash_fuse": hash_fuse is not None, "fp32_grid": dG is not None,
+                                "interleaved": plan.interleaved(backward=True)})
     partials = torch.empty((plan.max_items * (plan.lds_bytes // 4),), dtype=_f32, device=genc.device)
     am, am_count, am_stride = absmax if absmax is not None else (None, 0, 0)
     ride = link.take_reduce(genc.device) if link is not None else None        # a decoder slab reduction waiting for a launch to ride on
@@ -1033,7 +1065,9 @@ class EncodeFunction(torch.autograd.Function):
             if ctx.needs_input_grad[3]:
                 # F = 2, <= 16 staged levels (the level-interleaved kernels): the pixel stage of the backward adds its exact
                 # fixed-point sums straight into a 64-bit vertex grid (cleared here; + scale and poison words), no gather pass
-                use64 = DG64 and F == 2 and plan.Ls <= 16
+                # (the launcher decides whether that kernel runs — e.g. not at the 4096^2 shape, whose interleaved image exceeds
+                # the LDS: the generic kernels accumulate into a ZEROED fp32 grid instead)
+                use64 = DG64 and F == 2 and plan.Ls <= 16 and plan.interleaved(backward=True)
                 dgrid = (torch.empty((plan.vtot * F + 2,), dtype=_i64, device=tables.device) if use64
                          else torch.empty((plan.vtot, F), dtype=_f32, device=tables.device))
                 pre = [torch.empty(tables.shape, dtype=_f32, device=tables.device), dgrid]
@@ -1079,6 +1113,8 @@ class EncodeFunction(torch.autograd.Function):
             dG64 = pre[1] if (pre and pre[1].dtype == _i64) else None
             if dG64 is not None and absmax is None:            # no bound on |genc| from its producer: the per-item scales need the fp32 path
                 dG64 = None
+            if dG64 is not None and not plan.interleaved(backward=True):
+                dG64 = None                                     # gngf_set_tiled_interleaved changed since the forward pass: fp32 path
             fuse = (dtables, T) if (HASH_VERTEX_FUSION and vert_idx is None and exchange is None) else None
             # vertex-table source in slot order, single rank, no d w: the vertex stage reads the fixed-point grid itself (no
             # fp32 copy of the vertex-grid gradient, no conversion launch)
@@ -1467,7 +1503,7 @@ def encode_kernels(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, genc,
                                                plan.tile_shift, plan.lds_bytes, s())
         order = slot_order(vert_idx, plan.n_ls_host[:plan.Ls], vstride) if vert_idx is not None else None
         out["encode_bwd:tiled"] = lambda: _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, (am, 1, 0), None)
-        if F == 2 and plan.Ls <= 16:
+        if F == 2 and plan.Ls <= 16 and plan.interleaved(backward=True):
             dG64 = torch.zeros((plan.vtot * F + 2,), dtype=_i64, device=xy.device)
 
             def bwd64():

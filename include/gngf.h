@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNGF_ABI_VERSION 9
+#define GNGF_ABI_VERSION 10
 #define GNGF_MAX_LEVELS 32
 #define GNGF_MAX_TOPK 32
 
@@ -129,6 +129,10 @@ int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, const int32
  * levels: vertex i of level l in row i, column l of 8-byte slots, so that the 16 level-lanes of a pixel never share an LDS
  * column); NULL, or gngf_set_tiled_interleaved(0): the back-to-back layout.  Results do not depend on the layout. */
 int gngf_set_tiled_interleaved(int on);       /* returns the previous setting (default 1) */
+/* 1 when gngf_encode_tiled_fwd (backward = 0) / gngf_encode_tiled_bwd (backward = 1) will run the level-interleaved kernel for
+ * this shape under the current setting, else 0 (host logic only, no launch).  Only the interleaved backward fills dG64: callers
+ * ask here before handing one over (gngf_encode_tiled_bwd rejects a dG64 + bound for a shape the generic kernels take). */
+int gngf_tiled_interleaved_applies(const int32_t* n_ls_host, int Ls, int F, int tile_shift, int lds_bytes, int backward);
 /* diagnostic: per-phase cycle totals of workgroup 0 of the interleaved backward kernel since the last call (read and cleared;
  * synchronises): [0] tail wait, [1] setup, [2] clear + bound, [3] main loop, [4] wait for the other waves, [5] store pass,
  * [6] items, [7] pixels */

@@ -113,6 +113,41 @@ void orc_encode_bwd(const float* xy, const float* tables, const int32_t* vert_id
     }
 }
 
+/* The same scatter with the SUM kept in double precision (dtables64 (L,T,F) double, zero on entry): every term is the
+ * reference's own fp32 product chain (genc * c, then * w), only the accumulation is wide.  Checks of full-size gradients use
+ * it: an fp32 accumulation of ~10^4 terms per coarse-level row carries ~1e-5 of order-dependent rounding of its own. */
+void orc_encode_bwd_f64(const float* xy, const int32_t* vert_idx, const float* vert_w, const int32_t* n_ls, const float* genc,
+                        double* dtables64, int64_t P, int L, int F, int64_t T, int K, int vstride) {
+#pragma omp parallel for schedule(static)
+  for (int64_t p = 0; p < P; ++p)
+    for (int l = 0; l < L; ++l) {
+      cell_t c = make_cell(xy[2 * p], xy[2 * p + 1], n_ls[l]);
+      double* dtab = dtables64 + (int64_t)l * T * F;
+      for (int v = 0; v < 4; ++v) {
+        int gx = c.gx + (v & 1), gy = c.gy + (v >> 1);
+        if (!vert_idx) {
+          double* r = dtab + hash2(gx, gy, T) * F;
+          for (int f = 0; f < F; ++f) {
+            float add = genc[(p * L + l) * F + f] * c.c[v];
+#pragma omp atomic
+            r[f] += (double)add;
+          }
+        } else {
+          int64_t vid = (int64_t)gy * vstride + gx;
+          for (int k = 0; k < K; ++k) {
+            double* r = dtab + (int64_t)vert_idx[vid * K + k] * F;
+            float w = vert_w[vid * K + k];
+            for (int f = 0; f < F; ++f) {
+              float add = (genc[(p * L + l) * F + f] * c.c[v]) * w;
+#pragma omp atomic
+              r[f] += (double)add;
+            }
+          }
+        }
+      }
+    }
+}
+
 /* decoder in -> 64 -> 64 -> out (ReLU, ReLU, Sigmoid).  W* are (out,in).  h1,h2 (P,64) kept for backward.
  * Every dot product keeps its k-ordered chain of separately rounded multiply-adds (what a scalar port does), but the loops
  * run over the OUTPUT index innermost on transposed weights, so that the compiler vectorises them (a dependent sum over k

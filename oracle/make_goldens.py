@@ -681,7 +681,43 @@ def g16(F_, U_, M, P_):
         rh.set_flag(mods, "should_use_hash_function", False)
 
 
-GROUPS = {"G15": g15, "G16": g16, "G3b": g3b, "G11": g11, "G12": g12, "G13": g13, "G14": g14, "G10": g10, "G1": g1, "G2": g2_g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
+def g17(F_, U_, M, P_):
+    """should_softmax_topk_features in {None, False} at MODEL level (models.py:212-217, params.py:14): the K gathered rows are
+    blended with the raw top-K probabilities (None) or with the probabilities normalised by their sum (False) instead of their
+    softmax.  cfg1 shape, GNGF indexing, one step: outputs, loss terms, every gradient (the HPD receives the blend's backward)."""
+    mods = (F_, U_, M)
+    img, X, Y, h, w = load_strawberry()
+    torch.manual_seed(SEED + 17)
+    perm = torch.randperm(h * w)
+    B = 2048
+    try:
+        for tag, flag in (("raw", None), ("norm", False)):
+            rh.set_flag(mods + (P_,), "should_softmax_topk_features", flag)
+            net = make_net(M, mods, hash_mode=False, T=256, L=4, n_min=8, n_max=32, K=4)
+            # the default table init (+-1e-4) makes the blend invisible in rgb: scale the tables so that the variants differ
+            with torch.no_grad():
+                for l in range(4):
+                    net.encoding._hash_tables[l].weight.mul_(3000.0)
+            loss_fn = U_.Loss(delta=1, gamma=-2, epsilon=1)
+            out = {"perm": perm[:B].numpy().astype(np.int64), "hw": np.array([h, w])}
+            for k_, v_ in net.state_dict().items():
+                out["init_" + k_.replace(".", "_")] = np32(v_)
+            bx, by = X[perm[:B]], Y[perm[:B]]
+            rgb, probs, idx, counts = net(bx, 1 / 3, should_calc_counts=False)
+            mse, kls, coll = loss_fn(rgb, by, probs.shape[-1], probs, torch.tensor([]), torch.tensor([]))
+            loss = 1 * mse + ((1 * kls) + (1e-3 * coll if coll.nelement() != 0 else 1)).sum(0)
+            loss.backward()
+            out["rgb"], out["idx"], out["mse"], out["kls"], out["loss"] = np32(rgb), np32(idx), np32(mse), np32(kls), np32(loss)
+            for k_, p_ in net.named_parameters():
+                if p_.grad is not None:
+                    out["grad_" + k_.replace(".", "_")] = np32(p_.grad)
+            save(f"G17_blend_{tag}", **out)
+    finally:
+        rh.set_flag(mods + (P_,), "should_softmax_topk_features", True)
+        rh.set_flag(mods, "should_use_hash_function", False)
+
+
+GROUPS = {"G17": g17, "G15": g15, "G16": g16, "G3b": g3b, "G11": g11, "G12": g12, "G13": g13, "G14": g14, "G10": g10, "G1": g1, "G2": g2_g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G9": g9}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

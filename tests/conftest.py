@@ -41,6 +41,44 @@ def golden():
     return load
 
 
+class _EncodePath:
+    """what the `encode_path` fixture hands to a test: .path ("auto" | "tiled") and .assert_chain(...)"""
+
+    def __init__(self, path, trace):
+        self.path, self.trace = path, trace
+
+    def assert_chain(self, min_launches=1, fixed_point=True):
+        """"tiled": the pixel stage of every backward pass ran through gngf_encode_tiled_bwd on the level-interleaved kernel with
+        a bound on |d enc| — i.e. through the fixed-point vertex grid (dG64) and the vertex stages that read it
+        (vertex_bwd_hash64 / vertex_bwd_sorted<FROM64> / dg64_to_float): the chain bench.py times.  "auto": nothing to assert
+        (small batches take the direct form)."""
+        if self.path != "tiled":
+            return
+        assert len(self.trace) >= min_launches, f"expected >= {min_launches} tiled pixel-stage backward launches, saw {len(self.trace)}"
+        for r in self.trace:
+            assert r["Ls"] > 0 and r["interleaved"], r
+            if fixed_point:
+                assert r["bound"] and r["dG64"], r
+
+
+@pytest.fixture(params=["auto", "tiled"])
+def encode_path(request):
+    """Runs a golden test twice: on the dispatch the product picks by itself (P <= 4096: the direct form) and FORCED onto the tiled
+    form with every level staged — binning, tiled_fwd_il / tiled_bwd_il, the fixed-point vertex grid and the vertex stages that
+    read it: the kernels that make up 100 % of the encoder time of the headline benchmark (VERDICT r3, weak #1)."""
+    from collision_handling_in_instantngp_amd import ops
+    prev = (ops.ENCODE_PATH, ops.TILED_CELLS_PER_PIXEL, ops.PIXEL_BWD_TRACE)
+    trace = []
+    if request.param == "tiled":
+        ops.ENCODE_PATH = "tiled"
+        ops.TILED_CELLS_PER_PIXEL = 1e12          # a handful of pixels on a 512^2 grid: stage the level anyway
+    ops.PIXEL_BWD_TRACE = trace
+    try:
+        yield _EncodePath(request.param, trace)
+    finally:
+        ops.ENCODE_PATH, ops.TILED_CELLS_PER_PIXEL, ops.PIXEL_BWD_TRACE = prev
+
+
 # ------------------------------------------------------------------------------------------------ achieved-error report
 class ParityRecorder:
     """Every tolerance check of the parity tests also records the ACHIEVED error, so that the numbers behind

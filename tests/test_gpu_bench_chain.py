@@ -1,0 +1,301 @@
+"""GPU: the EXACT chain of launches bench.py times, checked against the CPU oracle at full size, plus the cases VERDICT r3 / ADVICE r3
+named as uncovered:
+  * cfg2 / cfg3, P = 2^20, the step as bench.py builds it (bench.build_model + train.GraphedStep + net.fused_mse(gloss=1), both index
+    sources): rgb, ALL 16 x 2^19 table-gradient rows and the six decoder gradients against oracle/gngf_oracle_c.c (pinned by
+    tests/test_oracle_c.py to the numpy oracle, which is pinned to the reference's goldens);
+  * the encoder chain alone on the step's own d enc: every table-gradient row against the double-precision sum of the reference's
+    fp32 terms, with a RELATIVE bound on rows far below the maximum (the fixed-point grid has one scale per launch);
+  * the 4096^2 shape through the MODEL (fused decoder => a bound on |d enc| exists) — the shape whose staged levels do not fit the
+    level-interleaved image, so the generic pixel-stage kernels run and must start from a zeroed vertex grid;
+  * should_softmax_topk_features in {None, False} at model level (golden G17, written by the reference) and at the kernel
+    (gngf_blend_fwd / _bwd codes 1, 2 against oracle.blend_weights and its backward)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import parity_close
+from oracle import c_oracle, gngf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+P = 2 ** 20
+
+
+def _poison_allocator(nbytes=3 << 30):
+    """Fills the caching allocator's free blocks with NaN so that any buffer the step leaves uninitialised (torch.empty) shows:
+    a gradient that reads it is NaN instead of whatever the previous test left there."""
+    blocks = []
+    for sz in (nbytes // 2, nbytes // 4, nbytes // 8, 64 << 20, 16 << 20, 16 << 20, 4 << 20, 4 << 20):
+        blocks.append(torch.full((sz // 4,), float("nan"), dtype=torch.float32, device=DEV))
+    del blocks
+    torch.cuda.synchronize()
+
+
+def _numpy_state(net, L):
+    sd = {k: v.detach().float().cpu().numpy() for k, v in net.state_dict().items() if v.dtype.is_floating_point}
+    tables = np.ascontiguousarray(np.stack([sd[f"encoding._hash_tables.{l}.weight"] for l in range(L)]))
+    dw = [np.ascontiguousarray(sd[f"mlp.{i}.0.weight"]) for i in range(3)]
+    db = [np.ascontiguousarray(sd[f"mlp.{i}.0.bias"]) for i in range(3)]
+    return tables, dw, db
+
+
+def _oracle_step(x, y, n_ls, tables, dw, db, vidx=None, vw=None, vstride=0, genc_override=None):
+    """forward + MSE gradient + backward of the path on the host (C/OpenMP oracle): rgb, d enc, decoder gradients, and the table
+    gradient as the double-precision sum of the reference's fp32 terms."""
+    enc = c_oracle.encode_fwd(x, tables, n_ls, vidx, vw, vstride)
+    rgb, h1, h2 = c_oracle.decoder_fwd(enc, dw, db)
+    drgb = ((2.0 / rgb.size) * (rgb - y)).astype(np.float32)                 # MSELoss backward seeded with 1 (utils.py:99)
+    genc, gdec = c_oracle.decoder_bwd(enc, h1, h2, rgb, drgb, dw)
+    g_used = genc if genc_override is None else genc_override
+    dt64 = c_oracle.encode_bwd_f64(x, tables.shape, n_ls, np.ascontiguousarray(g_used), vidx, vw, vstride)
+    return {"enc": enc, "rgb": rgb, "genc": genc, "gdec": gdec, "dt64": dt64,
+            "mse": float(np.mean((rgb.astype(np.float64) - y) ** 2))}
+
+
+@pytest.mark.skipif(not c_oracle.available(), reason="oracle/libgngf_oracle_c.so not built (make -C oracle)")
+@pytest.mark.parametrize("mode", ["hash", "gngf_frozen"])
+def test_bench_step_at_full_size_matches_the_oracle(mode):
+    """VERDICT r3 item 2(b).  The model, the batch and the step are built by bench.py's own functions; the graph is replayed twice
+    (the second replay is what a timed step is).  The encoder runs binning -> tiled_fwd_il -> decoder_train -> tiled_bwd_il (dG64)
+    -> vertex_bwd_hash64 | vertex_bwd_sorted<FROM64>."""
+    import bench
+    from collision_handling_in_instantngp_amd import models, ops, train
+    cfg = bench.MODES[mode]
+    c = bench.SHAPES[cfg]
+    L, T, F = c["L"], c["T"], c["F"]
+    xy, target, bounds = bench.make_batch(cfg, P, 0, torch.device(DEV))
+    _poison_allocator()
+    trace = []
+    prev_trace, ops.PIXEL_BWD_TRACE = ops.PIXEL_BWD_TRACE, trace
+    try:
+        net, _ = bench.build_model(mode, torch.device(DEV), bounds)
+        # tables at 100x the reference's init (+-1e-4): at the init scale the decoder output barely depends on the encoder and the
+        # table gradient of every row is the same few bits; the kernels do not care, the comparison does
+        with torch.no_grad():
+            net.encoding.packed_tables().mul_(100.0)
+        loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
+        gs = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3, unroll=2)          # as bench.py: several steps per replayed graph
+        res = gs.run_many([(xy, target)] * 2)
+        res = gs.run_many([(xy, target)] * 2)
+        torch.cuda.synchronize()
+        r = res[-1]
+        assert len(trace) >= 2 and all(t_["dG64"] and t_["interleaved"] and t_["Ls"] == L and t_["P"] == P for t_ in trace), trace[:2]
+        assert all(t_["hash_fuse"] == (mode == "hash") and t_["fp32_grid"] == (mode == "hash") for t_ in trace) or mode != "hash", trace[:2]
+        if mode == "gngf_frozen":
+            assert all(not t_["fp32_grid"] for t_ in trace), trace[:2]                # vertex_bwd_sorted reads the fixed-point grid itself
+        tables, dw, db = _numpy_state(net, L)
+        n_ls = np.array(net._n_ls_host, np.int32)
+        vidx = vw = None
+        vstride = 0
+        if mode == "gngf_frozen":
+            tv, ti, w, vstride, NV, order = net._frozen_vertex_table(ops.BLEND_CODES[True])
+            vidx, vw = np.ascontiguousarray(ti.cpu().numpy()), np.ascontiguousarray(w.cpu().numpy())
+        x_np, y_np = np.ascontiguousarray(xy.cpu().numpy()), np.ascontiguousarray(target.cpu().numpy())
+        want = _oracle_step(x_np, y_np, n_ls, tables, dw, db, vidx, vw, vstride)
+        parity_close(r.out, want["rgb"], 0, 1e-5, f"bench step {mode}: rgb, all 2^20 pixels vs C oracle")
+        parity_close(r.mse, want["mse"], 1e-5, 0, f"bench step {mode}: MSE value")
+        got_dt = torch.stack([net.encoding._hash_tables[l].weight.grad for l in range(L)]).double().cpu().numpy()
+        assert np.isfinite(got_dt).all()
+        mx = float(np.abs(want["dt64"]).max())
+        parity_close(got_dt, want["dt64"], 0, 1e-5 * mx, f"bench step {mode}: table gradient, all {L} x 2^19 rows vs C oracle (atol 1e-5 of max)")
+        touched = np.abs(want["dt64"]) > 0
+        assert np.array_equal(got_dt != 0, touched) or (np.abs(got_dt[~touched]).max() == 0), "rows no pixel touches stay exactly zero"
+        names = ["mlp.0.0.weight", "mlp.0.0.bias", "mlp.1.0.weight", "mlp.1.0.bias", "mlp.2.0.weight", "mlp.2.0.bias"]
+        params = dict(net.named_parameters())
+        for nm, wg in zip(names, want["gdec"]):
+            scale = float(np.abs(wg).max()) + 1e-30
+            parity_close(params[nm].grad, wg, 1e-3, 2e-5 * scale, f"bench step {mode}: grad {nm} vs C oracle")
+    finally:
+        ops.PIXEL_BWD_TRACE = prev_trace
+        models.should_use_hash_function = False
+
+
+@pytest.mark.skipif(not c_oracle.available(), reason="oracle/libgngf_oracle_c.so not built (make -C oracle)")
+@pytest.mark.parametrize("mode", ["hash", "gngf_frozen"])
+def test_fixed_point_chain_on_the_steps_own_gradient_keeps_small_rows(mode):
+    """VERDICT r3 weak #3.  The encoder backward of the bench's chain on the d enc the step itself produced (captured with a tensor
+    hook), against the double-precision sum of the reference's fp32 terms g * c (* w) over all 2^20 pixels.  One scale per launch
+    means a quantum of 2^-40 of the BATCH maximum per term: rows at 1e-4 .. 1e-7 of the largest row must still carry a relative
+    accuracy of ~1e-4 (they hold >= 5 digits), which a bound relative to the maximum alone would not show."""
+    import bench
+    from collision_handling_in_instantngp_amd import models, ops
+    cfg = bench.MODES[mode]
+    c = bench.SHAPES[cfg]
+    L, T, F = c["L"], c["T"], c["F"]
+    xy, target, bounds = bench.make_batch(cfg, P, 0, torch.device(DEV))
+    _poison_allocator()
+    trace, captured = [], []
+    prev_trace, ops.PIXEL_BWD_TRACE = ops.PIXEL_BWD_TRACE, trace
+    real_decoder_apply = ops.decoder_apply
+
+    def spy(enc, *a, **kw):
+        enc.register_hook(lambda g: captured.append(g.detach().clone()))
+        return real_decoder_apply(enc, *a, **kw)
+    try:
+        net, _ = bench.build_model(mode, torch.device(DEV), bounds)
+        with torch.no_grad():
+            net.encoding.packed_tables().mul_(100.0)
+        ops.decoder_apply = spy
+        with net.fused_mse(target, gloss=1.0):
+            rgb, _probs, _idx, _c = net(xy, 1.0)
+        loss = ops.mse_loss(rgb, target)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.decoder_apply = real_decoder_apply
+        ops.PIXEL_BWD_TRACE = prev_trace
+        models.should_use_hash_function = False
+    assert len(captured) == 1 and len(trace) == 1 and trace[0]["dG64"] and trace[0]["interleaved"], trace
+    genc = np.ascontiguousarray(captured[0].cpu().numpy())
+    n_ls = np.array(net._n_ls_host, np.int32)
+    vidx = vw = None
+    vstride = 0
+    if mode == "gngf_frozen":
+        tv, ti, w, vstride, NV, order = net._frozen_vertex_table(ops.BLEND_CODES[True])
+        vidx, vw = np.ascontiguousarray(ti.cpu().numpy()), np.ascontiguousarray(w.cpu().numpy())
+    want = c_oracle.encode_bwd_f64(np.ascontiguousarray(xy.cpu().numpy()), (L, T, F), n_ls, genc, vidx, vw, vstride)
+    got = torch.stack([net.encoding._hash_tables[l].weight.grad for l in range(L)]).double().cpu().numpy()
+    mx = float(np.abs(want).max())
+    parity_close(got, want, 0, 2e-6 * mx, f"dG64 chain {mode}: table gradient on the step's own d enc, all rows (atol 2e-6 of max)")
+    a = np.abs(want)
+    small = (a < 1e-4 * mx) & (a > 1e-7 * mx)
+    assert small.sum() > 1000, int(small.sum())
+    rel = np.abs(got[small] - want[small]) / a[small]
+    print(f"[dG64 {mode}] rows in (1e-7, 1e-4) x max: {int(small.sum())}, worst relative error {rel.max():.2e}, median {np.median(rel):.2e}")
+    # hash: a row is one vertex' sum -> only the final fp32 rounding and the 2^-40 quantum show.  Vertex-table source: up to
+    # thousands of vertices meet in a row through fp32 atomics in a different order than the oracle's (the reference's
+    # index_put accumulate is order-dependent too): the bound is that of an fp32 sum of its terms
+    parity_close(got[small], want[small], 2e-4 if mode == "hash" else 2e-3, 0,
+                 f"dG64 chain {mode}: rows between 1e-7 and 1e-4 of the largest row, RELATIVE")
+
+
+@pytest.mark.parametrize("mode", ["hash", "gngf_frozen"])
+@pytest.mark.parametrize("interleaved_off", [False, True])
+def test_model_gradients_when_the_generic_pixel_stage_runs(mode, interleaved_off):
+    """ADVICE r3 (high).  With a bound on |d enc| (every step through the fused decoder has one) the Python side used to hand the
+    C side an UNINITIALISED fp32 vertex grid next to the fixed-point one whenever the level-interleaved kernel did not apply —
+    the 4096^2 shape (297 KB image), or any shape after gngf_set_tiled_interleaved(0) — and the generic kernels accumulated
+    into it.  Now the launcher's own decision (gngf_tiled_interleaved_applies) picks the buffers.  The allocator is poisoned with
+    NaN first; the table gradient of the tiled dispatch must equal the direct form's (float atomics: fp32 round-off)."""
+    import bench
+    from collision_handling_in_instantngp_amd import models, ops, _lib
+    shape = "cfg2" if interleaved_off else "cfg4"
+    c = bench.SHAPES[shape]
+    L, T, F = c["L"], c["T"], c["F"]
+    xy, target, bounds = bench.make_batch(shape, P, 0, torch.device(DEV))
+    models.should_use_hash_function = mode == "hash"
+    prev_il = _lib.query("gngf_set_tiled_interleaved", 0 if interleaved_off else 1)
+    trace = []
+    prev_trace, ops.PIXEL_BWD_TRACE = ops.PIXEL_BWD_TRACE, trace
+    try:
+        torch.manual_seed(7)
+        net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=T, num_levels=L, n_min=c["n_min"], n_max=c["n_max"],
+                                              MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
+                                              HPD_out_features=T, feature_dim=F, topk_k=4).to(DEV)
+        net.return_indices = False
+        net.dense_probs = False
+        if mode == "gngf_frozen":
+            for p_ in net.HPD.parameters():
+                p_.requires_grad = False
+            net.compute_pbar = False
+        with torch.no_grad():
+            net.encoding.packed_tables().mul_(100.0)
+        grads = {}
+        for path in ("tiled", "direct"):
+            net.zero_grad()
+            ops.ENCODE_PATH = path
+            _poison_allocator()
+            try:
+                with net.fused_mse(target, gloss=1.0):
+                    rgb, _p, _i, _c = net(xy, 1.0)
+                ops.mse_loss(rgb, target).backward()
+            finally:
+                ops.ENCODE_PATH = "auto"
+            torch.cuda.synchronize()
+            grads[path] = torch.stack([net.encoding._hash_tables[l].weight.grad for l in range(L)]).clone()
+        assert len(trace) == 1 and not trace[0]["interleaved"] and not trace[0]["dG64"] and trace[0]["bound"], trace
+        assert 0 < trace[0]["Ls"] <= L
+        gt, gd = grads["tiled"], grads["direct"]
+        assert bool(torch.isfinite(gt).all()), "the tiled dispatch read an uninitialised buffer (NaN-poisoned allocator)"
+        mx = float(gd.abs().max())
+        assert mx > 0
+        parity_close(gt, gd, 1e-3, 2e-5 * mx, f"{shape} {mode} interleaved_off={interleaved_off}: model table gradient, tiled (generic kernels) vs direct form")
+    finally:
+        ops.PIXEL_BWD_TRACE = prev_trace
+        _lib.query("gngf_set_tiled_interleaved", prev_il)
+        models.should_use_hash_function = False
+
+
+# ------------------------------------------------------------------------------------------------ blend variants
+def t(a, dtype=None):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(DEV)
+
+
+@pytest.mark.parametrize("tag,flag", [("raw", None), ("norm", False)])
+def test_blend_variants_at_model_level_match_reference(golden, tag, flag, encode_path):
+    """G17, written by the reference: should_softmax_topk_features in {None, False} (models.py:212-217) through
+    GeneralNeuralGaugeFields.forward — the fast path (per-vertex table + gngf_blend_fwd / _bwd codes 1, 2), direct and tiled."""
+    from collision_handling_in_instantngp_amd import models, train
+    g = golden(f"G17_blend_{tag}")
+    models.should_use_hash_function = False
+    prev = models.should_softmax_topk_features
+    models.should_softmax_topk_features = flag
+    try:
+        net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=256, num_levels=4, n_min=8, n_max=32,
+                                              MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
+                                              HPD_out_features=256, feature_dim=2, topk_k=4)
+        sd = net.state_dict()
+        net.load_state_dict({k: (t(g["init_" + k.replace(".", "_")]) if "init_" + k.replace(".", "_") in g else v) for k, v in sd.items()})
+        img = golden("strawberry_rgb")["img"]
+        h, w = img.shape[:2]
+        rows, cols = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+        X = (torch.tensor(np.stack([rows, cols], -1).reshape(-1, 2)).float() / (max(w, h) - 1)).to(DEV)
+        Y = torch.tensor(img.reshape(-1, 3) / 255).float().to(DEV)
+        sl = t(g["perm"])
+        rgb, probs, idx, _ = net(X[sl], 1 / 3)
+        empty = torch.tensor([], device=DEV)
+        mse, kls, coll = train.Loss(delta=1, gamma=-2, epsilon=1)(rgb, Y[sl], probs.shape[-1], probs, empty, empty)
+        loss = train.assemble_loss(mse, kls, coll, 1, 1, 1e-3)
+        loss.backward()
+        parity_close(rgb, g["rgb"], 2e-5, 2e-6, f"G17 {tag} rgb")
+        parity_close(mse, g["mse"], 2e-5, 0, f"G17 {tag} mse")
+        parity_close(kls, g["kls"], 2e-4, 1e-9, f"G17 {tag} JS/KL")
+        parity_close(loss, g["loss"], 2e-5, 0, f"G17 {tag} loss")
+        assert (idx.cpu().numpy() == g["idx"]).mean() > 0.995
+        n = 0
+        for k_, p_ in net.named_parameters():
+            gk = "grad_" + k_.replace(".", "_")
+            if gk in g:
+                scale = np.abs(g[gk]).max() + 1e-30
+                parity_close(p_.grad, g[gk], 5e-3, 2e-4 * scale, f"G17 {tag} grad " + k_)
+                n += 1
+        assert n >= 4 + 8 + 6
+        encode_path.assert_chain()
+    finally:
+        models.should_softmax_topk_features = prev
+
+
+@pytest.mark.parametrize("flag", [True, None, False])
+def test_blend_kernels_all_codes_vs_oracle(flag):
+    """gngf_blend_fwd / _bwd (ops.BlendFunction) against oracle.blend_weights and the oracle's blend backward (the dp branch of
+    oracle.encoding_backward), for the three values of should_softmax_topk_features; K in {1, 4, 7}, rows incl. ragged counts."""
+    from collision_handling_in_instantngp_amd import ops
+    rng = np.random.default_rng(17)
+    for U, K in ((1, 4), (1000, 4), (4099, 7), (257, 1)):
+        q = rng.random((U, K)).astype(np.float32) * (0.5 if K > 1 else 1.0) + 1e-3
+        d = rng.standard_normal((U, K)).astype(np.float32)
+        qt = t(q).requires_grad_(True)
+        w = ops.BlendFunction.apply(qt, ops.BLEND_CODES[flag])
+        w.backward(t(d))
+        parity_close(w, orc.blend_weights(q, flag), 2e-6, 1e-9, f"blend fwd code {ops.BLEND_CODES[flag]} ({U}x{K})")
+        q64, d64 = q.astype(np.float64), d.astype(np.float64)
+        if flag is None:
+            want = d64
+        elif flag:
+            w64 = np.exp(q64 - q64.max(-1, keepdims=True))
+            w64 /= w64.sum(-1, keepdims=True)
+            want = w64 * (d64 - (w64 * d64).sum(-1, keepdims=True))
+        else:
+            s = q64.sum(-1, keepdims=True)
+            want = d64 / s - (d64 * q64).sum(-1, keepdims=True) / (s * s)
+        parity_close(qt.grad, want, 2e-5, 2e-6 * float(np.abs(want).max()), f"blend bwd code {ops.BLEND_CODES[flag]} ({U}x{K})")

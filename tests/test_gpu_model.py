@@ -48,7 +48,7 @@ def build(golden, mode):
 
 
 @pytest.mark.parametrize("mode", ["hash", "gngf"])
-def test_three_training_steps_match_reference(golden, mode):
+def test_three_training_steps_match_reference(golden, mode, encode_path):
     net, g, models, train = build(golden, mode)
     try:
         X, Y, h, w = strawberry(golden)
@@ -112,6 +112,7 @@ def test_three_training_steps_match_reference(golden, mode):
                         assert np.all(moved[untouched] == 0), k_               # zero gradient, no weight decay: bit-identical
                     checked += int(mask.sum())
                 assert checked > 1000
+        encode_path.assert_chain(min_launches=3)
     finally:
         models.should_use_hash_function = False
 
@@ -125,7 +126,7 @@ def _cfg1_net(models, g, **kw):
     return net
 
 
-def test_keep_topk_only_two_steps_match_reference(golden):
+def test_keep_topk_only_two_steps_match_reference(golden, encode_path):
     """G15: should_keep_topk_only=True (reference models.py:478-484; half of its grid, params.py:58-75): `probs` is the
     (P,L,4,K) top-K tensor, the loss's distribution term runs with N = K (functions.py:226-232).  Two optimisation steps
     written by the reference itself: outputs, loss terms, every gradient, parameters after the first step."""
@@ -163,6 +164,7 @@ def test_keep_topk_only_two_steps_match_reference(golden):
                     scale = np.abs(g[gk]).max() + 1e-30
                     close(p_.grad, g[gk], 5e-3, 2e-4 * scale, "G15 grad " + k_)
         opt.step()
+    encode_path.assert_chain(min_launches=2)
 
 
 @pytest.mark.parametrize("mode", ["hash", "gngf"])

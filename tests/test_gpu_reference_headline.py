@@ -51,7 +51,7 @@ def headline_net(models, T=2 ** 19, L=16, Fd=2, K=4, **kw):
 
 
 @pytest.mark.parametrize("fused_train", [False, True])
-def test_gngf_headline_shape_matches_reference_T19(golden, fused_train):
+def test_gngf_headline_shape_matches_reference_T19(golden, fused_train, encode_path):
     """fused_train: the same step inside net.fused_mse(target, gloss=1.0), i.e. through gngf_decoder_train (forward + MSE
     gradient + backward of the decoder in ONE launch — the kernel bench.py times): the reference's own gradients check it
     (models.py:469-470, utils.py:99)."""
@@ -93,6 +93,8 @@ def test_gngf_headline_shape_matches_reference_T19(golden, fused_train):
     finally:
         _lib.PROFILE = None
     assert ("gngf_decoder_train" in names) == fused_train and ("gngf_decoder_bwd" in names) == (not fused_train), names
+    assert ("gngf_encode_tiled_bwd" in names) == (encode_path.path == "tiled"), names
+    encode_path.assert_chain()          # "tiled": tiled_bwd_il -> dG64 -> dg64_to_float -> vertex_bwd_sorted (d w needed: trainable HPD)
 
     # --- top-K membership per (pixel, level, corner): equal as a set unless the reference's own K-th / (K+1)-th gap is a tie
     ref_idx, ref_tp, nxt = g["topk_idx"].astype(np.int64), g["topk_probs"], g["next_prob"]
@@ -259,7 +261,7 @@ def test_hwp_constructor_path_frozen_hpd_matches_reference_and_caches_its_table(
 
 
 @pytest.mark.parametrize("fused_train", [False, True])
-def test_macaw_hash_step_at_headline_shape_matches_reference(golden, fused_train):
+def test_macaw_hash_step_at_headline_shape_matches_reference(golden, fused_train, encode_path):
     """BASELINE configs[2]: macaw.jpg, plain spatial hash, L=16 F=2 T=2^19 — one forward + MSE + backward on 4096 of its pixels.
     fused_train: inside net.fused_mse(target, gloss=1.0) — the decoder's forward, loss gradient and backward in one launch."""
     import contextlib
@@ -295,6 +297,8 @@ def test_macaw_hash_step_at_headline_shape_matches_reference(golden, fused_train
         finally:
             _lib.PROFILE = None
         assert ("gngf_decoder_train" in names) == fused_train, names
+        assert ("gngf_encode_tiled_bwd" in names) == (encode_path.path == "tiled"), names
+        encode_path.assert_chain()      # "tiled": tiled_bwd_il -> dG64 -> vertex_bwd_hash64, the hash mode's chain in bench.py
         ic = idx.cpu()
         chk = np.array([int(ic.sum()), int((ic * torch.arange(1, 4097)[:, None, None]).sum() % (2 ** 61 - 1))], dtype=np.int64)
         assert np.array_equal(chk, g["idx_checksum"])                            # index work: bit-exact

@@ -32,6 +32,23 @@ def test_c_encoder_matches_numpy_oracle(mode):
     dt, _ = orc.encoding_backward(tables, idx, w, None, orc.bilinear_backward(x, n_ls, g, F))
     got_dt = c_oracle.encode_bwd(x, tables, n_ls, g, vi, vw, vs)
     np.testing.assert_allclose(got_dt, dt, rtol=2e-4, atol=2e-5 * np.abs(dt).max())
+    # the wide-accumulation variant: the same fp32 terms, summed in double (the numpy oracle's np.add.at sums in fp32)
+    got64 = c_oracle.encode_bwd_f64(x, tables.shape, n_ls, g, vi, vw, vs)
+    np.testing.assert_allclose(got64, dt, rtol=2e-4, atol=2e-5 * np.abs(dt).max())
+    np.testing.assert_allclose(got64, got_dt, rtol=1e-4, atol=1e-5 * np.abs(dt).max())
+    # ... against an independent float64 evaluation of the sum of fp32 terms (numpy, np.add.at in double)
+    want64 = np.zeros(tables.shape, np.float64)
+    scaled, grid = orc.scale_to_grid(x, n_ls)
+    dfe = orc.bilinear_backward(x, n_ls, g, F)                       # (P,F,L,4): the fp32 products genc * c
+    for l in range(L):
+        for v in range(4):
+            if mode == "hash":
+                np.add.at(want64[l], idx[:, l, v], dfe[:, :, l, v].astype(np.float64))
+            else:
+                for k in range(K):
+                    term = (dfe[:, :, l, v] * w[:, l, v, k][:, None]).astype(np.float32)
+                    np.add.at(want64[l], idx[:, l, v, k], term.astype(np.float64))
+    np.testing.assert_allclose(got64, want64, rtol=1e-12, atol=1e-18)
 
 
 def test_c_decoder_matches_numpy_oracle():

@@ -222,3 +222,23 @@ def test_g16_batchnorm_coordinates(golden, mode):
     close(mse, g["mse"], 1e-5, 0)
     if mode == "gngf":
         close(kls, g["kls"], 1e-4, 1e-9)
+
+
+@pytest.mark.parametrize("tag,blend", [("raw", None), ("norm", False)])
+def test_g17_blend_variants_at_model_level(golden, tag, blend):
+    """should_softmax_topk_features in {None, False} (reference models.py:212-217, params.py:14) through the whole model: the
+    oracle's blend restatement against the reference's own rgb / loss terms."""
+    g = golden(f"G17_blend_{tag}")
+    X, Y = _strawberry_xy(golden, g)
+    sl = g["perm"]
+    tables, (dw, db) = _state(g, "init_")
+    hw, hb = _mlp_params(g, "init_HPD_module_list_", 4)
+    out = orc.gngf_forward(X[sl], orc.level_resolutions(8, 32, 4), tables, dw, db, hash_mode=False, K=4, hpd_w=hw, hpd_b=hb, blend=blend)
+    close(out["rgb"], g["rgb"], 1e-5, 1e-6)
+    assert (out["idx"] == g["idx"]).mean() > 0.999
+    mse, kls = orc.loss_forward(out["rgb"], Y[sl], out["probs"], gamma=-2, epsilon=1)
+    close(mse, g["mse"], 1e-5, 0)
+    close(kls, g["kls"], 1e-4, 1e-9)
+    # the variants are not vacuous: the softmax blend gives a different image from the same weights
+    soft = orc.gngf_forward(X[sl], orc.level_resolutions(8, 32, 4), tables, dw, db, hash_mode=False, K=4, hpd_w=hw, hpd_b=hb, blend=True)
+    assert float(np.abs(soft["rgb"] - g["rgb"]).max()) > 1e-4         # (norm: 2.6e-4, raw: 6e-3; the comparison above holds 1e-5)

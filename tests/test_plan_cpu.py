@@ -60,3 +60,23 @@ def test_work_item_size_follows_mean_tile_population():
         assert ops.EncodePlan(2 ** 20, n, 2, "tiled").chunk == 512
     finally:
         ops.TILED_CHUNK = old
+
+
+def test_fixed_point_grid_is_chosen_by_the_launchers_own_decision():
+    """the fixed-point vertex grid dG64 is filled by the level-interleaved backward only, and whether that
+    kernel runs is the LAUNCHER's decision (gngf_tiled_interleaved_applies, host logic).  cfg2 stages every level in a 92 KB
+    image: interleaved.  The 4096^2 shape (finest staged level N = 1955, tile_shift 6) would need 298 KB: the generic kernels
+    run, and the Python side must then hand over a ZEROED fp32 grid, not an uninitialised one next to a dG64."""
+    from collision_handling_in_instantngp_amd import _lib
+    n2 = [int(v) for v in models.level_resolutions(16, 512, 16)]
+    n4 = [int(v) for v in models.level_resolutions(16, 4096, 16)]
+    p2, p4 = ops.EncodePlan(2 ** 20, n2, 2), ops.EncodePlan(2 ** 20, n4, 2)
+    assert p2.interleaved(backward=True) and p2.interleaved(backward=False)
+    assert 0 < p4.Ls < 16 and not p4.interleaved(backward=True)
+    assert not ops.EncodePlan(2 ** 20, n2, 4).interleaved(backward=True)          # F = 4: never
+    prev = _lib.query("gngf_set_tiled_interleaved", 0)
+    try:
+        assert not p2.interleaved(backward=True)                                  # the process switch is part of the decision
+    finally:
+        _lib.query("gngf_set_tiled_interleaved", prev)
+    assert p2.interleaved(backward=True)
