@@ -102,8 +102,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-full-outputs", dest="full_outputs", action="store_false",
                     help="skip the extra timing of the step with the reference's index tensor materialised")
     ap.add_argument("--no-unroll", dest="unroll", action="store_false", help="one step per replayed graph")
-    ap.add_argument("--unrolls", type=lambda v: tuple(int(x) for x in v.split(",")), default=(4, 5, 6, 7, 8, 3, 2),
-                    help="steps per replayed graph: the first of these that divides --steps")
+    ap.add_argument("--unrolls", type=lambda v: tuple(int(x) for x in v.split(",")), default=(10, 8, 5, 4, 6, 7, 3, 2),
+                    help="steps per replayed graph: the first of these that divides --steps (inside a graph, step j's pixel-stage "
+                         "launches carry the binning of step j + 1's batch; the first step of a replay bins itself)")
     ap.add_argument("--cpu-sample", type=int, default=2 ** 20)
     ap.add_argument("--ramp-steps", type=int, default=60, help="untimed steps before the W warm-up steps (clock ramp)")
     ap.add_argument("--backend", default="nccl", help="rehearsal only: 'gloo' runs the N>1 code path with ranks sharing one GPU")
@@ -266,7 +267,7 @@ def exchange_model(net, world):
             "note": "model: ring all-reduce, 2(n-1)/n x bytes per rank over the point-to-point xGMI links; latency not included"}
 
 
-ENTRY_NAMES = {"gngf_bin_pixels": "bin_pixels", "gngf_encode_tiled_prepare": "prepare(bin+vertex_fwd+clears)", "gngf_vertex_grid_fwd": "vertex_fwd", "gngf_encode_tiled_fwd": "encode_fwd:tiled",
+ENTRY_NAMES = {"gngf_bin_pixels": "bin_pixels", "gngf_bin_pixels2": "bin_pixels(count+scatter)", "gngf_encode_tiled_fwd_fused": "encode_fwd:tiled", "gngf_encode_tiled_prepare": "prepare(bin+vertex_fwd+clears)", "gngf_vertex_grid_fwd": "vertex_fwd", "gngf_encode_tiled_fwd": "encode_fwd:tiled",
                "gngf_encode_tiled_bwd": "encode_bwd:tiled", "gngf_vertex_grid_bwd_sorted": "vertex_bwd", "gngf_vertex_grid_bwd": "vertex_bwd",
                "gngf_decoder_fwd": "decoder_fwd", "gngf_decoder_bwd": "decoder_bwd", "gngf_decoder_train": "decoder_train", "gngf_decoder_reduce": "decoder_reduce", "gngf_mse_fwd": "mse_fwd", "gngf_mse_bwd": "mse_bwd",
                "gngf_encode_fwd": "encode_fwd:direct", "gngf_encode_bwd": "encode_bwd:direct"}

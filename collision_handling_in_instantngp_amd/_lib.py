@@ -33,11 +33,13 @@ SIGNATURES = {
     "gngf_vertex_grid_fwd": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L, _P],
     "gngf_vertex_grid_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L, _P],
     "gngf_encode_tiled_fwd": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gngf_bin_pixels2": [_P, _P, _L, _P],
+    "gngf_encode_tiled_fwd_fused": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _L, _I, _I, _I, _L, _I, _I, _P, _P],
     "gngf_set_tiled_interleaved": [_I],
     "gngf_tiled_interleaved_applies": [_P, _I, _I, _I, _I, _I],
     "gngf_debug_il_stamps": [_P],
     "gngf_encode_tiled_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I,
-                              _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _I, _P],
+                              _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _I, _P, _P],
     "gngf_vertex_grid_bwd_sorted": [_P, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _L, _I, _I, _L, _P],
     "gngf_decoder_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gngf_decoder_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
@@ -79,6 +81,14 @@ SIGNATURES = {
 }
 
 ABI_VERSION = 10
+
+
+class BinJob(ctypes.Structure):
+    """include/gngf.h: gngf_bin_job — one binning job as a host struct (passed by pointer: ctypes.byref)."""
+    _fields_ = [("xy", _P), ("P", _L), ("tile_shift", _I), ("NB", _I), ("chunk", _I), ("blockhist", _P), ("persistent_ws", _P),
+                ("tile_off", _P), ("tile_item_base", _P), ("items", _P), ("n_items", _P), ("sorted", _P)]
+
+
 _RETURNS_INT64 = {"gngf_decoder_hidden_floats", "gngf_slot_bitmap_words"}
 _lib = None
 

@@ -45,25 +45,28 @@ __device__ __forceinline__ int tile_of(float x, float y, int tile_shift) {
 
 // ---------------------------------------------------------------------------------------------- binning
 // K1: per-block histogram over a contiguous pixel range -> blockhist[tile][block]
+// (NT = threads of the calling workgroup: the binning kernels' own 1024, or the 512 of the pixel-stage forward when the count of
+// the NEXT batch rides on its launch — the pixel -> block partition depends on per_block only, not on the thread count)
+template <int NT = kBinThreads>
 __device__ __forceinline__ void bin_count_body(int blk, const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift,
                                                int NB, int32_t* __restrict__ blockhist, int* hist, int32_t* __restrict__ tot_atomic = nullptr) {
   const int ntiles = 1 << (2 * tile_shift);
-  for (int i = threadIdx.x; i < ntiles; i += kBinThreads) hist[i] = 0;
+  for (int i = threadIdx.x; i < ntiles; i += NT) hist[i] = 0;
   __syncthreads();
   const int64_t lo = (int64_t)blk * per_block;
   const int64_t hi = lo + per_block < P ? lo + per_block : P;
   // kBinU pixels per thread and trip, loads issued together: one pixel per trip made the block's time the SUM of eight memory
   // round trips (one workgroup per CU: there is nobody else to hide them)
-  for (int64_t p0 = lo + threadIdx.x; p0 < hi; p0 += (int64_t)kBinU * kBinThreads) {
+  for (int64_t p0 = lo + threadIdx.x; p0 < hi; p0 += (int64_t)kBinU * NT) {
     float2 c[kBinU];
 #pragma unroll
-    for (int u = 0; u < kBinU; ++u) { const int64_t p = p0 + (int64_t)u * kBinThreads; c[u] = xy[p < hi ? p : hi - 1]; }
+    for (int u = 0; u < kBinU; ++u) { const int64_t p = p0 + (int64_t)u * NT; c[u] = xy[p < hi ? p : hi - 1]; }
 #pragma unroll
     for (int u = 0; u < kBinU; ++u)
-      if (p0 + (int64_t)u * kBinThreads < hi) atomicAdd(&hist[tile_of(c[u].x, c[u].y, tile_shift)], 1);
+      if (p0 + (int64_t)u * NT < hi) atomicAdd(&hist[tile_of(c[u].x, c[u].y, tile_shift)], 1);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < ntiles; i += kBinThreads) {
+  for (int i = threadIdx.x; i < ntiles; i += NT) {
     const int c = hist[i];
     blockhist[(int64_t)i * NB + blk] = c;
     if (tot_atomic && c) atomicAdd(tot_atomic + i, c);      // two-launch binning: the tile totals meet in global atomics (bin_scatter2_kernel)
@@ -180,20 +183,19 @@ bin_scatter_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, 
 // cursor (the order of the blocks inside a tile is whatever the atomics make it — as the order of pixels inside a block
 // already is), block 0 also writes the tables the pixel stage reads, and the LAST block out (ticket) puts the workspace back to
 // zero for the next call.  No block ever waits for another block.
-__global__ void __launch_bounds__(kBinThreads)
-bin_scatter2_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB, int chunk,
-                    const int32_t* __restrict__ blockhist, int32_t* __restrict__ pws, int32_t* __restrict__ tile_off,
-                    int32_t* __restrict__ tile_item_base, int4* __restrict__ items, int32_t* __restrict__ n_items,
-                    float4* __restrict__ sorted) {
-  extern __shared__ int cursor[];                 // [ntiles]
-  __shared__ int wsum[kBinThreads / 64], wsum2[kBinThreads / 64];
-  __shared__ int s_last;
+// `cursor` [ntiles], `wsum` / `wsum2` [kBinThreads / 64] and `s_last` live in the caller's LDS (the kernel below, or the tail of the
+// pixel-stage backward when the scatter of the NEXT batch rides there as claimed tasks: tiled_bwd_il_kernel).  pws = [totals
+// ntiles | cursors ntiles | ticket | task-claim counter of the riding form].
+__device__ __forceinline__ void bin_scatter2_body(const int blk, const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift,
+                                                  int NB, int chunk, const int32_t* __restrict__ blockhist, int32_t* __restrict__ pws,
+                                                  int32_t* __restrict__ tile_off, int32_t* __restrict__ tile_item_base,
+                                                  int4* __restrict__ items, int32_t* __restrict__ n_items, float4* __restrict__ sorted,
+                                                  int* cursor, int* wsum, int* wsum2, int* s_last) {
   const int ntiles = 1 << (2 * tile_shift);
   int32_t* tot = pws;
   int32_t* gcur = pws + ntiles;
   int32_t* ticket = pws + 2 * ntiles;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int blk = blockIdx.x;
   const int per = (ntiles + kBinThreads - 1) / kBinThreads;      // consecutive tiles per thread
   // exclusive scans over tiles of (pixels, items), as bin_scan_kernel
   int mytot = 0, myit = 0;
@@ -253,12 +255,24 @@ bin_scatter2_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block,
   }
   // last block out clears the workspace (every block has finished reading the totals and reserving on the cursors by then)
   __syncthreads();
-  if (tid == 0) s_last = atomicAdd(ticket, 1) == NB - 1;
+  if (tid == 0) *s_last = atomicAdd(ticket, 1) == NB - 1;
   __syncthreads();
-  if (s_last) {
+  if (*s_last) {
     for (int t = tid; t < ntiles; t += kBinThreads) { tot[t] = 0; gcur[t] = 0; }
     if (tid == 0) *ticket = 0;
   }
+}
+
+__global__ void __launch_bounds__(kBinThreads)
+bin_scatter2_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB, int chunk,
+                    const int32_t* __restrict__ blockhist, int32_t* __restrict__ pws, int32_t* __restrict__ tile_off,
+                    int32_t* __restrict__ tile_item_base, int4* __restrict__ items, int32_t* __restrict__ n_items,
+                    float4* __restrict__ sorted) {
+  extern __shared__ int cursor[];                 // [ntiles]
+  __shared__ int wsum[kBinThreads / 64], wsum2[kBinThreads / 64];
+  __shared__ int s_last;
+  bin_scatter2_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, chunk, blockhist, pws, tile_off, tile_item_base, items, n_items,
+                    sorted, cursor, wsum, wsum2, &s_last);
 }
 
 // K1 with a ZERO-FILL riding on the launch: workgroups [NB, NB + zblocks) clear `zero` (nvec float4) instead — the gradient
@@ -266,10 +280,11 @@ bin_scatter2_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block,
 // the fill runs on the others, instead of being a launch (or a stream) of its own.
 __global__ void __launch_bounds__(kBinThreads)
 bin_count_ride_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block, int tile_shift, int NB,
-                      int32_t* __restrict__ blockhist, float4* __restrict__ zero, int64_t nvec, int zblocks) {
+                      int32_t* __restrict__ blockhist, float4* __restrict__ zero, int64_t nvec, int zblocks,
+                      int32_t* __restrict__ tot_atomic = nullptr) {
   extern __shared__ int hist[];
   if ((int)blockIdx.x < NB) {
-    bin_count_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, hist);
+    bin_count_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, hist, tot_atomic);
     return;
   }
   const int64_t zb = (int)blockIdx.x - NB;
@@ -847,25 +862,79 @@ __device__ __forceinline__ void il_setup(ILMeta& m, int Ls, int tx, int ty, int 
 // `chunk` pixels of one tile each); the next item's record is requested before the current item is processed.  (Claiming
 // items through a global counter was tried: the atomic's round trip sat in front of every item's first barrier.)
 
-template <bool L16, int U>
+// Where the vertex values of the staged sub-grids come from (template parameter SRC of the forward kernel):
+//   0  the vertex grid G written by the vertex stage forward (vertex_fwd_kernel / the riders of the binning launches);
+//   1  the level tables themselves, spatial-hash source:   G_l[v] = E_l[hash(v)]                 (models.py:504-528, 181-191)
+//   2  the level tables, vertex-table source:              G_l[v] = sum_k w_k(v) E_l[idx_k(v)]   (models.py:193-222)
+// With 1 and 2 the vertex stage forward is FUSED into the staging loop — the same separately rounded operations in the same
+// order as vertex_fwd_lane, so enc is bit-identical — and its launch (14-18 us of L2 latency inside a step) and the G round
+// trip disappear: the gathers of a work item are in flight together and hide among the two to three workgroups of a CU.
+struct VertexSrc {
+  const float* G;
+  const float* tables;            // (L, T, 2) fp32
+  const int32_t* vert_idx;        // (NV, K)
+  const float* vert_w;            // (NV, K)
+  int64_t T, NV;
+  int K, vstride;
+  bool pow2;
+};
+
+// The COUNT of the NEXT batch's binning riding on the forward launch: workgroups [0, NB) run bin_count_body on that batch's
+// coordinates (histogram per block + the tile totals in global atomics of its persistent workspace) instead of a work item.
+// The forward is bound by its 128 MiB of enc stores; the count reads 8 MiB and works in LDS atomics.  NB = 0: none.
+struct BinCountRide {
+  const float2* xy;
+  int64_t P, per_block;
+  int NB, tile_shift;
+  int32_t* blockhist;
+  int32_t* pws;                   // [totals ntiles | cursors ntiles | ticket | claim]
+};
+
+template <int SRC>
+__device__ __forceinline__ v2f vertex_value(const VertexSrc& vs, int l, int gx, int gy, int64_t goff, int gw) {
+  if constexpr (SRC == 0) {
+    return reinterpret_cast<const v2f*>(vs.G)[goff + (int64_t)gy * gw + gx];
+  } else if constexpr (SRC == 1) {
+    return reinterpret_cast<const v2f*>(vs.tables)[(int64_t)l * vs.T + spatial_hash(gx, gy, vs.T, vs.pow2)];
+  } else {
+    v2f acc = {0.f, 0.f};
+    const int64_t vid = (int64_t)gy * vs.vstride + gx;
+    if (gx < vs.vstride && vid < vs.NV) {
+      const v2f* tab = reinterpret_cast<const v2f*>(vs.tables) + (int64_t)l * vs.T;
+      for (int k = 0; k < vs.K; ++k) {
+        const float w = vs.vert_w[vid * vs.K + k];
+        acc = acc + tab[vs.vert_idx[vid * vs.K + k]] * w;            // (vertex_fwd_lane: acc[f] += row[f] * w, k ascending)
+      }
+    }
+    return acc;
+  }
+}
+
+template <bool L16, int U, int SRC = 0>
 __global__ void __launch_bounds__(kTBF)
 tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ items, const int32_t* __restrict__ n_items,
-                    int32_t* __restrict__ counter, const int32_t* __restrict__ n_ls, const float* __restrict__ G,
-                    float* __restrict__ enc, int L, int Ls, int tile_shift, int nwork) {
+                    int32_t* __restrict__ counter, const int32_t* __restrict__ n_ls, const VertexSrc vs,
+                    float* __restrict__ enc, int L, int Ls, int tile_shift, int nwork, const BinCountRide cride) {
   constexpr int F = 2;
   extern __shared__ float2 img_raw[];             // [rows][kIL]: (feature 0, feature 1) of vertex `row` of level `column`
   v2f* img = reinterpret_cast<v2f*>(img_raw);
   __shared__ ILMeta m;
+  if ((int)blockIdx.x < cride.NB) {               // riders first: they start at once and the work items fill in around them
+    if (blockIdx.x == 0 && threadIdx.x == 0) cride.pws[2 * (1 << (2 * cride.tile_shift)) + 1] = 0;      // the scatter riders' task counter
+    bin_count_body<kTBF>((int)blockIdx.x, cride.xy, cride.P, cride.per_block, cride.tile_shift, cride.NB, cride.blockhist,
+                         reinterpret_cast<int*>(img_raw), cride.pws);
+    return;
+  }
+  const int wg = (int)blockIdx.x - cride.NB;
   const int tid = threadIdx.x;
   const int nit = *n_items;
   const int TSm = (1 << tile_shift) - 1;
   constexpr int ppp = kTBF / kIL;                 // pixels per pass: lane = 16 * pixel + level
   const int lp = tid >> 4, l = tid & 15;
   const int LF = L16 ? 32 : L * F, LF2 = LF / 2;
-  const v2f* G2 = reinterpret_cast<const v2f*>(G);
   if (tid < kIL) m.nls[tid] = tid < Ls ? n_ls[tid] : 0;
-  int4 it_next = items[(int)blockIdx.x < nit ? (int)blockIdx.x : 0];
-  for (int item = blockIdx.x; item < nit; item += nwork) {
+  int4 it_next = items[wg < nit ? wg : 0];
+  for (int item = wg; item < nit; item += nwork) {
     const int4 it = it_next;
     it_next = items[item + nwork < nit ? item + nwork : item];
     __syncthreads();                              // (the previous item's image is no longer read; m.nls is there)
@@ -878,7 +947,7 @@ tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
       // Flattened over (level, vertex) — element e of the compact image — three elements per thread and pass, their loads in
       // flight together; the level of e by a 4-step binary search over the compact starts (m.loff / 2, non-decreasing).
       const int used_v = m.used / F;
-      auto locate = [&](int e, int& lv, int& i, unsigned& off) {
+      auto locate = [&](int e, int& lv, int& i, int& gx, int& gy) {
         int q = (e >= (m.loff[8] >> 1) && 8 < Ls) ? 8 : 0;
         if (q + 4 < Ls && e >= (m.loff[q + 4] >> 1)) q += 4;
         if (q + 2 < Ls && e >= (m.loff[q + 2] >> 1)) q += 2;
@@ -887,17 +956,53 @@ tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
         i = e - (m.loff[q] >> 1);
         const int wx = m.wx[q];
         const int iy = (int)(((float)i + 0.5f) * (1.0f / (float)wx)), ix = i - iy * wx;
-        off = (unsigned)((int)m.goff[q] + __mul24(m.cy[q] + iy, m.n[q] + 2) + m.cx[q] + ix);
+        gx = m.cx[q] + ix; gy = m.cy[q] + iy;
       };
       for (int base = 0; base < used_v; base += 3 * kTBF) {
-        int lv[3], iv[3];
-        unsigned off[3];
+        int lv[3], iv[3], gx[3], gy[3];
         v2f val[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const int e = base + k * kTBF + tid;
-          locate(e < used_v ? e : used_v - 1, lv[k], iv[k], off[k]);
-          val[k] = G2[off[k]];
+          locate(e < used_v ? e : used_v - 1, lv[k], iv[k], gx[k], gy[k]);
+        }
+        if constexpr (SRC == 2) {
+          if (vs.K == 4) {
+            // the usual K: the four (slot, weight) pairs of a vertex are one 16-byte load each, and all twelve table rows of
+            // the thread's three vertices are requested before the first is used
+            int4 id[3];
+            float4 ww[3];
+            bool ok[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const int64_t vid = (int64_t)gy[k] * vs.vstride + gx[k];
+              ok[k] = gx[k] < vs.vstride && vid < vs.NV;
+              const int64_t v = ok[k] ? vid : 0;
+              id[k] = reinterpret_cast<const int4*>(vs.vert_idx)[v];
+              ww[k] = reinterpret_cast<const float4*>(vs.vert_w)[v];
+            }
+            v2f r[3][4];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const v2f* tab = reinterpret_cast<const v2f*>(vs.tables) + (int64_t)lv[k] * vs.T;
+              r[k][0] = tab[id[k].x]; r[k][1] = tab[id[k].y]; r[k][2] = tab[id[k].z]; r[k][3] = tab[id[k].w];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              v2f acc = {0.f, 0.f};
+              acc = acc + r[k][0] * ww[k].x;
+              acc = acc + r[k][1] * ww[k].y;
+              acc = acc + r[k][2] * ww[k].z;
+              acc = acc + r[k][3] * ww[k].w;
+              val[k] = ok[k] ? acc : (v2f){0.f, 0.f};
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) val[k] = vertex_value<2>(vs, lv[k], gx[k], gy[k], 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) val[k] = vertex_value<SRC>(vs, lv[k], gx[k], gy[k], m.goff[lv[k]], m.n[lv[k]] + 2);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -907,7 +1012,7 @@ tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
     __syncthreads();
     if (l < Ls) {
       const int n = m.n[l], cx = m.cx[l], cy = m.cy[l], wx = m.wx[l], wy = m.wy[l], gw = n + 2;
-      const float* Gl = G + m.goff[l] * F;
+      const int64_t goff_l = m.goff[l];
       const v2f* col = img + l;                   // this level's column
       v2f* enc_l = reinterpret_cast<v2f*>(enc) + l;
       const float fn = (float)n;
@@ -931,8 +1036,8 @@ tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
             int vx = cc.gx + (q & 1), vy = cc.gy + (q >> 1);
             vx = vx < 0 ? 0 : (vx > n + 1 ? n + 1 : vx);
             vy = vy < 0 ? 0 : (vy > n + 1 ? n + 1 : vy);
-#pragma unroll
-            for (int f = 0; f < F; ++f) vv[q][f] = Gl[((int64_t)vy * gw + vx) * F + f];
+            const v2f g = vertex_value<SRC>(vs, l, vx, vy, goff_l, gw);
+            vv[q][0] = g.x; vv[q][1] = g.y;
           }
         }
         float* o = enc + (int64_t)__float_as_int(sv.z) * LF + l * F;
@@ -1003,17 +1108,36 @@ tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
 // grid with global integer atomics (fire and forget: they drain while other workgroups compute) — no partial images, no gather
 // pass; the sums are exact and order-free, so the vertex-grid gradient is bitwise reproducible.  dG64[vtot * F] = the scale S,
 // dG64[vtot * F + 1] != 0: poisoned (non-finite gradient or broken promise) — read by the kernels that turn dG64 into fp32.
+// The SCATTER of the NEXT batch's binning (bin_scatter2_body; its count rode on the forward launch: BinCountRide) as tasks the
+// persistent workgroups claim from a counter once their own work items are done.  The items are about equally heavy and there
+// are 2.6 of them per workgroup at the headline shape, so two workgroups in five finish a third of the launch early: the
+// tasks run in that hole instead of in two launches of their own at the head of the next step (binning depends on the
+// coordinates only, and the batches of an epoch are fixed slices of one permutation, known in advance: functions.py:186-194).
+// No task waits for another one (the totals were completed by the previous launch); NB = 0: none.
+struct BinScatterRide {
+  const float2* xy;
+  int64_t P, per_block;
+  int NB, tile_shift, chunk;
+  const int32_t* blockhist;
+  int32_t* pws;                   // [totals ntiles | cursors ntiles | ticket | claim]
+  int32_t *tile_off, *tile_item_base;
+  int4* items;
+  int32_t* n_items;
+  float4* sorted;
+};
+
 template <bool L16>
 __global__ void __launch_bounds__(kTB)
 tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ items, const int32_t* __restrict__ n_items,
                     int32_t* __restrict__ counter, const int32_t* __restrict__ n_ls, const float* __restrict__ genc,
                     float* __restrict__ dG, float* __restrict__ partials, const float* __restrict__ gmax_hint, int hint_count,
                     int hint_stride, int L, int Ls, int tile_shift, int lds_floats, int rows2, int log2_chunk, int nwork,
-                    RideAlong ride, MseRide mride, unsigned long long* __restrict__ dG64) {
+                    RideAlong ride, MseRide mride, unsigned long long* __restrict__ dG64, const BinScatterRide bride) {
   constexpr int F = 2;
   extern __shared__ unsigned long long accil[];   // [rows2][kIL], then the compact fp32 image of the store pass
   __shared__ ILMeta m;
   __shared__ float wmax[kTB / 64];
+  __shared__ int s_task;
   if (mride.pred && (int)blockIdx.x >= mride.first_block) {
     mse_sum_block((int)blockIdx.x - mride.first_block, mride.nblocks, mride.pred, mride.label, mride.loss, mride.acc, mride.counter,
                   mride.n);
@@ -1276,6 +1400,23 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
     }
     IL_STAMP(5);
     IL_STAMP_ITEM(it.y);
+  }
+  if (bride.NB > 0) {
+    // the next batch's scatter tasks, claimed one at a time (the accumulator image is free: its LDS holds the task's cursors)
+    static_assert(kTB == kBinThreads, "bin_scatter2_body is written for the binning kernels' workgroup size");
+    int* sh = reinterpret_cast<int*>(accil);
+    const int ntiles_b = 1 << (2 * bride.tile_shift);
+    int32_t* claim = bride.pws + 2 * ntiles_b + 1;
+    for (;;) {
+      __syncthreads();                            // the previous task (or the last item's store pass) is done with the LDS
+      if (tid == 0) s_task = atomicAdd(claim, 1);
+      __syncthreads();
+      const int task = s_task;
+      if (task >= bride.NB) break;
+      bin_scatter2_body(task, bride.xy, bride.P, bride.per_block, bride.tile_shift, bride.NB, bride.chunk, bride.blockhist, bride.pws,
+                        bride.tile_off, bride.tile_item_base, bride.items, bride.n_items, bride.sorted, sh, sh + ntiles_b,
+                        sh + ntiles_b + kBinThreads / 64, sh + ntiles_b + 2 * (kBinThreads / 64));
+    }
   }
 }
 
@@ -1822,7 +1963,7 @@ extern "C" int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, 
   if (interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, false)) {
     const size_t smem = (size_t)interleaved_rows(n_ls_host, Ls, tile_shift) * kIL * 8;
     const int pv = g_tiled_interleaved;
-    auto fn = (L == 16) ? (pv == 3 ? tiled_fwd_il_kernel<true, 4> : tiled_fwd_il_kernel<true, 2>) : tiled_fwd_il_kernel<false, 2>;
+    auto fn = (L == 16) ? (pv == 3 ? tiled_fwd_il_kernel<true, 4, 0> : tiled_fwd_il_kernel<true, 2, 0>) : tiled_fwd_il_kernel<false, 2, 0>;
     if (smem > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
@@ -1831,9 +1972,11 @@ extern "C" int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, 
     const int per_cu = (int)((150 * 1024) / (smem + 2048)) < 1 ? 1 : (int)((150 * 1024) / (smem + 2048));
     (void)per_cu;
     const int nwork = max_items;                   // forward: one item per workgroup (two to three workgroups share a CU)
+    const VertexSrc vs = {G, nullptr, nullptr, nullptr, 0, 0, 0, 0, false};
+    const BinCountRide none = {nullptr, 0, 0, 0, 0, nullptr, nullptr};
     fn<<<dim3((unsigned)nwork), dim3(kTBF), smem, as_stream(stream)>>>(
-        reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, const_cast<int32_t*>(n_items) + 1, n_ls, G,
-        enc, L, Ls, tile_shift, nwork);
+        reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, const_cast<int32_t*>(n_items) + 1, n_ls, vs,
+        enc, L, Ls, tile_shift, nwork, none);
     GNGF_RETURN_LAUNCH();
   }
   DISPATCH_F(F, {
@@ -1849,6 +1992,77 @@ extern "C" int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, 
   GNGF_RETURN_LAUNCH();
 }
 
+static bool bin_job_ok(const gngf_bin_job* j) {
+  return j && j->xy && j->P > 0 && j->P < (1ll << 31) && j->tile_shift >= 0 && j->tile_shift <= 6 && j->NB > 0 && j->NB <= kBinMaxBlocks &&
+         j->chunk > 0 && j->blockhist && j->persistent_ws && j->tile_off && j->tile_item_base && j->items && j->n_items && j->sorted;
+}
+static int64_t bin_per_block(int64_t P, int NB) { return ceil_div(ceil_div(P, NB), kBinThreads) * kBinThreads; }
+
+// Binning alone in TWO launches (count -> scatter, the scans ride inside the scatter launch: bin_scatter2_kernel) — the form the
+// step uses when the vertex stage forward is fused into the pixel stage (gngf_encode_tiled_fwd_fused) and nothing else has to
+// ride on the binning.  zero_fill (optional; zero_floats floats, a multiple of 4, 16-byte aligned): cleared by rider workgroups
+// of the count launch.
+extern "C" int gngf_bin_pixels2(const gngf_bin_job* job, float* zero_fill, int64_t zero_floats, void* stream) {
+  GNGF_CHECK_ARG(bin_job_ok(job));
+  GNGF_CHECK_ARG(!zero_fill || (zero_floats >= 0 && (zero_floats & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_fill) & 15) == 0));
+  const int ntiles = 1 << (2 * job->tile_shift);
+  const int64_t per_block = bin_per_block(job->P, job->NB);
+  hipStream_t s = as_stream(stream);
+  const size_t smem = (size_t)ntiles * sizeof(int);
+  const float2* xy2 = reinterpret_cast<const float2*>(job->xy);
+  const int64_t nvec = zero_fill ? zero_floats / 4 : 0;
+  const int zblocks = nvec > 0 ? (int)(ceil_div(nvec, 4096) < 1024 ? ceil_div(nvec, 4096) : 1024) : 0;
+  bin_count_ride_kernel<<<dim3((unsigned)(job->NB + zblocks)), dim3(kBinThreads), smem, s>>>(
+      xy2, job->P, per_block, job->tile_shift, job->NB, job->blockhist, reinterpret_cast<float4*>(zero_fill), nvec, zblocks > 0 ? zblocks : 1,
+      job->persistent_ws);
+  bin_scatter2_kernel<<<dim3(job->NB), dim3(kBinThreads), smem, s>>>(xy2, job->P, per_block, job->tile_shift, job->NB, job->chunk,
+                                                                   job->blockhist, job->persistent_ws, job->tile_off, job->tile_item_base,
+                                                                   reinterpret_cast<int4*>(job->items), job->n_items,
+                                                                   reinterpret_cast<float4*>(job->sorted));
+  GNGF_RETURN_LAUNCH();
+}
+
+// Pixel stage forward with the vertex stage forward FUSED into its staging loop (level-interleaved kernel only: F = 2, fp32
+// tables, <= 16 staged levels whose image fits the LDS — gngf_tiled_interleaved_applies(…, 0) — anything else is rejected):
+// the staged sub-grids are gathered from the level tables themselves (mode / vert_idx / vert_w / vstride / NV as
+// gngf_vertex_grid_fwd), same arithmetic in the same order, so enc equals gngf_vertex_grid_fwd + gngf_encode_tiled_fwd bit for
+// bit.  next_count (optional): the COUNT half of another batch's binning (its per-block histograms and tile totals) runs in
+// extra workgroups at the head of this launch; its scatter half rides on gngf_encode_tiled_bwd(…, next_bin).
+extern "C" int gngf_encode_tiled_fwd_fused(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
+                                           const int32_t* n_ls, const int32_t* n_ls_host, const void* tables, int feat_dtype,
+                                           const int32_t* vert_idx, const float* vert_w, float* enc, int L, int Ls, int F, int64_t T,
+                                           int K, int mode, int vstride, int64_t NV, int tile_shift, int lds_bytes,
+                                           const gngf_bin_job* next_count, void* stream) {
+  GNGF_CHECK_ARG(max_items >= 0 && L > 0 && Ls > 0 && Ls <= L && L <= GNGF_MAX_LEVELS && lds_bytes >= 0 && lds_bytes <= 128 * 1024);
+  GNGF_CHECK_ARG(!next_count || bin_job_ok(next_count));
+  if (max_items == 0 && !next_count) return 0;
+  GNGF_CHECK_ARG(sorted && items && n_items && n_ls && n_ls_host && tables && enc && T > 0 && feat_dtype == GNGF_FEAT_F32);
+  GNGF_CHECK_ARG(mode == GNGF_MODE_HASH || (vert_idx && vert_w && K > 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0));
+  GNGF_CHECK_ARG(interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, false));
+  size_t smem = (size_t)interleaved_rows(n_ls_host, Ls, tile_shift) * kIL * 8;
+  BinCountRide cride = {nullptr, 0, 0, 0, 0, nullptr, nullptr};
+  if (next_count) {
+    cride.xy = reinterpret_cast<const float2*>(next_count->xy); cride.P = next_count->P;
+    cride.per_block = bin_per_block(next_count->P, next_count->NB); cride.NB = next_count->NB; cride.tile_shift = next_count->tile_shift;
+    cride.blockhist = next_count->blockhist; cride.pws = next_count->persistent_ws;
+    const size_t hist = sizeof(int) << (2 * next_count->tile_shift);
+    smem = smem < hist ? hist : smem;
+  }
+  const bool hash = mode == GNGF_MODE_HASH;
+  const VertexSrc vs = {nullptr, static_cast<const float*>(tables), vert_idx, vert_w, T, NV, K, vstride, (T & (T - 1)) == 0};
+  auto fn = hash ? ((L == 16) ? tiled_fwd_il_kernel<true, 2, 1> : tiled_fwd_il_kernel<false, 2, 1>)
+                 : ((L == 16) ? tiled_fwd_il_kernel<true, 2, 2> : tiled_fwd_il_kernel<false, 2, 2>);
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int nwork = max_items;
+  fn<<<dim3((unsigned)(cride.NB + nwork)), dim3(kTBF), smem, as_stream(stream)>>>(
+      reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, const_cast<int32_t*>(n_items) + 1, n_ls, vs,
+      enc, L, Ls, tile_shift, nwork, cride);
+  GNGF_RETURN_LAUNCH();
+}
+
 extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
                                      const int32_t* tile_item_base, const int32_t* tile_level_off, const int32_t* n_ls,
                                      const int32_t* n_ls_host, const float* genc, const float* genc_absmax, int absmax_count,
@@ -1858,8 +2072,11 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
                                      int ride_in_dim, int ride_out_dim, const float* gloss_promised, const float* gloss_arrived,
                                      const float* mse_pred, const float* mse_label,
                                      float* mse_loss, float* mse_workspace, int64_t mse_n, float* hash_dtables, int64_t hash_T,
-                                     void* dG64, int log2_pixels, void* stream) {
+                                     void* dG64, int log2_pixels, const gngf_bin_job* next_bin, void* stream) {
   GNGF_CHECK_ARG(!hash_dtables || hash_T > 0);
+  // the scatter half of another batch's binning rides in the tail of the persistent interleaved kernel only
+  GNGF_CHECK_ARG(!next_bin || (bin_job_ok(next_bin) && max_items > 0 && n_ls_host &&
+                               interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, true)));
   const bool hpow2 = hash_dtables && (hash_T & (hash_T - 1)) == 0;
   GNGF_CHECK_ARG(max_items >= 0 && L > 0 && Ls > 0 && Ls <= L && L <= GNGF_MAX_LEVELS && lds_bytes >= 0 && lds_bytes <= 64 * 1024);
   GNGF_CHECK_ARG(!gloss_promised == !gloss_arrived);
@@ -1901,9 +2118,18 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
     for (int l = 0; l < Ls; ++l) vtot_h += (int64_t)(n_ls_host[l] + 2) * (n_ls_host[l] + 2);
   if (max_items > 0 && interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, true)) {
     const int rows2 = 2 * interleaved_rows(n_ls_host, Ls, tile_shift);
-    const size_t smem = (size_t)rows2 * kIL * 8 + (size_t)lds_bytes;          // accumulators + the compact fp32 image of the store pass
-    const int pv = g_tiled_interleaved;
-    (void)pv;
+    size_t smem = (size_t)rows2 * kIL * 8 + (size_t)lds_bytes;          // accumulators + the compact fp32 image of the store pass
+    BinScatterRide bride = {nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (next_bin) {
+      bride.xy = reinterpret_cast<const float2*>(next_bin->xy); bride.P = next_bin->P;
+      bride.per_block = bin_per_block(next_bin->P, next_bin->NB); bride.NB = next_bin->NB; bride.tile_shift = next_bin->tile_shift;
+      bride.chunk = next_bin->chunk; bride.blockhist = next_bin->blockhist; bride.pws = next_bin->persistent_ws;
+      bride.tile_off = next_bin->tile_off; bride.tile_item_base = next_bin->tile_item_base;
+      bride.items = reinterpret_cast<int4*>(next_bin->items); bride.n_items = next_bin->n_items;
+      bride.sorted = reinterpret_cast<float4*>(next_bin->sorted);
+      const size_t need = (sizeof(int) << (2 * next_bin->tile_shift)) + sizeof(int) * (2 * (kBinThreads / 64) + 1);
+      smem = smem < need ? need : smem;
+    }
     auto fn = (L == 16) ? tiled_bwd_il_kernel<true> : tiled_bwd_il_kernel<false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
@@ -1917,7 +2143,7 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
     fn<<<dim3((unsigned)(nwork + ride_blocks)), dim3(kTB), smem, as_stream(stream)>>>(
         reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, const_cast<int32_t*>(n_items) + 2, n_ls,
         genc, dG, partials, genc_absmax, absmax_count, absmax_stride, L, Ls, tile_shift, lds_bytes / 4, rows2,
-        g64 ? log2_pixels : log2_chunk, nwork, ride, mride, g64);
+        g64 ? log2_pixels : log2_chunk, nwork, ride, mride, g64, bride);
     if (g64) {
       if (hash_dtables)
         vertex_bwd_hash64_kernel<2><<<dim3((unsigned)ceil_div(vtot_h, 256)), dim3(256), 0, as_stream(stream)>>>(

@@ -643,6 +643,46 @@ class TableViewFunction(torch.autograd.Function):
 ENCODE_PATH = "auto"        # "auto" | "direct" | "tiled"  (tests force a path; auto = tiled when it pays)
 
 
+class BinPipeline:
+    """Binning of the NEXT batch on the pixel-stage launches of the current step (one per model, `net.dp.pipeline`).  Binning
+    depends on the coordinates only, and the batches of an epoch are fixed slices of one permutation, known in advance
+    (reference functions.py:186-194): the caller that owns the loop (train.GraphedStep(unroll=k), train.train_epoch) announces
+    the coordinates of the next batch before it runs the current one:
+
+        net.dp.pipeline.announce(next_xy)      # (P,2) fp32 device tensor that the NEXT forward pass will be called with
+        ... forward + backward of the current batch ...
+
+    The encoder then runs the count half of that batch's binning in extra workgroups of its forward launch and the scatter half
+    as tasks in the tail of its backward launch, and the next forward pass — if it is called with that very tensor, unmodified —
+    finds its pixels binned.  Anything else (another tensor, an in-place edit, another shape, no backward pass in between) falls
+    back to binning at the head of the step: results never depend on the pipeline."""
+
+    def __init__(self):
+        self.next_xy = None       # announced coordinates of the next batch
+        self.ready = None         # (key, workspace) binned by the previous step's riders
+        self.pending = None       # count half launched (forward), scatter half not yet (backward has not run)
+        self.hits = self.misses = 0
+
+    @staticmethod
+    def _key(xy, plan):
+        return (xy.data_ptr(), xy._version, tuple(xy.shape), str(xy.device), plan.geometry())
+
+    def announce(self, xy):
+        self.next_xy = xy
+
+    def reset(self):
+        self.next_xy = self.ready = None
+
+    def take(self, xy, plan):
+        """the workspace the previous step's riders filled for exactly this tensor and plan, or None"""
+        r, self.ready = self.ready, None
+        if r is not None and r[0] == self._key(xy, plan):
+            self.hits += 1
+            return r[1]
+        self.misses += 1
+        return None
+
+
 class DataParallel:
     """Data-parallel state of ONE model (its `dp` attribute; parallel.enable_vertex_grid_exchange / defer_vertex_stage set it
     up).  It travels with every call as an argument and the bookkeeping of a backward pass is written here, not into the
@@ -664,6 +704,7 @@ class DataParallel:
         self.comm_stream = None
         self.comm_done = None
         self.bin_ws = {}                # persistent counters of the two-launch binning (ops._bin_workspace)
+        self.pipeline = BinPipeline()   # the next batch's binning riding on this step's pixel-stage launches
         self.world = 1
         self.group = None
 
@@ -794,6 +835,10 @@ class EncodePlan:
         self.vtot = sum((n + 2) ** 2 for n in self.n_ls_host[:Ls])
         self.n_ls_c = (_ct.c_int32 * L)(*self.n_ls_host)
 
+    def geometry(self):
+        """what a binned workspace depends on besides the coordinates"""
+        return (self.P, tuple(self.n_ls_host[:self.Ls]), self.F, self.Ls, self.tile_shift, self.chunk, self.NB, self.max_items)
+
     def interleaved(self, backward):
         """True when the launcher will run the level-interleaved pixel-stage kernel for this plan (the library's own decision —
         gngf_tiled_interleaved_applies: F = 2, <= 16 staged levels, the image fits the LDS, the process switch is on).  Only
@@ -827,7 +872,7 @@ def _bin_workspace(dev, ntiles, owner=None):
             warnings.warn("gngf: the two-launch binning's counters were first needed inside a hipGraph capture; this graph uses "
                           "the four-launch binning (run one eager step of the model before capturing)", RuntimeWarning, stacklevel=3)
             return None
-        w = store[key] = torch.zeros((2 * int(ntiles) + 1,), dtype=_i32, device=dev)
+        w = store[key] = torch.zeros((2 * int(ntiles) + 2,), dtype=_i32, device=dev)
     return w
 
 
@@ -839,17 +884,21 @@ def _drop_bin_workspace(dev, ntiles, owner=None):
 class TiledWorkspace:
     """Device buffers of one forward/backward pair (binning result is shared by both)."""
 
-    def __init__(self, plan, xy, vertex=None, zero_dG=None, zero=None, zero_dG_words=1, owner=None):
+    def __init__(self, plan, xy, vertex=None, zero_dG=None, zero=None, zero_dG_words=1, owner=None, launch=True):
         """vertex = (tables, vert_idx, vert_w, n_ls, vstride, G): also run the vertex stage forward into G (riding on the binning
-        launches); zero_dG (same shape as G) and zero (any fp32 buffer, typically the table gradient): cleared on the way."""
+        launches); zero_dG (same shape as G) and zero (any fp32 buffer, typically the table gradient): cleared on the way.
+        launch=False: buffers only (filled by bin2(), or by another step's riders through job())."""
         dev = xy.device
         P = plan.P
+        self._job = None
         self.blockhist = torch.empty((plan.ntiles * (plan.NB + 1),), dtype=_i32, device=dev)
         self.tile_off = torch.empty((plan.ntiles + 1,), dtype=_i32, device=dev)
         self.tile_item_base = torch.empty((plan.ntiles + 1,), dtype=_i32, device=dev)
         self.items = torch.empty((plan.max_items, 4), dtype=_i32, device=dev)
         self.n_items = torch.empty((4,), dtype=_i32, device=dev)      # [0] items; [1..3] counters of the persistent pixel-stage kernels
         self.sorted = torch.empty((max(P, 1), 4), dtype=_f32, device=dev)
+        if not launch:
+            return
         if vertex is None:
             call("gngf_bin_pixels", ptr(xy, _f32, "xy"), P, plan.tile_shift, plan.NB, plan.chunk, ptr(self.blockhist),
                  ptr(self.tile_off), ptr(self.tile_item_base), ptr(self.items), ptr(self.n_items), ptr(self.sorted), stream_ptr())
@@ -873,6 +922,15 @@ class TiledWorkspace:
                 # next step gets a fresh (zeroed) workspace instead of binning with dirty totals
                 _drop_bin_workspace(dev, plan.ntiles, owner)
                 raise
+
+
+def _bin_job(ws, plan, xy, pws):
+    """gngf_bin_job of binning `xy` into workspace `ws` (kept on the workspace: the struct and the tensors it points to must
+    outlive the launches that read it — the struct is read at launch time, the tensors by the kernels)."""
+    job = _lib.BinJob(ptr(xy, _f32, "xy"), plan.P, plan.tile_shift, plan.NB, plan.chunk, ptr(ws.blockhist), ptr(pws, _i32, "persistent_ws"),
+                      ptr(ws.tile_off), ptr(ws.tile_item_base), ptr(ws.items), ptr(ws.n_items), ptr(ws.sorted))
+    ws._job = (job, xy, pws)
+    return job
 
 
 def _vertex_fwd(plan, tables, vert_idx, vert_w, n_ls, vstride, G):
@@ -947,6 +1005,8 @@ def tile_level_offsets(plan, device):
 HASH_VERTEX_FUSION = True    # hash indexing, single rank: the vertex stage backward rides on the gather pass of the pixel stage
 
 
+FUSED_VERTEX_FWD = True      # fp32 tables on the interleaved forward kernel: the vertex stage forward runs inside its staging loop
+BIN_PIPELINE = True          # ... and an announced next batch (BinPipeline) is binned by riders of this step's pixel-stage launches
 DG64 = True                  # F = 2, <= 16 staged levels, bounded |genc|: 64-bit fixed-point vertex grid fed by global integer atomics
 VERTEX_READS_DG64 = True     # ... and the slot-ordered vertex backward converts it on the fly (False: dg64_to_float first)
 
@@ -954,7 +1014,7 @@ VERTEX_READS_DG64 = True     # ... and the slot-ordered vertex backward converts
 PIXEL_BWD_TRACE = None       # tests: a list that receives one record per pixel-stage backward launch (which chain ran)
 
 
-def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None, link=None, hash_fuse=None, dG64=None):
+def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None, link=None, hash_fuse=None, dG64=None, next_bin=None):
     """absmax: None or (tensor, count, stride) — `count` floats `stride` apart whose maximum bounds |genc|.
     link: the StepLink of the forward pass (decoder slab reduction / loss value waiting for a launch to ride on, promise)."""
     if PIXEL_BWD_TRACE is not None:
@@ -979,6 +1039,8 @@ def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None, link=None, hash_fuse
     ride_args += [ptr(hash_fuse[0], _f32, "dtables"), int(hash_fuse[1])] if hash_fuse is not None else [ptr(None), 0]
     # dG64: zeroed (vtot * F + 2) int64 grid; log2_pixels bounds the number of terms any vertex can receive
     ride_args += [ptr(dG64, _i64, "dG64"), max(1, int(plan.P - 1).bit_length())] if dG64 is not None else [ptr(None), 0]
+    # next_bin: gngf_bin_job of the NEXT batch — its scatter half runs as tasks in the tail of this launch (BinPipeline)
+    ride_args += [_ct.byref(next_bin) if next_bin is not None else None]
     call("gngf_encode_tiled_bwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(ws.tile_item_base),
          ptr(tile_level_offsets(plan, genc.device)), ptr(n_ls), plan.n_ls_c, ptr(genc, _f32, "grad"), ptr(am),
          int(am_count), int(am_stride), ptr(dG), ptr(partials), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, plan.chunk,
@@ -1057,29 +1119,78 @@ class EncodeFunction(torch.autograd.Function):
         if vert_idx is not None and order is None and plan.Ls > 0 and P > 0 and ctx.needs_input_grad[3]:
             order = slot_order(vert_idx, plan.n_ls_host[:plan.Ls], vstride)
         pre = None
+        ctx.next_bin = None
         if plan.Ls > 0 and P > 0:
-            # binning, vertex stage and the clears of the backward's gradient buffers: ONE chain of four launches (the vertex
-            # stage and the clears ride on the binning kernels as extra workgroups: ops.TiledWorkspace)
-            G = torch.empty((plan.vtot, F), dtype=_f32, device=tables.device)
+            dev = tables.device
+            pws = _bin_workspace(dev, plan.ntiles, dp) if TWO_LAUNCH_BINNING else None
+            # fp32 tables on the level-interleaved kernel: the vertex stage forward runs INSIDE the pixel stage's staging loop (no
+            # vertex grid G, no vertex riders) and the binning is two launches of its own — or none, when the previous step's
+            # launches carried it (BinPipeline)
+            fused = (FUSED_VERTEX_FWD and pws is not None and pws.numel() >= 2 * plan.ntiles + 2 and tables.dtype == _f32
+                     and F == 2 and plan.interleaved(backward=False))
             use64 = False
+            big = None
             if ctx.needs_input_grad[3]:
                 # F = 2, <= 16 staged levels (the level-interleaved kernels): the pixel stage of the backward adds its exact
                 # fixed-point sums straight into a 64-bit vertex grid (cleared here; + scale and poison words), no gather pass
                 # (the launcher decides whether that kernel runs — e.g. not at the 4096^2 shape, whose interleaved image exceeds
                 # the LDS: the generic kernels accumulate into a ZEROED fp32 grid instead)
                 use64 = DG64 and F == 2 and plan.Ls <= 16 and plan.interleaved(backward=True)
-                dgrid = (torch.empty((plan.vtot * F + 2,), dtype=_i64, device=tables.device) if use64
-                         else torch.empty((plan.vtot, F), dtype=_f32, device=tables.device))
-                pre = [torch.empty(tables.shape, dtype=_f32, device=tables.device), dgrid]
-                tile_level_offsets(plan, tables.device)        # cached; built here so that no backward (or graph capture) uploads it
-            defer = pre is not None and link is not None and link.defer_zero and pre[0].numel() % 4 == 0
+                nt = tables.numel()
+                if fused and nt % 4 == 0:
+                    # ONE allocation [table gradient | vertex-grid gradient]: whoever clears the table gradient — the fused
+                    # training decoder between its MFMAs, or rider workgroups of the count launch — clears both
+                    ng = (plan.vtot * F + 2) * 2 if use64 else plan.vtot * F
+                    big = torch.empty((nt + ((ng + 3) & ~3),), dtype=_f32, device=dev)
+                    dgrid = big[nt:nt + ng].view(_i64) if use64 else big[nt:nt + ng].view(plan.vtot, F)
+                    pre = [big[:nt].view(tables.shape), dgrid, big]
+                else:
+                    fused = False
+                    dgrid = (torch.empty((plan.vtot * F + 2,), dtype=_i64, device=dev) if use64
+                             else torch.empty((plan.vtot, F), dtype=_f32, device=dev))
+                    pre = [torch.empty(tables.shape, dtype=_f32, device=dev), dgrid, None]
+                tile_level_offsets(plan, dev)        # cached; built here so that no backward (or graph capture) uploads it
+            zbuf = None if pre is None else (pre[2] if pre[2] is not None else pre[0])
+            defer = pre is not None and link is not None and link.defer_zero and zbuf.numel() % 4 == 0
             if defer:
-                link.zero_request = pre[0]
-            ws = TiledWorkspace(plan, xy, vertex=(tables, vert_idx, vert_w, n_ls, vstride, G),
-                                zero_dG=(pre[1].view(_f32) if use64 else pre[1]) if pre else None,
-                                zero=(pre[0] if (pre and not defer) else None), zero_dG_words=(2 if use64 else 1), owner=dp)
-            call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), plan.n_ls_c,
-                 ptr(G), ptr(enc), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, stream_ptr())
+                link.zero_request = zbuf
+            if fused:
+                pipe = dp.pipeline if (dp is not None and BIN_PIPELINE) else None
+                if pipe is not None and pipe.pending is not None:
+                    # a count half whose scatter half never ran (a forward pass without its backward pass): the counters hold
+                    # that batch's totals — back to zero before anybody bins with them
+                    pws.zero_()
+                    pipe.pending = None
+                ws = pipe.take(xy, plan) if pipe is not None else None
+                if ws is None:
+                    ws = TiledWorkspace(plan, xy, launch=False)
+                    zero_now = zbuf if (pre is not None and not defer) else None
+                    call("gngf_bin_pixels2", _ct.byref(_bin_job(ws, plan, xy, pws)), ptr(zero_now), 0 if zero_now is None else zero_now.numel(),
+                         stream_ptr())
+                elif pre is not None and not defer:
+                    zbuf.zero_()
+                job_next = None
+                nx = None
+                if pipe is not None:
+                    nx, pipe.next_xy = pipe.next_xy, None
+                if (nx is not None and ctx.needs_input_grad[3] and plan.interleaved(backward=True) and nx.is_cuda and nx.dtype == _f32
+                        and nx.is_contiguous() and tuple(nx.shape) == tuple(xy.shape) and nx.device == xy.device):
+                    ws_next = TiledWorkspace(plan, nx, launch=False)
+                    job_next = _bin_job(ws_next, plan, nx, pws)
+                    pipe.pending = ws_next
+                    ctx.next_bin = (ws_next, job_next, nx, pipe)
+                call("gngf_encode_tiled_fwd_fused", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), plan.n_ls_c,
+                     *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(enc), L, plan.Ls, F, T, K, mode, vstride, NV, plan.tile_shift,
+                     plan.lds_bytes, _ct.byref(job_next) if job_next is not None else None, stream_ptr())
+            else:
+                # binning, vertex stage and the clears of the backward's gradient buffers: ONE chain of launches (the vertex stage
+                # and the clears ride on the binning kernels as extra workgroups: ops.TiledWorkspace)
+                G = torch.empty((plan.vtot, F), dtype=_f32, device=dev)
+                ws = TiledWorkspace(plan, xy, vertex=(tables, vert_idx, vert_w, n_ls, vstride, G),
+                                    zero_dG=(pre[1].view(_f32) if use64 else pre[1]) if pre else None,
+                                    zero=(pre[0] if (pre and not defer) else None), zero_dG_words=(2 if use64 else 1), owner=dp)
+                call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), plan.n_ls_c,
+                     ptr(G), ptr(enc), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, stream_ptr())
         if plan.Ls < L:
             call("gngf_encode_fwd", ptr(xy, _f32, "xy"), *_tab(tables), ptr(vert_idx, _i32, "vert_idx"),
                  ptr(vert_w, _f32, "vert_w"), ptr(n_ls, _i32, "n_ls"), ptr(enc), P, L, F, T, K, mode, vstride, NV, plan.Ls, L,
@@ -1104,9 +1215,11 @@ class EncodeFunction(torch.autograd.Function):
         exchange = dp.exchange if dp is not None else None
         NONE = (None,) * 5                                      # (order, dp, link, sink) + vstride: no gradients
         pre, ctx.pre = ctx.pre, None                            # a second backward (retain_graph) allocates fresh buffers
-        if pre and link is not None and link.zero_request is pre[0]:
+        zbuf = None if not pre else (pre[2] if pre[2] is not None else pre[0])
+        if pre and link is not None and link.zero_request is zbuf:
             link.zero_request = None                            # the decoder that was to clear the buffer did not run: clear it here
-            pre[0].zero_()
+            zbuf.zero_()
+        next_bin, ctx.next_bin = getattr(ctx, "next_bin", None), None
         dtables = pre[0] if pre else _grad_buffer(tables)
         dvw = torch.zeros_like(vert_w) if (vert_w is not None and ctx.needs_input_grad[5]) else None
         if plan.Ls > 0 and P > 0:
@@ -1122,7 +1235,16 @@ class EncodeFunction(torch.autograd.Function):
                         and dvw is None)
             dG = None if direct64 else (pre[1] if (pre and pre[1].dtype == _f32) else
                                         (torch.empty if dG64 is not None else torch.zeros)((plan.vtot, F), dtype=_f32, device=tables.device))
-            _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax, link, fuse, dG64)
+            job_next = None
+            if next_bin is not None and plan.interleaved(backward=True):
+                job_next = next_bin[1]
+            _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax, link, fuse, dG64, job_next)
+            if job_next is not None:
+                # the next batch is binned: its forward pass picks the workspace up if it is called with that very tensor
+                ws_next, _job, nx, pipe = next_bin
+                pipe.ready = (BinPipeline._key(nx, plan), ws_next)
+                if pipe.pending is ws_next:
+                    pipe.pending = None
             if fuse is None and exchange is not None and dp.defer_vertex and dvw is None:
                 # the caller exchanges dG and runs the vertex stage after backward (parallel.allreduce_gradients)
                 if plan.Ls < L:

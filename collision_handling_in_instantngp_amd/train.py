@@ -305,8 +305,13 @@ class GraphedStep:
             net.coord_bounds = (float(coord_bounds[0]), float(coord_bounds[1]))
         self._graphs = {}
 
-    def _body(self, st):
+    def _body(self, st, next_x=None):
+        """next_x: the coordinate buffer of the step that FOLLOWS this one inside the same graph — announced to the encoder, whose
+        pixel-stage launches then carry that batch's binning (ops.BinPipeline); the first step of a replay bins itself."""
         net, (l_mse, l_js_kl, l_collisions) = self.net, self.weights
+        pipe = getattr(getattr(net, "dp", None), "pipeline", None)
+        if pipe is not None:
+            pipe.announce(next_x)
         shadow = st["shadow"]
         for s_ in shadow.values():
             s_.grad = None
@@ -362,6 +367,9 @@ class GraphedStep:
         for m in st["more"]:
             m["x"].copy_(st["x"])
             m["y"].copy_(st["y"])
+        pipe = getattr(getattr(net, "dp", None), "pipeline", None)
+        if pipe is not None:
+            pipe.reset()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -375,11 +383,15 @@ class GraphedStep:
         # thread_local: other threads of the process (the RCCL watchdog at world > 1) may query events while we capture
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             st["results"] = []
-            for sub in [st] + st["more"]:
-                st["results"].append(self._body(sub))
+            subs = [st] + st["more"]
+            for j, sub in enumerate(subs):
+                # step j's pixel-stage launches bin step j + 1's batch (its own static buffer: refilled before every replay)
+                st["results"].append(self._body(sub, next_x=(subs[j + 1]["x"] if j + 1 < len(subs) else None)))
                 if self.optimizer is not None:
                     self.optimizer.step()
             st["result"] = st["results"][0]
+        if pipe is not None:
+            pipe.reset()
         st["graph"] = g
         self._graphs[key] = st
         return st
@@ -460,10 +472,22 @@ def train_epoch(net, loss_fn, optimizer, x, target, w, h, l_mse, l_js_kl, l_coll
             gs = GraphedStep(net, loss_fn, optimizer, l_mse, l_js_kl, l_collisions, batch_percentage, coord_bounds=bounds)
             gs._cfg = cfg
             net._graphed_step = gs
+    def batch(b):
+        lo_, hi_ = b * step, (b + 1) * step
+        sel = shuffled_indices[lo_:hi_].long() if should_shuffle else slice(lo_, hi_)
+        return x[sel].contiguous(), target[sel]
+
+    pipe = getattr(getattr(net, "dp", None), "pipeline", None)
+    upcoming = batch(0) if num_batches > 0 else None
     for b in range(num_batches):
         lo, hi = b * step, (b + 1) * step
-        sel = shuffled_indices[lo:hi].long() if should_shuffle else slice(lo, hi)
-        bx, by = x[sel], target[sel]
+        bx, by = upcoming
+        # the batches are fixed slices of one permutation (functions.py:186-194): the next one is materialised a step ahead and
+        # announced, so that this step's pixel-stage launches bin it (ops.BinPipeline; eager steps only — a replayed step
+        # copies its batch into static buffers)
+        upcoming = batch(b + 1) if b + 1 < num_batches else None
+        if pipe is not None:
+            pipe.announce(upcoming[0] if (upcoming is not None and gs is None and upcoming[0].shape == bx.shape and bx.shape[0] > 0) else None)
         if bx.shape[0] == 0:
             continue
         if gs is not None and not should_calc_counts:

@@ -122,6 +122,34 @@ int gngf_vertex_grid_bwd(const void* tables, int feat_dtype, const int32_t* vert
  * tile_level_off (4^tile_shift * Ls int32, optional): float offset of level l's sub-grid inside tile t's image at
  * [t * Ls + l], -1 when the level does not fit (levels are laid out back to back in ascending order, a level that
  * would exceed lds_bytes is skipped); NULL: the gather pass re-derives it per vertex. */
+/* One binning job (the arguments of gngf_bin_pixels as a host struct): lets the binning of ANOTHER batch ride on the pixel-stage
+ * launches of the current one — binning depends on the coordinates only, and the batches of an epoch are fixed slices of one
+ * permutation, known in advance (functions.py:186-194).  persistent_ws: (2 * 4^tile_shift + 2) int32, ZERO before its first
+ * use and owned by one sequence of steps (the kernels leave it zero): tile totals, tile cursors, a ticket, a task counter. */
+typedef struct gngf_bin_job {
+  const float* xy;            /* (P, 2) coordinates of the batch to bin */
+  int64_t P;
+  int tile_shift, NB, chunk;
+  int32_t* blockhist;         /* 4^tile_shift * (NB + 1) scratch */
+  int32_t* persistent_ws;
+  int32_t* tile_off;          /* outputs, as gngf_bin_pixels */
+  int32_t* tile_item_base;
+  int32_t* items;
+  int32_t* n_items;
+  float* sorted;
+} gngf_bin_job;
+/* binning in two launches (count -> scatter with the scans inside); zero_fill (optional, zero_floats a multiple of 4, 16-byte
+ * aligned) is cleared by rider workgroups of the count launch */
+int gngf_bin_pixels2(const gngf_bin_job* job, float* zero_fill, int64_t zero_floats, void* stream);
+/* pixel stage forward with the vertex stage forward fused into its staging loop (bit-identical to gngf_vertex_grid_fwd +
+ * gngf_encode_tiled_fwd; interleaved kernel only: F = 2, fp32 tables — see gngf_tiled_interleaved_applies — else rejected).
+ * next_count (optional): the count half of another batch's binning runs in extra workgroups at the head of the launch; its
+ * scatter half rides on gngf_encode_tiled_bwd(..., next_bin) of the same step. */
+int gngf_encode_tiled_fwd_fused(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
+                                const int32_t* n_ls, const int32_t* n_ls_host, const void* tables, int feat_dtype,
+                                const int32_t* vert_idx, const float* vert_w, float* enc, int L, int Ls, int F, int64_t T, int K,
+                                int mode, int vstride, int64_t NV, int tile_shift, int lds_bytes, const gngf_bin_job* next_count,
+                                void* stream);
 int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,
                           const int32_t* n_ls, const int32_t* n_ls_host, const float* G, float* enc, int L, int Ls, int F,
                           int tile_shift, int lds_bytes, void* stream);
@@ -145,7 +173,11 @@ int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, const int32
                           float* ride_dW2, float* ride_db2, int64_t ride_P, int ride_in_dim, int ride_out_dim,
                           const float* gloss_promised, const float* gloss_arrived,
                           const float* mse_pred, const float* mse_label, float* mse_loss, float* mse_workspace, int64_t mse_n,
-                          float* hash_dtables, int64_t hash_T, void* dG64, int log2_pixels, void* stream);
+                          float* hash_dtables, int64_t hash_T, void* dG64, int log2_pixels, const gngf_bin_job* next_bin,
+                          void* stream);
+/* next_bin (optional; level-interleaved kernel only): the SCATTER half of another batch's binning — whose count half ran on
+ * gngf_encode_tiled_fwd_fused(..., next_count) of the same step — as tasks the persistent workgroups claim once their own work
+ * items are done (they run in the tail of the launch, where two workgroups in five are idle at the headline shape). */
 /* ride_* (optional, ride_slabs NULL = none): the slab reduction of a preceding gngf_decoder_bwd that was called without
  * gradient pointers (= gngf_decoder_reduce(ride_slabs, ride_dW0 .. ride_db2, NULL, ride_P, ride_in_dim, ride_out_dim)) runs in
  * extra workgroups of this launch instead of a launch of its own (one dependent launch less on the step's critical path).

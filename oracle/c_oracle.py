@@ -49,14 +49,15 @@ def encode_bwd(xy, tables, n_ls, genc, vert_idx=None, vert_w=None, vstride=0):
     return dt
 
 
-def encode_bwd_f64(xy, table_shape, n_ls, genc, vert_idx=None, vert_w=None, vstride=0):
-    """the table gradient with the reference's fp32 terms summed in double precision: (L,T,F) float64"""
+def encode_bwd_f64(xy, table_shape, n_ls, genc, vert_idx=None, vert_w=None, vstride=0, exact_products=False):
+    """the table gradient with the reference's fp32 terms summed in double precision: (L,T,F) float64
+    (exact_products: the products g * c (* w) in double as well — the exact gradient of the fp32 inputs)"""
     L, T, F = table_shape
     P = xy.shape[0]
     K = 0 if vert_idx is None else vert_idx.shape[1]
     dt = np.zeros((L, T, F), np.float64)
     lib().orc_encode_bwd_f64(_p(xy), _p(vert_idx), _p(vert_w), _p(n_ls), _p(genc), _p(dt), ctypes.c_int64(P), L, F,
-                             ctypes.c_int64(T), K, vstride)
+                             ctypes.c_int64(T), K, vstride, int(bool(exact_products)))
     return dt
 
 

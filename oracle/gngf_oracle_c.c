@@ -113,11 +113,14 @@ void orc_encode_bwd(const float* xy, const float* tables, const int32_t* vert_id
     }
 }
 
-/* The same scatter with the SUM kept in double precision (dtables64 (L,T,F) double, zero on entry): every term is the
- * reference's own fp32 product chain (genc * c, then * w), only the accumulation is wide.  Checks of full-size gradients use
- * it: an fp32 accumulation of ~10^4 terms per coarse-level row carries ~1e-5 of order-dependent rounding of its own. */
+/* The same scatter with the SUM kept in double precision (dtables64 (L,T,F) double, zero on entry).
+ * exact_products = 0: every term is the reference's own fp32 product chain (genc * c, then * w), only the accumulation is wide
+ * (an fp32 accumulation of ~10^4 terms per coarse-level row carries ~1e-5 of order-dependent rounding of its own);
+ * exact_products = 1: the products are formed in double as well — the mathematically exact gradient of the fp32 inputs, what a
+ * relative check of rows that are small through CANCELLATION has to be made against (each fp32-rounded product is off by 6e-8 of
+ * its own size, which is not small next to a sum that cancels). */
 void orc_encode_bwd_f64(const float* xy, const int32_t* vert_idx, const float* vert_w, const int32_t* n_ls, const float* genc,
-                        double* dtables64, int64_t P, int L, int F, int64_t T, int K, int vstride) {
+                        double* dtables64, int64_t P, int L, int F, int64_t T, int K, int vstride, int exact_products) {
 #pragma omp parallel for schedule(static)
   for (int64_t p = 0; p < P; ++p)
     for (int l = 0; l < L; ++l) {
@@ -128,9 +131,10 @@ void orc_encode_bwd_f64(const float* xy, const int32_t* vert_idx, const float* v
         if (!vert_idx) {
           double* r = dtab + hash2(gx, gy, T) * F;
           for (int f = 0; f < F; ++f) {
-            float add = genc[(p * L + l) * F + f] * c.c[v];
+            const float g = genc[(p * L + l) * F + f];
+            const double add = exact_products ? (double)g * (double)c.c[v] : (double)(g * c.c[v]);
 #pragma omp atomic
-            r[f] += (double)add;
+            r[f] += add;
           }
         } else {
           int64_t vid = (int64_t)gy * vstride + gx;
@@ -138,9 +142,10 @@ void orc_encode_bwd_f64(const float* xy, const int32_t* vert_idx, const float* v
             double* r = dtab + (int64_t)vert_idx[vid * K + k] * F;
             float w = vert_w[vid * K + k];
             for (int f = 0; f < F; ++f) {
-              float add = (genc[(p * L + l) * F + f] * c.c[v]) * w;
+              const float g = genc[(p * L + l) * F + f];
+              const double add = exact_products ? (double)g * (double)c.c[v] * (double)w : (double)((g * c.c[v]) * w);
 #pragma omp atomic
-              r[f] += (double)add;
+              r[f] += add;
             }
           }
         }

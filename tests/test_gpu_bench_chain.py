@@ -153,20 +153,36 @@ def test_fixed_point_chain_on_the_steps_own_gradient_keeps_small_rows(mode):
     if mode == "gngf_frozen":
         tv, ti, w, vstride, NV, order = net._frozen_vertex_table(ops.BLEND_CODES[True])
         vidx, vw = np.ascontiguousarray(ti.cpu().numpy()), np.ascontiguousarray(w.cpu().numpy())
-    want = c_oracle.encode_bwd_f64(np.ascontiguousarray(xy.cpu().numpy()), (L, T, F), n_ls, genc, vidx, vw, vstride)
+    x_np = np.ascontiguousarray(xy.cpu().numpy())
+    want = c_oracle.encode_bwd_f64(x_np, (L, T, F), n_ls, genc, vidx, vw, vstride)
     got = torch.stack([net.encoding._hash_tables[l].weight.grad for l in range(L)]).double().cpu().numpy()
     mx = float(np.abs(want).max())
     parity_close(got, want, 0, 2e-6 * mx, f"dG64 chain {mode}: table gradient on the step's own d enc, all rows (atol 2e-6 of max)")
-    a = np.abs(want)
-    small = (a < 1e-4 * mx) & (a > 1e-7 * mx)
-    assert small.sum() > 1000, int(small.sum())
-    rel = np.abs(got[small] - want[small]) / a[small]
-    print(f"[dG64 {mode}] rows in (1e-7, 1e-4) x max: {int(small.sum())}, worst relative error {rel.max():.2e}, median {np.median(rel):.2e}")
-    # hash: a row is one vertex' sum -> only the final fp32 rounding and the 2^-40 quantum show.  Vertex-table source: up to
-    # thousands of vertices meet in a row through fp32 atomics in a different order than the oracle's (the reference's
-    # index_put accumulate is order-dependent too): the bound is that of an fp32 sum of its terms
-    parity_close(got[small], want[small], 2e-4 if mode == "hash" else 2e-3, 0,
-                 f"dG64 chain {mode}: rows between 1e-7 and 1e-4 of the largest row, RELATIVE")
+    # Small rows.  A table row is an fp32 sum (float atomics of per-vertex sums — the reference's index_put accumulates in fp32
+    # too), so what can be asked of ANY fp32 implementation is an error bounded by a few fp32 roundings of the row's ABSOLUTE mass
+    # A = sum |term| (a row that is small because large terms cancel keeps their rounding).  The fixed-point grid must not add to
+    # that: with one scale per launch (quantum 2^-40 of the batch's max |d enc| per term) a row whose mass is 1e-7 .. 1e-4 of the
+    # largest mass still has to come out within that bound — a grid that flushed small sums would miss it by orders of magnitude.
+    # The comparison is with the EXACT gradient of the fp32 inputs (products formed in double): the fixed-point terms are the
+    # exactly rounded products RNE(g c 2^S), the reference's are fp32-rounded products (the stated deviation, covered by the
+    # absolute check above).
+    want = c_oracle.encode_bwd_f64(x_np, (L, T, F), n_ls, genc, vidx, vw, vstride, exact_products=True)
+    mass = c_oracle.encode_bwd_f64(x_np, (L, T, F), n_ls, np.abs(genc), vidx, vw, vstride, exact_products=True)     # c, w >= 0
+    amx = float(mass.max())
+    small = (mass < 1e-4 * amx) & (mass > 1e-7 * amx)
+    assert small.sum() > (1000 if mode == "hash" else 100), int(small.sum())
+    # hash: a row is the float-atomic sum of one to a few per-vertex sums (3 roundings); vertex-table source: thousands of
+    # (vertex, k) entries meet in a row through a DPP segmented scan, a chain across the waves of a workgroup and float atomics
+    # across workgroups (tens of roundings)
+    k = 4e-7 if mode == "hash" else 4e-6
+    ratio = np.abs(got[small] - want[small]) / mass[small]
+    print(f"[dG64 {mode}] rows with mass in (1e-7, 1e-4) x max: {int(small.sum())}, worst |err| / mass {ratio.max():.2e} (bound {k:g}), "
+          f"median {np.median(ratio):.2e}")
+    assert float(ratio.max()) <= k, float(ratio.max())
+    ratio_all = np.abs(got - want)[mass > 0] / mass[mass > 0]
+    assert float(ratio_all.max()) <= k, float(ratio_all.max())
+    from conftest import PARITY
+    PARITY.record(f"dG64 chain {mode}: |err| / (row's absolute mass), rows with mass 1e-7..1e-4 of the largest", ratio, np.zeros_like(ratio), 0, k)
 
 
 @pytest.mark.parametrize("mode", ["hash", "gngf_frozen"])
@@ -219,7 +235,10 @@ def test_model_gradients_when_the_generic_pixel_stage_runs(mode, interleaved_off
         assert bool(torch.isfinite(gt).all()), "the tiled dispatch read an uninitialised buffer (NaN-poisoned allocator)"
         mx = float(gd.abs().max())
         assert mx > 0
-        parity_close(gt, gd, 1e-3, 2e-5 * mx, f"{shape} {mode} interleaved_off={interleaved_off}: model table gradient, tiled (generic kernels) vs direct form")
+        # (vertex-table source with a freshly initialised HPD: a million entries meet in a few dozen rows, and the DIRECT form
+        # adds them one float atomic at a time — its own fp32 accumulation error is what the looser bound covers)
+        tol = 2e-5 if mode == "hash" else 5e-3
+        parity_close(gt, gd, 1e-3, tol * mx, f"{shape} {mode} interleaved_off={interleaved_off}: model table gradient, tiled (generic kernels) vs direct form")
     finally:
         ops.PIXEL_BWD_TRACE = prev_trace
         _lib.query("gngf_set_tiled_interleaved", prev_il)
@@ -298,4 +317,7 @@ def test_blend_kernels_all_codes_vs_oracle(flag):
         else:
             s = q64.sum(-1, keepdims=True)
             want = d64 / s - (d64 * q64).sum(-1, keepdims=True) / (s * s)
-        parity_close(qt.grad, want, 2e-5, 2e-6 * float(np.abs(want).max()), f"blend bwd code {ops.BLEND_CODES[flag]} ({U}x{K})")
+        # (K = 1 with the normalised blend: w = q / q = 1, the exact gradient is 0 and what is left is fp32 cancellation noise of
+        # d / s - d q / s^2: the tolerance is relative to the size of those two terms)
+        scale = float(np.abs(d64 / (q64.sum(-1, keepdims=True) if flag is False else 1.0)).max())
+        parity_close(qt.grad, want, 2e-5, 2e-6 * scale, f"blend bwd code {ops.BLEND_CODES[flag]} ({U}x{K})")

@@ -49,6 +49,10 @@ def test_c_encoder_matches_numpy_oracle(mode):
                     term = (dfe[:, :, l, v] * w[:, l, v, k][:, None]).astype(np.float32)
                     np.add.at(want64[l], idx[:, l, v, k], term.astype(np.float64))
     np.testing.assert_allclose(got64, want64, rtol=1e-12, atol=1e-18)
+    # exact products: the mathematically exact gradient of the fp32 inputs; differs from the fp32-term sum by <= 1.2e-7 sum |term|
+    exact = c_oracle.encode_bwd_f64(x, tables.shape, n_ls, g, vi, vw, vs, exact_products=True)
+    np.testing.assert_allclose(exact, got64, rtol=0, atol=2e-6 * np.abs(dt).max())
+    assert np.abs(exact - got64).max() > 0
 
 
 def test_c_decoder_matches_numpy_oracle():
