@@ -57,7 +57,7 @@ SIGNATURES = {
     "gngf_linear_bwd_weight": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gngf_gemm_acc": [_P, _P, _P, _L, _L, _L, _I, _I, _P],
     "gngf_softmax_topk": [_P, _P, _P, _P, _L, _L, _I, _P],
-    "gngf_softmax_bwd_lowrank": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _L, _I, _P],
+    "gngf_softmax_bwd_lowrank": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _L, _I, _P],
     "gngf_logits_topk_pbar": [_P, _P, _P, _P, _P, _I, _P, _L, _L, _I, _P],
     "gngf_topk": [_P, _P, _P, _L, _L, _I, _P],
     "gngf_softmax_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _L, _L, _I, _P],
@@ -76,6 +76,8 @@ SIGNATURES = {
     "gngf_js_kl_bwd": [_P, _P, _P, _I, _L, _F, _F, _P],
     "gngf_slot_bitmap_words": [_I, _I, _L],
     "gngf_distinct_slot_counts": [_P, _L, _I, _I, _I, _L, _P, _P, _P],
+    "gngf_mark_batch_slots": [_P, _P, _L, _I, _P, _I, _L, _I, _L, _P, _P, _P],
+    "gngf_count_slot_bits": [_P, _I, _I, _L, _P, _P],
     "gngf_adam_block_elems": [],
     "gngf_adam_step": [_P, _I, _L, _P, _P, _P, _I, _F, _F, _F, _F, _P],
 }

@@ -603,6 +603,18 @@ __global__ void softmax_bwd_topk_dot_kernel(const float* __restrict__ Z, const f
   atomicAdd(dot + r, p * dq[e]);
 }
 
+// dot[r] = sum_k p_k dq_k from the top-K probabilities the FORWARD saved (topk_val: the very values exp(z_k - max) / sum of these
+// logits) — written, not added: it also replaces the clear of `dot`, and it does not touch the logits (softmax_bwd_topk_dot_kernel
+// re-read them at random: 1.4 ms per chunk beside the GEMM stream, for 16 K numbers)
+__global__ void softmax_bwd_dot_init_kernel(const float* __restrict__ pk, const float* __restrict__ dq, float* __restrict__ dot,
+                                            int64_t U, int K) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= U) return;
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s += pk[r * K + k] * dq[r * K + k];
+  dot[r] = s;
+}
+
 __global__ void softmax_bwd_topk_fix_kernel(float* __restrict__ dZ, const float* __restrict__ dq, const int32_t* __restrict__ topi,
                                             const float* __restrict__ pk, float* __restrict__ db, int64_t U, int64_t T, int K) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -717,6 +729,30 @@ expand_kernel(const float2* __restrict__ xy, const int32_t* __restrict__ n_ls, c
   }
 }
 
+// K = 4, indices only (the reference's (P,L,4,K) int64 return tensor, 2 GiB per step at 2^20 pixels): the four slots of a vertex
+// are ONE 16-byte load and leave as two 16-byte non-temporal stores — 32 consecutive bytes per lane, whole lines per wave —
+// instead of four 8-byte stores from a runtime loop (0.96 ms -> streaming-store rate).
+__global__ void __launch_bounds__(256)
+expand_idx4_kernel(const float2* __restrict__ xy, const int32_t* __restrict__ n_ls, const int32_t* __restrict__ src_i,
+                   int64_t* __restrict__ vid_out, int64_t* __restrict__ out_i, int64_t total, int L, int vstride, int64_t NV) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over P*L*4
+  if (gid >= total) return;
+  const int v = (int)(gid & 3);
+  const int64_t pl = gid >> 2;
+  const int64_t p = pl / L;
+  const int l = (int)(pl - p * L);
+  const float2 c = xy[p];
+  const Cell cell = make_cell(c.x, c.y, n_ls[l]);
+  int64_t vid = (int64_t)(cell.gy + (v >> 1)) * vstride + (cell.gx + (v & 1));
+  vid = vid < 0 ? 0 : (vid >= NV ? NV - 1 : vid);
+  if (vid_out) vid_out[gid] = vid;
+  const int4 s4 = reinterpret_cast<const int4*>(src_i)[vid];
+  typedef long long ll2 __attribute__((ext_vector_type(2)));
+  ll2* o = reinterpret_cast<ll2*>(out_i + gid * 4);
+  __builtin_nontemporal_store((ll2){(long long)s4.x, (long long)s4.y}, o);
+  __builtin_nontemporal_store((ll2){(long long)s4.z, (long long)s4.w}, o + 1);
+}
+
 }  // namespace gngf
 
 using namespace gngf;
@@ -794,16 +830,21 @@ extern "C" int gngf_softmax_bwd(const float* probs, const float* dq, const int32
 // rowstat (U,2) from gngf_softmax_topk; dq/topk_idx (U,K) or K = 0; mw (U,L) and G (L,T) or L = 0;
 // db (T) += column sums of d logits (NULL: skipped); scratch: (U + U*K) floats.
 extern "C" int gngf_softmax_bwd_lowrank(float* logits_dz, const float* rowstat, const float* dq, const int32_t* topk_idx,
-                                        const float* mw, const float* G, int L, float* db, float* scratch, int64_t U, int64_t T,
-                                        int K, void* stream) {
+                                        const float* mw, const float* G, int L, float* db, float* scratch, const float* topk_p,
+                                        int64_t U, int64_t T, int K, void* stream) {
   GNGF_CHECK_ARG(U >= 0 && T > 0 && K >= 0 && K <= GNGF_MAX_TOPK && L >= 0 && L <= GNGF_MAX_LEVELS);
   if (U == 0) return 0;
   GNGF_CHECK_ARG(logits_dz && rowstat && scratch && (K == 0 || (dq && topk_idx)) && (L == 0 || (mw && G)));
   hipStream_t s = as_stream(stream);
   float* dot = scratch;
   float* pk = scratch + U;
-  hipError_t e = hipMemsetAsync(dot, 0, sizeof(float) * (size_t)U, s);
-  if (e != hipSuccess) return (int)e;
+  const bool saved_p = K > 0 && topk_p != nullptr;       // the forward's top-K probabilities: no second look at the logits
+  if (saved_p) {
+    softmax_bwd_dot_init_kernel<<<dim3((unsigned)ceil_div(U, 256)), dim3(256), 0, s>>>(topk_p, dq, dot, U, K);
+  } else {
+    hipError_t e = hipMemsetAsync(dot, 0, sizeof(float) * (size_t)U, s);
+    if (e != hipSuccess) return (int)e;
+  }
   const bool mfma = (T % 32 == 0) && T < (1 << 24) && L <= 32;      // 32 rows * T * 4 B and L * T * 4 B inside 32-bit offsets
   const dim3 grid(mfma ? (unsigned)ceil_div(T, kLrCols) : (unsigned)ceil_div(T, kSbCols),
                   mfma ? (unsigned)ceil_div(U, kLrRows) : (unsigned)ceil_div(U, kSbRows));
@@ -817,7 +858,7 @@ extern "C" int gngf_softmax_bwd_lowrank(float* logits_dz, const float* rowstat, 
     else if (L <= 16) softmax_bwd_tile_kernel<false, 16><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, nullptr, U, T);
     else softmax_bwd_tile_kernel<false, 32><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, nullptr, U, T);
   }
-  if (K > 0)
+  if (K > 0 && !saved_p)
     softmax_bwd_topk_dot_kernel<<<dim3((unsigned)ceil_div(U * K, 256)), dim3(256), 0, s>>>(logits_dz, rowstat, dq, topk_idx, pk,
                                                                                           dot, U, T, K);
   if (mfma) {
@@ -828,7 +869,8 @@ extern "C" int gngf_softmax_bwd_lowrank(float* logits_dz, const float* rowstat, 
   else if (L <= 16) softmax_bwd_tile_kernel<true, 16><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, db, U, T);
   else softmax_bwd_tile_kernel<true, 32><<<grid, dim3(256), 0, s>>>(logits_dz, rowstat, mw, G, L, dot, db, U, T);
   if (K > 0)
-    softmax_bwd_topk_fix_kernel<<<dim3((unsigned)ceil_div(U * K, 256)), dim3(256), 0, s>>>(logits_dz, dq, topk_idx, pk, db, U, T, K);
+    softmax_bwd_topk_fix_kernel<<<dim3((unsigned)ceil_div(U * K, 256)), dim3(256), 0, s>>>(logits_dz, dq, topk_idx, saved_p ? topk_p : pk,
+                                                                                          db, U, T, K);
   GNGF_RETURN_LAUNCH();
 }
 
@@ -883,6 +925,11 @@ extern "C" int gngf_expand_vertex_table(const float* xy, const int32_t* n_ls, co
   if (P == 0) return 0;
   GNGF_CHECK_ARG(xy && n_ls && (!out_idx || src_idx) && (!out_val || src_val));
   const int64_t total = P * L * 4;
+  if (K == 4 && out_idx && !out_val && (reinterpret_cast<uintptr_t>(src_idx) & 15) == 0 && (reinterpret_cast<uintptr_t>(out_idx) & 15) == 0) {
+    expand_idx4_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream)>>>(
+        reinterpret_cast<const float2*>(xy), n_ls, src_idx, vid_out, out_idx, total, L, vstride, NV);
+    GNGF_RETURN_LAUNCH();
+  }
   expand_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream)>>>(
       reinterpret_cast<const float2*>(xy), n_ls, src_idx, src_val, vid_out, out_idx, out_val, total, L, K, vstride, NV);
   GNGF_RETURN_LAUNCH();

@@ -249,6 +249,8 @@ class GeneralNeuralGaugeFields(nn.Module):
         self.hpd_stats = {}                # shape of the last chunked HPD evaluation (rows, chunks, chunks kept)
         self.loss_value_aside = False      # the caller joins the fused loss value itself (train.GraphedStep)
         self._last_link = None             # ops.StepLink of the most recent forward pass
+        self.track_collisions = False      # every forward pass also marks the table slots its batch uses (start_collision_tracking)
+        self._slot_maps = None             # (slot bit maps (K|1, L, T bits), touched-vertex workspace)
         self.to(device)
 
     # ------------------------------------------------------------------ helpers
@@ -353,6 +355,9 @@ class GeneralNeuralGaugeFields(nn.Module):
             enc = ops.encode_apply(x, n_ls, self._n_ls_host, tables, None, None, 0, path=("direct" if should_batchnorm_data else None),
                                    dp=dp, link=link, sink=sink)
             rgb = self._decode(enc, link)
+            if self.track_collisions and not should_batchnorm_data:
+                vs = self._n_max + 2
+                self._mark_batch_slots(x.detach(), n_ls, None, vs, vs * vs)
             idx = ops.hash_indices(x.detach(), n_ls, T) if (self.return_indices or should_calc_counts) else None
             counts = self._calc_counts_per_level(idx, x.detach(), n_ls) if should_calc_counts else []
             return rgb, None, idx, counts
@@ -384,6 +389,8 @@ class GeneralNeuralGaugeFields(nn.Module):
             order = None
         enc = ops.encode_apply(x, n_ls, self._n_ls_host, tables, ti, w, vstride, order=order, dp=dp, link=link, sink=sink)
         rgb = self._decode(enc, link)
+        if self.track_collisions:
+            self._mark_batch_slots(x.detach(), n_ls, ti, vstride, NV)
 
         need_vid = want_dense or keep_topk or should_calc_counts
         need_idx = self.return_indices or should_calc_counts
@@ -459,32 +466,91 @@ class GeneralNeuralGaugeFields(nn.Module):
              ptr(counts), stream_ptr())
         return counts
 
+    def _level_vertex_counts(self):
+        n = self._n_ls.reshape(-1).cpu().numpy().astype(np.int64)
+        return 4 + (n + 1 - 2) * 4 + (n + 1 - 2) ** 2                        # = (N_l + 1)^2   (models.py:577-582)
+
+    def _collisions_from_used(self, used, dev):
+        """used: (K|1, L) int32 device tensor of distinct slots per (top-K rank, level) -> the reference's (collisions,
+        min_possible_collisions) of models.py:568-619."""
+        nverts = self._level_vertex_counts()
+        if self._hash_mode:
+            coll = torch.from_numpy(nverts - used[0].cpu().numpy().astype(np.int64))
+        else:
+            coll = torch.from_numpy(nverts.astype(np.float32)).to(dev)[None, :] - used.to(torch.float32)     # (K,L)
+            coll = coll.mean(0)
+            coll[coll < 0] = 0
+        min_possible = torch.tensor(nverts - self._hash_table_size).to(dev)
+        min_possible[min_possible < 0] = 0
+        return coll, min_possible
+
     @torch.no_grad()
     def calc_hash_collisions(self, indices: torch.Tensor):
         """reference models.py:568-619: (#vertices of the level) - (#distinct slots used), per level."""
-        n = self._n_ls.reshape(-1).cpu().numpy().astype(np.int64)
-        nverts = 4 + (n + 1 - 2) * 4 + (n + 1 - 2) ** 2                      # = (N_l + 1)^2
+        nverts = self._level_vertex_counts()
         L = self._num_levels
         on_gpu = indices.is_cuda and indices.dtype == torch.int64 and indices.shape[1] == L
+        if on_gpu:
+            return self._collisions_from_used(self._distinct_slot_counts(indices, L, self._hash_table_size), indices.device)
         if self._hash_mode:
-            if on_gpu:
-                used = self._distinct_slot_counts(indices, L, self._hash_table_size)[0].cpu().numpy().astype(np.int64)
-                coll = torch.from_numpy(nverts - used)
-            else:
-                per_level = indices.permute(1, 0, 2).reshape(L, -1)
-                coll = torch.tensor([int(nverts[i]) - int(torch.unique(per_level[i]).numel()) for i in range(L)])
+            per_level = indices.permute(1, 0, 2).reshape(L, -1)
+            coll = torch.tensor([int(nverts[i]) - int(torch.unique(per_level[i]).numel()) for i in range(L)])
         else:
             Kk = indices.shape[-1]
-            if on_gpu:
-                used = self._distinct_slot_counts(indices, L, self._hash_table_size).to(torch.float32)     # (K,L)
-                coll = torch.from_numpy(nverts.astype(np.float32)).to(indices.device)[None, :] - used
-            else:
-                coll = torch.empty((Kk, L), device=indices.device)
-                for k in range(Kk):
-                    per_level = indices[..., k].permute(1, 0, 2).reshape(L, -1)
-                    coll[k] = torch.tensor([float(int(nverts[i]) - int(torch.unique(per_level[i]).numel())) for i in range(L)])
+            coll = torch.empty((Kk, L), device=indices.device)
+            for k in range(Kk):
+                per_level = indices[..., k].permute(1, 0, 2).reshape(L, -1)
+                coll[k] = torch.tensor([float(int(nverts[i]) - int(torch.unique(per_level[i]).numel())) for i in range(L)])
             coll = coll.mean(0)
             coll[coll < 0] = 0
         min_possible = torch.tensor(nverts - self._hash_table_size).to(indices.device)
         min_possible[min_possible < 0] = 0
         return coll, min_possible
+
+    # ---- the same statistic without the index tensor: the forward passes mark the slots their batches use
+    def start_collision_tracking(self):
+        """From now on every forward pass marks, into per-(rank, level) T-bit maps on the device, the table slots its batch uses
+        (csrc/stats.hip: gngf_mark_batch_slots — both index sources depend on (level, vertex) only, so these are the slots of
+        the batch's TOUCHED vertices: ~0.1 ms per step instead of writing and re-reading the 2 GiB (P,L,4,K) int64 tensor).
+        tracked_hash_collisions() then returns what calc_hash_collisions(indices of every batch since) would.  Call it once
+        per epoch; the maps accumulate over the batches in between (a trainable HPD changes the per-vertex table from batch to
+        batch: each batch marks with its own, as the reference's per-batch indices do, functions.py:211-216, 327)."""
+        from ._lib import query
+        L, T = self._num_levels, self._hash_table_size
+        K = 1 if self._hash_mode else self._topk_k
+        dev = self.encoding._hash_tables[0].weight.device
+        vs = self._n_max + 2
+        words = query("gngf_slot_bitmap_words", L, K, T)
+        if self._slot_maps is None or self._slot_maps[0].numel() != words or self._slot_maps[0].device != dev:
+            self._slot_maps = (torch.zeros((words,), dtype=torch.int32, device=dev),
+                               torch.zeros((L * ((vs * vs + 31) // 32),), dtype=torch.int32, device=dev))
+        else:
+            self._slot_maps[0].zero_()
+        self.track_collisions = True
+
+    def stop_collision_tracking(self):
+        self.track_collisions = False
+
+    @torch.no_grad()
+    def _mark_batch_slots(self, x, n_ls, vert_idx, vstride, NV):
+        from ._lib import call, ptr, stream_ptr
+        bitmap, touched = self._slot_maps
+        if int(NV) > (self._n_max + 2) ** 2:
+            raise ValueError("collision tracking: the per-vertex table exceeds the [0, 1]^2 vertex grid")
+        K = 1 if vert_idx is None else vert_idx.shape[1]
+        call("gngf_mark_batch_slots", ptr(x, torch.float32, "x"), ptr(n_ls, torch.int32), x.shape[0], self._num_levels,
+             ptr(vert_idx, torch.int32), K, self._hash_table_size, int(vstride), int(NV), ptr(touched), ptr(bitmap), stream_ptr())
+
+    @torch.no_grad()
+    def tracked_hash_collisions(self):
+        """(collisions, min_possible_collisions) over every batch seen since start_collision_tracking() — equal to
+        calc_hash_collisions(torch.cat(their index tensors)) (reference models.py:568-619, called at functions.py:327)."""
+        from ._lib import call, ptr, stream_ptr
+        if self._slot_maps is None:
+            raise RuntimeError("tracked_hash_collisions(): call start_collision_tracking() before the epoch's forward passes")
+        L, T = self._num_levels, self._hash_table_size
+        K = 1 if self._hash_mode else self._topk_k
+        bitmap = self._slot_maps[0]
+        used = torch.empty((K, L), dtype=torch.int32, device=bitmap.device)
+        call("gngf_count_slot_bits", ptr(bitmap), L, K, T, ptr(used), stream_ptr())
+        return self._collisions_from_used(used, bitmap.device)

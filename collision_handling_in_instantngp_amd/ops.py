@@ -368,9 +368,14 @@ class HpdVertexFunction(torch.autograd.Function):
             # (the previous step's kept chunks come back from there), minus the reserve for the backward's own buffers
             free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
             budget = min(HPD_Z_CACHE_BYTES, free - HPD_Z_CACHE_RESERVE)
+        # The hidden layers (2 -> 32 -> 64 -> 128 at the reference's widths) are evaluated for ALL vertices in one go, outside the
+        # chunk loop, and kept for the backward pass (0.9 KB per vertex): inside the loop they were ~10 launches per chunk of
+        # microseconds of work each, and a small launch that has to find free CUs beside a 5 ms streaming pass on the helper
+        # stream takes 0.2-0.4 ms — 108 ms of a 890 ms step at 44 chunks (profiles/r03_kernel_stats_gngf_learning.txt).
+        hs_all = HpdVertexFunction._hidden(vertex_coords(0, NV, vstride, dev), params, n_layers)
         for u0 in range(0, NV, rows):
             n = min(rows, NV - u0)
-            hs = HpdVertexFunction._hidden(vertex_coords(u0, n, vstride, dev), params, n_layers)
+            hs = [h[u0:u0 + n] for h in hs_all]
             z = probs[u0:u0 + n] if keep_probs else None
             if keep_z:
                 need = n * T * 4
@@ -415,18 +420,23 @@ class HpdVertexFunction(torch.autograd.Function):
             aux.stats.update(rows_total=int(NV), T=int(T), rows_per_chunk=int(rows), chunks=-(-NV // rows), chunks_kept=len(zcache))
         ctx.cfg = (NV, vstride, K, rows, n_layers, T, keep_probs)
         ctx.zcache = zcache
-        ctx.save_for_backward(ti, mw, probs, rowstat, *params)
+        ctx.hidden = hs_all if any(ctx.needs_input_grad[7:]) else None      # activations of every vertex (no recomputation in backward)
+        ctx.save_for_backward(ti, mw, probs, rowstat, tv, *params)
         ctx.mark_non_differentiable(ti)
         return tv, ti, pbar, probs
 
     @staticmethod
     def backward(ctx, g_tv, g_ti, g_pbar, g_probs):
         NV, vstride, K, rows, n_layers, T, keep_probs = ctx.cfg
-        ti, mw, probs, rowstat = ctx.saved_tensors[:4]
-        params = ctx.saved_tensors[4:]
+        ti, mw, probs, rowstat, tv = ctx.saved_tensors[:5]
+        params = ctx.saved_tensors[5:]
         W_last, b_last = params[-2], params[-1]
         dev = W_last.device
         grads = [torch.zeros_like(p) for p in params]
+        hs_all, ctx.hidden = getattr(ctx, "hidden", None), None
+        if hs_all is None:
+            hs_all = HpdVertexFunction._hidden(vertex_coords(0, NV, vstride, dev), params, n_layers)
+        dH = torch.zeros((NV, W_last.shape[1]), dtype=_f32, device=dev)       # d loss / d (last hidden layer), every vertex
         g_tv = _c(g_tv) if g_tv is not None else None
         g_pbar = _c(g_pbar) if (g_pbar is not None and mw is not None) else None
         g_probs = _c(g_probs) if g_probs is not None else None
@@ -455,10 +465,13 @@ class HpdVertexFunction(torch.autograd.Function):
                 dz_buf = dz_bufs[0] if dz_bufs else None
                 dz_bufs = None
         if pipelined:
-            return HpdVertexFunction._backward_pipelined(ctx.cfg, ti, mw, rowstat, params, grads, g_tv, g_pbar, L, zcache, scratch, main, side, dz_bufs)
+            HpdVertexFunction._backward_pipelined(ctx.cfg, ti, mw, rowstat, tv, params, grads, g_tv, g_pbar, L, zcache, scratch, main, side,
+                                                  dz_bufs, hs_all, dH)
+            HpdVertexFunction._hidden_backward(hs_all, dH, params, grads, n_layers)
+            return (None, None, None, None, None, None, None, *grads)
         for u0 in range(0, NV, rows):
             n = min(rows, NV - u0)
-            hs = HpdVertexFunction._hidden(vertex_coords(u0, n, vstride, dev), params, n_layers)
+            hs = [h[u0:u0 + n] for h in hs_all]
             dz = zcache.pop(u0, None)       # this chunk's logits, kept by the forward (freed as soon as the chunk is done)
             have_z = dz is not None
             if not have_z:
@@ -473,7 +486,8 @@ class HpdVertexFunction(torch.autograd.Function):
                 call("gngf_softmax_bwd_lowrank", ptr(dz), ptr(rowstat[u0:u0 + n]),
                      ptr(g_tv[u0:u0 + n] if g_tv is not None else None), ptr(ti[u0:u0 + n]),
                      ptr(mw[u0:u0 + n] if g_pbar is not None else None), ptr(g_pbar), L if g_pbar is not None else 0,
-                     ptr(grads[-1]), ptr(scratch), n, T, K if g_tv is not None else 0, stream_ptr())
+                     ptr(grads[-1]), ptr(scratch), ptr(tv[u0:u0 + n] if g_tv is not None else None), n, T,
+                     K if g_tv is not None else 0, stream_ptr())
                 with _split_gemm():
                     linear_bwd_weight(dz, None, hs[-1], grads[-2], None, ACT_NONE)
             else:
@@ -489,18 +503,22 @@ class HpdVertexFunction(torch.autograd.Function):
                      ptr(g_probs[u0:u0 + n]), ptr(mw[u0:u0 + n] if g_pbar is not None else None), ptr(g_pbar), L, ptr(dz), n, T,
                      K if g_tv is not None else 0, stream_ptr())
                 linear_bwd_weight(dz, None, hs[-1], grads[-2], grads[-1], ACT_NONE)
-            g = torch.zeros((n, W_last.shape[1]), dtype=_f32, device=dev)
             with _split_gemm():
-                gemm_acc(dz, W_last, g, n, W_last.shape[1], T, ta=False, tb=False)     # dh = dz @ W_last, split over T
-            for i in range(n_layers - 2, -1, -1):
-                linear_bwd_weight(g, hs[i + 1], hs[i], grads[2 * i], grads[2 * i + 1], ACT_RELU)
-                if i > 0:
-                    g = linear_bwd_input(g, hs[i + 1], params[2 * i], ACT_RELU)
+                gemm_acc(dz, W_last, dH[u0:u0 + n], n, W_last.shape[1], T, ta=False, tb=False)     # dh = dz @ W_last, split over T
+        HpdVertexFunction._hidden_backward(hs_all, dH, params, grads, n_layers)
         return (None, None, None, None, None, None, None, *grads)
 
+    @staticmethod
+    def _hidden_backward(hs_all, dH, params, grads, n_layers):
+        """backward of the hidden layers for ALL vertices at once (behind the chunk loop: eight launches per step, not per chunk)"""
+        g = dH
+        for i in range(n_layers - 2, -1, -1):
+            linear_bwd_weight(g, hs_all[i + 1], hs_all[i], grads[2 * i], grads[2 * i + 1], ACT_RELU)
+            if i > 0:
+                g = linear_bwd_input(g, hs_all[i + 1], params[2 * i], ACT_RELU)
 
     @staticmethod
-    def _backward_pipelined(cfg, ti, mw, rowstat, params, grads, g_tv, g_pbar, L, zcache, scratch, main, side, dz_bufs):
+    def _backward_pipelined(cfg, ti, mw, rowstat, tv, params, grads, g_tv, g_pbar, L, zcache, scratch, main, side, dz_bufs, hs_all, dH):
         """The low-rank backward with its chunks software-pipelined over two streams.  Per chunk: A (main) logits again unless
         kept; B (side) softmax / top-K / batch-mean backward in place, HBM bound; C (main) the dW and dh GEMMs and the small
         layers, matrix-pipe bound.  Issue order on main: A_0, A_1, C_0, A_2, C_1, ... so that C_i runs beside B_{i+1}.  Un-kept
@@ -511,22 +529,15 @@ class HpdVertexFunction(torch.autograd.Function):
         dev = W_last.device
         n_unkept, alive, pending = 0, [], None
 
-        def stage_c(dz, hs, done_b, n):
+        def stage_c(dz, hs, done_b, n, u0):
             main.wait_event(done_b)
             with _split_gemm():
                 linear_bwd_weight(dz, None, hs[-1], grads[-2], None, ACT_NONE)
-            g = torch.zeros((n, W_last.shape[1]), dtype=_f32, device=dev)
-            with _split_gemm():
-                gemm_acc(dz, W_last, g, n, W_last.shape[1], T, ta=False, tb=False)     # dh = dz @ W_last, split over T
-            for i in range(n_layers - 2, -1, -1):
-                linear_bwd_weight(g, hs[i + 1], hs[i], grads[2 * i], grads[2 * i + 1], ACT_RELU)
-                if i > 0:
-                    g = linear_bwd_input(g, hs[i + 1], params[2 * i], ACT_RELU)
-            alive.append(g)
+                gemm_acc(dz, W_last, dH[u0:u0 + n], n, W_last.shape[1], T, ta=False, tb=False)     # dh = dz @ W_last, split over T
 
         for u0 in range(0, NV, rows):
             n = min(rows, NV - u0)
-            hs = HpdVertexFunction._hidden(vertex_coords(u0, n, vstride, dev), params, n_layers)
+            hs = [h[u0:u0 + n] for h in hs_all]
             dz = zcache.pop(u0, None)
             if dz is None:                                     # A: not kept by the forward
                 dz = dz_bufs[n_unkept % len(dz_bufs)][:n]
@@ -541,18 +552,18 @@ class HpdVertexFunction(torch.autograd.Function):
                 call("gngf_softmax_bwd_lowrank", ptr(dz), ptr(rowstat[u0:u0 + n]),
                      ptr(g_tv[u0:u0 + n] if g_tv is not None else None), ptr(ti[u0:u0 + n]),
                      ptr(mw[u0:u0 + n] if g_pbar is not None else None), ptr(g_pbar), L if g_pbar is not None else 0,
-                     ptr(grads[-1]), ptr(scratch), n, T, K if g_tv is not None else 0, stream_ptr())
+                     ptr(grads[-1]), ptr(scratch), ptr(tv[u0:u0 + n] if g_tv is not None else None), n, T,
+                     K if g_tv is not None else 0, stream_ptr())
                 done_b = torch.cuda.Event()
                 done_b.record(side)
             if pending is not None:                            # C of the previous chunk, beside this chunk's B
                 stage_c(*pending)
-            pending = (dz, hs, done_b, n)
+            pending = (dz, hs, done_b, n, u0)
         if pending is not None:
             stage_c(*pending)
         main.wait_stream(side)
         side.wait_stream(main)       # the helper's next use starts behind everything issued here
         del alive[:]
-        return (None, None, None, None, None, None, None, *grads)
 
 
 class BlendFunction(torch.autograd.Function):

@@ -463,10 +463,19 @@ def train_epoch(net, loss_fn, optimizer, x, target, w, h, l_mse, l_js_kl, l_coll
     indices = None
     rec = {"loss": [], "mse": [], "kls": [], "colls": [], "counts": []}
     one = torch.ones((), device=dev)                 # seed of backward(): the same d loss / d loss = 1, without a fill per batch
+    # the reference's collision statistic (functions.py:327) without the index tensor: when the model does not return indices the
+    # forward passes mark the slots their batches use (models.start_collision_tracking) and train_step reads the maps
+    tracked = (hasattr(net, "start_collision_tracking") and not getattr(net, "return_indices", True) and not should_calc_counts
+               and not models.should_batchnorm_data)
+    if tracked:
+        net.start_collision_tracking()
+    elif hasattr(net, "stop_collision_tracking"):
+        net.stop_collision_tracking()
+    rec["tracked"] = tracked
     gs = None
     if graph:
         gs = getattr(net, "_graphed_step", None)
-        cfg = (id(loss_fn), id(optimizer), l_mse, l_js_kl, l_collisions, batch_percentage)
+        cfg = (id(loss_fn), id(optimizer), l_mse, l_js_kl, l_collisions, batch_percentage, tracked)
         if gs is None or gs._cfg != cfg:
             bounds = None if models.should_use_hash_function else (float(x[:, 0].max()), float(x[:, 1].max()))
             gs = GraphedStep(net, loss_fn, optimizer, l_mse, l_js_kl, l_collisions, batch_percentage, coord_bounds=bounds)
@@ -515,6 +524,9 @@ def train_epoch(net, loss_fn, optimizer, x, target, w, h, l_mse, l_js_kl, l_coll
             rec["colls"].append(colls.detach().clone() if colls.nelement() != 0 else torch.ones_like(kls.detach()))
         rec["counts"].append(counts)
     rec["outputs"], rec["indices"] = outputs, indices
+    if tracked:
+        rec["collisions"] = net.tracked_hash_collisions()
+        net.stop_collision_tracking()
     return rec
 
 
@@ -558,7 +570,9 @@ def train_step(net, loss_fn, optimizer, x, target, w, h, hash_table_size, topk_k
         indices_per_level = [dict(zip(*np.unique(level, return_counts=True))) for level in flat]
     if indices is not None:
         collisions, min_possible_collisions = net.calc_hash_collisions(indices)
-    else:                                               # return_indices = False: the statistic is skipped
+    elif rec.get("collisions") is not None:             # return_indices = False: the slot maps the forward passes marked
+        collisions, min_possible_collisions = rec["collisions"]
+    else:
         collisions, min_possible_collisions = torch.tensor([]), torch.tensor([])
     to_show_img = (outputs * 255).reshape((h, w, 3) if not should_bw else (h, w)).int().detach().cpu().numpy()
     counts_per_level = [

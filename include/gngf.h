@@ -300,7 +300,10 @@ int gngf_softmax_bwd(const float* probs, const float* dq, const int32_t* topk_id
  * p = exp(z - rowstat.max) / rowstat.sum;  g = mw (U,L) * G (L,T) + dq at topk_idx;  dz = p .* (g - <p,g>);
  * db (T) += column sums of dz (NULL: skipped).  scratch: U + U*K floats.  L = 0 / K = 0 drop the respective term. */
 int gngf_softmax_bwd_lowrank(float* logits_dz, const float* rowstat, const float* dq, const int32_t* topk_idx, const float* mw,
-                             const float* G, int L, float* db, float* scratch, int64_t U, int64_t T, int K, void* stream);
+                             const float* G, int L, float* db, float* scratch, const float* topk_p, int64_t U, int64_t T, int K,
+                             void* stream);
+/* topk_p (optional; (U,K)): the top-K probabilities gngf_logits_topk_pbar / gngf_softmax_topk returned for these logits — the
+ * backward then takes p at the top-K slots from them instead of reading the logits again at random. */
 
 /* verts[i] = (gx, gy) fp32 of vertex id u0+i (vid = gy*vstride + gx): the raw-integer HPD input of models.py:416-418 */
 int gngf_vertex_coords(float* verts, int64_t u0, int64_t count, int vstride, void* stream);
@@ -344,6 +347,14 @@ int gngf_js_kl_bwd(const float* pbar, const float* gout, float* dpbar, int L, in
 int64_t gngf_slot_bitmap_words(int L, int K, int64_t T);
 int gngf_distinct_slot_counts(const int64_t* indices, int64_t P, int L, int V, int K, int64_t T, uint32_t* bitmap,
                               int32_t* counts, void* stream);
+/* The same statistic without the index tensor (2 GiB per step at the headline shape): both index sources depend on (level,
+ * vertex) only, so a batch's distinct slots are the slots of its touched vertices.  Marks the slots batch `xy` uses into
+ * `bitmap` (gngf_slot_bitmap_words(L, K, T) 32-bit words, ACCUMULATED over calls: the caller clears it once per epoch);
+ * vert_idx (NV,K) int32 with vid = gy * vstride + gx, or NULL for the spatial hash (K = 1, vstride >= N_max + 2, NV = vstride^2);
+ * touched: workspace of L * ceil(NV / 32) words.  gngf_count_slot_bits then gives counts (K,L) as gngf_distinct_slot_counts. */
+int gngf_mark_batch_slots(const float* xy, const int32_t* n_ls, int64_t P, int L, const int32_t* vert_idx, int K, int64_t T,
+                          int vstride, int64_t NV, uint32_t* touched, uint32_t* bitmap, void* stream);
+int gngf_count_slot_bits(const uint32_t* bitmap, int L, int K, int64_t T, int32_t* counts, void* stream);
 
 /* ---- optimizer (row f2: the caller of the path) ---------------------------------------------------------------------
  * torch.optim.Adam as get_optimizer builds it (functions.py:96-127: betas (0.9, 0.99), eps 1e-15, L2-style weight

@@ -214,8 +214,11 @@ def test_fused_decoder_vs_numpy(ops, P, in_dim, out_dim, leaky):
                                       # T % 32 == 0: the MFMA form of the two passes (ragged last row block, 1..32 levels)
                                       (200, 4096 + 64, 4, 16), (130, 8192, 3, 5), (33, 96, 2, 3), (70, 1024, 6, 0),
                                       (129, 640, 0, 29)])
-def test_softmax_bwd_lowrank_from_logits_vs_numpy(ops, U, T, K, Lv):
-    """streamed softmax / top-K / batch-mean backward from recomputed logits (chunked per-vertex path)"""
+@pytest.mark.parametrize("saved_p", [False, True])
+def test_softmax_bwd_lowrank_from_logits_vs_numpy(ops, U, T, K, Lv, saved_p):
+    """streamed softmax / top-K / batch-mean backward from recomputed logits (chunked per-vertex path).
+    saved_p: the probabilities at the top-K slots come from the forward's topk_val (what ops.HpdVertexFunction passes since
+    round 4) instead of a second, random read of the logits."""
     from collision_handling_in_instantngp_amd._lib import call, ptr, stream_ptr
     rng = np.random.default_rng(U + T)
     z = (rng.standard_normal((U, T)) * 2).astype(np.float32)
@@ -240,8 +243,9 @@ def test_softmax_bwd_lowrank_from_logits_vs_numpy(ops, U, T, K, Lv):
     dq_t = t(dq[:, :K].copy()) if K else None                # keep every device tensor alive across the launch
     ti_t = tib[:, :K].contiguous() if K else None
     mw_t, G_t = (t(mw), t(G)) if Lv else (None, None)
+    tp_t = tvb[:, :K].contiguous() if (K and saved_p) else None
     call("gngf_softmax_bwd_lowrank", ptr(logits), ptr(rowstat), ptr(dq_t), ptr(ti_t), ptr(mw_t), ptr(G_t), Lv, ptr(db),
-         ptr(scratch), U, T, K, stream_ptr())
+         ptr(scratch), ptr(tp_t), U, T, K, stream_ptr())
     scale = np.abs(want).max()
     close(logits, want, 2e-4, 2e-6 * scale)
     close(db, want.sum(0), 2e-4, 2e-5 * scale)

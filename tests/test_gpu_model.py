@@ -312,6 +312,66 @@ def test_diagnostics_contract_matches_reference(golden, mode):
         models.should_use_hash_function = False
 
 
+@pytest.mark.parametrize("mode", ["hash", "gngf", "gngf_frozen"])
+def test_tracked_collision_statistic_equals_the_one_taken_from_the_index_tensor(golden, mode):
+    """calc_hash_collisions only needs the distinct slots per (level, rank) among the batch's corners
+    (reference models.py:568-619, called at functions.py:327).  With start_collision_tracking() the forward passes mark them from
+    the per-vertex table and a touched-vertex map (csrc/stats.hip) — no (P,L,4,K) int64 tensor.  Equal, batch by batch and
+    accumulated over three batches, to calc_hash_collisions on the concatenated index tensors of the same passes; and
+    train_step(return_indices=False) hands the reference's collision tensors back."""
+    from collision_handling_in_instantngp_amd import models, train
+    models.should_use_hash_function = (mode == "hash")
+    try:
+        torch.manual_seed(11)
+        net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=2 ** 12, num_levels=8, n_min=8, n_max=96,
+                                              MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
+                                              HPD_out_features=2 ** 12, feature_dim=2, topk_k=4)
+        if mode == "gngf_frozen":
+            for p in net.HPD.parameters():
+                p.requires_grad = False
+            net.dense_probs = False
+            net.compute_pbar = False
+        X, Y, h, w = strawberry(golden)
+        net.return_indices = True
+        net.start_collision_tracking()
+        idxs = []
+        for lo in (0, 50000, 120000):
+            with torch.no_grad():
+                _rgb, _p, idx, _c = net(X[lo:lo + 30000].contiguous(), 1 / 3)
+            idxs.append(idx)
+            got, got_min = net.tracked_hash_collisions()
+            want, want_min = net.calc_hash_collisions(torch.cat(idxs))
+            assert torch.equal(got.cpu(), want.cpu()) and torch.equal(got_min.cpu(), want_min.cpu()), (lo, got, want)
+            if mode == "gngf":                       # a trainable HPD: the table changes between batches, each batch marks its own
+                with torch.no_grad():
+                    net.HPD.module_list[3][0].bias.add_(torch.randn(2 ** 12, device=DEV))
+        assert float(want.sum()) > 0
+        net.start_collision_tracking()               # a new epoch starts from empty maps
+        with torch.no_grad():
+            _rgb, _p, idx, _c = net(X[:30000].contiguous(), 1 / 3)
+        got, _ = net.tracked_hash_collisions()
+        assert torch.equal(got.cpu(), net.calc_hash_collisions(idx)[0].cpu())
+        net.stop_collision_tracking()
+        # the reference's train_step contract with return_indices = False
+        loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
+        opt = train.get_optimizer(net, 1e-4, 1e-3, 1e-3, 0, 1e-6, 1e-6)
+        perm = torch.randperm(h * w, generator=torch.Generator().manual_seed(3)).to(DEV)
+        outs = {}
+        for ret in (True, False):
+            net.return_indices = ret
+            for graph in ((False, True) if mode != "gngf" else (False,)):
+                r = train.train_step(net, loss_fn, opt, X, Y, w, h, 2 ** 12, 4, 1, 1, 1e-3, batch_percentage=1 / 3, num_levels=8,
+                                     shuffled_indices=perm, graph=graph)
+                outs[(ret, graph)] = (r[2], r[3])
+                assert r[2].numel() == 8 and r[3].numel() == 8
+        if mode != "gngf":                            # (a trainable HPD moves between the epochs: the statistic moves with it)
+            base = outs[(True, False)]
+            for k_, v_ in outs.items():
+                assert torch.equal(v_[0].cpu().double(), base[0].cpu().double()) and torch.equal(v_[1].cpu(), base[1].cpu()), k_
+    finally:
+        models.should_use_hash_function = False
+
+
 def test_keep_topk_only_bw_and_leaky_variants_run_and_differentiate(golden):
     """constructor switches of the reference: should_keep_topk_only (probs = (P,L,4,K)), should_bw (1 output), LeakyReLU."""
     from collision_handling_in_instantngp_amd import models, train
