@@ -477,6 +477,10 @@ def main():
             dt = timed(step, steps // per, -(-warmup // per), world)       # exactly `steps` steps: steps / per replays of `per` steps each
             res = results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                                    "launch": launch, "shape": {k: v for k, v in SHAPES[cfg_name].items()}}
+            if not learning:
+                # the contract's window is `steps` steps (8 ms at the default K): five more windows of the same length, each bracketed
+                # like the first, show how much one window moves (every rank runs them: the barriers stay matched)
+                res["ms_per_step_windows"] = [timed(step, steps // per, 0, world) / steps * 1e3 for _ in range(5)]
             # the target's own metric: per-instance algorithmic bytes x pixels/s against the HBM peak.  For
             # GNGF indexing that figure assumes one table gather per (pixel, corner, k); the per-vertex de-duplicated algorithm does
             # not move those bytes, so its ratio exceeds 1 — it is printed as what it is, next to the hash modes' real fractions.
@@ -588,10 +592,22 @@ def main():
         c_fwd, c_bwd = compulsory_bytes(a.mode)
         times = {k: v for k, v in kt.items() if isinstance(v, float)}
         dec_flops = 2 * (L * F * 64 + 64 * 64 + 64 * 3)          # per pixel, forward; backward (dX + dW) = 2x
-        traffic = {}
+        # HBM bytes per launch from the round's PMC passes (profiles/traffic.json, written by tools/make_traffic.py together with
+        # the signature of the step's kernel chain it was measured on).  A file measured on ANOTHER chain is not reported.
+        traffic, traffic_source = {}, None
         tr_path = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.isfile(tr_path):
-            traffic = json.load(open(tr_path))
+            raw = json.load(open(tr_path))
+            meta = raw.pop("_meta", {})
+            if meta.get("chain") == ops.STEP_CHAIN_SIGNATURE:
+                traffic = raw
+                traffic_source = {"file": "profiles/traffic.json", **meta, "matches_running_build": True}
+            else:
+                traffic_source = {"file": "profiles/traffic.json", **meta, "matches_running_build": False,
+                                  "running_chain": ops.STEP_CHAIN_SIGNATURE,
+                                  "note": "measured on another kernel chain than the one this build runs: traffic not reported"}
+                print(f"[bench] profiles/traffic.json was measured on chain {meta.get('chain')!r}, this build runs "
+                      f"{ops.STEP_CHAIN_SIGNATURE!r}: roofline.traffic dropped", file=sys.stderr)
 
         def pmc(name):
             return (traffic.get(name) or {}).get("hbm_bytes_per_launch")
@@ -655,7 +671,8 @@ def main():
             "collective_ranks": collective_ranks, "rccl_ranks": (collective_ranks if (world > 1 and a.backend == "nccl") else None),
             "backend": (a.backend if world > 1 else None),
             "modes": results, "kernel_ms": {k: (v * 1e3 if isinstance(v, float) else v) for k, v in kt.items()},
-            "roofline": roof, "roofline_encoder": roof_enc, "roofline_step": roof_step,
+            "roofline": roof, "roofline_encoder": roof_enc, "roofline_step": roof_step, "traffic_source": traffic_source,
+            "ms_per_step_windows": head.get("ms_per_step_windows"),
             "hbm_copy_measured_GBs": hbm_copy, "hbm_peak_GBs": HBM_PEAK_GBS,
             "roofline_survey": {m: r_["roofline_survey"]["frac_of_8TBs"] for m, r_ in results.items() if "roofline_survey" in r_},
             "roofline_survey_note": "SURVEY 8(d) algorithmic bytes/pixel x pixels/s / 8 TB/s per mode (the target's '>= 60 % of the HBM-read "

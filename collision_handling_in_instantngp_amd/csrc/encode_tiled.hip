@@ -919,13 +919,17 @@ tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
   extern __shared__ float2 img_raw[];             // [rows][kIL]: (feature 0, feature 1) of vertex `row` of level `column`
   v2f* img = reinterpret_cast<v2f*>(img_raw);
   __shared__ ILMeta m;
-  if ((int)blockIdx.x < cride.NB) {               // riders first: they start at once and the work items fill in around them
-    if (blockIdx.x == 0 && threadIdx.x == 0) cride.pws[2 * (1 << (2 * cride.tile_shift)) + 1] = 0;      // the scatter riders' task counter
-    bin_count_body<kTBF>((int)blockIdx.x, cride.xy, cride.P, cride.per_block, cride.tile_shift, cride.NB, cride.blockhist,
+  // The riders come LAST in the grid.  At the headline shape the 670 work items fit the chip at once (three workgroups per CU:
+  // 768 places), so the launch lasts as long as its slowest item; riders placed first took 128 of those places and sent 30 items
+  // into a second round (41.3 us), riders placed last take the ~100 free places at once and the rest as items retire (40.1 us).
+  if ((int)blockIdx.x >= nwork) {
+    const int rb = (int)blockIdx.x - nwork;
+    if (rb == 0 && threadIdx.x == 0) cride.pws[2 * (1 << (2 * cride.tile_shift)) + 1] = 0;      // the scatter riders' task counter
+    bin_count_body<kTBF>(rb, cride.xy, cride.P, cride.per_block, cride.tile_shift, cride.NB, cride.blockhist,
                          reinterpret_cast<int*>(img_raw), cride.pws);
     return;
   }
-  const int wg = (int)blockIdx.x - cride.NB;
+  const int wg = (int)blockIdx.x;
   const int tid = threadIdx.x;
   const int nit = *n_items;
   const int TSm = (1 << tile_shift) - 1;
@@ -2057,7 +2061,7 @@ extern "C" int gngf_encode_tiled_fwd_fused(const float* sorted, const int32_t* i
     if (e != hipSuccess) return (int)e;
   }
   const int nwork = max_items;
-  fn<<<dim3((unsigned)(cride.NB + nwork)), dim3(kTBF), smem, as_stream(stream)>>>(
+  fn<<<dim3((unsigned)(nwork + cride.NB)), dim3(kTBF), smem, as_stream(stream)>>>(
       reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, const_cast<int32_t*>(n_items) + 1, n_ls, vs,
       enc, L, Ls, tile_shift, nwork, cride);
   GNGF_RETURN_LAUNCH();

@@ -1016,6 +1016,9 @@ def tile_level_offsets(plan, device):
 HASH_VERTEX_FUSION = True    # hash indexing, single rank: the vertex stage backward rides on the gather pass of the pixel stage
 
 
+# The kernel chain of one training step at the headline shape, as a string that changes whenever the chain does: PMC traffic
+# figures (profiles/traffic.json) are stamped with it and bench.py reports them only for the chain they were measured on.
+STEP_CHAIN_SIGNATURE = "r4: [bin_count_ride+bin_scatter2 | riders of the previous step] > tiled_fwd_il<SRC tables>(+count riders) > decoder_train > tiled_bwd_il(+scatter tasks, reduce, mse) > vertex_bwd_hash64|vertex_bwd_sorted<FROM64>"
 FUSED_VERTEX_FWD = True      # fp32 tables on the interleaved forward kernel: the vertex stage forward runs inside its staging loop
 BIN_PIPELINE = True          # ... and an announced next batch (BinPipeline) is binned by riders of this step's pixel-stage launches
 DG64 = True                  # F = 2, <= 16 staged levels, bounded |genc|: 64-bit fixed-point vertex grid fed by global integer atomics

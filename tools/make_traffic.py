@@ -4,6 +4,7 @@ the bytes of wide (16 B/lane) reads (MI355X_MICROARCH.md §HBM); WRITE_SIZE (KiB
 import json, os, subprocess, sys
 summ = json.loads(subprocess.check_output([sys.executable, "tools/pmc_summary.py"] + sys.argv[1:]))
 groups = {     # round 3 kernel names (the round-2 names stay listed: general shapes still run those kernels)
+    "bin_pixels(count+scatter)": [],      # (round 4: same kernels as the entry below when no vertex riders are needed; kept under one name)
     "prepare(bin+vertex_fwd+clears)": ["gngf::bin_count_ride_kernel", "gngf::bin_count_vride_kernel", "gngf::bin_rowscan_kernel", "gngf::bin_scan_kernel",
                                        "gngf::bin_scatter_ride_kernel<2", "gngf::bin_scatter_kernel", "gngf::bin_scatter2_kernel"],
     "encode_fwd:tiled": ["gngf::tiled_fwd_kernel<2>", "gngf::tiled_fwd_il_kernel"],
@@ -29,5 +30,14 @@ for name, ks in groups.items():
         ff = fetch_factor.get(name, 2.0)
         out[name] = {"hbm_bytes_per_launch": (ff * f + w) * 1024, "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB": w, "fetch_factor": ff,
                      "note": "bytes = (fetch_factor*FETCH_SIZE + WRITE_SIZE)*1024; gfx950 FETCH_SIZE counts wide (16 B/lane) reads at half"}
+# stamp: the kernel chain the passes were taken on (bench.py reports the figures only for that chain), commit, kernel names
+sys.path.insert(0, os.getcwd())
+from collision_handling_in_instantngp_amd import ops as _ops   # noqa: E402
+try:
+    commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    commit = os.environ.get("GNGF_COMMIT", "unknown")
+out["_meta"] = {"chain": _ops.STEP_CHAIN_SIGNATURE, "commit": commit,
+                "kernels": sorted(k for k in summ if any(k.startswith(p_) for ks in groups.values() for p_ in ks))}
 json.dump(out, open(os.environ.get("GNGF_TRAFFIC_OUT", "profiles/traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

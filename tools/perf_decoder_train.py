@@ -21,7 +21,14 @@ def two():
     call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(None), ptr(target), ptr(one), ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(Ws[3]), ptr(Ws[4]), ptr(denc), *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(hidden), P, in_dim, out_dim, 0, stream_ptr())
 def fused():
     call("gngf_decoder_train", ptr(enc), ptr(target), ptr(one), *[ptr(w) for w in Ws], ptr(rgb), ptr(denc), *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(None), 0, P, in_dim, out_dim, 0, stream_ptr())
-for name, fn in (("decoder_fwd + decoder_bwd", two), ("decoder_train", fused)):
+zbuf = torch.empty((16 * 2 ** 19 * 2 + 4 * 720000,), device=dev)       # the step's [table gradient | fixed-point vertex grid]: 75 MiB
+zsmall = torch.empty((4 * 720000,), device=dev)                       # the fixed-point vertex grid alone: 11 MiB
+def fused_clear(z):
+    def fn():
+        call("gngf_decoder_train", ptr(enc), ptr(target), ptr(one), *[ptr(w) for w in Ws], ptr(rgb), ptr(denc), *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(z), z.numel(), P, in_dim, out_dim, 0, stream_ptr())
+    return fn
+for name, fn in (("decoder_fwd + decoder_bwd", two), ("decoder_train", fused), ("decoder_train + 75 MiB clear", fused_clear(zbuf)),
+                 ("decoder_train + 11 MiB clear", fused_clear(zsmall)), ("decoder_train", fused)):
     for _ in range(60): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
