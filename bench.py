@@ -446,21 +446,24 @@ def main():
                     unroll = 1
                     if world == 1 and a.unroll:
                         unroll = next((u for u in a.unrolls if steps % u == 0), 1)
-                    gs = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3, unroll=unroll)
-                    if unroll > 1:
-                        gs.run_many([(xy, target)] * unroll)
-                    else:
-                        gs(xy, target)                      # captures; the batch stays in the static buffers
+                    # cross_replay: the last step of a replay bins the first batch of the next one (three calls capture the cold
+                    # graph and the two steady ones; the batches stay in the static buffers)
+                    gs = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3, unroll=unroll, cross_replay=True)
+                    for _ in range(3):
+                        if unroll > 1:
+                            gs.run_many([(xy, target)] * unroll, next_first=xy)
+                        else:
+                            gs(xy, target, next_first=xy)
                     if world > 1:
                         # the exchange (RCCL) and the deferred vertex stage go to the model's communication stream; the next
                         # replay waits for them on the device (it overwrites the exchanged buffers from its first kernel on)
                         def step(gs=gs, net=net):
                             parallel.wait_for_gradients(net)
-                            gs.replay_only()
+                            gs.replay_steady()
                             parallel.allreduce_gradients(net, world, keep_tables_flag=True, overlap=True)
                         launch = "hipGraph + exchange on a communication stream"
                     else:
-                        step = gs.replay_only
+                        step = gs.replay_steady
                         launch = "hipGraph" if unroll == 1 else f"hipGraph ({unroll} steps per replay)"
                 except Exception as e:  # pragma: no cover
                     print(f"[bench] graph capture failed ({e!r}); running eagerly", file=sys.stderr)

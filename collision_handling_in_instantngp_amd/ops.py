@@ -670,6 +670,7 @@ class BinPipeline:
 
     def __init__(self):
         self.next_xy = None       # announced coordinates of the next batch
+        self.next_ws = None       # ... and (optional) the workspace its binning must land in (train.GraphedStep across replays)
         self.ready = None         # (key, workspace) binned by the previous step's riders
         self.pending = None       # count half launched (forward), scatter half not yet (backward has not run)
         self.hits = self.misses = 0
@@ -678,11 +679,19 @@ class BinPipeline:
     def _key(xy, plan):
         return (xy.data_ptr(), xy._version, tuple(xy.shape), str(xy.device), plan.geometry())
 
-    def announce(self, xy):
-        self.next_xy = xy
+    def announce(self, xy, workspace=None):
+        """workspace (optional, an ops.TiledWorkspace(plan, xy, launch=False)): where the riders put the binned batch — a caller
+        that replays captured steps owns it, so that ANOTHER captured graph can be told where its pixels are (seed)."""
+        self.next_xy, self.next_ws = xy, (workspace if xy is not None else None)
+
+    def seed(self, xy, workspace):
+        """Declares `xy` binned in `workspace` — by the riders of a step that ran (or, inside a replayed graph, WILL have run) before
+        the forward pass this is for.  The caller vouches for the CONTENT: the workspace must hold the binning of the coordinates
+        the tensor holds when the kernels run (train.GraphedStep(cross_replay=True) does)."""
+        self.ready = ((xy.data_ptr(), xy._version, tuple(xy.shape), str(xy.device), workspace.geometry), workspace)
 
     def reset(self):
-        self.next_xy = self.ready = None
+        self.next_xy = self.next_ws = self.ready = None
 
     def take(self, xy, plan):
         """the workspace the previous step's riders filled for exactly this tensor and plan, or None"""
@@ -908,6 +917,7 @@ class TiledWorkspace:
         self.items = torch.empty((plan.max_items, 4), dtype=_i32, device=dev)
         self.n_items = torch.empty((4,), dtype=_i32, device=dev)      # [0] items; [1..3] counters of the persistent pixel-stage kernels
         self.sorted = torch.empty((max(P, 1), 4), dtype=_f32, device=dev)
+        self.geometry = plan.geometry()
         if not launch:
             return
         if vertex is None:
@@ -1184,12 +1194,13 @@ class EncodeFunction(torch.autograd.Function):
                 elif pre is not None and not defer:
                     zbuf.zero_()
                 job_next = None
-                nx = None
+                nx = nws = None
                 if pipe is not None:
-                    nx, pipe.next_xy = pipe.next_xy, None
+                    nx, nws, pipe.next_xy, pipe.next_ws = pipe.next_xy, pipe.next_ws, None, None
                 if (nx is not None and ctx.needs_input_grad[3] and plan.interleaved(backward=True) and nx.is_cuda and nx.dtype == _f32
-                        and nx.is_contiguous() and tuple(nx.shape) == tuple(xy.shape) and nx.device == xy.device):
-                    ws_next = TiledWorkspace(plan, nx, launch=False)
+                        and nx.is_contiguous() and tuple(nx.shape) == tuple(xy.shape) and nx.device == xy.device
+                        and (nws is None or (nws.geometry == plan.geometry() and nws is not ws))):
+                    ws_next = nws if nws is not None else TiledWorkspace(plan, nx, launch=False)
                     job_next = _bin_job(ws_next, plan, nx, pws)
                     pipe.pending = ws_next
                     ctx.next_bin = (ws_next, job_next, nx, pipe)

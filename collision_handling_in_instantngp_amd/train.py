@@ -291,10 +291,16 @@ class GraphedStep:
         __slots__ = ("out", "probs", "idx", "loss", "mse", "kls", "colls")
 
     def __init__(self, net, loss_fn, optimizer, l_mse=1.0, l_js_kl=1.0, l_collisions=1e-3, batch_percentage=1.0,
-                 coord_bounds=None, warm=2, unroll=1):
+                 coord_bounds=None, warm=2, unroll=1, cross_replay=False):
         """unroll = k > 1: ONE graph holds k consecutive steps on k batches (run_many): a replay costs ~9 us of launch latency
-        on top of its kernels whatever it contains, so k steps per replay spread it over k steps."""
+        on top of its kernels whatever it contains, so k steps per replay spread it over k steps.
+        cross_replay: the LAST step of a replay also bins the first batch of the NEXT replay (ops.BinPipeline riders) when the caller
+        names it in advance — run_many(batches, next_first=x) / gs(x, y, next_first=x) — so that no step of a steady sequence bins
+        at its head, at any unroll (with unroll = 1, the data-parallel case, every step's binning rides on the step before).
+        Three graphs instead of one per batch shape: `cold` (its first step bins itself) and two `steady` ones that read one of
+        two binning workspaces and fill the other."""
         self.unroll = int(unroll)
+        self.cross_replay = bool(cross_replay)
         if optimizer is not None and not isinstance(optimizer, FusedAdam):
             raise TypeError("GraphedStep captures FusedAdam.step(); torch.optim.Adam's step is not capturable here")
         self.net, self.loss_fn, self.optimizer = net, loss_fn, optimizer
@@ -305,13 +311,17 @@ class GraphedStep:
             net.coord_bounds = (float(coord_bounds[0]), float(coord_bounds[1]))
         self._graphs = {}
 
-    def _body(self, st, next_x=None):
-        """next_x: the coordinate buffer of the step that FOLLOWS this one inside the same graph — announced to the encoder, whose
-        pixel-stage launches then carry that batch's binning (ops.BinPipeline); the first step of a replay bins itself."""
+    def _body(self, st, next_x=None, next_ws=None, binned_in=None):
+        """next_x: the coordinate buffer of the step that FOLLOWS this one (inside the same graph, or — cross_replay — the first step
+        of the next replay) — announced to the encoder, whose pixel-stage launches then carry that batch's binning
+        (ops.BinPipeline), into workspace next_ws if given.  binned_in: the workspace that holds THIS step's binned pixels (filled by
+        the previous replay's last step); None: found through the pipeline, or binned at the head of the step."""
         net, (l_mse, l_js_kl, l_collisions) = self.net, self.weights
         pipe = getattr(getattr(net, "dp", None), "pipeline", None)
         if pipe is not None:
-            pipe.announce(next_x)
+            pipe.announce(next_x, next_ws)
+            if binned_in is not None:
+                pipe.seed(st["x"], binned_in)
         shadow = st["shadow"]
         for s_ in shadow.values():
             s_.grad = None
@@ -379,25 +389,80 @@ class GraphedStep:
                 self.optimizer.prepare_capture(self.unroll)      # no optimizer step is taken before the first real batch
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        # thread_local: other threads of the process (the RCCL watchdog at world > 1) may query events while we capture
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            st["results"] = []
-            subs = [st] + st["more"]
-            for j, sub in enumerate(subs):
-                # step j's pixel-stage launches bin step j + 1's batch (its own static buffer: refilled before every replay)
-                st["results"].append(self._body(sub, next_x=(subs[j + 1]["x"] if j + 1 < len(subs) else None)))
-                if self.optimizer is not None:
-                    self.optimizer.step()
-            st["result"] = st["results"][0]
-        if pipe is not None:
-            pipe.reset()
-        st["graph"] = g
+        st["variants"] = {}
+        st["pre"] = None                 # (index of the workspace that holds the next replay's first batch, identity of that batch)
+        if self.cross_replay and pipe is not None and ops.BIN_PIPELINE:
+            plan = ops.EncodePlan(st["x"].shape[0], net._n_ls_host, net._feature_dim)
+            if plan.Ls > 0 and plan.interleaved(backward=True) and st["x"].shape[0] > 0:
+                # two binning workspaces, allocated outside every capture: each steady graph reads one and fills the other
+                st["W"] = [ops.TiledWorkspace(plan, st["x"], launch=False) for _ in range(2)]
+                st["x_next"] = st["x"].clone()
+        self._capture(st, "cold")
+        st["graph"], st["results"] = st["variants"]["cold"]
+        st["result"] = st["results"][0]
         self._graphs[key] = st
         return st
 
-    def run_many(self, batches, previous_collisions=None, previous_min_possible_collisions=None):
-        """unroll consecutive steps in ONE replay: batches = [(x, target)] * unroll (same shapes).  Returns the list of results."""
+    _VARIANTS = {"cold": (None, 0), "01": (0, 1), "10": (1, 0)}      # name -> (workspace read by the first step, filled by the last)
+
+    def _capture(self, st, name):
+        net = self.net
+        pipe = getattr(getattr(net, "dp", None), "pipeline", None)
+        reads, fills = self._VARIANTS[name]
+        W = st.get("W")
+        if self.optimizer is not None and st["variants"]:
+            self.optimizer.prepare_capture(self.unroll)
+        if pipe is not None:
+            pipe.reset()
+        g = torch.cuda.CUDAGraph()
+        results = []
+        # thread_local: other threads of the process (the RCCL watchdog at world > 1) may query events while we capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            subs = [st] + st["more"]
+            for j, sub in enumerate(subs):
+                last = j + 1 == len(subs)
+                # step j's pixel-stage launches bin step j + 1's batch (its own static buffer: refilled before every replay); the
+                # last step's bin the first batch of the NEXT replay (cross_replay: the caller puts it into x_next beforehand)
+                nx = subs[j + 1]["x"] if not last else (st["x_next"] if W is not None else None)
+                results.append(self._body(sub, next_x=nx, next_ws=(W[fills] if (last and W is not None) else None),
+                                          binned_in=(W[reads] if (j == 0 and W is not None and reads is not None) else None)))
+                if self.optimizer is not None:
+                    self.optimizer.step()
+        if pipe is not None:
+            pipe.reset()
+        st["variants"][name] = (g, results)
+        return st["variants"][name]
+
+    @staticmethod
+    def _ident(t):
+        return (id(t), t.data_ptr(), t._version, tuple(t.shape))
+
+    def _replay(self, st, batches, pc, pm, next_first):
+        """copies the batches in, picks the graph (steady when the previous call announced exactly batches[0][0]), announces the
+        next replay's first batch, replays"""
+        use = "cold"
+        pre = st.get("pre")
+        if "W" in st and pre is not None and batches is not None and pre[1] == self._ident(batches[0][0]):
+            use = "01" if pre[0] == 0 else "10"
+        if batches is not None:
+            for sub, (bx, by) in zip([st] + st["more"], batches):
+                sub["x"].copy_(bx)
+                sub["y"].copy_(by)
+        if pc is not None and pc.numel():
+            st["pc"].copy_(pc)
+            st["pm"].copy_(pm)
+        st["pre"] = None
+        if "W" in st and next_first is not None and tuple(next_first.shape) == tuple(st["x"].shape):
+            st["x_next"].copy_(next_first)
+            st["pre"] = (self._VARIANTS[use][1], self._ident(next_first))
+        g, results = st["variants"].get(use) or self._capture(st, use)
+        g.replay()
+        return results
+
+    def run_many(self, batches, previous_collisions=None, previous_min_possible_collisions=None, next_first=None):
+        """unroll consecutive steps in ONE replay: batches = [(x, target)] * unroll (same shapes).  Returns the list of results.
+        next_first (cross_replay): the coordinates of the first batch of the NEXT call — pass that very tensor, unmodified, as its
+        batches[0][0] and no step of that replay bins at its head."""
         if len(batches) != self.unroll:
             raise ValueError(f"run_many needs exactly unroll = {self.unroll} batches")
         (x0, y0) = batches[0]
@@ -409,14 +474,7 @@ class GraphedStep:
         st = self._graphs.get(key)
         if st is None:
             st = self._build(key, x0, y0, pc, pm)
-        for sub, (bx, by) in zip([st] + st["more"], batches):
-            sub["x"].copy_(bx)
-            sub["y"].copy_(by)
-        if pc.numel():
-            st["pc"].copy_(pc)
-            st["pm"].copy_(pm)
-        st["graph"].replay()
-        return st["results"]
+        return self._replay(st, batches, pc, pm, next_first)
 
     def replay_only(self, key=None):
         """Replays the (only, or the named) captured step on the batch already in its static buffers (benchmarks)."""
@@ -424,7 +482,21 @@ class GraphedStep:
         st["graph"].replay()
         return st["result"]
 
-    def __call__(self, batch_x, batch_target, previous_collisions=None, previous_min_possible_collisions=None):
+    def replay_steady(self, key=None):
+        """Benchmarks, cross_replay: replays the steady graph on the batches already in the static buffers (x_next holds the first
+        batch again), alternating between the two binning workspaces.  Needs one run_many(..., next_first=batches[0][0]) before."""
+        st = self._graphs[key] if key is not None else next(iter(self._graphs.values()))
+        pre = st.get("pre")
+        if "W" not in st or pre is None:
+            st["graph"].replay()
+            return st["result"]
+        use = "01" if pre[0] == 0 else "10"
+        g, results = st["variants"].get(use) or self._capture(st, use)
+        st["pre"] = (self._VARIANTS[use][1], pre[1])
+        g.replay()
+        return results[0]
+
+    def __call__(self, batch_x, batch_target, previous_collisions=None, previous_min_possible_collisions=None, next_first=None):
         dev = batch_x.device
         empty = torch.tensor([], device=dev)
         pc = empty if previous_collisions is None else previous_collisions.to(dev)
@@ -435,13 +507,7 @@ class GraphedStep:
         st = self._graphs.get(key)
         if st is None:
             st = self._build(key, batch_x, batch_target, pc, pm)
-        st["x"].copy_(batch_x)
-        st["y"].copy_(batch_target)
-        if pc.numel():
-            st["pc"].copy_(pc)
-            st["pm"].copy_(pm)
-        st["graph"].replay()
-        return st["result"]
+        return self._replay(st, [(batch_x, batch_target)], pc, pm, next_first)[0]
 
 
 def train_epoch(net, loss_fn, optimizer, x, target, w, h, l_mse, l_js_kl, l_collisions, batch_percentage=1.0,
@@ -478,7 +544,8 @@ def train_epoch(net, loss_fn, optimizer, x, target, w, h, l_mse, l_js_kl, l_coll
         cfg = (id(loss_fn), id(optimizer), l_mse, l_js_kl, l_collisions, batch_percentage, tracked)
         if gs is None or gs._cfg != cfg:
             bounds = None if models.should_use_hash_function else (float(x[:, 0].max()), float(x[:, 1].max()))
-            gs = GraphedStep(net, loss_fn, optimizer, l_mse, l_js_kl, l_collisions, batch_percentage, coord_bounds=bounds)
+            gs = GraphedStep(net, loss_fn, optimizer, l_mse, l_js_kl, l_collisions, batch_percentage, coord_bounds=bounds,
+                             cross_replay=True)
             gs._cfg = cfg
             net._graphed_step = gs
     def batch(b):
@@ -500,7 +567,9 @@ def train_epoch(net, loss_fn, optimizer, x, target, w, h, l_mse, l_js_kl, l_coll
         if bx.shape[0] == 0:
             continue
         if gs is not None and not should_calc_counts:
-            r = gs(bx, by, previous_collisions, previous_min_possible_collisions)
+            # (the next slice is named a step ahead: this replay's launches bin it, the next replay starts on binned pixels)
+            nf = upcoming[0] if (upcoming is not None and upcoming[0].shape == bx.shape) else None
+            r = gs(bx, by, previous_collisions, previous_min_possible_collisions, next_first=nf)
             out, idx, loss, mse, kls, colls, counts = r.out, r.idx, r.loss, r.mse, r.kls, r.colls, []
         else:
             optimizer.zero_grad()

@@ -232,3 +232,47 @@ def test_train_epoch_announces_the_next_slice(golden):
     finally:
         ops.BIN_PIPELINE = prev
         models.should_use_hash_function = False
+
+
+@pytest.mark.parametrize("unroll", [1, 3])
+def test_binning_across_replays_equals_binning_at_the_head_of_every_replay(unroll):
+    """GraphedStep(cross_replay=True): the LAST step of a replay bins the first batch of the NEXT one when the caller names it in
+    advance (run_many(..., next_first=) / gs(x, y, next_first=)); with unroll = 1 — the data-parallel case — every step's binning
+    rides on the step before.  Three graphs per shape (cold, and two steady ones ping-ponging between two workspaces).  Results
+    equal a GraphedStep without it on the same sequence of DIFFERENT batches; an announcement that is not honoured (another
+    tensor, or none) falls back to the cold graph."""
+    from collision_handling_in_instantngp_amd import models, ops, train
+    P = 2 ** 17
+    models.should_use_hash_function = True
+    try:
+        seq = [_batches(unroll, P, seed=100 + r) for r in range(5)]
+        res = {}
+        for cross in (False, True):
+            net = _net(models, "hash")
+            loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
+            opt = train.get_optimizer(net, 1e-3, 1e-3, 1e-3, 0.0, 0.0, 1e-6)
+            gs = train.GraphedStep(net, loss_fn, opt, 1, 1, 1e-3, unroll=unroll, cross_replay=cross)
+            outs, used = [], []
+            for r, batches in enumerate(seq):
+                nf = seq[r + 1][0][0] if r + 1 < len(seq) else None
+                if r == 2:
+                    nf = seq[0][0][0]                      # announce one batch, run another at r = 3: cold graph again
+                st = next(iter(gs._graphs.values())) if gs._graphs else None
+                before = None if st is None else st.get("pre")
+                rs = gs.run_many(batches, next_first=nf) if unroll > 1 else [gs(*batches[0], next_first=nf)]
+                torch.cuda.synchronize()
+                outs.append([(x.out.clone(), x.mse.clone()) for x in rs])
+                used.append(before)
+            st = next(iter(gs._graphs.values()))
+            if cross:
+                assert set(st["variants"]) == {"cold", "01", "10"} or set(st["variants"]) == {"cold", "01"}, set(st["variants"])
+                assert used[1] is not None and used[2] is not None and used[4] is not None      # announced and honoured
+            else:
+                assert set(st["variants"]) == {"cold"} and "W" not in st
+            res[cross] = (outs, {k: p.detach().clone() for k, p in net.named_parameters()})
+        for a, b in zip(res[True][0], res[False][0]):
+            for (oa, ma), (ob, mb) in zip(a, b):
+                assert float((oa - ob).abs().max()) <= 2e-3 and float((ma - mb).abs()) <= 1e-4 * float(mb.abs())
+        assert torch.equal(res[True][0][0][0][0], res[False][0][0][0][0])          # the very first step: identical
+    finally:
+        models.should_use_hash_function = False
