@@ -220,9 +220,14 @@ def timed(step, steps, warmup, world):
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)                   # every rank's own clock over the same barrier-bracketed region
+        LAST_PER_RANK[:] = [float(e.item()) for e in every]
+        dt = max(LAST_PER_RANK)                      # the contract's value: the slowest rank
     return dt
+
+
+LAST_PER_RANK = []     # seconds each rank measured in the last timed() call (N > 1)
 
 
 def measure_hbm_copy_gbs(dev):
@@ -480,6 +485,8 @@ def main():
             dt = timed(step, steps // per, -(-warmup // per), world)       # exactly `steps` steps: steps / per replays of `per` steps each
             res = results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                                    "launch": launch, "shape": {k: v for k, v in SHAPES[cfg_name].items()}}
+            if world > 1:
+                res["ms_per_step_per_rank"] = [t_ / steps * 1e3 for t_ in LAST_PER_RANK]
             if not learning:
                 # the contract's window is `steps` steps (8 ms at the default K): five more windows of the same length, each bracketed
                 # like the first, show how much one window moves (every rank runs them: the barriers stay matched)
@@ -539,11 +546,12 @@ def main():
                 # step turns it off (net.return_indices = False, build_model) — its cost is reported here, never in `value`
                 try:
                     net.return_indices = True
-                    gsf = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3)
-                    r = gsf(xy, target)
+                    gsf = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3, cross_replay=True)      # one step per replay, binning on the step before
+                    for _ in range(3):
+                        r = gsf(xy, target, next_first=xy)
                     assert r.idx is not None and r.idx.shape[0] == P
                     nfull = max(4, steps // 4)
-                    dtf = timed(gsf.replay_only, nfull, 2, world)
+                    dtf = timed(gsf.replay_steady, nfull, 2, world)
                     res["with_full_outputs_ms_per_step"] = dtf / nfull * 1e3
                     res["full_outputs_note"] = f"return_indices=True: indices {tuple(r.idx.shape)} int64 materialised every step"
                     del gsf, r
@@ -675,7 +683,7 @@ def main():
             "backend": (a.backend if world > 1 else None),
             "modes": results, "kernel_ms": {k: (v * 1e3 if isinstance(v, float) else v) for k, v in kt.items()},
             "roofline": roof, "roofline_encoder": roof_enc, "roofline_step": roof_step, "traffic_source": traffic_source,
-            "ms_per_step_windows": head.get("ms_per_step_windows"),
+            "ms_per_step_windows": head.get("ms_per_step_windows"), "ms_per_step_per_rank": head.get("ms_per_step_per_rank"),
             "hbm_copy_measured_GBs": hbm_copy, "hbm_peak_GBs": HBM_PEAK_GBS,
             "roofline_survey": {m: r_["roofline_survey"]["frac_of_8TBs"] for m, r_ in results.items() if "roofline_survey" in r_},
             "roofline_survey_note": "SURVEY 8(d) algorithmic bytes/pixel x pixels/s / 8 TB/s per mode (the target's '>= 60 % of the HBM-read "
