@@ -4,9 +4,10 @@ the bytes of wide (16 B/lane) reads (MI355X_MICROARCH.md §HBM); WRITE_SIZE (KiB
 import json, os, subprocess, sys
 summ = json.loads(subprocess.check_output([sys.executable, "tools/pmc_summary.py"] + sys.argv[1:]))
 groups = {     # round 3 kernel names (the round-2 names stay listed: general shapes still run those kernels)
-    "bin_pixels(count+scatter)": [],      # (round 4: same kernels as the entry below when no vertex riders are needed; kept under one name)
-    "prepare(bin+vertex_fwd+clears)": ["gngf::bin_count_ride_kernel", "gngf::bin_count_vride_kernel", "gngf::bin_rowscan_kernel", "gngf::bin_scan_kernel",
-                                       "gngf::bin_scatter_ride_kernel<2", "gngf::bin_scatter_kernel", "gngf::bin_scatter2_kernel"],
+    # round 4 (gngf_bin_pixels2: the head-of-step binning of a step whose vertex stage is fused into the pixel stage)
+    "bin_pixels(count+scatter)": ["gngf::bin_count_ride_kernel", "gngf::bin_scatter2_kernel"],
+    "prepare(bin+vertex_fwd+clears)": ["gngf::bin_count_vride_kernel", "gngf::bin_rowscan_kernel", "gngf::bin_scan_kernel",
+                                       "gngf::bin_scatter_ride_kernel<2", "gngf::bin_scatter_kernel"],
     "encode_fwd:tiled": ["gngf::tiled_fwd_kernel<2>", "gngf::tiled_fwd_il_kernel"],
     "encode_bwd:tiled": ["gngf::tiled_bwd_kernel<2>", "gngf::gather_partials_kernel<2", "gngf::tiled_bwd_il_kernel", "gngf::dg64_to_float_kernel",
                          "gngf::vertex_bwd_hash64_kernel"],
@@ -21,7 +22,7 @@ def pick(prefix, counter):          # kernel names carry their full template arg
 # kernels whose dominant reads are 16 B per lane report exactly half (factor 2: decoder_fwd reads 128 MiB of enc and
 # FETCH_SIZE says 64.2 MiB); tiled_bwd reads its 128 MiB of d-enc rows as 8 B per lane and FETCH_SIZE already says
 # 154 MiB = rows + binned pixels (factor 1).
-fetch_factor = {"encode_bwd:tiled": 1.0, "prepare(bin+vertex_fwd+clears)": 1.0, "vertex_bwd": 1.0}
+fetch_factor = {"encode_bwd:tiled": 1.0, "prepare(bin+vertex_fwd+clears)": 1.0, "bin_pixels(count+scatter)": 1.0, "vertex_bwd": 1.0}
 out = {}
 for name, ks in groups.items():
     f = sum(pick(k, "FETCH_SIZE") for k in ks)
