@@ -275,6 +275,155 @@ bin_scatter2_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_block,
                     sorted, cursor, wsum, wsum2, &s_last);
 }
 
+// RESERVING COUNT -> SCATTER (round 4, late): the form gngf_bin_pixels2 and the riders use.  A scatter task of the form above
+// spends a third of its ~14 us on work every task repeats — the scan over the tile totals, one global atomic per non-empty tile
+// to reserve its places — and as a task in the tail of the pixel-stage backward it has to fit a hole of one work item (22 us): one
+// fits, two do not.  Here the COUNT side does that work once: a count block reserves its places in every tile as soon as it
+// knows its histogram (one RETURNING atomic per non-empty tile on the tile's cursor — the cursors end up holding the tile
+// totals) and keeps the offsets, block-major, for the scatter block of the same index; the LAST count block out (ticket: its
+// own atomics have returned before it takes one, so every reservation is performed) scans the totals — read with device-scope
+// atomic loads: they were only ever touched by atomics — and writes the tile tables and the work items.  A scatter block then
+// reads two coalesced rows (tile offsets + its own offsets) and moves its pixels: no scan, no global atomics at all.
+// Nobody puts the cursors back to zero either (that took a "last scatter block out" ticket: a returning atomic and two barriers per
+// task): they RUN ON from job to job, and the last count block out notes where this job's successor starts (`start`); offsets and
+// totals are differences in unsigned arithmetic, correct through any wrap-around.
+// pws = [cursors ntiles | start ntiles | (unused) | task counter | count ticket]: zero before its first use, never reset.
+struct BinJobDev {
+  const float2* xy;
+  int64_t P, per_block;
+  int NB, tile_shift, chunk;
+  int32_t* blockbase;            // [NB][ntiles]: first place of block b in tile t, relative to the tile's start
+  int32_t* pws;
+  int32_t *tile_off, *tile_item_base;
+  int4* items;
+  int32_t* n_items;
+  float4* sorted;
+};
+
+template <int NT>
+__device__ __forceinline__ void bin_count_reserve_body(const int blk, const BinJobDev& j, int* hist /* LDS: ntiles + 2 NT/64 + 1 ints */) {
+  const int ntiles = 1 << (2 * j.tile_shift);
+  int* wsum = hist + ntiles;
+  int* wsum2 = wsum + NT / 64;
+  int* s_last = wsum2 + NT / 64;
+  unsigned* gcur = reinterpret_cast<unsigned*>(j.pws);
+  unsigned* start = gcur + ntiles;                            // the cursors' values when this job began (written by its predecessor)
+  int32_t* tcount = j.pws + 2 * ntiles + 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < ntiles; i += NT) hist[i] = 0;
+  __syncthreads();
+  const int64_t lo = (int64_t)blk * j.per_block;
+  const int64_t hi = lo + j.per_block < j.P ? lo + j.per_block : j.P;
+  for (int64_t p0 = lo + tid; p0 < hi; p0 += (int64_t)kBinU * NT) {              // (loads together: see bin_count_body)
+    float2 c[kBinU];
+#pragma unroll
+    for (int u = 0; u < kBinU; ++u) { const int64_t p = p0 + (int64_t)u * NT; c[u] = j.xy[p < hi ? p : hi - 1]; }
+#pragma unroll
+    for (int u = 0; u < kBinU; ++u)
+      if (p0 + (int64_t)u * NT < hi) atomicAdd(&hist[tile_of(c[u].x, c[u].y, j.tile_shift)], 1);
+  }
+  __syncthreads();
+  int32_t* mybase = j.blockbase + (int64_t)blk * ntiles;
+  for (int i = tid; i < ntiles; i += NT) {
+    const int c = hist[i];
+    mybase[i] = c ? (int)(atomicAdd(gcur + i, (unsigned)c) - start[i]) : 0;      // the store needs the atomic's return: it has been performed by then
+  }
+  __syncthreads();
+  if (tid == 0) *s_last = atomicAdd(tcount, 1) == j.NB - 1;
+  __syncthreads();
+  if (!*s_last) return;
+  // last count block out: cursors = tile totals.  Exclusive scans over tiles of (pixels, items), as bin_scan_kernel.
+  const int per = (ntiles + NT - 1) / NT;                   // consecutive tiles per thread
+  int mytot = 0, myit = 0;
+  for (int q = 0; q < per; ++q) {
+    const int t = tid * per + q;
+    if (t < ntiles) {
+      const unsigned now = __hip_atomic_load(gcur + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int c = (int)(now - start[t]);
+      start[t] = now;                                        // where the NEXT job's reservations begin (every block of this one is done)
+      hist[t] = c;                                           // (the histogram is no longer needed: keep the totals there)
+      mytot += c; myit += (c + j.chunk - 1) / j.chunk;
+    }
+  }
+  int a = mytot, n2 = myit;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int ua = __shfl_up(a, o, 64), un = __shfl_up(n2, o, 64);
+    if (lane >= o) { a += ua; n2 += un; }
+  }
+  if (lane == 63) { wsum[wave] = a; wsum2[wave] = n2; }
+  __syncthreads();
+  int off = a - mytot, ioff = n2 - myit;
+  for (int w = 0; w < wave; ++w) { off += wsum[w]; ioff += wsum2[w]; }
+  for (int q = 0; q < per; ++q) {
+    const int t = tid * per + q;
+    if (t < ntiles) {
+      const int total = hist[t];
+      const int nit = (total + j.chunk - 1) / j.chunk;
+      j.tile_off[t] = off;
+      j.tile_item_base[t] = ioff;
+      for (int jj = 0; jj < nit; ++jj) {
+        const int cnt = (total - jj * j.chunk) < j.chunk ? (total - jj * j.chunk) : j.chunk;
+        j.items[ioff + jj] = make_int4(off + jj * j.chunk, cnt, t, nit);
+      }
+      off += total;
+      ioff += nit;
+    }
+  }
+  if (tid == NT - 1) {
+    j.tile_off[ntiles] = off; j.tile_item_base[ntiles] = ioff;
+    j.n_items[0] = ioff;
+    j.n_items[1] = j.n_items[2] = j.n_items[3] = 0;
+    *tcount = 0;                                             // (read again by atomics of a LATER launch only)
+  }
+}
+
+// scatter block `blk` (1024 threads): cursor [ntiles] in the caller's LDS
+__device__ __forceinline__ void bin_scatter3_body(const int blk, const BinJobDev& j, int* cursor) {
+  const int ntiles = 1 << (2 * j.tile_shift);
+  const int tid = threadIdx.x;
+  const int32_t* mybase = j.blockbase + (int64_t)blk * ntiles;
+  for (int t = tid; t < ntiles; t += kBinThreads) cursor[t] = j.tile_off[t] + mybase[t];
+  __syncthreads();
+  const int64_t lo = (int64_t)blk * j.per_block;
+  const int64_t hi = lo + j.per_block < j.P ? lo + j.per_block : j.P;
+  for (int64_t p0 = lo + tid; p0 < hi; p0 += (int64_t)kBinU * kBinThreads) {
+    float2 c[kBinU];
+    int pos[kBinU];
+#pragma unroll
+    for (int u = 0; u < kBinU; ++u) { const int64_t p = p0 + (int64_t)u * kBinThreads; c[u] = j.xy[p < hi ? p : hi - 1]; }
+#pragma unroll
+    for (int u = 0; u < kBinU; ++u)
+      pos[u] = (p0 + (int64_t)u * kBinThreads < hi) ? atomicAdd(&cursor[tile_of(c[u].x, c[u].y, j.tile_shift)], 1) : -1;
+#pragma unroll
+    for (int u = 0; u < kBinU; ++u)
+      if (pos[u] >= 0) j.sorted[pos[u]] = make_float4(c[u].x, c[u].y, __int_as_float((int)(p0 + (int64_t)u * kBinThreads)), 0.f);
+  }
+}
+
+// the two as launches of their own (gngf_bin_pixels2: the first step of a replay, eager steps); workgroups [NB, NB + zblocks)
+// of the count launch clear `zero` (as bin_count_ride_kernel)
+__global__ void __launch_bounds__(kBinThreads)
+bin_count_reserve_kernel(const BinJobDev j, float4* __restrict__ zero, int64_t nvec, int zblocks) {
+  extern __shared__ int hist[];
+  if ((int)blockIdx.x < j.NB) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) j.pws[2 * (1 << (2 * j.tile_shift)) + 1] = 0;      // the riding form's task counter
+    bin_count_reserve_body<kBinThreads>((int)blockIdx.x, j, hist);
+    return;
+  }
+  const int64_t zb = (int)blockIdx.x - j.NB;
+  const int64_t per = (nvec + zblocks - 1) / zblocks;
+  const int64_t lo = zb * per, hi = lo + per < nvec ? lo + per : nvec;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t e = lo + threadIdx.x; e < hi; e += kBinThreads) zero[e] = z;
+}
+
+__global__ void __launch_bounds__(kBinThreads)
+bin_scatter3_kernel(const BinJobDev j) {
+  extern __shared__ int cursor[];                 // [ntiles]
+  bin_scatter3_body((int)blockIdx.x, j, cursor);
+}
+
 // K1 with a ZERO-FILL riding on the launch: workgroups [NB, NB + zblocks) clear `zero` (nvec float4) instead — the gradient
 // buffer the backward pass will accumulate into (64 MiB at T = 2^19).  The count keeps 128 of the 256 CUs busy for ~8 us;
 // the fill runs on the others, instead of being a launch (or a stream) of its own.
@@ -882,13 +1031,7 @@ struct VertexSrc {
 // The COUNT of the NEXT batch's binning riding on the forward launch: workgroups [0, NB) run bin_count_body on that batch's
 // coordinates (histogram per block + the tile totals in global atomics of its persistent workspace) instead of a work item.
 // The forward is bound by its 128 MiB of enc stores; the count reads 8 MiB and works in LDS atomics.  NB = 0: none.
-struct BinCountRide {
-  const float2* xy;
-  int64_t P, per_block;
-  int NB, tile_shift;
-  int32_t* blockhist;
-  int32_t* pws;                   // [totals ntiles | cursors ntiles | ticket | claim]
-};
+typedef BinJobDev BinCountRide;   // (the reserving count: bin_count_reserve_body)
 
 template <int SRC>
 __device__ __forceinline__ v2f vertex_value(const VertexSrc& vs, int l, int gx, int gy, int64_t goff, int gw) {
@@ -925,8 +1068,7 @@ tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
   if ((int)blockIdx.x >= nwork) {
     const int rb = (int)blockIdx.x - nwork;
     if (rb == 0 && threadIdx.x == 0) cride.pws[2 * (1 << (2 * cride.tile_shift)) + 1] = 0;      // the scatter riders' task counter
-    bin_count_body<kTBF>(rb, cride.xy, cride.P, cride.per_block, cride.tile_shift, cride.NB, cride.blockhist,
-                         reinterpret_cast<int*>(img_raw), cride.pws);
+    bin_count_reserve_body<kTBF>(rb, cride, reinterpret_cast<int*>(img_raw));
     return;
   }
   const int wg = (int)blockIdx.x;
@@ -1118,17 +1260,7 @@ tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
 // tasks run in that hole instead of in two launches of their own at the head of the next step (binning depends on the
 // coordinates only, and the batches of an epoch are fixed slices of one permutation, known in advance: functions.py:186-194).
 // No task waits for another one (the totals were completed by the previous launch); NB = 0: none.
-struct BinScatterRide {
-  const float2* xy;
-  int64_t P, per_block;
-  int NB, tile_shift, chunk;
-  const int32_t* blockhist;
-  int32_t* pws;                   // [totals ntiles | cursors ntiles | ticket | claim]
-  int32_t *tile_off, *tile_item_base;
-  int4* items;
-  int32_t* n_items;
-  float4* sorted;
-};
+typedef BinJobDev BinScatterRide;   // (bin_scatter3_body)
 
 template <bool L16>
 __global__ void __launch_bounds__(kTB)
@@ -1407,7 +1539,7 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
   }
   if (bride.NB > 0) {
     // the next batch's scatter tasks, claimed one at a time (the accumulator image is free: its LDS holds the task's cursors)
-    static_assert(kTB == kBinThreads, "bin_scatter2_body is written for the binning kernels' workgroup size");
+    static_assert(kTB == kBinThreads, "bin_scatter3_body is written for the binning kernels' workgroup size");
     int* sh = reinterpret_cast<int*>(accil);
     const int ntiles_b = 1 << (2 * bride.tile_shift);
     int32_t* claim = bride.pws + 2 * ntiles_b + 1;
@@ -1417,9 +1549,7 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
       __syncthreads();
       const int task = s_task;
       if (task >= bride.NB) break;
-      bin_scatter2_body(task, bride.xy, bride.P, bride.per_block, bride.tile_shift, bride.NB, bride.chunk, bride.blockhist, bride.pws,
-                        bride.tile_off, bride.tile_item_base, bride.items, bride.n_items, bride.sorted, sh, sh + ntiles_b,
-                        sh + ntiles_b + kBinThreads / 64, sh + ntiles_b + 2 * (kBinThreads / 64));
+      bin_scatter3_body(task, bride, sh);
     }
   }
 }
@@ -1951,6 +2081,24 @@ static bool interleaved_applies(const int32_t* n_ls_host, int Ls, int F, int til
   return bytes <= (backward ? 112 : 72) * 1024;
 }
 
+static bool bin_job_ok(const gngf_bin_job* j) {
+  return j && j->xy && j->P > 0 && j->P < (1ll << 31) && j->tile_shift >= 0 && j->tile_shift <= 6 && j->NB > 0 && j->NB <= kBinMaxBlocks &&
+         j->chunk > 0 && j->blockhist && j->persistent_ws && j->tile_off && j->tile_item_base && j->items && j->n_items && j->sorted;
+}
+static int64_t bin_per_block(int64_t P, int NB) { return ceil_div(ceil_div(P, NB), kBinThreads) * kBinThreads; }
+static BinJobDev bin_job_dev(const gngf_bin_job* j) {
+  BinJobDev d;
+  d.xy = reinterpret_cast<const float2*>(j->xy); d.P = j->P; d.per_block = bin_per_block(j->P, j->NB);
+  d.NB = j->NB; d.tile_shift = j->tile_shift; d.chunk = j->chunk;
+  d.blockbase = j->blockhist; d.pws = j->persistent_ws; d.tile_off = j->tile_off; d.tile_item_base = j->tile_item_base;
+  d.items = reinterpret_cast<int4*>(j->items); d.n_items = j->n_items; d.sorted = reinterpret_cast<float4*>(j->sorted);
+  return d;
+}
+static BinJobDev bin_job_none() {
+  BinJobDev d = {nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  return d;
+}
+
 // The launcher's own decision, for callers that size / initialise buffers differently for the two kernel families (the
 // fixed-point vertex grid dG64 is only filled by the interleaved backward): 1 = the level-interleaved kernel will run.
 extern "C" int gngf_tiled_interleaved_applies(const int32_t* n_ls_host, int Ls, int F, int tile_shift, int lds_bytes, int backward) {
@@ -1977,7 +2125,7 @@ extern "C" int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, 
     (void)per_cu;
     const int nwork = max_items;                   // forward: one item per workgroup (two to three workgroups share a CU)
     const VertexSrc vs = {G, nullptr, nullptr, nullptr, 0, 0, 0, 0, false};
-    const BinCountRide none = {nullptr, 0, 0, 0, 0, nullptr, nullptr};
+    const BinCountRide none = bin_job_none();
     fn<<<dim3((unsigned)nwork), dim3(kTBF), smem, as_stream(stream)>>>(
         reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, const_cast<int32_t*>(n_items) + 1, n_ls, vs,
         enc, L, Ls, tile_shift, nwork, none);
@@ -1996,12 +2144,6 @@ extern "C" int gngf_encode_tiled_fwd(const float* sorted, const int32_t* items, 
   GNGF_RETURN_LAUNCH();
 }
 
-static bool bin_job_ok(const gngf_bin_job* j) {
-  return j && j->xy && j->P > 0 && j->P < (1ll << 31) && j->tile_shift >= 0 && j->tile_shift <= 6 && j->NB > 0 && j->NB <= kBinMaxBlocks &&
-         j->chunk > 0 && j->blockhist && j->persistent_ws && j->tile_off && j->tile_item_base && j->items && j->n_items && j->sorted;
-}
-static int64_t bin_per_block(int64_t P, int NB) { return ceil_div(ceil_div(P, NB), kBinThreads) * kBinThreads; }
-
 // Binning alone in TWO launches (count -> scatter, the scans ride inside the scatter launch: bin_scatter2_kernel) — the form the
 // step uses when the vertex stage forward is fused into the pixel stage (gngf_encode_tiled_fwd_fused) and nothing else has to
 // ride on the binning.  zero_fill (optional; zero_floats floats, a multiple of 4, 16-byte aligned): cleared by rider workgroups
@@ -2010,19 +2152,14 @@ extern "C" int gngf_bin_pixels2(const gngf_bin_job* job, float* zero_fill, int64
   GNGF_CHECK_ARG(bin_job_ok(job));
   GNGF_CHECK_ARG(!zero_fill || (zero_floats >= 0 && (zero_floats & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_fill) & 15) == 0));
   const int ntiles = 1 << (2 * job->tile_shift);
-  const int64_t per_block = bin_per_block(job->P, job->NB);
   hipStream_t s = as_stream(stream);
-  const size_t smem = (size_t)ntiles * sizeof(int);
-  const float2* xy2 = reinterpret_cast<const float2*>(job->xy);
+  const BinJobDev j = bin_job_dev(job);
   const int64_t nvec = zero_fill ? zero_floats / 4 : 0;
   const int zblocks = nvec > 0 ? (int)(ceil_div(nvec, 4096) < 1024 ? ceil_div(nvec, 4096) : 1024) : 0;
-  bin_count_ride_kernel<<<dim3((unsigned)(job->NB + zblocks)), dim3(kBinThreads), smem, s>>>(
-      xy2, job->P, per_block, job->tile_shift, job->NB, job->blockhist, reinterpret_cast<float4*>(zero_fill), nvec, zblocks > 0 ? zblocks : 1,
-      job->persistent_ws);
-  bin_scatter2_kernel<<<dim3(job->NB), dim3(kBinThreads), smem, s>>>(xy2, job->P, per_block, job->tile_shift, job->NB, job->chunk,
-                                                                   job->blockhist, job->persistent_ws, job->tile_off, job->tile_item_base,
-                                                                   reinterpret_cast<int4*>(job->items), job->n_items,
-                                                                   reinterpret_cast<float4*>(job->sorted));
+  const size_t smem_c = ((size_t)ntiles + 2 * (kBinThreads / 64) + 1) * sizeof(int);
+  bin_count_reserve_kernel<<<dim3((unsigned)(job->NB + zblocks)), dim3(kBinThreads), smem_c, s>>>(
+      j, reinterpret_cast<float4*>(zero_fill), nvec, zblocks > 0 ? zblocks : 1);
+  bin_scatter3_kernel<<<dim3(job->NB), dim3(kBinThreads), (size_t)ntiles * sizeof(int), s>>>(j);
   GNGF_RETURN_LAUNCH();
 }
 
@@ -2044,12 +2181,10 @@ extern "C" int gngf_encode_tiled_fwd_fused(const float* sorted, const int32_t* i
   GNGF_CHECK_ARG(mode == GNGF_MODE_HASH || (vert_idx && vert_w && K > 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0));
   GNGF_CHECK_ARG(interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, false));
   size_t smem = (size_t)interleaved_rows(n_ls_host, Ls, tile_shift) * kIL * 8;
-  BinCountRide cride = {nullptr, 0, 0, 0, 0, nullptr, nullptr};
+  BinCountRide cride = bin_job_none();
   if (next_count) {
-    cride.xy = reinterpret_cast<const float2*>(next_count->xy); cride.P = next_count->P;
-    cride.per_block = bin_per_block(next_count->P, next_count->NB); cride.NB = next_count->NB; cride.tile_shift = next_count->tile_shift;
-    cride.blockhist = next_count->blockhist; cride.pws = next_count->persistent_ws;
-    const size_t hist = sizeof(int) << (2 * next_count->tile_shift);
+    cride = bin_job_dev(next_count);
+    const size_t hist = (sizeof(int) << (2 * next_count->tile_shift)) + sizeof(int) * (2 * (kTBF / 64) + 1);
     smem = smem < hist ? hist : smem;
   }
   const bool hash = mode == GNGF_MODE_HASH;
@@ -2123,15 +2258,10 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
   if (max_items > 0 && interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, true)) {
     const int rows2 = 2 * interleaved_rows(n_ls_host, Ls, tile_shift);
     size_t smem = (size_t)rows2 * kIL * 8 + (size_t)lds_bytes;          // accumulators + the compact fp32 image of the store pass
-    BinScatterRide bride = {nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    BinScatterRide bride = bin_job_none();
     if (next_bin) {
-      bride.xy = reinterpret_cast<const float2*>(next_bin->xy); bride.P = next_bin->P;
-      bride.per_block = bin_per_block(next_bin->P, next_bin->NB); bride.NB = next_bin->NB; bride.tile_shift = next_bin->tile_shift;
-      bride.chunk = next_bin->chunk; bride.blockhist = next_bin->blockhist; bride.pws = next_bin->persistent_ws;
-      bride.tile_off = next_bin->tile_off; bride.tile_item_base = next_bin->tile_item_base;
-      bride.items = reinterpret_cast<int4*>(next_bin->items); bride.n_items = next_bin->n_items;
-      bride.sorted = reinterpret_cast<float4*>(next_bin->sorted);
-      const size_t need = (sizeof(int) << (2 * next_bin->tile_shift)) + sizeof(int) * (2 * (kBinThreads / 64) + 1);
+      bride = bin_job_dev(next_bin);
+      const size_t need = (sizeof(int) << (2 * next_bin->tile_shift)) + sizeof(int);
       smem = smem < need ? need : smem;
     }
     auto fn = (L == 16) ? tiled_bwd_il_kernel<true> : tiled_bwd_il_kernel<false>;

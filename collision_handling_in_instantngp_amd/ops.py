@@ -875,14 +875,16 @@ TWO_LAUNCH_BINNING = True     # count -> scatter (the scans ride inside the scat
 _BIN_WORKSPACES = {}
 
 
-def _bin_workspace(dev, ntiles, owner=None):
+def _bin_workspace(dev, ntiles, owner=None, kind="prepare"):
     """Persistent zero-initialised counters of the two-launch binning (tile totals, tile cursors, a ticket).  The kernels put
     them back to zero themselves, so one buffer serves every step — including every replay of a captured step (it is allocated
     at warm-up, outside the capture).  It belongs to ONE sequence of steps: `owner` is the model's DataParallel object (one per
     model: two models stepping concurrently on two streams do not share counters); calls without an owner (the op used on its
     own) share one buffer per device and tiling and must not overlap in time."""
     store = owner.bin_ws if owner is not None else _BIN_WORKSPACES
-    key = (dev.type, dev.index, int(ntiles))
+    # kind: the two binning protocols keep different things in their counters ("prepare": totals / cursors / ticket, left zero;
+    # "reserve" — gngf_bin_pixels2 and the riders: running cursors, never reset) and must not share a buffer
+    key = (dev.type, dev.index, int(ntiles)) if kind == "prepare" else (dev.type, dev.index, int(ntiles), kind)
     w = store.get(key)
     if w is None:
         if torch.cuda.is_current_stream_capturing():
@@ -892,7 +894,7 @@ def _bin_workspace(dev, ntiles, owner=None):
             warnings.warn("gngf: the two-launch binning's counters were first needed inside a hipGraph capture; this graph uses "
                           "the four-launch binning (run one eager step of the model before capturing)", RuntimeWarning, stacklevel=3)
             return None
-        w = store[key] = torch.zeros((2 * int(ntiles) + 2,), dtype=_i32, device=dev)
+        w = store[key] = torch.zeros((2 * int(ntiles) + 3,), dtype=_i32, device=dev)
     return w
 
 
@@ -1146,11 +1148,11 @@ class EncodeFunction(torch.autograd.Function):
         ctx.next_bin = None
         if plan.Ls > 0 and P > 0:
             dev = tables.device
-            pws = _bin_workspace(dev, plan.ntiles, dp) if TWO_LAUNCH_BINNING else None
+            pws = _bin_workspace(dev, plan.ntiles, dp, kind="reserve") if (TWO_LAUNCH_BINNING and FUSED_VERTEX_FWD) else None
             # fp32 tables on the level-interleaved kernel: the vertex stage forward runs INSIDE the pixel stage's staging loop (no
             # vertex grid G, no vertex riders) and the binning is two launches of its own — or none, when the previous step's
             # launches carried it (BinPipeline)
-            fused = (FUSED_VERTEX_FWD and pws is not None and pws.numel() >= 2 * plan.ntiles + 2 and tables.dtype == _f32
+            fused = (FUSED_VERTEX_FWD and pws is not None and pws.numel() >= 2 * plan.ntiles + 3 and tables.dtype == _f32
                      and F == 2 and plan.interleaved(backward=False))
             use64 = False
             big = None
@@ -1181,9 +1183,8 @@ class EncodeFunction(torch.autograd.Function):
             if fused:
                 pipe = dp.pipeline if (dp is not None and BIN_PIPELINE) else None
                 if pipe is not None and pipe.pending is not None:
-                    # a count half whose scatter half never ran (a forward pass without its backward pass): the counters hold
-                    # that batch's totals — back to zero before anybody bins with them
-                    pws.zero_()
+                    # a count half whose scatter half never ran (a forward pass without its backward pass): nothing to repair —
+                    # the cursors run on from job to job and the abandoned job noted where its successor starts
                     pipe.pending = None
                 ws = pipe.take(xy, plan) if pipe is not None else None
                 if ws is None:

@@ -124,8 +124,11 @@ int gngf_vertex_grid_bwd(const void* tables, int feat_dtype, const int32_t* vert
  * would exceed lds_bytes is skipped); NULL: the gather pass re-derives it per vertex. */
 /* One binning job (the arguments of gngf_bin_pixels as a host struct): lets the binning of ANOTHER batch ride on the pixel-stage
  * launches of the current one — binning depends on the coordinates only, and the batches of an epoch are fixed slices of one
- * permutation, known in advance (functions.py:186-194).  persistent_ws: (2 * 4^tile_shift + 2) int32, ZERO before its first
- * use and owned by one sequence of steps (the kernels leave it zero): tile totals, tile cursors, a ticket, a task counter. */
+ * permutation, known in advance (functions.py:186-194).  persistent_ws: (2 * 4^tile_shift + 3) int32, ZERO before its first
+ * use, owned by one sequence of steps and used by these entry points only (NOT shared with gngf_encode_tiled_prepare's): running
+ * tile cursors, their values at the start of the current job, the count half's ticket, the task counter of the riding scatter —
+ * never reset.  blockhist: 4^tile_shift * (NB + 1) int32 of scratch that carries each count block's reserved offsets to the
+ * scatter block of the same index. */
 typedef struct gngf_bin_job {
   const float* xy;            /* (P, 2) coordinates of the batch to bin */
   int64_t P;
