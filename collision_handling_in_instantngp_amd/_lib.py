@@ -59,6 +59,9 @@ SIGNATURES = {
     "gngf_softmax_topk": [_P, _P, _P, _P, _L, _L, _I, _P],
     "gngf_softmax_bwd_lowrank": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _L, _I, _P],
     "gngf_logits_topk_pbar": [_P, _P, _P, _P, _P, _I, _P, _L, _L, _I, _P],
+    "gngf_linear_fwd_rowstats": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "gngf_rowstats_topk": [_P, _P, _P, _P, _P, _L, _L, _I, _P],
+    "gngf_pbar_accumulate": [_P, _P, _P, _I, _P, _L, _L, _P],
     "gngf_topk": [_P, _P, _P, _L, _L, _I, _P],
     "gngf_softmax_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _L, _L, _I, _P],
     "gngf_vertex_coords": [_P, _L, _L, _I, _P],

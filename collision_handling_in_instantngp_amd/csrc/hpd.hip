@@ -270,6 +270,116 @@ logits_stats_topk_kernel(const float* __restrict__ z, float* __restrict__ topv, 
   }
 }
 
+// Row statistics and top-K from the PARTIALS the logits GEMM left in its epilogue (linear.hip: gemm128_split_kernel, rowparts:
+// (max, sum exp(z - max)) per row and 64-column block) — instead of logits_stats_topk_kernel's pass over the logits themselves
+// (8 GiB per 4096-row chunk at T = 2^19; the partials are 1/32 of that).  One 256-thread block per row:
+//   M = max_b m_b,  S = sum_b s_b exp(m_b - M)                    (the online-softmax merge, as logits_stats_topk_kernel's)
+//   the K largest logits of the row lie inside the K blocks with the largest maxima (if a top-K element sat in another block,
+//   K blocks would each hold an element above it): those K x 64 logits are the only ones read, and the selection among them is
+//   the same (value desc, index asc) merge.  A NaN anywhere in the row (a NaN partial sum) makes the row all-zero after
+//   nan_to_num, slots 0..K-1, as in logits_stats_topk_kernel.
+__global__ void __launch_bounds__(kRowBlock)
+rowstats_topk_kernel(const float* __restrict__ z, const float2* __restrict__ parts, int nparts, float* __restrict__ topv,
+                     int32_t* __restrict__ topi, float* __restrict__ rowstat, int64_t T, int K) {
+  extern __shared__ float smem[];
+  float* lv = smem;                                              // [K][256] per-thread sorted lists (block maxima, then logits)
+  int* li = reinterpret_cast<int*>(smem + (size_t)K * kRowBlock);
+  float* red = smem + (size_t)2 * K * kRowBlock;
+  int* redi = reinterpret_cast<int*>(red + 8);
+  int* cand = redi + 8;                                          // [K] block indices of the K largest maxima
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float2* pr = parts + (int64_t)blockIdx.x * nparts;
+  constexpr float kLog2e = 1.4426950408889634f;
+  float thr;
+  auto reset = [&]() { for (int k = 0; k < K; ++k) { lv[k * kRowBlock + tid] = -INFINITY; li[k * kRowBlock + tid] = INT_MAX; } thr = -INFINITY; };
+  auto consider = [&](float v, int t) {
+    if (v > thr) {
+      int k = K - 1;
+      while (k > 0 && lv[(k - 1) * kRowBlock + tid] < v) {
+        lv[k * kRowBlock + tid] = lv[(k - 1) * kRowBlock + tid];
+        li[k * kRowBlock + tid] = li[(k - 1) * kRowBlock + tid];
+        --k;
+      }
+      lv[k * kRowBlock + tid] = v;
+      li[k * kRowBlock + tid] = t;
+      thr = lv[(K - 1) * kRowBlock + tid];
+    }
+  };
+  // the r-th best (value, index) over the whole block, r = 0 .. K-1, each round popping the winner's list (as logits_stats_topk_kernel)
+  auto select = [&](auto&& emit) {
+    int head = 0;
+    for (int r = 0; r < K; ++r) {
+      float cv = head < K ? lv[head * kRowBlock + tid] : -INFINITY;
+      int ci = head < K ? li[head * kRowBlock + tid] : INT_MAX;
+      int owner = tid;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(cv, o, 64);
+        const int oi = __shfl_xor(ci, o, 64);
+        const int oo = __shfl_xor(owner, o, 64);
+        if (beats(ov, oi, cv, ci)) { cv = ov; ci = oi; owner = oo; }
+      }
+      if (lane == 0) { red[wave] = cv; redi[wave] = ci; redi[4 + wave] = owner; }
+      __syncthreads();
+      float bv = red[0]; int bi = redi[0], bo = redi[4];
+#pragma unroll
+      for (int w = 1; w < 4; ++w)
+        if (beats(red[w], redi[w], bv, bi)) { bv = red[w]; bi = redi[w]; bo = redi[4 + w]; }
+      if (tid == bo) ++head;
+      emit(r, bv, bi);
+      __syncthreads();
+    }
+  };
+  // pass over the partials: online merge of (max, sum), K largest block maxima
+  reset();
+  float m = -INFINITY, s = 0.f;
+  bool has_nan = false;
+  for (int b = tid; b < nparts; b += kRowBlock) {
+    const float2 p = pr[b];
+    has_nan |= (p.y != p.y) || (p.x != p.x);
+    if (p.x > m) { s = (m == -INFINITY) ? 0.f : s * __builtin_amdgcn_exp2f((m - p.x) * kLog2e); m = p.x; }
+    if (p.x > -INFINITY && p.y == p.y) s += p.y * __builtin_amdgcn_exp2f((p.x - m) * kLog2e);
+    consider(p.x, b);
+  }
+  const float wm = wave_max(m);
+  const unsigned long long nanmask = __ballot(has_nan);
+  if (lane == 0) { red[wave] = wm; redi[wave] = nanmask != 0ull; }
+  __syncthreads();
+  const float M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const bool row_nan = (redi[0] | redi[1] | redi[2] | redi[3]) != 0;
+  __syncthreads();
+  float sc = (m == -INFINITY) ? 0.f : s * expf(m - M);
+  sc = wave_sum(sc);
+  if (lane == 0) red[wave] = sc;
+  __syncthreads();
+  const float S = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
+  if (tid == 0) {
+    rowstat[2 * (int64_t)blockIdx.x] = M;
+    rowstat[2 * (int64_t)blockIdx.x + 1] = row_nan ? __int_as_float(0x7fc00000) : S;
+  }
+  select([&](int r, float, int bi) { if (tid == 0) cand[r] = bi; });
+  // the K candidate blocks' logits: K * 64 values, one or a few per thread
+  reset();
+  const float* zr = z + (int64_t)blockIdx.x * T;
+  for (int e = tid; e < K * 64; e += kRowBlock) {
+    const int cb = cand[e >> 6];
+    if (cb < 0 || cb >= nparts) continue;                        // (fewer than K blocks in the row)
+    const int t = cb * 64 + (e & 63);
+    const float v = zr[t];
+    if (v == v) consider(v, t);                                  // (a NaN row is reported through row_nan)
+  }
+  select([&](int r, float bv, int bi) {
+    if (tid == 0) {
+      float q = expf(bv - M) / S;
+      if (row_nan || q != q) q = 0.f;                            // nan_to_num (models.py:111)
+      else if (q > 3.4028234663852886e38f) q = 3.4028234663852886e38f;
+      topv[(int64_t)blockIdx.x * K + r] = q;
+      topi[(int64_t)blockIdx.x * K + r] = row_nan ? r : bi;      // a NaN row is all zeros after nan_to_num: slots 0..K-1
+    }
+  });
+}
+
 // pbar[l][t] += sum_r mw[r][l] * exp(z[r][t] - m_r) / s_r  over the rows of one chunk.  A block owns 256 columns for the
 // whole chunk (plain read-modify-write, no atomics: launches of successive chunks are stream-ordered); row statistics
 // and multiplicity weights are wave-uniform scalar loads.
@@ -775,6 +885,8 @@ extern "C" int gngf_softmax_topk(float* logits_probs, float* topk_val, int32_t* 
 
 // Streaming forward of the per-vertex HPD tail: logits (U,T) are only READ.  topk_val/topk_idx (U,K), rowstat (U,2);
 // when mw (U,L) is given, pbar (L,T) += mw^T * softmax(logits).
+static int launch_pbar(const float* logits, const float* rowstat, const float* mw, int L, float* pbar, int64_t U, int64_t T, hipStream_t s);
+
 extern "C" int gngf_logits_topk_pbar(const float* logits, float* topk_val, int32_t* topk_idx, float* rowstat, const float* mw,
                                      int L, float* pbar, int64_t U, int64_t T, int K, void* stream) {
   GNGF_CHECK_ARG(U >= 0 && T > 0 && K > 0 && K <= GNGF_MAX_TOPK && K <= T && T < INT_MAX && L >= 0 && L <= GNGF_MAX_LEVELS);
@@ -788,15 +900,43 @@ extern "C" int gngf_logits_topk_pbar(const float* logits, float* topk_val, int32
     if (e != hipSuccess) return (int)e;
   }
   logits_stats_topk_kernel<<<dim3((unsigned)U), dim3(kRowBlock), smem, s>>>(logits, topk_val, topk_idx, rowstat, T, K);
-  if (L > 0) {
-    const dim3 grid((unsigned)ceil_div(T, 1024));
-    if (T % 32 == 0 && T < (1 << 22) && L > 4)          // 128 rows * T * 4 B inside 31-bit offsets
-      pbar_mfma_kernel<<<dim3((unsigned)ceil_div(T, 128)), dim3(256), 0, s>>>(logits, rowstat, mw, L, pbar, U, T);
-    else if (L <= 4) pbar_accum_kernel<4><<<grid, dim3(256), 0, s>>>(logits, rowstat, mw, L, pbar, U, T);
-    else if (L <= 16) pbar_accum_kernel<16><<<grid, dim3(256), 0, s>>>(logits, rowstat, mw, L, pbar, U, T);
-    else pbar_accum_kernel<32><<<grid, dim3(256), 0, s>>>(logits, rowstat, mw, L, pbar, U, T);
-  }
+  if (L > 0) return launch_pbar(logits, rowstat, mw, L, pbar, U, T, s);
   GNGF_RETURN_LAUNCH();
+}
+
+// The two halves of gngf_logits_topk_pbar as calls of their own, for logits whose row partials came out of the GEMM's epilogue
+// (gngf_linear_fwd_rowstats): statistics + top-K from the partials (T % 64 == 0: (U, T / 64) pairs), and the batch-mean accumulation.
+extern "C" int gngf_rowstats_topk(const float* logits, const float* rowparts, float* topk_val, int32_t* topk_idx, float* rowstat,
+                                  int64_t U, int64_t T, int K, void* stream) {
+  GNGF_CHECK_ARG(U >= 0 && T > 0 && T % 64 == 0 && K > 0 && K <= GNGF_MAX_TOPK && K <= T && T < INT_MAX && (int64_t)K * 64 <= T);
+  if (U == 0) return 0;
+  GNGF_CHECK_ARG(logits && rowparts && topk_val && topk_idx && rowstat);
+  const size_t smem = ((size_t)2 * K * kRowBlock + 16 + GNGF_MAX_TOPK) * sizeof(float);
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowstats_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  rowstats_topk_kernel<<<dim3((unsigned)U), dim3(kRowBlock), smem, as_stream(stream)>>>(
+      logits, reinterpret_cast<const float2*>(rowparts), (int)(T / 64), topk_val, topk_idx, rowstat, T, K);
+  GNGF_RETURN_LAUNCH();
+}
+
+static int launch_pbar(const float* logits, const float* rowstat, const float* mw, int L, float* pbar, int64_t U, int64_t T, hipStream_t s) {
+  const dim3 grid((unsigned)ceil_div(T, 1024));
+  if (T % 32 == 0 && T < (1 << 22) && L > 4)          // 128 rows * T * 4 B inside 31-bit offsets
+    pbar_mfma_kernel<<<dim3((unsigned)ceil_div(T, 128)), dim3(256), 0, s>>>(logits, rowstat, mw, L, pbar, U, T);
+  else if (L <= 4) pbar_accum_kernel<4><<<grid, dim3(256), 0, s>>>(logits, rowstat, mw, L, pbar, U, T);
+  else if (L <= 16) pbar_accum_kernel<16><<<grid, dim3(256), 0, s>>>(logits, rowstat, mw, L, pbar, U, T);
+  else pbar_accum_kernel<32><<<grid, dim3(256), 0, s>>>(logits, rowstat, mw, L, pbar, U, T);
+  return (int)hipGetLastError();
+}
+
+extern "C" int gngf_pbar_accumulate(const float* logits, const float* rowstat, const float* mw, int L, float* pbar, int64_t U,
+                                    int64_t T, void* stream) {
+  GNGF_CHECK_ARG(U >= 0 && T > 0 && T < INT_MAX && L > 0 && L <= GNGF_MAX_LEVELS);
+  if (U == 0) return 0;
+  GNGF_CHECK_ARG(logits && rowstat && mw && pbar);
+  return launch_pbar(logits, rowstat, mw, L, pbar, U, T, as_stream(stream));
 }
 
 // DifferentiableTopk.forward alone (models.py:11): top-K of arbitrary rows, values sorted descending, ties -> lower index.

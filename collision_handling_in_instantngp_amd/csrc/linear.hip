@@ -400,7 +400,8 @@ template <bool TA, bool TB>
 __global__ void __launch_bounds__(256, 3)
 gemm128_split_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                      int64_t lda, int64_t ldb, int64_t ldc, const float* __restrict__ bias, int act, int64_t K,
-                     int64_t kchunk, int atomic_out, int tiles_m, int tiles_n) {
+                     int64_t kchunk, int atomic_out, int tiles_m, int tiles_n, float2* __restrict__ rowparts = nullptr,
+                     int nparts = 0) {
   constexpr int BKF = 32;
   constexpr int NV4 = BKF / 8;
   __shared__ float As[BKF * LDS2];
@@ -494,6 +495,49 @@ gemm128_split_kernel(const float* __restrict__ A, const float* __restrict__ B, f
         const float v = acc[tm][tn][r] + bv;
         if (atomic_out) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rsc, oc, so, 0);
         else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(act_fwd(v, act)), rsc, oc, so, 0);
+        if (rowparts) acc[tm][tn][r] = v;                        // (the statistics below are taken on the stored values)
+      }
+  }
+  if (rowparts) {
+    // ROW STATISTICS OF THE TILE IN THE EPILOGUE (the logits product of the chunked HashProbDistribution, reference
+    // models.py:85,105-116): for every row of the tile and each 64-column half (this wave's columns) the maximum and
+    // sum exp(z - max) — 8 bytes per 256 bytes of logits — so that the row maxima / normalisers and the top-K (which lies inside
+    // the K half-tiles with the largest maxima) come out of a merge over these partials instead of a second pass over the logits
+    // (hpd.hip: rowstats_topk_kernel).  Reduction over the 32 lanes that share a row: four DPP steps inside each 16-lane row
+    // (quad_perm, half mirror, mirror: every lane of the row ends up with the row's result) and row_bcast15 into rows 1 / 3;
+    // lanes 16 (h = 0) and 48 (h = 1) store.  A NaN logit makes the half's sum NaN (the maximum ignores it, as fmaxf does).
+    constexpr float kLog2e = 1.4426950408889634f;
+    const int64_t part = (n0 >> 6) + wn;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float a = acc[tm][0][r], b = acc[tm][1][r];
+        float m = fmaxf(a, b);
+        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0xB1, 0xF, 0xF, false)));
+        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x4E, 0xF, 0xF, false)));
+        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x141, 0xF, 0xF, false)));
+        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x140, 0xF, 0xF, false)));
+        // rows 1 and 3 take lane 15 of rows 0 and 2; rows 0 and 2 keep their own value (it is not used)
+        const float mo = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x142, 0xA, 0xF, false));
+        m = fmaxf(m, mo);
+        // every lane needs the maximum of ALL 32 lanes for its exponentials: lane 16 holds it for h = 0, lane 48 for h = 1
+        const float m_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 16));
+        const float m_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 48));
+        const float mall = h ? m_hi : m_lo;
+        float sx = (mall == -INFINITY) ? 0.f
+                                       : __builtin_amdgcn_exp2f((a - mall) * kLog2e) + __builtin_amdgcn_exp2f((b - mall) * kLog2e);
+        if (a != a || b != b) sx = __int_as_float(0x7fc00000);
+        sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0xB1, 0xF, 0xF, false));
+        sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x4E, 0xF, 0xF, false));
+        sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x141, 0xF, 0xF, false));
+        sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x140, 0xF, 0xF, false));
+        const float so2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x142, 0xA, 0xF, true));
+        sx += so2;                                               // (rows 0 / 2 receive 0: bound_ctrl; their sums are not used)
+        if (i == 16) {
+          const int64_t row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          rowparts[row * nparts + part] = make_float2(mall, sx);
+        }
       }
   }
 }
@@ -524,8 +568,18 @@ colsum_kernel(const float* __restrict__ dY, const float* __restrict__ Ymask, int
 template <bool TA, bool TB>
 static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                        int64_t ldc, const float* bias, int act, const float* amask, int mask_act, int splitk,
-                       hipStream_t s, bool force_atomic = false) {
+                       hipStream_t s, bool force_atomic = false, float2* rowparts = nullptr) {
   if (M == 0 || N == 0) return 0;
+  if (rowparts) {      // row statistics in the epilogue: the split-bf16 128 x 128 kernel only, whole tiles, one K slice, plain stores
+    const bool aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0;
+    const bool windows32 = lda < (1 << 22) && ldb < (1 << 22) && ldc < (1 << 22);
+    if (!(M % BM2 == 0 && N % BN2 == 0 && K % 32 == 0 && !amask && aligned && windows32 && splitk <= 1 && !force_atomic && act == 0))
+      return (int)hipErrorInvalidValue;
+    const unsigned tm_ = (unsigned)(M / BM2), tn_ = (unsigned)(N / BN2);
+    gemm128_split_kernel<TA, TB><<<dim3(tm_ * tn_, 1), dim3(256), 0, s>>>(A, B, C, lda, ldb, ldc, bias, act, K, K, 0, (int)tm_, (int)tn_,
+                                                                       rowparts, (int)(N / 64));
+    return (int)hipGetLastError();
+  }
   int64_t kchunk = K;
   if (splitk > 1) {
     kchunk = ceil_div(ceil_div(K, splitk), BK) * BK;
@@ -584,6 +638,19 @@ extern "C" int gngf_linear_fwd(const float* X, const float* W, const float* b, f
   if (M == 0) return 0;
   GNGF_CHECK_ARG(X && W && Y);
   return launch_gemm<false, true>(X, W, Y, M, N, K, K, K, N, b, act, nullptr, 0, 1, as_stream(stream));
+}
+
+// The same product (no activation) with ROW STATISTICS of Y in the epilogue: rowparts (M, N / 64) pairs (max, sum exp(y - max)) over
+// each row's 64-column blocks, for gngf_rowstats_topk.  Only for whole 128 x 128 tiles (M % 128 == 0, N % 128 == 0, K % 32 == 0,
+// 16-byte aligned operands): anything else is rejected (the caller then takes gngf_linear_fwd + gngf_logits_topk_pbar).  Always on
+// the split-bf16 kernel (exact three-way split, fp32 accumulation).
+extern "C" int gngf_linear_fwd_rowstats(const float* X, const float* W, const float* b, float* Y, float* rowparts, int64_t M, int N,
+                                        int K, void* stream) {
+  GNGF_CHECK_ARG(M >= 0 && N > 0 && K > 0);
+  if (M == 0) return 0;
+  GNGF_CHECK_ARG(X && W && Y && rowparts);
+  return launch_gemm<false, true>(X, W, Y, M, N, K, K, K, N, b, 0, nullptr, 0, 1, as_stream(stream), false,
+                                  reinterpret_cast<float2*>(rowparts));
 }
 
 // dX[M,K] = (dY .* act'(Y))[M,N] * W[N,K]      Y = the layer's activated output (NULL / act 0: no activation)

@@ -299,6 +299,11 @@ HPD_PIPELINE = True
 # fp32; measured error against float64 equal to or below the exact-fp32 MFMA kernel's, 1.2-1.3x its speed).  False: exact
 # fp32 MFMA for these as well.
 HPD_GEMM_SPLIT_BF16 = True
+# The logits GEMM leaves per-row (max, sum exp) partials per 64-column block in its epilogue and the row statistics + top-K come
+# out of a merge over them (1/32 of the logits' bytes) instead of a pass over the logits: one of the step's ~8.4 passes over the
+# (U, T) logit matrix less (learning mode is HBM-bound as a whole).  Needs the split-bf16 GEMM and whole 128 x 128 tiles; other
+# chunks (the ragged last one) take the separate statistics pass as before.
+HPD_EPILOGUE_STATS = True
 
 
 class _split_gemm:
@@ -373,6 +378,8 @@ class HpdVertexFunction(torch.autograd.Function):
         # microseconds of work each, and a small launch that has to find free CUs beside a 5 ms streaming pass on the helper
         # stream takes 0.2-0.4 ms — 108 ms of a 890 ms step at 44 chunks (profiles/r03_kernel_stats_gngf_learning.txt).
         hs_all = HpdVertexFunction._hidden(vertex_coords(0, NV, vstride, dev), params, n_layers)
+        parts, parts_free, n_parts = None, None, 0          # row partials of the GEMM epilogue (two buffers when pipelined)
+        L = mw.shape[1] if mw is not None else 0
         for u0 in range(0, NV, rows):
             n = min(rows, NV - u0)
             hs = [h[u0:u0 + n] for h in hs_all]
@@ -392,26 +399,51 @@ class HpdVertexFunction(torch.autograd.Function):
                 z = scratch[sb][:n]
                 if scratch_free[sb] is not None:
                     main.wait_event(scratch_free[sb])
-            with _split_gemm():
-                call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(z), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
+            # statistics in the GEMM's epilogue when the chunk is whole 128 x 128 tiles on the split-bf16 kernel
+            epi = (HPD_EPILOGUE_STATS and HPD_GEMM_SPLIT_BF16 and not keep_probs and n % 128 == 0 and T % 128 == 0
+                   and W_last.shape[1] % 32 == 0 and K * 64 <= T and T < (1 << 22))
+            if epi:
+                if parts is None:
+                    parts = [torch.empty((min(rows, NV), T // 64, 2), dtype=_f32, device=dev) for _ in range(2 if pipelined else 1)]
+                    parts_free = [None] * len(parts)
+                pb = n_parts % len(parts)
+                n_parts += 1
+                if parts_free[pb] is not None:
+                    main.wait_event(parts_free[pb])
+                call("gngf_linear_fwd_rowstats", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(z), ptr(parts[pb]), n, T, W_last.shape[1],
+                     stream_ptr())
+            else:
+                with _split_gemm():
+                    call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(z), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
+
+            def passes():
+                if epi:
+                    call("gngf_rowstats_topk", ptr(z), ptr(parts[pb]), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), ptr(rowstat[u0:u0 + n]),
+                         n, T, K, stream_ptr())
+                    if pbar is not None:
+                        call("gngf_pbar_accumulate", ptr(z), ptr(rowstat[u0:u0 + n]), ptr(mw[u0:u0 + n]), L, ptr(pbar), n, T, stream_ptr())
+                else:
+                    call("gngf_logits_topk_pbar", ptr(z), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), ptr(rowstat[u0:u0 + n]),
+                         ptr(mw[u0:u0 + n] if pbar is not None else None), L if pbar is not None else 0, ptr(pbar), n, T, K, stream_ptr())
             if pipelined:
                 ready = torch.cuda.Event()
                 ready.record(main)
                 with torch.cuda.stream(side):
                     side.wait_event(ready)
-                    call("gngf_logits_topk_pbar", ptr(z), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), ptr(rowstat[u0:u0 + n]),
-                         ptr(mw[u0:u0 + n] if pbar is not None else None), L if pbar is not None else 0, ptr(pbar), n, T, K, stream_ptr())
+                    passes()
                     if sb is not None:
                         scratch_free[sb] = torch.cuda.Event()
                         scratch_free[sb].record(side)
+                    if epi:
+                        parts_free[pb] = torch.cuda.Event()
+                        parts_free[pb].record(side)
                 continue
             if keep_probs:      # dense distribution requested (small shapes): softmax in place, p-bar by GEMM
                 call("gngf_softmax_topk", ptr(z), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), ptr(rowstat[u0:u0 + n]), n, T, K, stream_ptr())
                 if pbar is not None:
                     gemm_acc(mw[u0:u0 + n], z, pbar, L, T, n, ta=True, tb=False)
-            else:               # streaming: the logits are only read (stats + top-K in one pass, p-bar in a second)
-                call("gngf_logits_topk_pbar", ptr(z), ptr(tv[u0:u0 + n]), ptr(ti[u0:u0 + n]), ptr(rowstat[u0:u0 + n]),
-                     ptr(mw[u0:u0 + n] if pbar is not None else None), L if pbar is not None else 0, ptr(pbar), n, T, K, stream_ptr())
+            else:               # streaming: the logits are only read (stats + top-K in one pass — or from the GEMM's partials —, p-bar in a second)
+                passes()
         if pipelined:
             main.wait_stream(side)
         if pbar is not None and aux is not None and aux.mean is not None:

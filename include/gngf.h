@@ -299,6 +299,18 @@ int gngf_topk(const float* x, float* topk_val, int32_t* topk_idx, int64_t U, int
 int gngf_softmax_bwd(const float* probs, const float* dq, const int32_t* topk_idx, const float* gdense, const float* mw,
                      const float* G, int L, float* dlogits, int64_t U, int64_t T, int K, void* stream);
 
+/* The logits product with ROW STATISTICS in its epilogue, and their consumers (round 4): gngf_linear_fwd_rowstats = gngf_linear_fwd
+ * without activation + rowparts (M, N / 64) float pairs (max, sum exp(y - max)) per row and 64-column block (whole 128 x 128 tiles
+ * only: M % 128 == 0, N % 128 == 0, K % 32 == 0, 16-byte aligned — else hipErrorInvalidValue and the caller takes gngf_linear_fwd +
+ * gngf_logits_topk_pbar); gngf_rowstats_topk = the statistics / top-K half of gngf_logits_topk_pbar from those partials (it reads
+ * K x 64 logits per row instead of all T: the K largest logits lie inside the K blocks with the largest maxima);
+ * gngf_pbar_accumulate = its batch-mean half.  Same results as gngf_logits_topk_pbar (models.py:85,105-123; utils.py:138,159). */
+int gngf_linear_fwd_rowstats(const float* X, const float* W, const float* b, float* Y, float* rowparts, int64_t M, int N, int K,
+                             void* stream);
+int gngf_rowstats_topk(const float* logits, const float* rowparts, float* topk_val, int32_t* topk_idx, float* rowstat, int64_t U,
+                       int64_t T, int K, void* stream);
+int gngf_pbar_accumulate(const float* logits, const float* rowstat, const float* mw, int L, float* pbar, int64_t U, int64_t T,
+                         void* stream);
 /* the same backward from RECOMPUTED LOGITS, in place (logits in, d logits out), for the chunked per-vertex path:
  * p = exp(z - rowstat.max) / rowstat.sum;  g = mw (U,L) * G (L,T) + dq at topk_idx;  dz = p .* (g - <p,g>);
  * db (T) += column sums of dz (NULL: skipped).  scratch: U + U*K floats.  L = 0 / K = 0 drop the respective term. */

@@ -809,3 +809,61 @@ def test_fused_adam_fp16_parameters_keep_fp32_master_and_moments(ops):
     ob2.load_state_dict(sd)
     assert ob2.state[p16[0]]["master"].dtype == torch.float32 and ob2.state[p16[0]]["exp_avg_sq"].dtype == torch.float32
     assert torch.equal(ob2.state[p16[0]]["master"], oa.state[p16[0]]["master"])
+
+
+@pytest.mark.parametrize("M,T,K", [(128, 1024, 4), (256, 8192, 4), (128, 4096, 1), (384, 2048, 8), (128, 128, 2)])
+def test_logits_gemm_with_epilogue_statistics_equals_the_separate_pass(ops, M, T, K):
+    """Round 4: gngf_linear_fwd_rowstats leaves (max, sum exp) per row and 64-column block in the GEMM's epilogue and
+    gngf_rowstats_topk merges them into the row statistics and reads only the K blocks with the largest maxima for the top-K —
+    against gngf_linear_fwd (same split-bf16 kernel) + gngf_logits_topk_pbar, which reads every logit (reference models.py:85,
+    105-116): logits bit-identical, top-K indices identical (ties -> lower index, also across blocks), probabilities and row
+    statistics to fp32 rounding; NaN rows (nan_to_num: all zero, slots 0..K-1); p-bar through gngf_pbar_accumulate."""
+    from collision_handling_in_instantngp_amd._lib import call, ptr, stream_ptr, query
+    rng = np.random.default_rng(M + T + K)
+    Kc = 128
+    x = t((rng.standard_normal((M, Kc)) * 0.7).astype(np.float32))
+    W = (rng.standard_normal((T, Kc)) * 0.5).astype(np.float32)
+    b = (rng.standard_normal(T) * 0.3).astype(np.float32)
+    # ties: make a few columns identical (same weights and bias) in different 64-column blocks, and dominant
+    if T >= 256:
+        W[5] = W[T - 3] = W[70] = 0.0
+        b[5] = b[T - 3] = b[70] = 50.0
+    Wt, bt = t(W), t(b)
+    xx = x.clone()
+    if M >= 3:
+        xx[2, 7] = float("nan")                                  # a NaN input row -> NaN logits in that row
+    z0 = torch.empty((M, T), device=DEV)
+    z1 = torch.empty((M, T), device=DEV)
+    parts = torch.empty((M, T // 64, 2), device=DEV)
+    prev = query("gngf_set_gemm_split_bf16", 1)
+    try:
+        call("gngf_linear_fwd", ptr(xx), ptr(Wt), ptr(bt), ptr(z0), M, T, Kc, 0, stream_ptr())
+    finally:
+        query("gngf_set_gemm_split_bf16", prev)
+    call("gngf_linear_fwd_rowstats", ptr(xx), ptr(Wt), ptr(bt), ptr(z1), ptr(parts), M, T, Kc, stream_ptr())
+    assert torch.equal(torch.nan_to_num(z0, nan=-7.0), torch.nan_to_num(z1, nan=-7.0))
+    Lv = 5
+    mw = t(rng.random((M, Lv)).astype(np.float32))
+    tv0, ti0, rs0 = torch.empty((M, K), device=DEV), torch.empty((M, K), dtype=torch.int32, device=DEV), torch.empty((M, 2), device=DEV)
+    tv1, ti1, rs1 = torch.empty_like(tv0), torch.empty_like(ti0), torch.empty_like(rs0)
+    pb0, pb1 = torch.zeros((Lv, T), device=DEV), torch.zeros((Lv, T), device=DEV)
+    call("gngf_logits_topk_pbar", ptr(z0), ptr(tv0), ptr(ti0), ptr(rs0), ptr(mw), Lv, ptr(pb0), M, T, K, stream_ptr())
+    call("gngf_rowstats_topk", ptr(z1), ptr(parts), ptr(tv1), ptr(ti1), ptr(rs1), M, T, K, stream_ptr())
+    call("gngf_pbar_accumulate", ptr(z1), ptr(rs1), ptr(mw), Lv, ptr(pb1), M, T, stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(ti0, ti1), (ti0[:4], ti1[:4])
+    if T >= 256 and K >= 3:
+        good = [r for r in range(M) if r != 2]
+        assert set(ti1[good[0]].tolist()[:3]) == {5, 70, T - 3} and ti1[good[0]].tolist()[:3] == [5, 70, T - 3]     # ties -> lower index
+    ok = torch.ones(M, dtype=torch.bool, device=DEV)
+    if M >= 3:
+        ok[2] = False
+        assert float(tv1[2].abs().max()) == 0.0 and ti1[2].tolist() == list(range(K)) and bool(torch.isnan(rs1[2, 1]))
+    close(rs1[ok][:, 0], rs0[ok][:, 0], 0, 0, "row maxima from the epilogue partials")
+    close(rs1[ok][:, 1], rs0[ok][:, 1], 1e-5, 0, "row sums exp(z - max) from the epilogue partials")
+    close(tv1, tv0, 1e-5, 1e-12, "top-K probabilities from the epilogue partials")
+    close(pb1, pb0, 1e-5, 1e-9, "p-bar from the merged statistics")
+    # shapes the epilogue form does not take are REJECTED (the caller falls back), never computed wrongly
+    import pytest as _pt
+    with _pt.raises(RuntimeError):
+        call("gngf_linear_fwd_rowstats", ptr(xx[:100].contiguous()), ptr(Wt), ptr(bt), ptr(z1), ptr(parts), 100, T, Kc, stream_ptr())
