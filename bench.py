@@ -572,7 +572,7 @@ def main():
                         kt, kcalls = k_t, k_c
                     if learning:
                         res["entry_ms"] = {k: v * 1e3 for k, v in sorted(k_t.items(), key=lambda kv: -kv[1])[:12]}
-                        gemm_t = sum(v for k, v in k_t.items() if k in ("gngf_linear_fwd", "gngf_gemm_acc", "gngf_linear_bwd_weight", "gngf_hpd_last_bwd"))
+                        gemm_t = sum(v for k, v in k_t.items() if k in ("gngf_linear_fwd", "gngf_linear_fwd_rowstats", "gngf_gemm_acc", "gngf_linear_bwd_weight", "gngf_hpd_last_bwd"))
                         if gemm_t > 0 and "roofline" in res:
                             fl, _ = learning_flops(res["hpd"])
                             res["roofline"]["gemm_entries_ms"] = gemm_t * 1e3
