@@ -396,8 +396,11 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
 // reads.  (A variant that splits once per workgroup on the way into LDS — bf16 planes, 16-byte fragment reads — was not
 // faster on any of the three shapes, and slower where both operands are staged transposed: the kernel is bound by its
 // per-K-block barriers and the short K = 128 of the logits product, not by the splitting.)
+#ifndef GNGF_SPLIT_WGS
+#define GNGF_SPLIT_WGS 3
+#endif
 template <bool TA, bool TB>
-__global__ void __launch_bounds__(256, 3)
+__global__ void __launch_bounds__(256, GNGF_SPLIT_WGS)
 gemm128_split_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                      int64_t lda, int64_t ldb, int64_t ldc, const float* __restrict__ bias, int act, int64_t K,
                      int64_t kchunk, int atomic_out, int tiles_m, int tiles_n, float2* __restrict__ rowparts = nullptr,
