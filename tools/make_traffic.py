@@ -5,7 +5,7 @@ import json, os, subprocess, sys
 summ = json.loads(subprocess.check_output([sys.executable, "tools/pmc_summary.py"] + sys.argv[1:]))
 groups = {     # round 3 kernel names (the round-2 names stay listed: general shapes still run those kernels)
     # round 4 (gngf_bin_pixels2: the head-of-step binning of a step whose vertex stage is fused into the pixel stage)
-    "bin_pixels(count+scatter)": ["gngf::bin_count_ride_kernel", "gngf::bin_scatter2_kernel"],
+    "bin_pixels(count+scatter)": ["gngf::bin_count_reserve_kernel", "gngf::bin_scatter3_kernel"],
     "prepare(bin+vertex_fwd+clears)": ["gngf::bin_count_vride_kernel", "gngf::bin_rowscan_kernel", "gngf::bin_scan_kernel",
                                        "gngf::bin_scatter_ride_kernel<2", "gngf::bin_scatter_kernel"],
     "encode_fwd:tiled": ["gngf::tiled_fwd_kernel<2>", "gngf::tiled_fwd_il_kernel"],
