@@ -42,7 +42,7 @@ SIGNATURES = {
                               _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _I, _P, _P],
     "gngf_vertex_grid_bwd_sorted": [_P, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _L, _I, _I, _L, _P],
     "gngf_decoder_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
-    "gngf_decoder_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "gngf_decoder_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _P],
     "gngf_decoder_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "gngf_decoder_train": [_P] * 20 + [_L, _L, _I, _I, _I, _P],
     "gngf_decoder_bwd_last_span_ns": [_P],

@@ -545,7 +545,10 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
   // Workgroup b owns vectors [b per, (b + 1) per); every tile of its loop clears zper vectors per thread.
   int64_t zlo = 0, zhi = 0;
   int zper = 0;
-  if constexpr (TRAIN) {
+  // (besides the training kernel, the exact 64-feature backward — no training kernel exists at that width — clears the buffer:
+  // gngf_decoder_bwd; the other variants stay as they were: the 32-feature hybrid backward spilled 16 registers with it)
+  constexpr bool kClears = TRAIN || (KIN == 64 && EXACT && !HYB);
+  if constexpr (kClears) {
     if (zero_fill && zero_vecs > 0) {
       const int64_t per = (zero_vecs + gridDim.x - 1) / gridDim.x;
       zlo = (int64_t)blockIdx.x * per + threadIdx.x;
@@ -1216,7 +1219,7 @@ decoder_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Yout, 
           }
         }
     }
-    if constexpr (TRAIN) {
+    if constexpr (kClears) {
       for (int z = 0; z < zper; ++z, zlo += kDecThreads)
         if (zlo < zhi) zero_fill[zlo] = float4{0.f, 0.f, 0.f, 0.f};
     }
@@ -1407,8 +1410,12 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
                                 const float* W0, const float* b0,
                                 const float* W1, const float* b1, const float* W2, float* denc, float* dW0, float* db0,
                                 float* dW1, float* db1, float* dW2, float* db2, float* slabs, float* denc_absmax,
-                                const float* hidden, int64_t P, int in_dim, int out_dim, int leaky, void* stream) {
+                                const float* hidden, float* zero_fill, int64_t zero_floats, int64_t P, int in_dim, int out_dim,
+                                int leaky, void* stream) {
   GNGF_CHECK_ARG(P >= 0 && in_dim > 0 && in_dim <= 64 && out_dim > 0 && out_dim <= 4);
+  GNGF_CHECK_ARG(!zero_fill || (zero_floats >= 0 && (zero_floats & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_fill) & 15) == 0));
+  float4* zf = reinterpret_cast<float4*>(zero_fill);
+  const int64_t zv = zero_fill ? zero_floats / 4 : 0;
   const bool reduce_here = dW0 || db0 || dW1 || db1 || dW2 || db2;       // all NULL: the caller runs gngf_decoder_reduce
   GNGF_CHECK_ARG(slabs && (!reduce_here || (dW0 && db0 && dW1 && db1 && dW2 && db2)));
   const int nslab = slab_size(in_dim, out_dim);
@@ -1417,8 +1424,17 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
   if (P == 0) {
     hipError_t e = hipMemsetAsync(slabs, 0, sizeof(float) * (size_t)nslab, s);
     if (e != hipSuccess) return (int)e;
+    if (zero_fill && zero_floats > 0) {
+      e = hipMemsetAsync(zero_fill, 0, sizeof(float) * (size_t)zero_floats, s);
+      if (e != hipSuccess) return (int)e;
+    }
   } else {
     GNGF_CHECK_ARG(enc && rgb && (target ? gloss != nullptr : drgb != nullptr) && W0 && b0 && W1 && b1 && W2 && denc);
+    // only decoder_bwd_kernel<64, ., EXACT = true, ...> clears on the way (kClears); every other kernel of this entry gets a memset
+    if (zero_fill && zero_floats > 0 && in_dim != 64) {
+      hipError_t e = hipMemsetAsync(zero_fill, 0, sizeof(float) * (size_t)zero_floats, s);
+      if (e != hipSuccess) return (int)e;
+    }
 #if defined(GNGF_DECODER_SPLIT_KERNELS)
     if (decoder_split_applies(in_dim) && in_dim == 32) {
       const size_t main_loop = SplitBwd<32>::kMainBytes, epilogue = sizeof(float) * 4 * (size_t)nslab;
@@ -1435,7 +1451,7 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
       fn<<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, hidden, P, in_dim, out_dim,
-                                                                 target, gloss, nullptr, nullptr, 0);
+                                                                 target, gloss, nullptr, zf, zv);
     } else
     DISPATCH_KIN(in_dim, {
       const size_t smem = bwd_smem_bytes<kKIN>(in_dim, out_dim);
@@ -1453,7 +1469,7 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return (int)e;
       fn<<<dim3((unsigned)nslabs), dim3(kDecThreads), smem, s>>>(enc, rgb, drgb, W0, b0, W1, b1, W2, denc, slabs, hidden, P, in_dim, out_dim,
-                                                                 target, gloss, nullptr, nullptr, 0);
+                                                                 target, gloss, nullptr, zf, zv);
     });
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

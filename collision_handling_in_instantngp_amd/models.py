@@ -347,7 +347,12 @@ class GeneralNeuralGaugeFields(nn.Module):
         train_fused = (self._fused_mse_gloss is not None and self._fused_mse_target is not None and ops.DECODER_TRAIN_FUSION
                        and ops.DECODER_REDUCE_RIDES and L * self._feature_dim == 32 and P > 0
                        and ops.decoder_fused_ok((ops.ACT_RELU, ops.ACT_RELU, ops.ACT_SIGMOID), self._decoder_params()))
-        link = self._last_link = ops.StepLink(loss_value_aside=self.loss_value_aside, defer_zero=train_fused)
+        # (no training kernel — e.g. 64 encoder features — but the fused two-kernel decoder with the loss inside: its backward
+        # kernel clears the buffer)
+        bwd_clears = (not train_fused and ops.DECODER_BWD_CLEARS and self._fused_mse_target is not None and P > 0
+                      and torch.is_grad_enabled()
+                      and ops.decoder_fused_ok((ops.ACT_RELU, ops.ACT_RELU, ops.ACT_SIGMOID), self._decoder_params()))
+        link = self._last_link = ops.StepLink(loss_value_aside=self.loss_value_aside, defer_zero=train_fused or bwd_clears)
         dp = self.dp
 
         if self._hash_mode:

@@ -1439,6 +1439,9 @@ def _at_end_of_backward(fn):
 # and the tiled encoder backward compare the promised scalar with the gradient autograd delivers, no synchronisation, always
 # on): a broken promise turns every gradient of the step into NaN instead of handing over gradients for the wrong value.
 DECODER_TRAIN_FUSION = True
+# Without the training kernel (64 input features) the BACKWARD kernel of the two-kernel path clears the encoder's table-gradient
+# buffer on the way, instead of rider workgroups of the binning launch (4 GiB at BASELINE config 5: 0.69 ms of a 2.9 ms step there)
+DECODER_BWD_CLEARS = True
 _GLOSS_SCALARS = {}
 
 
@@ -1578,13 +1581,19 @@ def _decoder_bwd(ctx, drgb, gloss):
     common = (ptr(enc), ptr(rgb), ptr(None if fused else drgb, _f32, "grad"), ptr(target if fused else None), ptr(gloss if fused else None),
               ptr(W0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(denc))
     link.promise = None
+    # the encoder's table-gradient buffer, if it was left for a decoder kernel to clear (StepLink.defer_zero) and the training
+    # kernel did not run (64 input features: BASELINE config 5): this launch clears it between its MFMAs
+    zr = None
+    if DECODER_BWD_CLEARS and link.zero_request is not None and link.zero_request.numel() % 4 == 0:
+        zr, link.zero_request = link.zero_request, None
+    zargs = (ptr(zr), 0 if zr is None else zr.numel())
     if DECODER_REDUCE_RIDES and P > 0:
-        call("gngf_decoder_bwd", *common, *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(ctx.hidden), P, in_dim, out_dim, leaky, stream_ptr())
+        call("gngf_decoder_bwd", *common, *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(ctx.hidden), *zargs, P, in_dim, out_dim, leaky, stream_ptr())
         _schedule_reduce(ctx, link, dev, slabs, flat, grads, P, in_dim, out_dim)
         hint = (slabs[nslab - 1:], nslabs, nslab)         # the per-slab maxima: all the encoder backward needs from the slabs
     else:
         absmax = torch.empty((1,), dtype=_f32, device=dev)
-        call("gngf_decoder_bwd", *common, *[ptr(g) for g in grads], ptr(slabs), ptr(absmax), ptr(ctx.hidden), P, in_dim, out_dim, leaky,
+        call("gngf_decoder_bwd", *common, *[ptr(g) for g in grads], ptr(slabs), ptr(absmax), ptr(ctx.hidden), *zargs, P, in_dim, out_dim, leaky,
              stream_ptr())
         hint = (absmax, 1, 0)
     ctx.hidden = None

@@ -262,8 +262,11 @@ int64_t gngf_decoder_hidden_floats(int64_t P);
 int gngf_decoder_bwd(const float* enc, const float* rgb, const float* drgb, const float* target, const float* gloss,
                      const float* W0, const float* b0, const float* W1,
                      const float* b1, const float* W2, float* denc, float* dW0, float* db0, float* dW1, float* db1, float* dW2,
-                     float* db2, float* slabs, float* denc_absmax, const float* hidden, int64_t P, int in_dim, int out_dim,
-                     int leaky, void* stream);
+                     float* db2, float* slabs, float* denc_absmax, const float* hidden, float* zero_fill, int64_t zero_floats,
+                     int64_t P, int in_dim, int out_dim, int leaky, void* stream);
+/* zero_fill (optional; zero_floats floats, a multiple of 4, 16-byte aligned): cleared by the kernel on the way, a few 16-byte
+ * stores per lane and tile (as gngf_decoder_train's) — the table gradient the encoder backward is about to accumulate into, at
+ * shapes that have no fused training kernel (64 input features: BASELINE config 5). */
 /* target + gloss (1 float), optional, instead of drgb: the gradient of the fused pixel loss,
  * d rgb = gloss[0] * 2 / (P * out_dim) * (rgb - target) (MSELoss backward), is formed inside the kernel (drgb may be NULL). */
  /* The six gradient pointers may ALL be NULL: the kernel then stops at the slabs and gngf_decoder_reduce finishes (e.g. on a

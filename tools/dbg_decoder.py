@@ -13,8 +13,8 @@ for in_dim, P in ((8, 1000), (16, 1000), (32, 1000), (32, 70000), (64, 1000), (2
     denc = torch.empty_like(enc); grads = [torch.empty_like(w) for w in Ws]
     slabs = torch.empty((_lib.query("gngf_decoder_bwd_slabs", P) * _lib.query("gngf_decoder_slab_floats", in_dim, out_dim),), device=dev)
     hidden = torch.empty((_lib.query("gngf_decoder_hidden_floats", P),), device=dev) if os.environ.get("GNGF_RECOMPUTE", "0") != "1" else None
-    call("gngf_decoder_fwd", ptr(enc), *[ptr(w) for w in Ws], ptr(rgb), ptr(hidden), P, in_dim, out_dim, 0, stream_ptr())
-    call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(None), ptr(None), ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(Ws[3]), ptr(Ws[4]), ptr(denc), *[ptr(g) for g in grads], ptr(slabs), ptr(None), ptr(hidden), P, in_dim, out_dim, 0, stream_ptr())
+    call("gngf_decoder_fwd", ptr(enc), *[ptr(w) for w in Ws], ptr(rgb), ptr(hidden), ptr(None), 0, P, in_dim, out_dim, 0, stream_ptr())
+    call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(None), ptr(None), ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(Ws[3]), ptr(Ws[4]), ptr(denc), *[ptr(g) for g in grads], ptr(slabs), ptr(None), ptr(hidden), ptr(None), 0, P, in_dim, out_dim, 0, stream_ptr())
     x = enc.double().requires_grad_(); ps = [w.double().requires_grad_() for w in Ws]
     h1 = torch.relu(x @ ps[0].T + ps[1]); h2 = torch.relu(h1 @ ps[2].T + ps[3]); y = torch.sigmoid(h2 @ ps[4].T + ps[5])
     y.backward(drgb.double())

@@ -14,7 +14,7 @@ def run(split):
     query("gngf_set_decoder_split_bf16", split)
     rgb = torch.empty((P, out_dim), device=dev); denc = torch.full_like(enc, float("nan")); grads = [torch.empty_like(w) for w in Ws]
     call("gngf_decoder_fwd", ptr(enc), *[ptr(w) for w in Ws], ptr(rgb), ptr(None), P, in_dim, out_dim, 0, stream_ptr())
-    call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(None), ptr(None), ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(Ws[3]), ptr(Ws[4]), ptr(denc), *[ptr(g) for g in grads], ptr(slabs), ptr(None), ptr(None), P, in_dim, out_dim, 0, stream_ptr())
+    call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(None), ptr(None), ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(Ws[3]), ptr(Ws[4]), ptr(denc), *[ptr(g) for g in grads], ptr(slabs), ptr(None), ptr(None), ptr(None), 0, P, in_dim, out_dim, 0, stream_ptr())
     torch.cuda.synchronize()
     query("gngf_set_decoder_split_bf16", 0)
     return denc, grads

@@ -14,7 +14,7 @@ drgb = torch.randn((P, out_dim), device=dev) * 1e-6
 slabs = torch.empty((query("gngf_decoder_bwd_slabs", P) * query("gngf_decoder_slab_floats", in_dim, out_dim),), device=dev)
 hidden = torch.empty((query("gngf_decoder_hidden_floats", P),), device=dev)
 rgb = torch.empty((P, out_dim), device=dev)
-call("gngf_decoder_fwd", ptr(enc), *[ptr(w) for w in Ws], ptr(rgb), ptr(hidden), P, in_dim, out_dim, 0, stream_ptr())
+call("gngf_decoder_fwd", ptr(enc), *[ptr(w) for w in Ws], ptr(rgb), ptr(hidden), ptr(None), 0, P, in_dim, out_dim, 0, stream_ptr())
 n = 2**16
 x64 = enc[:n].double().requires_grad_(True)
 W64 = [w.double() for w in Ws]
@@ -24,7 +24,7 @@ res = {}
 for hyb in (0, 1):
     query("gngf_set_decoder_bwd_hybrid", hyb)
     denc = torch.empty_like(enc); grads = [torch.empty_like(w) for w in Ws]
-    fn = lambda: call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(None), ptr(None), ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(Ws[3]), ptr(Ws[4]), ptr(denc), *[ptr(g) for g in grads], ptr(slabs), ptr(None), ptr(hidden), P, in_dim, out_dim, 0, stream_ptr())
+    fn = lambda: call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(None), ptr(None), ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(Ws[3]), ptr(Ws[4]), ptr(denc), *[ptr(g) for g in grads], ptr(slabs), ptr(None), ptr(hidden), ptr(None), 0, P, in_dim, out_dim, 0, stream_ptr())
     for _ in range(60): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

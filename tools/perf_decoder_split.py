@@ -18,7 +18,7 @@ def run(split, with_bwd):
     rgb = torch.empty((P, out_dim), device=dev); denc = torch.empty_like(enc); grads = [torch.empty_like(w) for w in Ws]
     hid = None if split else hidden
     def fwd(): call("gngf_decoder_fwd", ptr(enc), *[ptr(w) for w in Ws], ptr(rgb), ptr(hid), P, in_dim, out_dim, 0, stream_ptr())
-    def bwd(): call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(None), ptr(None), ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(Ws[3]), ptr(Ws[4]), ptr(denc), *[ptr(g) for g in grads], ptr(slabs), ptr(None), ptr(hid), P, in_dim, out_dim, 0, stream_ptr())
+    def bwd(): call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(None), ptr(None), ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(Ws[3]), ptr(Ws[4]), ptr(denc), *[ptr(g) for g in grads], ptr(slabs), ptr(None), ptr(hid), ptr(None), 0, P, in_dim, out_dim, 0, stream_ptr())
     t = {}
     for name, fn in (("fwd", fwd),) + ((("bwd", bwd),) if with_bwd else ()):
         for _ in range(30): fn()

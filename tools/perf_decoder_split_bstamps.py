@@ -11,7 +11,7 @@ enc = torch.randn((P, in_dim), device=dev) * 0.5
 rgb = torch.rand((P, out_dim), device=dev); drgb = torch.randn((P, out_dim), device=dev) * 1e-6; denc = torch.empty_like(enc)
 slabs = torch.empty((query("gngf_decoder_bwd_slabs", P) * query("gngf_decoder_slab_floats", in_dim, out_dim),), device=dev)
 query("gngf_set_decoder_split_bf16", 1)
-fn = lambda: call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(None), ptr(None), ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(Ws[3]), ptr(Ws[4]), ptr(denc), *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(None), P, in_dim, out_dim, 0, stream_ptr())
+fn = lambda: call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(drgb), ptr(None), ptr(None), ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(Ws[3]), ptr(Ws[4]), ptr(denc), *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(None), ptr(None), 0, P, in_dim, out_dim, 0, stream_ptr())
 for _ in range(60): fn()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -17,8 +17,8 @@ slabs = torch.empty((query("gngf_decoder_bwd_slabs", P) * query("gngf_decoder_sl
 hidden = torch.empty((query("gngf_decoder_hidden_floats", P),), device=dev)
 rgb = torch.empty((P, out_dim), device=dev); denc = torch.empty_like(enc)
 def two():
-    call("gngf_decoder_fwd", ptr(enc), *[ptr(w) for w in Ws], ptr(rgb), ptr(hidden), P, in_dim, out_dim, 0, stream_ptr())
-    call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(None), ptr(target), ptr(one), ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(Ws[3]), ptr(Ws[4]), ptr(denc), *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(hidden), P, in_dim, out_dim, 0, stream_ptr())
+    call("gngf_decoder_fwd", ptr(enc), *[ptr(w) for w in Ws], ptr(rgb), ptr(hidden), ptr(None), 0, P, in_dim, out_dim, 0, stream_ptr())
+    call("gngf_decoder_bwd", ptr(enc), ptr(rgb), ptr(None), ptr(target), ptr(one), ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(Ws[3]), ptr(Ws[4]), ptr(denc), *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(hidden), ptr(None), 0, P, in_dim, out_dim, 0, stream_ptr())
 def fused():
     call("gngf_decoder_train", ptr(enc), ptr(target), ptr(one), *[ptr(w) for w in Ws], ptr(rgb), ptr(denc), *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(None), 0, P, in_dim, out_dim, 0, stream_ptr())
 zbuf = torch.empty((16 * 2 ** 19 * 2 + 4 * 720000,), device=dev)       # the step's [table gradient | fixed-point vertex grid]: 75 MiB
