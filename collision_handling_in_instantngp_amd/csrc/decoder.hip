@@ -1422,17 +1422,17 @@ extern "C" int gngf_decoder_bwd(const float* enc, const float* rgb, const float*
   hipStream_t s = as_stream(stream);
   const int nslabs = gngf_decoder_bwd_slabs(P);
   if (P == 0) {
-    hipError_t e = hipMemsetAsync(slabs, 0, sizeof(float) * (size_t)nslab, s);
+    hipError_t e = zero_async(slabs, sizeof(float) * (size_t)nslab, s);
     if (e != hipSuccess) return (int)e;
     if (zero_fill && zero_floats > 0) {
-      e = hipMemsetAsync(zero_fill, 0, sizeof(float) * (size_t)zero_floats, s);
+      e = zero_async(zero_fill, sizeof(float) * (size_t)zero_floats, s);
       if (e != hipSuccess) return (int)e;
     }
   } else {
     GNGF_CHECK_ARG(enc && rgb && (target ? gloss != nullptr : drgb != nullptr) && W0 && b0 && W1 && b1 && W2 && denc);
     // only decoder_bwd_kernel<64, ., EXACT = true, ...> clears on the way (kClears); every other kernel of this entry gets a memset
     if (zero_fill && zero_floats > 0 && in_dim != 64) {
-      hipError_t e = hipMemsetAsync(zero_fill, 0, sizeof(float) * (size_t)zero_floats, s);
+      hipError_t e = zero_async(zero_fill, sizeof(float) * (size_t)zero_floats, s);
       if (e != hipSuccess) return (int)e;
     }
 #if defined(GNGF_DECODER_SPLIT_KERNELS)

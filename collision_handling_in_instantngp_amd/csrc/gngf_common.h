@@ -51,6 +51,31 @@ __device__ __forceinline__ Cell make_cell(float x, float y, int n) {
 
 __device__ __forceinline__ bool is_pow2(int64_t v) { return (v & (v - 1)) == 0; }
 
+// Clearing a buffer from inside an entry point: a plain KERNEL, never hipMemsetAsync.  A memset NODE of a captured hipGraph was seen
+// to run out of order on replays after the first (round 4: a table-gradient clear captured as a memset node inside
+// gngf_decoder_bwd zeroed, on every replay but the first, part of a gradient buffer that a LATER step of the same graph had
+// legitimately placed in the same pool memory) — kernel nodes keep their stream order.  bytes: a multiple of 4.
+static __global__ void __launch_bounds__(256) zero_words_kernel(uint32_t* __restrict__ p, int64_t nwords) {
+  const int64_t n4 = nwords >> 2;
+  uint4* p4 = reinterpret_cast<uint4*>(p);
+  const bool aligned = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  if (aligned) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += stride) p4[e] = make_uint4(0u, 0u, 0u, 0u);
+    for (int64_t e = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; e < nwords; e += stride) p[e] = 0u;
+  } else {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nwords; e += stride) p[e] = 0u;
+  }
+}
+static inline hipError_t zero_async(void* p, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  const int64_t nwords = (int64_t)(bytes / 4);
+  int64_t blocks = (nwords / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  zero_words_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(static_cast<uint32_t*>(p), nwords);
+  return hipGetLastError();
+}
+
 // torch.nn.MSELoss() value (csrc/loss.hip): block `blk` of `nblocks` 1024-thread blocks adds its share of sum((pred-label)^2)
 // to a double and takes a ticket (the atomic's RETURN value feeds the ticket request, so the add is performed before the
 // ticket exists — no release fence, which writes the whole L2 back on this chip); the last ticket holder writes

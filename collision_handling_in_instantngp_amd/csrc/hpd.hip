@@ -982,7 +982,7 @@ extern "C" int gngf_softmax_bwd_lowrank(float* logits_dz, const float* rowstat, 
   if (saved_p) {
     softmax_bwd_dot_init_kernel<<<dim3((unsigned)ceil_div(U, 256)), dim3(256), 0, s>>>(topk_p, dq, dot, U, K);
   } else {
-    hipError_t e = hipMemsetAsync(dot, 0, sizeof(float) * (size_t)U, s);
+    hipError_t e = zero_async(dot, sizeof(float) * (size_t)U, s);
     if (e != hipSuccess) return (int)e;
   }
   const bool mfma = (T % 32 == 0) && T < (1 << 24) && L <= 32;      // 32 rows * T * 4 B and L * T * 4 B inside 32-bit offsets

@@ -116,7 +116,7 @@ extern "C" int gngf_mark_batch_slots(const float* xy, const int32_t* n_ls, int64
   GNGF_CHECK_ARG(xy && n_ls);
   hipStream_t s = as_stream(stream);
   const int64_t vwords = (NV + 31) / 32, words = (T + 31) / 32;
-  hipError_t e = hipMemsetAsync(touched, 0, sizeof(uint32_t) * (size_t)(vwords * L), s);
+  hipError_t e = zero_async(touched, sizeof(uint32_t) * (size_t)(vwords * L), s);
   if (e != hipSuccess) return (int)e;
   const int64_t total = P * L;
   touched_mark_kernel<<<dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s>>>(reinterpret_cast<const float2*>(xy), n_ls, total, L,
@@ -131,7 +131,7 @@ extern "C" int gngf_count_slot_bits(const uint32_t* bitmap, int L, int K, int64_
   GNGF_CHECK_ARG(L > 0 && K > 0 && T > 0 && bitmap && counts);
   hipStream_t s = as_stream(stream);
   const int64_t words = (T + 31) / 32;
-  hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)(L * K), s);
+  hipError_t e = zero_async(counts, sizeof(int32_t) * (size_t)(L * K), s);
   if (e != hipSuccess) return (int)e;
   const int64_t cw = ceil_div(words, 256 * 4);
   slot_count_kernel<<<dim3((unsigned)(cw > 64 ? 64 : (cw < 1 ? 1 : cw)), (unsigned)(L * K)), dim3(256), 0, s>>>(bitmap, words, counts);
@@ -147,9 +147,9 @@ extern "C" int gngf_distinct_slot_counts(const int64_t* indices, int64_t P, int 
   GNGF_CHECK_ARG(P >= 0 && L > 0 && V > 0 && K > 0 && T > 0 && bitmap && counts && (P == 0 || indices));
   hipStream_t s = as_stream(stream);
   const int64_t words = (T + 31) / 32;
-  hipError_t e = hipMemsetAsync(bitmap, 0, sizeof(uint32_t) * (size_t)(words * L * K), s);
+  hipError_t e = zero_async(bitmap, sizeof(uint32_t) * (size_t)(words * L * K), s);
   if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)(L * K), s);
+  e = zero_async(counts, sizeof(int32_t) * (size_t)(L * K), s);
   if (e != hipSuccess) return (int)e;
   const int64_t n = P * L * V * K;
   if (n > 0) {

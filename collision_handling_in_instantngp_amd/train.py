@@ -397,8 +397,7 @@ class GraphedStep:
                 # two binning workspaces, allocated outside every capture: each steady graph reads one and fills the other
                 st["W"] = [ops.TiledWorkspace(plan, st["x"], launch=False) for _ in range(2)]
                 st["x_next"] = st["x"].clone()
-        self._capture(st, "cold")
-        st["graph"], st["results"] = st["variants"]["cold"]
+        st["graph"], st["results"] = self._capture(st, "cold")
         st["result"] = st["results"][0]
         self._graphs[key] = st
         return st
@@ -430,8 +429,40 @@ class GraphedStep:
                     self.optimizer.step()
         if pipe is not None:
             pipe.reset()
-        st["variants"][name] = (g, results)
-        return st["variants"][name]
+        st["variants"][name] = (g, results, self._handover(st))
+        return st["variants"][name][:2]
+
+    def _handover(self, st):
+        """What a captured step leaves behind on the HOST side for its readers — the parameters' .grad / .grad_fp32, the
+        encoder's one-buffer table gradient (parallel.py all-reduces it), the data-parallel bookkeeping of the deferred vertex
+        stage — points into the memory pool of the graph that was captured LAST.  Each variant keeps its own set and _adopt()
+        puts it back before that variant is replayed: whoever reads p.grad after a replay reads what THAT replay wrote."""
+        net = self.net
+        dp = getattr(net, "dp", None)
+        owners = [m for m in net.modules() if hasattr(m, "_grad_base")]
+        return {"grads": [(p, p.grad, getattr(p, "grad_fp32", None)) for _n, p in st["named"]],
+                "bases": [(m, m._grad_base, getattr(m, "_grad_base_fp32", None)) for m in owners],
+                "dp": None if dp is None else (dp.deferred, dp.tables_reduced)}
+
+    def _adopt(self, handover):
+        for p, g, g32 in handover["grads"]:
+            p.grad = g
+            if g32 is not None or getattr(p, "grad_fp32", None) is not None:
+                p.grad_fp32 = g32
+        for m, base, base32 in handover["bases"]:
+            m._grad_base = base
+            if base32 is not None or getattr(m, "_grad_base_fp32", None) is not None:
+                m._grad_base_fp32 = base32
+        dp = getattr(self.net, "dp", None)
+        if dp is not None and handover["dp"] is not None:
+            dp.deferred, dp.tables_reduced = handover["dp"]
+
+    def _variant(self, st, use):
+        if use not in st["variants"]:
+            self._capture(st, use)
+        g, results, handover = st["variants"][use]
+        self._adopt(handover)
+        return g, results
 
     @staticmethod
     def _ident(t):
@@ -455,7 +486,7 @@ class GraphedStep:
         if "W" in st and next_first is not None and tuple(next_first.shape) == tuple(st["x"].shape):
             st["x_next"].copy_(next_first)
             st["pre"] = (self._VARIANTS[use][1], self._ident(next_first))
-        g, results = st["variants"].get(use) or self._capture(st, use)
+        g, results = self._variant(st, use)
         g.replay()
         return results
 
@@ -479,8 +510,9 @@ class GraphedStep:
     def replay_only(self, key=None):
         """Replays the (only, or the named) captured step on the batch already in its static buffers (benchmarks)."""
         st = self._graphs[key] if key is not None else next(iter(self._graphs.values()))
-        st["graph"].replay()
-        return st["result"]
+        g, results = self._variant(st, "cold")
+        g.replay()
+        return results[0]
 
     def replay_steady(self, key=None):
         """Benchmarks, cross_replay: replays the steady graph on the batches already in the static buffers (x_next holds the first
@@ -488,10 +520,9 @@ class GraphedStep:
         st = self._graphs[key] if key is not None else next(iter(self._graphs.values()))
         pre = st.get("pre")
         if "W" not in st or pre is None:
-            st["graph"].replay()
-            return st["result"]
+            return self.replay_only(key)
         use = "01" if pre[0] == 0 else "10"
-        g, results = st["variants"].get(use) or self._capture(st, use)
+        g, results = self._variant(st, use)
         st["pre"] = (self._VARIANTS[use][1], pre[1])
         g.replay()
         return results[0]

@@ -321,3 +321,48 @@ def test_blend_kernels_all_codes_vs_oracle(flag):
         # d / s - d q / s^2: the tolerance is relative to the size of those two terms)
         scale = float(np.abs(d64 / (q64.sum(-1, keepdims=True) if flag is False else 1.0)).max())
         parity_close(qt.grad, want, 2e-5, 2e-6 * scale, f"blend bwd code {ops.BLEND_CODES[flag]} ({U}x{K})")
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_sixty_four_feature_step_with_the_clear_inside_the_decoder_backward(half):
+    """BASELINE config 5's width (L F = 64: no fused training kernel): with net.fused_mse the table-gradient buffer is left for the
+    decoder BACKWARD kernel to clear on its way (gngf_decoder_bwd(..., zero_fill); ops.DECODER_BWD_CLEARS) instead of for rider
+    workgroups of the binning launch.  Same gradients either way, on a NaN-poisoned allocator; fp32 and fp16 table storage."""
+    from collision_handling_in_instantngp_amd import models, ops
+    Pn = 2 ** 17
+    g = torch.Generator(device=DEV).manual_seed(9)
+    xy = torch.rand((Pn, 2), device=DEV, generator=g)
+    target = torch.rand((Pn, 3), device=DEV, generator=g)
+    models.should_use_hash_function = True
+    prev = (ops.DECODER_BWD_CLEARS, ops.FP16_TABLE_GRAD_FP32)
+    try:
+        ops.FP16_TABLE_GRAD_FP32 = False
+        torch.manual_seed(5)
+        net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=2 ** 16, num_levels=16, n_min=16, n_max=1024,
+                                              MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
+                                              HPD_out_features=2 ** 16, feature_dim=4, topk_k=4,
+                                              table_dtype=(torch.float16 if half else torch.float32)).to(DEV)
+        net.return_indices = False
+        with torch.no_grad():
+            net.encoding.packed_tables().mul_(50.0)
+        out = {}
+        for on in (True, False):
+            ops.DECODER_BWD_CLEARS = on
+            net.zero_grad()
+            _poison_allocator(1 << 30)
+            with net.fused_mse(target, gloss=1.0):
+                rgb, _p, _i, _c = net(xy, 1.0)
+            ops.mse_loss(rgb, target).backward()
+            torch.cuda.synchronize()
+            out[on] = (rgb.detach().clone(), torch.stack([m.weight.grad.float() for m in net.encoding._hash_tables]).clone(),
+                       [p_.grad.clone() for p_ in net.mlp.parameters()])
+        assert torch.equal(out[True][0], out[False][0])
+        assert bool(torch.isfinite(out[True][1]).all())
+        mx = float(out[False][1].abs().max())
+        assert mx > 0
+        parity_close(out[True][1], out[False][1], 1e-3, (2e-3 if half else 2e-5) * mx, f"64-feature step (fp16 tables: {half}): table gradient, clear inside decoder_bwd vs riders")
+        for a, b in zip(out[True][2], out[False][2]):
+            assert torch.equal(a, b)
+    finally:
+        ops.DECODER_BWD_CLEARS, ops.FP16_TABLE_GRAD_FP32 = prev
+        models.should_use_hash_function = False

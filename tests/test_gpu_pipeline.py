@@ -276,3 +276,54 @@ def test_binning_across_replays_equals_binning_at_the_head_of_every_replay(unrol
         assert torch.equal(res[True][0][0][0][0], res[False][0][0][0][0])          # the very first step: identical
     finally:
         models.should_use_hash_function = False
+
+
+def test_gradients_a_caller_reads_after_a_replay_are_that_replays():
+    """Three graphs per shape (cold / two steady) each write their gradients into their OWN pool memory; p.grad, the encoder's
+    one-buffer table gradient and the data-parallel bookkeeping have to follow the variant that was replayed (GraphedStep._adopt)
+    — they used to keep pointing at the variant captured LAST.  No optimizer: the gradients of every replay have an eager twin."""
+    from collision_handling_in_instantngp_amd import models, train
+    P = 40000
+    models.should_use_hash_function = True
+    try:
+        net = _net(models, "hash", L=8, T=2 ** 14, n_max=128)
+        g = torch.Generator(device=DEV).manual_seed(1)
+        xs = [torch.rand((P, 2), device=DEV, generator=g) for _ in range(3)]
+        ys = [torch.rand((P, 3), device=DEV, generator=g) for _ in range(3)]
+        loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
+        empty = torch.tensor([], device=DEV)
+
+        def table_grads():
+            return torch.stack([m.weight.grad for m in net.encoding._hash_tables]).clone()
+
+        ref = []
+        for x, y in zip(xs, ys):
+            net.zero_grad()
+            with net.fused_mse(y, gloss=1.0):
+                rgb, probs, _i, _c = net(x, 1.0)
+            mse, kls, coll = loss_fn(rgb, y, None, probs, empty, empty)
+            train.assemble_loss(mse, kls, coll, 1, 1, 1e-3).backward()
+            torch.cuda.synchronize()
+            ref.append((table_grads(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None and "hash" not in n}))
+        gs = train.GraphedStep(net, loss_fn, None, 1, 1, 1e-3, unroll=1, cross_replay=True)
+        seen = set()
+        for rep in range(2):
+            for k in range(3):
+                st = next(iter(gs._graphs.values())) if gs._graphs else None
+                pre = None if st is None else st.get("pre")
+                seen.add("cold" if pre is None else ("01" if pre[0] == 0 else "10"))
+                gs(xs[k], ys[k], next_first=xs[(k + 1) % 3])
+                torch.cuda.synchronize()
+                got = table_grads()
+                scale = float(ref[k][0].abs().max())
+                assert float((got - ref[k][0]).abs().max()) <= 2e-5 * scale, (rep, k)
+                base = net.encoding._grad_base if net.encoding._grad_base is not None else net.encoding._grad_base_fp32
+                if base is not None:
+                    assert float((base.float() - ref[k][0]).abs().max()) <= 2e-5 * scale, (rep, k)
+                for n, p in net.named_parameters():
+                    if n in ref[k][1]:
+                        want = ref[k][1][n]
+                        assert float((p.grad - want).abs().max()) <= 2e-4 * float(want.abs().max()) + 1e-9, (rep, k, n)
+        assert seen == {"cold", "01", "10"}, seen
+    finally:
+        models.should_use_hash_function = False
