@@ -27,6 +27,8 @@ SIGNATURES = {
     "gngf_bilinear_bwd": [_P, _P, _P, _P, _L, _I, _I, _P],
     "gngf_encode_fwd": [_P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _L, _I, _I, _P],
     "gngf_encode_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _L, _I, _I, _P],
+    "gngf_encode_bwd_bucketed_plan": [_L, _I, _L, _I, _I, _P],
+    "gngf_encode_bwd_bucketed": [_P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _I, _P, _P, _P, _P],
     "gngf_bin_pixels": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "gngf_encode_tiled_prepare": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _I, _L,
                                   _P, _L, _P, _P],
@@ -85,7 +87,7 @@ SIGNATURES = {
     "gngf_adam_step": [_P, _I, _L, _P, _P, _P, _I, _F, _F, _F, _F, _P],
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class BinJob(ctypes.Structure):

@@ -145,6 +145,46 @@ class BilinearFunction(torch.autograd.Function):
         return None, None, dfeats
 
 
+# Backward of the direct levels, hash source: above BUCKETED_MIN_PIXELS the contributions are counting-sorted by table slice and summed
+# in LDS images (csrc/encode_bucket.hip) instead of one memory-side atomic each (20.6 G row updates/s on this chip wherever the rows
+# lie: tools/micro/atomic_window.cpp).  Bitwise reproducible; the terms are the same fp32 products, summed exactly, rounded once.
+BUCKETED_DIRECT_BWD = True
+BUCKETED_MIN_PIXELS = 1 << 16
+BUCKET_IMAGE_BYTES = 64 * 1024
+# contributions per table row of a level below which the atomics win: every bucket costs its image's clear and its slice's
+# write-out whatever it holds (measured, tools/perf_bucket.py: 1.0 per row at the 4096^2 shape: 407 -> 188 us; 0.25 per row at
+# the 8192^2 one: 817 -> 822 us)
+BUCKETED_MIN_DENSITY = 0.5
+
+
+def bucketed_plan(P, F, T, nl):
+    """(bucket_shift, buckets per level, pixel blocks, matrix ints, base ints, item bytes) or None — the library's own decision"""
+    if not BUCKETED_DIRECT_BWD or P < BUCKETED_MIN_PIXELS or nl <= 0 or 4.0 * P < BUCKETED_MIN_DENSITY * T:
+        return None
+    plan = (_ct.c_int64 * 6)()
+    if query("gngf_encode_bwd_bucketed_plan", int(P), int(F), int(T), int(nl), int(BUCKET_IMAGE_BYTES), plan) != 1:
+        return None
+    return tuple(int(v) for v in plan)
+
+
+def _direct_bwd(xy, tables, vert_idx, vert_w, n_ls, genc, dtables, dvw, P, L, F, T, K, mode, vstride, NV, l0, l1, fresh=False):
+    """d tables of levels [l0, l1) in the direct form.  fresh: those levels of dtables hold NOTHING yet (not even zeros) — the
+    bucketed form writes every row of them, the atomics form clears them first."""
+    plan = bucketed_plan(P, F, T, l1 - l0) if (mode == MODE_HASH and dtables.dtype == _f32) else None
+    if plan is None:
+        if fresh:
+            dtables[l0:l1].zero_()
+        call("gngf_encode_bwd", ptr(xy), *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc, _f32, "grad"),
+             ptr(dtables), ptr(dvw), P, L, F, T, K, mode, vstride, NV, l0, l1, stream_ptr())
+        return
+    dev = dtables.device
+    matrix = torch.empty((plan[3],), dtype=_i32, device=dev)
+    base = torch.empty((plan[4],), dtype=_i32, device=dev)
+    items = torch.empty((plan[5],), dtype=torch.uint8, device=dev)
+    call("gngf_encode_bwd_bucketed", ptr(xy), ptr(n_ls), ptr(genc, _f32, "grad"), ptr(dtables), P, L, F, T, l0, l1,
+         int(BUCKET_IMAGE_BYTES), 0 if fresh else 1, ptr(matrix), ptr(base), ptr(items), stream_ptr())
+
+
 class EncodeDirectFunction(torch.autograd.Function):
     """Fused coords -> (P, L*F) encoder, direct form (include/gngf.h: gngf_encode_fwd / gngf_encode_bwd).
 
@@ -174,8 +214,7 @@ class EncodeDirectFunction(torch.autograd.Function):
         genc = _c(genc)
         dtables = _grad_buffer(tables)
         dvw = torch.zeros_like(vert_w) if (vert_w is not None and ctx.needs_input_grad[4]) else None
-        call("gngf_encode_bwd", ptr(xy), *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc, _f32, "grad"),
-             ptr(dtables), ptr(dvw), P, L, F, T, K, mode, vstride, NV, 0, L, stream_ptr())
+        _direct_bwd(xy, tables, vert_idx, vert_w, n_ls, genc, dtables, dvw, P, L, F, T, K, mode, vstride, NV, 0, L)
         return None, None, _grad_out(dtables, tables), None, dvw, None
 
 
@@ -1178,6 +1217,7 @@ class EncodeFunction(torch.autograd.Function):
             order = slot_order(vert_idx, plan.n_ls_host[:plan.Ls], vstride)
         pre = None
         ctx.next_bin = None
+        ctx.fresh_direct = False
         if plan.Ls > 0 and P > 0:
             dev = tables.device
             pws = _bin_workspace(dev, plan.ntiles, dp, kind="reserve") if (TWO_LAUNCH_BINNING and FUSED_VERTEX_FWD) else None
@@ -1201,14 +1241,18 @@ class EncodeFunction(torch.autograd.Function):
                     ng = (plan.vtot * F + 2) * 2 if use64 else plan.vtot * F
                     big = torch.empty((nt + ((ng + 3) & ~3),), dtype=_f32, device=dev)
                     dgrid = big[nt:nt + ng].view(_i64) if use64 else big[nt:nt + ng].view(plan.vtot, F)
-                    pre = [big[:nt].view(tables.shape), dgrid, big]
+                    pre = [big[:nt].view(tables.shape), dgrid, big, big]
                 else:
                     fused = False
                     dgrid = (torch.empty((plan.vtot * F + 2,), dtype=_i64, device=dev) if use64
                              else torch.empty((plan.vtot, F), dtype=_f32, device=dev))
-                    pre = [torch.empty(tables.shape, dtype=_f32, device=dev), dgrid, None]
+                    dt_ = torch.empty(tables.shape, dtype=_f32, device=dev)
+                    # direct levels whose backward WRITES every row (the bucketed form) are left out of the clear
+                    fresh = plan.Ls < L and mode == MODE_HASH and bucketed_plan(P, F, T, L - plan.Ls) is not None
+                    pre = [dt_, dgrid, None, dt_[:plan.Ls] if fresh else dt_]
+                    ctx.fresh_direct = fresh
                 tile_level_offsets(plan, dev)        # cached; built here so that no backward (or graph capture) uploads it
-            zbuf = None if pre is None else (pre[2] if pre[2] is not None else pre[0])
+            zbuf = None if pre is None else pre[3]
             defer = pre is not None and link is not None and link.defer_zero and zbuf.numel() % 4 == 0
             if defer:
                 link.zero_request = zbuf
@@ -1246,7 +1290,7 @@ class EncodeFunction(torch.autograd.Function):
                 G = torch.empty((plan.vtot, F), dtype=_f32, device=dev)
                 ws = TiledWorkspace(plan, xy, vertex=(tables, vert_idx, vert_w, n_ls, vstride, G),
                                     zero_dG=(pre[1].view(_f32) if use64 else pre[1]) if pre else None,
-                                    zero=(pre[0] if (pre and not defer) else None), zero_dG_words=(2 if use64 else 1), owner=dp)
+                                    zero=(pre[3] if (pre and not defer) else None), zero_dG_words=(2 if use64 else 1), owner=dp)
                 call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), plan.n_ls_c,
                      ptr(G), ptr(enc), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, stream_ptr())
         if plan.Ls < L:
@@ -1273,7 +1317,8 @@ class EncodeFunction(torch.autograd.Function):
         exchange = dp.exchange if dp is not None else None
         NONE = (None,) * 5                                      # (order, dp, link, sink) + vstride: no gradients
         pre, ctx.pre = ctx.pre, None                            # a second backward (retain_graph) allocates fresh buffers
-        zbuf = None if not pre else (pre[2] if pre[2] is not None else pre[0])
+        zbuf = None if not pre else pre[3]
+        fresh_direct = bool(pre) and getattr(ctx, "fresh_direct", False)        # (a second backward gets a zeroed buffer: nothing is fresh)
         if pre and link is not None and link.zero_request is zbuf:
             link.zero_request = None                            # the decoder that was to clear the buffer did not run: clear it here
             zbuf.zero_()
@@ -1306,8 +1351,8 @@ class EncodeFunction(torch.autograd.Function):
             if fuse is None and exchange is not None and dp.defer_vertex and dvw is None:
                 # the caller exchanges dG and runs the vertex stage after backward (parallel.allreduce_gradients)
                 if plan.Ls < L:
-                    call("gngf_encode_bwd", ptr(xy), *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc, _f32, "grad"),
-                         ptr(dtables), ptr(dvw), P, L, F, T, K, mode, vstride, NV, plan.Ls, L, stream_ptr())
+                    _direct_bwd(xy, tables, vert_idx, vert_w, n_ls, genc, dtables, dvw, P, L, F, T, K, mode, vstride, NV, plan.Ls, L,
+                                fresh=fresh_direct)
                 gout = _grad_out(dtables, tables, sink)
                 dp.deferred = (plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, order, gout)
                 dp.tables_reduced = plan.Ls
@@ -1327,8 +1372,8 @@ class EncodeFunction(torch.autograd.Function):
         else:
             dvw_t = None
         if plan.Ls < L:
-            call("gngf_encode_bwd", ptr(xy), *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), ptr(genc, _f32, "grad"),
-                 ptr(dtables), ptr(dvw), P, L, F, T, K, mode, vstride, NV, plan.Ls, L, stream_ptr())
+            _direct_bwd(xy, tables, vert_idx, vert_w, n_ls, genc, dtables, dvw, P, L, F, T, K, mode, vstride, NV, plan.Ls, L,
+                        fresh=fresh_direct)
         if dvw_t is not None:
             dvw = dvw + dvw_t
         return (None, None, None, _grad_out(dtables, tables, sink), None, dvw, *NONE)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNGF_ABI_VERSION 10
+#define GNGF_ABI_VERSION 11
 #define GNGF_MAX_LEVELS 32
 #define GNGF_MAX_TOPK 32
 
@@ -75,6 +75,20 @@ int gngf_encode_bwd(const float* xy, const void* tables, int feat_dtype, const i
                     const int32_t* n_ls, const float* genc, float* dtables, float* dvert_w,
                     int64_t P, int L, int F, int64_t T, int K, int mode, int vstride, int64_t NV, int l0, int l1,
                     void* stream);
+
+/* backward of levels [l0, l1), spatial-hash source, WITHOUT one memory-side atomic per contribution (csrc/encode_bucket.hip: the
+ * chip retires 20.6 G atomic row updates per second wherever the rows lie): the contributions are counting-sorted by table slice
+ * ("bucket" = slot >> bucket_shift) and one workgroup per (level, bucket) sums its slice in a 64-bit fixed-point LDS image — the
+ * result is bitwise reproducible.  Replaces the same reference lines as gngf_encode_bwd (models.py:382-392 backward).
+ * gngf_encode_bwd_bucketed_plan: 1 and plan[0..5] = bucket_shift, buckets per level, pixel blocks, matrix ints, base ints, bytes of
+ *   the item buffer — or 0 when the shape is not served (F not in {1,2,4}, > 8192 buckets per level, >= 2^31 contributions);
+ *   image_bytes: LDS bytes of a bucket's image (1 KiB .. 128 KiB).
+ * gngf_encode_bwd_bucketed: accumulate = 1 adds to dtables (L,T,F) fp32; 0 WRITES every row of levels [l0, l1) (no clear needed).
+ *   matrix / base / items: scratch of the sizes the plan names. */
+int gngf_encode_bwd_bucketed_plan(int64_t P, int F, int64_t T, int nl, int image_bytes, int64_t* plan);
+int gngf_encode_bwd_bucketed(const float* xy, const int32_t* n_ls, const float* genc, float* dtables, int64_t P, int L, int F,
+                             int64_t T, int l0, int l1, int image_bytes, int accumulate, int32_t* matrix, int32_t* base,
+                             void* items, void* stream);
 
 /* ---- a5..a12 fused, "tiled" form: vertex stage + spatially binned, LDS-privatised pixel stage.
  * gngf_bin_pixels: bins P pixels into 4^tile_shift tiles of [0,1]^2.  NB binning blocks (<= 512); `chunk` = max pixels

@@ -1,0 +1,172 @@
+"""GPU: the bucketed backward of the direct levels (csrc/encode_bucket.hip — counting sort of the contributions by table slice, one
+workgroup per slice summing in a 64-bit fixed-point LDS image) against the C oracle's sum of the reference's fp32 terms in double
+precision, against the atomics kernel it replaces, and its own properties: bitwise reproducible, both store modes (add to / write
+the levels), ragged shapes (T no power of two, P no multiple of a pixel block, a level sub-range, images from 1 KiB to 128 KiB),
+non-finite terms propagate to the rows they belong to and nowhere else."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle, gngf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _case(P, n_min, n_max, L, T, F, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.random((P, 2), dtype=np.float32)
+    x[:7] = np.array([[0, 0], [1, 1], [0, 1], [1, 0], [0.5, 0.5], [1 / 32, 31 / 32], [0.99999994, 1e-8]], np.float32)
+    x[7:2007] = x[7]                                   # 2000 pixels on one cell: long chains on a few rows
+    n_ls = orc.level_resolutions(n_min, n_max, L).astype(np.int32)
+    g = (rng.standard_normal((P, L * F)) * np.exp(rng.uniform(-12, 2, (P, 1)))).astype(np.float32)      # 6 decades of magnitudes
+    return x, n_ls, g
+
+
+def _bucketed(ops, _lib, x, n_ls, g, L, T, F, l0, l1, image, accumulate, into=None):
+    P = x.shape[0]
+    plan = (ctypes.c_int64 * 6)()
+    assert _lib.query("gngf_encode_bwd_bucketed_plan", P, F, T, l1 - l0, image, plan) == 1
+    dt = torch.zeros((L, T, F), device=DEV) if into is None else into
+    matrix = torch.empty((plan[3],), dtype=torch.int32, device=DEV)
+    base = torch.empty((plan[4],), dtype=torch.int32, device=DEV)
+    items = torch.empty((plan[5],), dtype=torch.uint8, device=DEV)
+    _lib.call("gngf_encode_bwd_bucketed", _lib.ptr(x), _lib.ptr(n_ls), _lib.ptr(g), _lib.ptr(dt), P, L, F, T, l0, l1, image, accumulate,
+              _lib.ptr(matrix), _lib.ptr(base), _lib.ptr(items), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    return dt, tuple(plan)
+
+
+@pytest.mark.parametrize("shape", [
+    # P, n_min, n_max, L, T, F, l0, l1, image bytes
+    (70001, 16, 512, 6, 1000, 1, 0, 6, 1024),               # T no power of two, 8 buckets of 128 slots, the last one partial
+    (2 ** 17 + 13, 16, 2048, 5, 2 ** 16, 2, 1, 5, 2048),    # a level sub-range, 512 buckets per level
+    (2 ** 16, 64, 4096, 3, 2 ** 20, 4, 0, 3, 65536),        # the cfg5 item layout (values and slots in two arrays)
+    (100000, 16, 4096, 4, 2 ** 18, 2, 2, 4, 131072),        # the largest image
+    (5000, 16, 256, 2, 300, 2, 0, 2, 65536),                # one bucket per level, one pixel block
+])
+def test_bucketed_direct_backward_vs_oracle_and_atomics(shape):
+    from collision_handling_in_instantngp_amd import _lib, ops
+    P, n_min, n_max, L, T, F, l0, l1, image = shape
+    x, n_ls, g = _case(P, n_min, n_max, L, T, F, seed=P % 97)
+    tx, tn, tg = torch.from_numpy(x).to(DEV), torch.from_numpy(n_ls).to(DEV), torch.from_numpy(g).to(DEV)
+    want = c_oracle.encode_bwd_f64(x, (L, T, F), n_ls, g)               # the reference's fp32 terms, summed in double
+    want[:l0] = 0
+    want[l1:] = 0
+    mass = np.zeros((L, T, F))                                            # sum |term| per row: what an fp32 sum's error scales with
+    absg = c_oracle.encode_bwd_f64(x, (L, T, F), n_ls, np.abs(g))
+    mass[l0:l1] = absg[l0:l1]
+    _, grid = orc.scale_to_grid(x, n_ls)
+    idx = orc.spatial_hash(grid.astype(np.int32), T)                      # (P, L, 4)
+    count = np.zeros((L, T, 1))
+    for l in range(l0, l1):
+        np.add.at(count[l, :, 0], idx[:, l].reshape(-1), 1)
+    got, plan = _bucketed(ops, _lib, tx, tn, tg, L, T, F, l0, l1, image, 1)
+    got = got.cpu().numpy().astype(np.float64)
+    # exact integer sums of the fp32 terms, one rounding at the end: half an fp32 ulp of the result + the image's quantum per term
+    # (2^-50 of the largest term of the row's bucket, bounded here by the largest term of the batch)
+    err = np.abs(got - want)
+    room = min(50, 61 - int(np.ceil(np.log2(max(1.0, count.max())))))       # (the kernel: per bucket, from its fullest row)
+    quantum = count * (2.0 ** -room) * float(np.abs(g).max())
+    bound = 6.0e-8 * np.abs(want) + quantum + 1e-45
+    assert np.all(err <= bound), float((err / bound).max())
+    assert np.count_nonzero(got[:l0]) == 0 and np.count_nonzero(got[l1:]) == 0
+    # the kernel it replaces (fp32 atomics in arrival order): equal up to its own accumulation error
+    tables = torch.zeros((L, T, F), device=DEV)
+    ref = torch.zeros((L, T, F), device=DEV)
+    _lib.call("gngf_encode_bwd", _lib.ptr(tx), *ops._tab(tables), _lib.ptr(None), _lib.ptr(None), _lib.ptr(tn), _lib.ptr(tg), _lib.ptr(ref),
+              _lib.ptr(None), P, L, F, T, 0, ops.MODE_HASH, 0, 0, l0, l1, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    dev_ = np.abs(ref.cpu().numpy() - got)
+    lim = 6e-8 * (count + 1) * mass + quantum + 1e-30
+    worst = np.unravel_index(np.argmax(dev_ / lim), dev_.shape)
+    assert np.all(dev_ <= lim), (worst, dev_[worst], lim[worst], count[worst[0], worst[1], 0], mass[worst], got[worst], want[worst])
+    # bitwise reproducible (the order of a bucket's items changes from run to run; integer sums do not care)
+    again, _ = _bucketed(ops, _lib, tx, tn, tg, L, T, F, l0, l1, image, 1)
+    assert np.array_equal(again.cpu().numpy().astype(np.float64), got)
+    # write mode: every row of [l0, l1) is written over whatever was there, the other levels are not touched
+    dirty = torch.full((L, T, F), float("nan"), device=DEV)
+    dirty[:l0] = 3.0
+    dirty[l1:] = 5.0
+    wrote, _ = _bucketed(ops, _lib, tx, tn, tg, L, T, F, l0, l1, image, 0, into=dirty)
+    w = wrote.cpu().numpy().astype(np.float64)
+    assert np.array_equal(w[l0:l1], got[l0:l1]) and np.all(w[:l0] == 3.0) and np.all(w[l1:] == 5.0)
+    # add mode on top of earlier gradients
+    twice, _ = _bucketed(ops, _lib, tx, tn, tg, L, T, F, l0, l1, image, 1, into=again.clone())
+    assert np.allclose(twice.cpu().numpy(), 2 * got, rtol=1e-6, atol=0)
+
+
+def test_non_finite_terms_reach_their_rows_only():
+    from collision_handling_in_instantngp_amd import _lib, ops
+    P, L, T, F = 2 ** 16, 2, 2 ** 14, 2
+    x, n_ls, g = _case(P, 256, 2048, L, T, F, seed=5)
+    g[12345, 1] = np.nan                                  # level 0, feature 1 of one pixel
+    g[777, 2] = np.inf                                    # level 1, feature 0 of another
+    tx, tn, tg = torch.from_numpy(x).to(DEV), torch.from_numpy(n_ls).to(DEV), torch.from_numpy(g).to(DEV)
+    got, _ = _bucketed(ops, _lib, tx, tn, tg, L, T, F, 0, L, 4096, 1)
+    got = got.cpu().numpy()
+    _, grid = orc.scale_to_grid(x[[12345, 777]], n_ls)
+    idx = orc.spatial_hash(grid.astype(np.int32), T)                     # (2, L, 4)
+    bad = np.zeros((L, T, F), bool)
+    bad[0, idx[0, 0], 1] = True
+    bad[1, idx[1, 1], 0] = True
+    assert np.all(~np.isfinite(got[bad])) and np.all(np.isfinite(got[~bad]))
+    g2 = g.copy()
+    g2[12345, 1] = 0
+    g2[777, 2] = 0
+    clean, _ = _bucketed(ops, _lib, tx, tn, torch.from_numpy(g2).to(DEV), L, T, F, 0, L, 4096, 1)
+    clean = clean.cpu().numpy()
+    # rows of buckets without a non-finite term: identical; rows that share a bucket with one were summed in fp32 instead
+    same_bucket = np.zeros((L, T, F), bool)
+    slots = 4096 // (8 * F)
+    for lv, rows in ((0, idx[0, 0]), (1, idx[1, 1])):
+        for r in rows:
+            same_bucket[lv, (r // slots) * slots:(r // slots + 1) * slots] = True
+    assert np.array_equal(got[~same_bucket], clean[~same_bucket])
+    ok = same_bucket & ~bad
+    assert np.allclose(got[ok], clean[ok], rtol=1e-4, atol=1e-6 * np.abs(clean).max())
+
+
+def test_shapes_the_bucketed_form_does_not_serve_are_refused_by_its_plan():
+    from collision_handling_in_instantngp_amd import _lib
+    plan = (ctypes.c_int64 * 6)()
+    q = lambda *a: _lib.query("gngf_encode_bwd_bucketed_plan", *a, plan)
+    assert q(2 ** 20, 2, 2 ** 22, 2, 65536) == 1 and tuple(plan)[:3] == (12, 1024, 256)
+    assert q(2 ** 20, 4, 2 ** 24, 4, 131072) == 1 and tuple(plan)[:3] == (12, 4096, 256) and plan[5] == 2 ** 20 * 16 * 20
+    assert q(2 ** 20, 8, 2 ** 19, 2, 65536) == 0             # F = 8
+    assert q(2 ** 20, 4, 2 ** 24, 4, 16384) == 0             # 2^15 buckets per level
+    assert q(2 ** 28, 2, 2 ** 22, 2, 65536) == 0             # 2^31 contributions
+    assert q(0, 2, 2 ** 22, 2, 65536) == 0
+
+
+@pytest.mark.parametrize("F,half", [(2, False), (4, True)])
+def test_encoder_backward_with_direct_levels_bucketed_equals_atomics(F, half):
+    """the op as the model calls it: staged levels through the tiled chain, the fine levels in the direct form — bucketed or not"""
+    from collision_handling_in_instantngp_amd import ops
+    P, L, T = 2 ** 17, 8, 2 ** 16
+    rng = np.random.default_rng(3)
+    n_host = [int(v) for v in orc.level_resolutions(16, 4096, L)]
+    n_ls = torch.tensor(n_host, dtype=torch.int32, device=DEV)
+    xy = torch.from_numpy(rng.random((P, 2), dtype=np.float32)).to(DEV)
+    g = torch.from_numpy(rng.standard_normal((P, L * F)).astype(np.float32)).to(DEV)
+    plan = ops.EncodePlan(P, n_host, F)
+    assert 0 < plan.Ls < L, plan.Ls
+    res = {}
+    prev = ops.BUCKETED_DIRECT_BWD
+    try:
+        for on in (True, False):
+            ops.BUCKETED_DIRECT_BWD = on
+            tab = torch.from_numpy(((rng.random((L, T, F), dtype=np.float32) - 0.5) * 2e-2)).to(DEV)
+            tab = (tab.half() if half else tab).requires_grad_()
+            enc = ops.encode_apply(xy, n_ls, n_host, tab, None, None, 0)
+            enc.backward(g)
+            torch.cuda.synchronize()
+            res[on] = tab.grad.float().clone()
+    finally:
+        ops.BUCKETED_DIRECT_BWD = prev
+    scale = float(res[False].abs().max())
+    tol = (2e-3 if half else 2e-6) * scale                       # fp16 .grad: one rounding to half
+    assert float((res[True] - res[False]).abs().max()) <= tol
+    assert float(res[True][plan.Ls:].abs().max()) > 0
