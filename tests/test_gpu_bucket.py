@@ -98,6 +98,23 @@ def test_bucketed_direct_backward_vs_oracle_and_atomics(shape):
     assert np.allclose(twice.cpu().numpy(), 2 * got, rtol=1e-6, atol=0)
 
 
+def test_a_batch_that_lands_in_four_rows_is_still_exact():
+    from collision_handling_in_instantngp_amd import _lib, ops
+    P, L, T, F = 2 ** 16 + 5, 2, 2 ** 16, 2
+    rng = np.random.default_rng(2)
+    x = np.tile(np.array([[0.3711, 0.6123]], np.float32), (P, 1))
+    x[-3000:] = rng.random((3000, 2), dtype=np.float32)
+    n_ls = np.array([1024, 4096], np.int32)
+    g = rng.standard_normal((P, L * F)).astype(np.float32)
+    tx, tn, tg = torch.from_numpy(x).to(DEV), torch.from_numpy(n_ls).to(DEV), torch.from_numpy(g).to(DEV)
+    want = c_oracle.encode_bwd_f64(x, (L, T, F), n_ls, g)
+    got, _ = _bucketed(ops, _lib, tx, tn, tg, L, T, F, 0, L, 8192, 1)
+    got = got.cpu().numpy().astype(np.float64)
+    # 65 k terms per row: room = 61 - 17 = 44 bits below the largest term
+    assert np.all(np.abs(got - want) <= 6.0e-8 * np.abs(want) + P * 4 * 2.0 ** -44 * float(np.abs(g).max()))
+    assert float(np.abs(want).max()) > 100
+
+
 def test_non_finite_terms_reach_their_rows_only():
     from collision_handling_in_instantngp_amd import _lib, ops
     P, L, T, F = 2 ** 16, 2, 2 ** 14, 2

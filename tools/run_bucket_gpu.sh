@@ -8,14 +8,3 @@ for f in glob.glob("gpurun_out/prof_bucket/**/*kernel_stats.csv", recursive=True
         if "gngf" in r["Name"]: print(r["Name"][:70].ljust(70), r["Calls"], r["AverageNs"], r["Percentage"])
 EOF2
 grep -E "us$|difference" gpurun_out/perf_bucket2.log
-python bench.py --mode cfg4_hash --steps 20 --warmup 5 --no-extra-modes --no-cpu-baseline --no-full-outputs > gpurun_out/b_cfg4.json 2> gpurun_out/b_cfg4.err; python - <<EOF3
-import json
-d=json.loads(open("gpurun_out/b_cfg4.json").read().strip().splitlines()[-1])
-print("cfg4", d["ms_per_step"], d.get("ms_per_step_windows"))
-EOF3
-python bench.py --mode cfg5_hash_fp16 --steps 20 --warmup 5 --no-extra-modes --no-cpu-baseline --no-full-outputs > gpurun_out/b_cfg5.json 2> gpurun_out/b_cfg5.err; python - <<EOF3
-import json
-d=json.loads(open("gpurun_out/b_cfg5.json").read().strip().splitlines()[-1])
-print("cfg5", d["ms_per_step"], d.get("ms_per_step_windows"))
-EOF3
-python -m pytest tests/test_gpu_fullsize.py -x -q > gpurun_out/t_fullsize.log 2>&1; tail -3 gpurun_out/t_fullsize.log
