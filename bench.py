@@ -275,7 +275,8 @@ def exchange_model(net, world):
 ENTRY_NAMES = {"gngf_bin_pixels": "bin_pixels", "gngf_bin_pixels2": "bin_pixels(count+scatter)", "gngf_encode_tiled_fwd_fused": "encode_fwd:tiled", "gngf_encode_tiled_prepare": "prepare(bin+vertex_fwd+clears)", "gngf_vertex_grid_fwd": "vertex_fwd", "gngf_encode_tiled_fwd": "encode_fwd:tiled",
                "gngf_encode_tiled_bwd": "encode_bwd:tiled", "gngf_vertex_grid_bwd_sorted": "vertex_bwd", "gngf_vertex_grid_bwd": "vertex_bwd",
                "gngf_decoder_fwd": "decoder_fwd", "gngf_decoder_bwd": "decoder_bwd", "gngf_decoder_train": "decoder_train", "gngf_decoder_reduce": "decoder_reduce", "gngf_mse_fwd": "mse_fwd", "gngf_mse_bwd": "mse_bwd",
-               "gngf_encode_fwd": "encode_fwd:direct", "gngf_encode_bwd": "encode_bwd:direct"}
+               "gngf_encode_fwd": "encode_fwd:direct", "gngf_encode_bwd": "encode_bwd:direct",
+               "gngf_encode_bwd_bucketed": "encode_bwd:direct(bucketed)"}
 
 
 def kernel_times_in_step(eager_step, n=20, warm=3):
@@ -407,7 +408,8 @@ def main():
         name, _, val = kv.partition("=")
         if not hasattr(ops, name):
             raise SystemExit(f"bench.py --set: ops has no switch {name!r}")
-        setattr(ops, name, type(getattr(ops, name))(int(val)) if isinstance(getattr(ops, name), (bool, int)) else val)
+        cur = getattr(ops, name)
+        setattr(ops, name, type(cur)(int(val)) if isinstance(cur, (bool, int)) else (float(val) if isinstance(cur, float) else val))
     P = a.pixels
 
     results = {}

@@ -155,11 +155,15 @@ BUCKET_IMAGE_BYTES = 64 * 1024
 # write-out whatever it holds (measured, tools/perf_bucket.py: 1.0 per row at the 4096^2 shape: 407 -> 188 us; 0.25 per row at
 # the 8192^2 one: 817 -> 822 us)
 BUCKETED_MIN_DENSITY = 0.5
+# ... when the bucketed form WRITES the levels (a fresh gradient buffer: those levels then need no clear — a quarter of the 4 GiB
+# clear at the 8192^2 shape): step 2.83 -> 2.63 ms there although the kernels themselves only draw with the atomics
+BUCKETED_MIN_DENSITY_FRESH = 0.2
 
 
-def bucketed_plan(P, F, T, nl):
+def bucketed_plan(P, F, T, nl, fresh=False):
     """(bucket_shift, buckets per level, pixel blocks, matrix ints, base ints, item bytes) or None — the library's own decision"""
-    if not BUCKETED_DIRECT_BWD or P < BUCKETED_MIN_PIXELS or nl <= 0 or 4.0 * P < BUCKETED_MIN_DENSITY * T:
+    density = BUCKETED_MIN_DENSITY_FRESH if fresh else BUCKETED_MIN_DENSITY
+    if not BUCKETED_DIRECT_BWD or P < BUCKETED_MIN_PIXELS or nl <= 0 or 4.0 * P < density * T:
         return None
     plan = (_ct.c_int64 * 6)()
     if query("gngf_encode_bwd_bucketed_plan", int(P), int(F), int(T), int(nl), int(BUCKET_IMAGE_BYTES), plan) != 1:
@@ -170,7 +174,7 @@ def bucketed_plan(P, F, T, nl):
 def _direct_bwd(xy, tables, vert_idx, vert_w, n_ls, genc, dtables, dvw, P, L, F, T, K, mode, vstride, NV, l0, l1, fresh=False):
     """d tables of levels [l0, l1) in the direct form.  fresh: those levels of dtables hold NOTHING yet (not even zeros) — the
     bucketed form writes every row of them, the atomics form clears them first."""
-    plan = bucketed_plan(P, F, T, l1 - l0) if (mode == MODE_HASH and dtables.dtype == _f32) else None
+    plan = bucketed_plan(P, F, T, l1 - l0, fresh) if (mode == MODE_HASH and dtables.dtype == _f32) else None
     if plan is None:
         if fresh:
             dtables[l0:l1].zero_()
@@ -1248,7 +1252,7 @@ class EncodeFunction(torch.autograd.Function):
                              else torch.empty((plan.vtot, F), dtype=_f32, device=dev))
                     dt_ = torch.empty(tables.shape, dtype=_f32, device=dev)
                     # direct levels whose backward WRITES every row (the bucketed form) are left out of the clear
-                    fresh = plan.Ls < L and mode == MODE_HASH and bucketed_plan(P, F, T, L - plan.Ls) is not None
+                    fresh = plan.Ls < L and mode == MODE_HASH and bucketed_plan(P, F, T, L - plan.Ls, True) is not None
                     pre = [dt_, dgrid, None, dt_[:plan.Ls] if fresh else dt_]
                     ctx.fresh_direct = fresh
                 tile_level_offsets(plan, dev)        # cached; built here so that no backward (or graph capture) uploads it

@@ -15,6 +15,8 @@ groups = {     # round 3 kernel names (the round-2 names stay listed: general sh
     "vertex_bwd": ["gngf::vertex_bwd_sorted_kernel<2", "gngf::vertex_bwd_kernel<2"],
     "encode_fwd:direct": ["gngf::encode_fwd_kernel"],
     "encode_bwd:direct": ["gngf::encode_bwd_kernel"],
+    "encode_bwd:direct(bucketed)": ["gngf::bucket_count_kernel", "gngf::bucket_prefix_kernel", "gngf::bucket_scatter_kernel",
+                                    "gngf::bucket_sum_kernel"],
 }
 def pick(prefix, counter):          # kernel names carry their full template argument lists: match by prefix
     return sum(v.get(counter, 0.0) for k, v in summ.items() if k.startswith(prefix))
