@@ -80,3 +80,25 @@ def test_fixed_point_grid_is_chosen_by_the_launchers_own_decision():
     finally:
         _lib.query("gngf_set_tiled_interleaved", prev)
     assert p2.interleaved(backward=True)
+
+
+def test_which_direct_levels_take_the_bucketed_backward():
+    """host policy + the library's own sizing (gngf_encode_bwd_bucketed_plan; no GPU needed): the bucketed form above half a
+    contribution per table row — a fifth when it also replaces the clear of the levels it writes — hash source, F in {1, 2, 4}"""
+    n4 = [int(v) for v in models.level_resolutions(16, 4096, 16)]
+    p4 = ops.EncodePlan(2 ** 20, n4, 2)
+    assert p4.Ls == 14
+    plan = ops.bucketed_plan(2 ** 20, 2, 2 ** 22, 16 - p4.Ls)                    # the 4096^2 shape: one contribution per row
+    assert plan is not None and plan[:3] == (12, 1024, 256) and plan[5] == 2 ** 20 * 4 * 2 * 16
+    assert plan[3] == 2 * 256 * 1024 and plan[4] == (2 * 1024 + 1) + 2 * 1024 + 32
+    assert ops.bucketed_plan(2 ** 20, 4, 2 ** 24, 4) is None                      # the 8192^2 shape: a quarter per row ...
+    assert ops.bucketed_plan(2 ** 20, 4, 2 ** 24, 4, fresh=True) is not None      # ... unless the levels are written (no clear)
+    assert ops.bucketed_plan(2 ** 20, 8, 2 ** 19, 2) is None                      # F = 8: not served by the library
+    assert ops.bucketed_plan(2 ** 14, 2, 2 ** 12, 2) is None                      # too few pixels for five launches
+    assert ops.bucketed_plan(2 ** 20, 2, 2 ** 22, 0) is None
+    prev = ops.BUCKETED_DIRECT_BWD
+    try:
+        ops.BUCKETED_DIRECT_BWD = False
+        assert ops.bucketed_plan(2 ** 20, 2, 2 ** 22, 2) is None
+    finally:
+        ops.BUCKETED_DIRECT_BWD = prev
