@@ -73,6 +73,9 @@ def test_bucketed_direct_backward_vs_oracle_and_atomics(shape):
     bound = 6.0e-8 * np.abs(want) + quantum + 1e-45
     assert np.all(err <= bound), float((err / bound).max())
     assert np.count_nonzero(got[:l0]) == 0 and np.count_nonzero(got[l1:]) == 0
+    from conftest import parity_close            # (a row in PARITY.md: the elementwise bound above is the assertion proper)
+    parity_close(got[l0:l1], want[l0:l1], 1.2e-7, float(quantum.max()) + 1e-30,
+                 f"bucketed direct backward vs C oracle (fp32 terms summed in double), P={P} L={l1 - l0} T={T} F={F} image={image}")
     # the kernel it replaces (fp32 atomics in arrival order): equal up to its own accumulation error
     tables = torch.zeros((L, T, F), device=DEV)
     ref = torch.zeros((L, T, F), device=DEV)
