@@ -177,7 +177,8 @@ bucket_scatter_kernel(const float2* __restrict__ xy, const int32_t* __restrict__
   int n[LG];
 #pragma unroll
   for (int i = 0; i < LG; ++i) n[i] = lv0 + i < nl ? n_ls[l0 + lv0 + i] : 1;
-  const bool vec4 = LG * F == 4 && lv0 + LG <= nl && (((int64_t)L * F) & 3) == 0 && (((l0 + lv0) * F) & 3) == 0;
+  const bool vec4 = LG * F == 4 && lv0 + LG <= nl && (((int64_t)L * F) & 3) == 0 && (((l0 + lv0) * F) & 3) == 0 &&
+                    (reinterpret_cast<uintptr_t>(genc) & 15) == 0;
 #pragma unroll
   for (int j = 0; j < kBkPixels; ++j) {
     const int64_t p = p0 + (int64_t)j * kBkThreads;
@@ -390,6 +391,9 @@ extern "C" int gngf_encode_bwd_bucketed(const float* xy, const int32_t* n_ls, co
   }
   GNGF_CHECK_ARG(gngf_encode_bwd_bucketed_plan(P, F, T, l1 - l0, image_bytes, plan) == 1);
   GNGF_CHECK_ARG(xy && n_ls && genc && dtables && matrix && base && items);
+  // vector accesses: items as 16-byte records, a table row (F floats) as one store, a gradient vector (F floats) as one load
+  GNGF_CHECK_ARG((reinterpret_cast<uintptr_t>(items) & 15) == 0 && (reinterpret_cast<uintptr_t>(dtables) & (4 * F - 1)) == 0 &&
+                 (reinterpret_cast<uintptr_t>(genc) & (4 * F - 1)) == 0 && (reinterpret_cast<uintptr_t>(xy) & 7) == 0);
   const int nl = l1 - l0, bshift = (int)plan[0], B = (int)plan[1], nblk = (int)plan[2];
   const int ncols = nl * B, ngroups = (int)ceil_div(ncols, kBkCols);
   int32_t* local = base + ncols + 1;
