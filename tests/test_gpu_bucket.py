@@ -101,6 +101,41 @@ def test_bucketed_direct_backward_vs_oracle_and_atomics(shape):
     assert np.allclose(twice.cpu().numpy(), 2 * got, rtol=1e-6, atol=0)
 
 
+def test_bucketed_direct_backward_on_random_ragged_shapes():
+    """twenty seeded random shapes (P from 1, any level sub-range, T with and without a power of two, every image size the plan
+    accepts): exact sums again, and nothing outside the levels asked for is touched"""
+    from collision_handling_in_instantngp_amd import _lib, ops
+    rng = np.random.default_rng(20261004)
+    done = 0
+    while done < 20:
+        P = int(rng.integers(1, 60000))
+        L = int(rng.integers(1, 6))
+        F = int(rng.choice([1, 2, 4]))
+        T = int(rng.choice([int(rng.integers(3, 5000)), 2 ** int(rng.integers(4, 18))]))
+        l0 = int(rng.integers(0, L))
+        l1 = int(rng.integers(l0 + 1, L + 1))
+        image = 2 ** int(rng.integers(10, 18))
+        n_max = int(rng.choice([64, 700, 4096]))
+        plan = (ctypes.c_int64 * 6)()
+        if _lib.query("gngf_encode_bwd_bucketed_plan", P, F, T, l1 - l0, image, plan) != 1:
+            continue
+        done += 1
+        x = rng.random((P, 2), dtype=np.float32)
+        x[: min(P, 3)] = np.array([[0, 0], [1, 1], [0.99999994, 1e-8]], np.float32)[: min(P, 3)]
+        n_ls = orc.level_resolutions(16, n_max, L).astype(np.int32) if L > 1 else np.array([n_max], np.int32)
+        g = rng.standard_normal((P, L * F)).astype(np.float32)
+        want = c_oracle.encode_bwd_f64(x, (L, T, F), n_ls, g)
+        tx, tn, tg = torch.from_numpy(x).to(DEV), torch.from_numpy(n_ls).to(DEV), torch.from_numpy(g).to(DEV)
+        into = torch.full((L, T, F), 7.0, device=DEV)
+        got, _ = _bucketed(ops, _lib, tx, tn, tg, L, T, F, l0, l1, image, 0, into=into)
+        got = got.cpu().numpy().astype(np.float64)
+        tag = (P, L, F, T, l0, l1, image, n_max)
+        assert np.all(got[:l0] == 7.0) and np.all(got[l1:] == 7.0), tag
+        err = np.abs(got[l0:l1] - want[l0:l1])
+        lim = 6.0e-8 * np.abs(want[l0:l1]) + 4 * P * 2.0 ** -44 * float(np.abs(g).max()) + 1e-45
+        assert np.all(err <= lim), (tag, float((err / lim).max()))
+
+
 def test_a_batch_that_lands_in_four_rows_is_still_exact():
     from collision_handling_in_instantngp_amd import _lib, ops
     P, L, T, F = 2 ** 16 + 5, 2, 2 ** 16, 2
