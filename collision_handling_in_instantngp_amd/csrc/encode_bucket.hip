@@ -345,6 +345,29 @@ bucket_sum_kernel(const void* __restrict__ items, int64_t total, const int32_t* 
   }
 }
 
+// Rows of the table gradient that the STAGED levels of a spatial-hash encoder can ever touch: hash(gx, gy) of every vertex of
+// every staged level — a set that depends on the level resolutions only, not on the batch.  A gradient buffer that lives from
+// step to step (ops.PERSISTENT_TABLE_GRAD) needs only these rows cleared before the next backward adds into it: 4.6 M rows of
+// 16 bytes at the 8192^2 shape instead of a dense 3 GiB.  One lane per (level, vertex), F floats per row in one store.
+template <int F>
+__global__ void __launch_bounds__(256)
+clear_hashed_rows_kernel(float* __restrict__ dtables, const int32_t* __restrict__ n_ls, int Ls, int64_t T, bool pow2) {
+  int l = 0, gw = n_ls[0] + 2;
+  int64_t goff = 0;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  while (l + 1 < Ls && e >= goff + (int64_t)gw * gw) { goff += (int64_t)gw * gw; ++l; gw = n_ls[l] + 2; }
+  if (e - goff >= (int64_t)gw * gw) return;
+  const int i = (int)(e - goff);
+  const int gy = i / gw, gx = i - gy * gw;
+  float* r = dtables + ((int64_t)l * T + spatial_hash(gx, gy, T, pow2)) * F;
+  if constexpr (F == 2) *reinterpret_cast<float2*>(r) = make_float2(0.f, 0.f);
+  else if constexpr (F == 4) *reinterpret_cast<float4*>(r) = make_float4(0.f, 0.f, 0.f, 0.f);
+  else {
+#pragma unroll
+    for (int f = 0; f < F; ++f) r[f] = 0.f;
+  }
+}
+
 // slots per bucket: the 64-bit image of a bucket is image_bytes of LDS
 static int bucket_shift_for(int F, int image_bytes) {
   int s = 0;
@@ -435,5 +458,23 @@ extern "C" int gngf_encode_bwd_bucketed(const float* xy, const int32_t* n_ls, co
   if (F == 1) GNGF_BUCKET_F(1) else if (F == 2) GNGF_BUCKET_F(2) else GNGF_BUCKET_F(4)
 #undef GNGF_BUCKET_F
 #undef GNGF_BUCKET_SCATTER
+  GNGF_RETURN_LAUNCH();
+}
+
+// dtables (L,T,F) fp32: zeroes row hash(gx, gy) of level l for every vertex (gx, gy) in [0, N_l + 1]^2 of levels [0, Ls) — every row
+// the staged levels of a hash-indexed encoder (models.py:504-528) can touch, whatever the batch.  vtot = sum (N_l + 2)^2.
+extern "C" int gngf_clear_hashed_rows(float* dtables, const int32_t* n_ls, int Ls, int F, int64_t T, int64_t vtot, void* stream) {
+  GNGF_CHECK_ARG(Ls >= 0 && Ls <= GNGF_MAX_LEVELS && T > 0 && vtot >= 0 && (F == 1 || F == 2 || F == 4 || F == 8));
+  if (Ls == 0 || vtot == 0) return 0;
+  GNGF_CHECK_ARG(dtables && n_ls && (reinterpret_cast<uintptr_t>(dtables) & (4 * (F > 4 ? 4 : F) - 1)) == 0);
+  const dim3 grid((unsigned)ceil_div(vtot, 256));
+  const bool pow2 = (T & (T - 1)) == 0;
+  hipStream_t s = as_stream(stream);
+  switch (F) {
+    case 1: clear_hashed_rows_kernel<1><<<grid, dim3(256), 0, s>>>(dtables, n_ls, Ls, T, pow2); break;
+    case 2: clear_hashed_rows_kernel<2><<<grid, dim3(256), 0, s>>>(dtables, n_ls, Ls, T, pow2); break;
+    case 4: clear_hashed_rows_kernel<4><<<grid, dim3(256), 0, s>>>(dtables, n_ls, Ls, T, pow2); break;
+    default: clear_hashed_rows_kernel<8><<<grid, dim3(256), 0, s>>>(dtables, n_ls, Ls, T, pow2); break;
+  }
   GNGF_RETURN_LAUNCH();
 }

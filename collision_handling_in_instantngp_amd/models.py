@@ -246,6 +246,7 @@ class GeneralNeuralGaugeFields(nn.Module):
         self._fused_mse_target = None      # see fused_mse()
         self._fused_mse_gloss = None
         self.dp = ops.DataParallel()       # data-parallel state of THIS model (parallel.enable_vertex_grid_exchange(net, ...))
+        self.dp.level_params = tuple(m.weight for m in self.encoding._hash_tables)
         self.hpd_stats = {}                # shape of the last chunked HPD evaluation (rows, chunks, chunks kept)
         self.loss_value_aside = False      # the caller joins the fused loss value itself (train.GraphedStep)
         self._last_link = None             # ops.StepLink of the most recent forward pass

@@ -189,6 +189,37 @@ def _direct_bwd(xy, tables, vert_idx, vert_w, n_ls, genc, dtables, dvw, P, L, F,
          int(BUCKET_IMAGE_BYTES), 0 if fresh else 1, ptr(matrix), ptr(base), ptr(items), stream_ptr())
 
 
+# Hash source, staged levels on the generic pixel-stage kernels (the big shapes): the table gradient lives in ONE buffer per model
+# from step to step instead of a freshly cleared allocation per step.  What a backward pass can write is known without looking at
+# the batch — the rows hash(gx, gy) of the staged levels' vertices (cleared by gngf_clear_hashed_rows: 74 MB of stores at the
+# 8192^2 shape) and every row of the direct levels (WRITTEN by the bucketed backward) — so the dense clear (3 GiB there: 0.49 ms
+# inside the decoder backward) goes.  The buffer is only taken when no level parameter's .grad / .grad_fp32 still lives in it
+# (gradient accumulation over several backward passes, or a caller that keeps the gradients): then the pass gets a zeroed
+# allocation of its own, as before.  `.grad` of consecutive steps aliases, as it does in torch with zero_grad(set_to_none=False).
+PERSISTENT_TABLE_GRAD = True
+
+
+def _persistent_grad(dp, tables, plan, n_ls):
+    """the model's step-to-step gradient buffer, staged levels' rows cleared — or None (in use / cannot be allocated here)"""
+    params = getattr(dp, "level_params", None)
+    if not params:
+        return None
+    buf = getattr(dp, "persist_grad", None)
+    shape = tuple(tables.shape)
+    if buf is None or tuple(buf.shape) != shape or buf.device != tables.device:
+        if torch.cuda.is_current_stream_capturing():
+            return None                                   # (a buffer born inside a capture belongs to that graph's pool)
+        buf = dp.persist_grad = torch.zeros(shape, dtype=_f32, device=tables.device)
+    base = buf.untyped_storage().data_ptr()
+    for w in params:
+        for g in (w.grad, getattr(w, "grad_fp32", None)):
+            if g is not None and g.is_cuda and g.untyped_storage().data_ptr() == base:
+                return None                               # the previous gradient has not been let go of: it stays intact
+    L, T, F = shape
+    call("gngf_clear_hashed_rows", ptr(buf), ptr(n_ls), plan.Ls, F, T, plan.vtot, stream_ptr())
+    return buf
+
+
 class EncodeDirectFunction(torch.autograd.Function):
     """Fused coords -> (P, L*F) encoder, direct form (include/gngf.h: gngf_encode_fwd / gngf_encode_bwd).
 
@@ -799,6 +830,8 @@ class DataParallel:
         self.comm_stream = None
         self.comm_done = None
         self.bin_ws = {}                # persistent counters of the two-launch binning (ops._bin_workspace)
+        self.level_params = None        # the encoder's level parameters (models.py sets it): whose .grad may live in persist_grad
+        self.persist_grad = None        # the step-to-step table-gradient buffer (ops.PERSISTENT_TABLE_GRAD)
         self.pipeline = BinPipeline()   # the next batch's binning riding on this step's pixel-stage launches
         self.world = 1
         self.group = None
@@ -1222,6 +1255,7 @@ class EncodeFunction(torch.autograd.Function):
         pre = None
         ctx.next_bin = None
         ctx.fresh_direct = False
+        ctx.persist = False
         if plan.Ls > 0 and P > 0:
             dev = tables.device
             pws = _bin_workspace(dev, plan.ntiles, dp, kind="reserve") if (TWO_LAUNCH_BINNING and FUSED_VERTEX_FWD) else None
@@ -1250,14 +1284,22 @@ class EncodeFunction(torch.autograd.Function):
                     fused = False
                     dgrid = (torch.empty((plan.vtot * F + 2,), dtype=_i64, device=dev) if use64
                              else torch.empty((plan.vtot, F), dtype=_f32, device=dev))
-                    dt_ = torch.empty(tables.shape, dtype=_f32, device=dev)
                     # direct levels whose backward WRITES every row (the bucketed form) are left out of the clear
                     fresh = plan.Ls < L and mode == MODE_HASH and bucketed_plan(P, F, T, L - plan.Ls, True) is not None
-                    pre = [dt_, dgrid, None, dt_[:plan.Ls] if fresh else dt_]
                     ctx.fresh_direct = fresh
+                    # ... and with a step-to-step buffer there is no dense clear at all (the backward takes the buffer, or a
+                    # zeroed allocation when the buffer is in use)
+                    ctx.persist = bool(PERSISTENT_TABLE_GRAD and mode == MODE_HASH and dp is not None and dp.exchange is None
+                                       and getattr(dp, "level_params", None) and (fresh or plan.Ls == L)
+                                       and (getattr(dp, "persist_grad", None) is not None or not torch.cuda.is_current_stream_capturing()))
+                    if ctx.persist:
+                        pre = [None, dgrid, None, None]
+                    else:
+                        dt_ = torch.empty(tables.shape, dtype=_f32, device=dev)
+                        pre = [dt_, dgrid, None, dt_[:plan.Ls] if fresh else dt_]
                 tile_level_offsets(plan, dev)        # cached; built here so that no backward (or graph capture) uploads it
             zbuf = None if pre is None else pre[3]
-            defer = pre is not None and link is not None and link.defer_zero and zbuf.numel() % 4 == 0
+            defer = zbuf is not None and link is not None and link.defer_zero and zbuf.numel() % 4 == 0
             if defer:
                 link.zero_request = zbuf
             if fused:
@@ -1269,10 +1311,10 @@ class EncodeFunction(torch.autograd.Function):
                 ws = pipe.take(xy, plan) if pipe is not None else None
                 if ws is None:
                     ws = TiledWorkspace(plan, xy, launch=False)
-                    zero_now = zbuf if (pre is not None and not defer) else None
+                    zero_now = zbuf if (zbuf is not None and not defer) else None
                     call("gngf_bin_pixels2", _ct.byref(_bin_job(ws, plan, xy, pws)), ptr(zero_now), 0 if zero_now is None else zero_now.numel(),
                          stream_ptr())
-                elif pre is not None and not defer:
+                elif zbuf is not None and not defer:
                     zbuf.zero_()
                 job_next = None
                 nx = nws = None
@@ -1294,7 +1336,8 @@ class EncodeFunction(torch.autograd.Function):
                 G = torch.empty((plan.vtot, F), dtype=_f32, device=dev)
                 ws = TiledWorkspace(plan, xy, vertex=(tables, vert_idx, vert_w, n_ls, vstride, G),
                                     zero_dG=(pre[1].view(_f32) if use64 else pre[1]) if pre else None,
-                                    zero=(pre[3] if (pre and not defer) else None), zero_dG_words=(2 if use64 else 1), owner=dp)
+                                    zero=(pre[3] if (pre and pre[3] is not None and not defer) else None),
+                                    zero_dG_words=(2 if use64 else 1), owner=dp)
                 call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), plan.n_ls_c,
                      ptr(G), ptr(enc), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, stream_ptr())
         if plan.Ls < L:
@@ -1323,11 +1366,16 @@ class EncodeFunction(torch.autograd.Function):
         pre, ctx.pre = ctx.pre, None                            # a second backward (retain_graph) allocates fresh buffers
         zbuf = None if not pre else pre[3]
         fresh_direct = bool(pre) and getattr(ctx, "fresh_direct", False)        # (a second backward gets a zeroed buffer: nothing is fresh)
-        if pre and link is not None and link.zero_request is zbuf:
+        if zbuf is not None and link is not None and link.zero_request is zbuf:
             link.zero_request = None                            # the decoder that was to clear the buffer did not run: clear it here
             zbuf.zero_()
         next_bin, ctx.next_bin = getattr(ctx, "next_bin", None), None
-        dtables = pre[0] if pre else _grad_buffer(tables)
+        dtables = pre[0] if pre else None
+        if dtables is None and pre and getattr(ctx, "persist", False):
+            dtables = _persistent_grad(dp, tables, plan, n_ls)  # staged levels' rows cleared; the direct levels will be written
+        if dtables is None:
+            dtables = _grad_buffer(tables)                      # a zeroed allocation of this pass's own
+            fresh_direct = False
         dvw = torch.zeros_like(vert_w) if (vert_w is not None and ctx.needs_input_grad[5]) else None
         if plan.Ls > 0 and P > 0:
             dG64 = pre[1] if (pre and pre[1].dtype == _i64) else None

@@ -327,6 +327,12 @@ class GraphedStep:
             s_.grad = None
             if getattr(s_, "grad_fp32", None) is not None:
                 s_.grad_fp32 = None
+        # the step begins with zero_grad (functions.py:199): the parameters let go of the previous step's gradients as well
+        # (they get this step's at the end) — a step-to-step gradient buffer (ops.PERSISTENT_TABLE_GRAD) is free to be reused
+        for _name, p in st["named"]:
+            p.grad = None
+            if getattr(p, "grad_fp32", None) is not None:
+                p.grad_fp32 = None
         # The step runs on SHADOW leaves (detached aliases of the parameters: same storage, fresh autograd identity).  An
         # autograd leaf's AccumulateGrad node is bound to the stream that was current when it was first created, and it stays
         # alive as long as any earlier graph does (a kept `loss` from an eager step on the default stream is enough): the

@@ -90,6 +90,11 @@ int gngf_encode_bwd_bucketed(const float* xy, const int32_t* n_ls, const float* 
                              int64_t T, int l0, int l1, int image_bytes, int accumulate, int32_t* matrix, int32_t* base,
                              void* items, void* stream);
 
+/* zeroes, in dtables (L,T,F) fp32, row hash(gx, gy) of level l for every vertex of levels [0, Ls): all the rows the staged levels
+ * of a hash-indexed encoder can touch, whatever the batch (a gradient buffer kept from step to step needs no dense clear).
+ * vtot = sum over those levels of (N_l + 2)^2.  Serves the zero_grad of functions.py:199 for such a buffer. */
+int gngf_clear_hashed_rows(float* dtables, const int32_t* n_ls, int Ls, int F, int64_t T, int64_t vtot, void* stream);
+
 /* ---- a5..a12 fused, "tiled" form: vertex stage + spatially binned, LDS-privatised pixel stage.
  * gngf_bin_pixels: bins P pixels into 4^tile_shift tiles of [0,1]^2.  NB binning blocks (<= 512); `chunk` = max pixels
  *   per work item.  Outputs: sorted (P,4) fp32 = x, y, bits(original index), 0;  items (max_items,4) int32 = start, count,

@@ -225,3 +225,71 @@ def test_encoder_backward_with_direct_levels_bucketed_equals_atomics(F, half):
     tol = (2e-3 if half else 2e-6) * scale                       # fp16 .grad: one rounding to half
     assert float((res[True] - res[False]).abs().max()) <= tol
     assert float(res[True][plan.Ls:].abs().max()) > 0
+
+
+def test_step_to_step_gradient_buffer_equals_a_cleared_allocation_per_step():
+    """ops.PERSISTENT_TABLE_GRAD (hash source, big shapes): the table gradient lives in one buffer per model, the rows the staged
+    levels can touch are cleared (gngf_clear_hashed_rows), the direct levels are written.  Three steps on DIFFERENT batches with
+    zero_grad between them equal the same steps on freshly cleared allocations; without zero_grad the second pass takes a buffer of
+    its own and the gradients accumulate as torch's do; a kept reference to the first gradient is not written over then."""
+    from collision_handling_in_instantngp_amd import models, ops, train
+    P, L, T = 2 ** 17, 8, 2 ** 16
+    models.should_use_hash_function = True
+    prev = ops.PERSISTENT_TABLE_GRAD
+    try:
+        g = torch.Generator(device=DEV).manual_seed(7)
+        xs = [torch.rand((P, 2), device=DEV, generator=g) for _ in range(3)]
+        ys = [torch.rand((P, 3), device=DEV, generator=g) for _ in range(3)]
+        loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
+        empty = torch.tensor([], device=DEV)
+
+        def build():
+            torch.manual_seed(11)
+            net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=T, num_levels=L, n_min=16, n_max=4096,
+                                                  MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
+                                                  HPD_out_features=T, feature_dim=4, topk_k=4)
+            net.return_indices = False
+            with torch.no_grad():
+                net.encoding.packed_tables().mul_(100.0)
+            return net
+
+        def step(net, k, zero=True):
+            if zero:
+                net.zero_grad()
+            with net.fused_mse(ys[k], gloss=1.0):
+                rgb, probs, _i, _c = net(xs[k], 1.0)
+            mse, kls, coll = loss_fn(rgb, ys[k], None, probs, empty, empty)
+            train.assemble_loss(mse, kls, coll, 1, 1, 1e-3).backward()
+            torch.cuda.synchronize()
+            return torch.stack([m.weight.grad for m in net.encoding._hash_tables])
+
+        plan = ops.EncodePlan(P, [int(v) for v in orc.level_resolutions(16, 4096, L)], 4)
+        assert 0 < plan.Ls < L and not plan.interleaved(backward=True)    # staged (generic kernels: four features) + direct levels
+        res = {}
+        for on in (False, True):
+            ops.PERSISTENT_TABLE_GRAD = on
+            net = build()
+            res[on] = [step(net, k).clone() for k in range(3)]
+            assert (net.dp.persist_grad is not None) == on
+            if on:
+                # accumulation: a second backward pass without zero_grad adds to the first (which sits in the buffer)
+                in_buffer = lambda: (net.encoding._hash_tables[0].weight.grad.untyped_storage().data_ptr()
+                                     == net.dp.persist_grad.untyped_storage().data_ptr())
+                first = step(net, 0)
+                assert in_buffer()
+                both = step(net, 1, zero=False)
+                assert in_buffer()                         # (the second pass took an allocation of its own and was ADDED to the first)
+                want = res[False][0] + res[False][1]
+                assert float((both - want).abs().max()) <= 2e-6 * float(want.abs().max())
+                # ... and after zero_grad the buffer is taken again
+                again = step(net, 2)
+                assert in_buffer()
+                assert float((again - res[False][2]).abs().max()) <= 2e-6 * float(res[False][2].abs().max())
+        for k in range(3):
+            scale = float(res[False][k].abs().max())
+            assert scale > 0 and float((res[True][k] - res[False][k]).abs().max()) <= 2e-6 * scale, k
+        # the staged levels (float atomics of the gather pass) differ in the order of additions only; the direct levels are exact sums
+        assert torch.equal(res[True][2][plan.Ls:], res[False][2][plan.Ls:])
+    finally:
+        ops.PERSISTENT_TABLE_GRAD = prev
+        models.should_use_hash_function = False
