@@ -353,7 +353,8 @@ class GeneralNeuralGaugeFields(nn.Module):
         bwd_clears = (not train_fused and ops.DECODER_BWD_CLEARS and self._fused_mse_target is not None and P > 0
                       and torch.is_grad_enabled()
                       and ops.decoder_fused_ok((ops.ACT_RELU, ops.ACT_RELU, ops.ACT_SIGMOID), self._decoder_params()))
-        link = self._last_link = ops.StepLink(loss_value_aside=self.loss_value_aside, defer_zero=train_fused or bwd_clears)
+        link = self._last_link = ops.StepLink(loss_value_aside=self.loss_value_aside, defer_zero=train_fused or bwd_clears,
+                                                  zero_hidden=train_fused)
         dp = self.dp
 
         if self._hash_mode:

@@ -197,6 +197,7 @@ def _direct_bwd(xy, tables, vert_idx, vert_w, n_ls, genc, dtables, dvw, P, L, F,
 # (gradient accumulation over several backward passes, or a caller that keeps the gradients): then the pass gets a zeroed
 # allocation of its own, as before.  `.grad` of consecutive steps aliases, as it does in torch with zero_grad(set_to_none=False).
 PERSISTENT_TABLE_GRAD = True
+PERSISTENT_MIN_BYTES = 1 << 30     # below this a clear hidden inside the training decoder (StepLink.zero_hidden) is cheaper
 
 
 def _persistent_grad(dp, tables, plan, n_ls):
@@ -849,15 +850,19 @@ class StepLink:
       loss_value      the fused pixel loss's value, deferred so that it rides on the same launch
       promise         (promised, arrived) device scalars of the fused training decoder's loss gradient (checked on the device)
     loss_value_aside: the caller owns the whole step and joins the loss value itself (train.GraphedStep)."""
-    __slots__ = ("pending_reduce", "absmax", "loss_value", "promise", "loss_value_aside", "defer_zero", "zero_request", "__weakref__")
+    __slots__ = ("pending_reduce", "absmax", "loss_value", "promise", "loss_value_aside", "defer_zero", "zero_hidden", "zero_request",
+                 "__weakref__")
 
-    def __init__(self, loss_value_aside=False, defer_zero=False):
+    def __init__(self, loss_value_aside=False, defer_zero=False, zero_hidden=False):
         self.pending_reduce = self.absmax = self.loss_value = self.promise = None
         self.loss_value_aside = bool(loss_value_aside)
         # defer_zero: the caller expects the fused training decoder to follow the encoder in this forward pass: the encoder then
         # does NOT clear its table-gradient buffer in rider workgroups of the binning launch but leaves it here (zero_request);
         # gngf_decoder_train clears it between its MFMAs.  If nobody took it, the encoder backward clears it itself.
         self.defer_zero = bool(defer_zero)
+        # zero_hidden: that decoder is the one-launch training kernel, which clears between its MFMAs at next to no cost (75 MiB in
+        # 4.4 us at cfg2; the 64-feature backward kernel does not: 3 GiB in 0.49 ms at cfg5)
+        self.zero_hidden = bool(zero_hidden)
         self.zero_request = None
 
     def take_absmax(self, genc):
@@ -1289,7 +1294,11 @@ class EncodeFunction(torch.autograd.Function):
                     ctx.fresh_direct = fresh
                     # ... and with a step-to-step buffer there is no dense clear at all (the backward takes the buffer, or a
                     # zeroed allocation when the buffer is in use)
-                    ctx.persist = bool(PERSISTENT_TABLE_GRAD and mode == MODE_HASH and dp is not None and dp.exchange is None
+                    # (not where the training decoder clears the buffer for free between its MFMAs — measured at the 4096^2 shape:
+                    # 448 MB cleared there against a sparse-clear launch of 7.3 M rows: 0.997 vs 1.005 ms — unless the buffer is
+                    # larger than that kernel can hide)
+                    hidden = link is not None and link.defer_zero and link.zero_hidden and tables.numel() * 4 <= PERSISTENT_MIN_BYTES
+                    ctx.persist = bool(PERSISTENT_TABLE_GRAD and not hidden and mode == MODE_HASH and dp is not None and dp.exchange is None
                                        and getattr(dp, "level_params", None) and (fresh or plan.Ls == L)
                                        and (getattr(dp, "persist_grad", None) is not None or not torch.cuda.is_current_stream_capturing()))
                     if ctx.persist:
