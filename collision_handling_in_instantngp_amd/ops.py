@@ -1294,9 +1294,9 @@ class EncodeFunction(torch.autograd.Function):
                     ctx.fresh_direct = fresh
                     # ... and with a step-to-step buffer there is no dense clear at all (the backward takes the buffer, or a
                     # zeroed allocation when the buffer is in use)
-                    # (not where the training decoder clears the buffer for free between its MFMAs — measured at the 4096^2 shape:
-                    # 448 MB cleared there against a sparse-clear launch of 7.3 M rows: 0.997 vs 1.005 ms — unless the buffer is
-                    # larger than that kernel can hide)
+                    # (not where the training decoder clears the buffer between its MFMAs — at the 4096^2 shape 448 MB cleared
+                    # there against a sparse-clear launch of 7.3 M rows is a draw: alternating A/B on one box 1.0155-1.0186 vs
+                    # 1.0147-1.0154 ms, tools/ab_persist_cfg4.sh — unless the buffer is larger than that kernel can hide)
                     hidden = link is not None and link.defer_zero and link.zero_hidden and tables.numel() * 4 <= PERSISTENT_MIN_BYTES
                     ctx.persist = bool(PERSISTENT_TABLE_GRAD and not hidden and mode == MODE_HASH and dp is not None and dp.exchange is None
                                        and getattr(dp, "level_params", None) and (fresh or plan.Ls == L)
