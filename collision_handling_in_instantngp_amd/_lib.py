@@ -32,7 +32,7 @@ SIGNATURES = {
     "gngf_clear_hashed_rows": [_P, _P, _I, _I, _L, _L, _P],
     "gngf_bin_pixels": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "gngf_encode_tiled_prepare": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _I, _L,
-                                  _P, _L, _P, _P],
+                                  _P, _L, _P, _P, _P],
     "gngf_vertex_grid_fwd": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L, _P],
     "gngf_vertex_grid_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _L, _P],
     "gngf_encode_tiled_fwd": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -457,16 +457,22 @@ template <int F, bool VT, typename TT>
 __device__ __forceinline__ void vertex_fwd_lane(const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx,
                                                 const float* __restrict__ vert_w, float* __restrict__ G, float* __restrict__ dG_zero,
                                                 int64_t T, int K, int vstride, int64_t NV, bool pow2, int l, int gw, int i, int64_t goff,
-                                                int zero_words = 1) {
+                                                int zero_words = 1, float* __restrict__ clear_rows = nullptr) {
   const int gy = i / gw, gx = i - gy * gw;
   const TT* tab = tables + (int64_t)l * T * F;
   float acc[F];
 #pragma unroll
   for (int f = 0; f < F; ++f) acc[f] = 0.f;
   if constexpr (!VT) {
-    const TT* r = tab + spatial_hash(gx, gy, T, pow2) * F;
+    const int64_t row = spatial_hash(gx, gy, T, pow2);
+    const TT* r = tab + row * F;
 #pragma unroll
     for (int f = 0; f < F; ++f) acc[f] = tload(r + f);
+    if (clear_rows) {                             // a step-to-step table gradient: the row this vertex can add to starts from zero
+      float* z = clear_rows + ((int64_t)l * T + row) * F;       // (as gngf_clear_hashed_rows, without a launch of its own)
+#pragma unroll
+      for (int f = 0; f < F; ++f) z[f] = 0.f;
+    }
   } else {
     const int64_t vid = (int64_t)gy * vstride + gx;
     if (gx < vstride && vid < NV) {
@@ -504,7 +510,7 @@ template <int F, bool VT, typename TT>
 __device__ __forceinline__ void vertex_ride_block(int vb, const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx,
                                                   const float* __restrict__ vert_w, const int32_t* __restrict__ n_ls, float* __restrict__ G,
                                                   float* __restrict__ dG_zero, int Ls, int64_t T, int K, int vstride, int64_t NV, bool pow2,
-                                                  int64_t vtot, int zero_words) {
+                                                  int64_t vtot, int zero_words, float* __restrict__ clear_rows = nullptr) {
   const int64_t e = (int64_t)vb * kBinThreads + threadIdx.x;
   if (e >= vtot) return;
   if (e == 0 && dG_zero && zero_words == 2) {     // the two 64-bit words behind the fixed-point grid: scale and poison flag
@@ -514,7 +520,8 @@ __device__ __forceinline__ void vertex_ride_block(int vb, const TT* __restrict__
   int l = 0, gw = n_ls[0] + 2;
   int64_t goff = 0;
   while (l + 1 < Ls && e >= goff + (int64_t)gw * gw) { goff += (int64_t)gw * gw; ++l; gw = n_ls[l] + 2; }
-  vertex_fwd_lane<F, VT, TT>(tables, vert_idx, vert_w, G, dG_zero, T, K, vstride, NV, pow2, l, gw, (int)(e - goff), goff, zero_words);
+  vertex_fwd_lane<F, VT, TT>(tables, vert_idx, vert_w, G, dG_zero, T, K, vstride, NV, pow2, l, gw, (int)(e - goff), goff, zero_words,
+                             clear_rows);
 }
 
 // K3 with the VERTEX STAGE FORWARD riding on the launch: workgroups [NB, NB + ceil(vtot / 1024)) evaluate one (level, vertex)
@@ -530,13 +537,14 @@ bin_scatter_ride_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_bl
                         const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx,
                         const float* __restrict__ vert_w, const int32_t* __restrict__ n_ls, float* __restrict__ G,
                         float* __restrict__ dG_zero, int Ls, int64_t T, int K, int vstride, int64_t NV, bool pow2, int64_t vtot,
-                        int zero_words) {
+                        int zero_words, float* __restrict__ clear_rows) {
   extern __shared__ int cursor[];
   if ((int)blockIdx.x < NB) {
     bin_scatter_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, tile_off, sorted, cursor);
     return;
   }
-  vertex_ride_block<F, VT, TT>((int)blockIdx.x - NB, tables, vert_idx, vert_w, n_ls, G, dG_zero, Ls, T, K, vstride, NV, pow2, vtot, zero_words);
+  vertex_ride_block<F, VT, TT>((int)blockIdx.x - NB, tables, vert_idx, vert_w, n_ls, G, dG_zero, Ls, T, K, vstride, NV, pow2, vtot, zero_words,
+                               clear_rows);
 }
 
 // K1 with the vertex stage forward riding on it (the count keeps half of the CUs busy for ~8 us): used when the launch does
@@ -548,13 +556,14 @@ bin_count_vride_kernel(const float2* __restrict__ xy, int64_t P, int64_t per_blo
                        int32_t* __restrict__ blockhist, const TT* __restrict__ tables, const int32_t* __restrict__ vert_idx,
                        const float* __restrict__ vert_w, const int32_t* __restrict__ n_ls, float* __restrict__ G,
                        float* __restrict__ dG_zero, int Ls, int64_t T, int K, int vstride, int64_t NV, bool pow2, int64_t vtot,
-                       int zero_words, int32_t* __restrict__ tot_atomic) {
+                       int zero_words, int32_t* __restrict__ tot_atomic, float* __restrict__ clear_rows) {
   extern __shared__ int hist[];
   if ((int)blockIdx.x < NB) {
     bin_count_body((int)blockIdx.x, xy, P, per_block, tile_shift, NB, blockhist, hist, tot_atomic);
     return;
   }
-  vertex_ride_block<F, VT, TT>((int)blockIdx.x - NB, tables, vert_idx, vert_w, n_ls, G, dG_zero, Ls, T, K, vstride, NV, pow2, vtot, zero_words);
+  vertex_ride_block<F, VT, TT>((int)blockIdx.x - NB, tables, vert_idx, vert_w, n_ls, G, dG_zero, Ls, T, K, vstride, NV, pow2, vtot, zero_words,
+                               clear_rows);
 }
 
 template <int F, bool VT, typename TT>
@@ -1923,8 +1932,12 @@ extern "C" int gngf_encode_tiled_prepare(const float* xy, int64_t P, int tile_sh
                                          float* sorted, const void* tables, int feat_dtype, const int32_t* vert_idx,
                                          const float* vert_w, const int32_t* n_ls, const int32_t* n_ls_host, float* G,
                                          float* dG_zero, int dG_zero_words, int Ls, int F, int64_t T, int K, int mode, int vstride,
-                                         int64_t NV, float* zero_fill, int64_t zero_floats, int32_t* persistent_ws, void* stream) {
+                                         int64_t NV, float* zero_fill, int64_t zero_floats, int32_t* persistent_ws, float* clear_rows,
+                                         void* stream) {
   GNGF_CHECK_ARG(dG_zero_words == 1 || dG_zero_words == 2);
+  // clear_rows (optional, spatial-hash source only): an (L,T,F) fp32 table gradient that lives from step to step — the vertex riders
+  // zero row hash(gx, gy) of every staged vertex's level on the way (gngf_clear_hashed_rows without a launch of its own)
+  GNGF_CHECK_ARG(!clear_rows || (mode == GNGF_MODE_HASH && (reinterpret_cast<uintptr_t>(clear_rows) & 3) == 0));
   GNGF_CHECK_ARG(P >= 0 && P < (1ll << 31) && tile_shift >= 0 && tile_shift <= 6 && NB > 0 && NB <= kBinMaxBlocks && chunk > 0);
   GNGF_CHECK_ARG(xy && blockhist && tile_off && tile_item_base && items && n_items && sorted);
   GNGF_CHECK_ARG(Ls > 0 && Ls <= GNGF_MAX_LEVELS && T > 0 && tables && n_ls && n_ls_host && G);
@@ -1947,11 +1960,11 @@ extern "C" int gngf_encode_tiled_prepare(const float* xy, int64_t P, int tile_sh
     if (mode == GNGF_MODE_HASH) {
       DISPATCH_TT(feat_dtype, DISPATCH_F(F, (bin_count_vride_kernel<kF, false, TT><<<dim3((unsigned)(NB + vblocks)), dim3(kBinThreads), smem, s>>>(
                                   xy2, P, per_block, tile_shift, NB, blockhist, static_cast<const TT*>(tables), nullptr, nullptr, n_ls, G,
-                                  dG_zero, Ls, T, 0, 0, 0, pow2, vtot, dG_zero_words, persistent_ws))));
+                                  dG_zero, Ls, T, 0, 0, 0, pow2, vtot, dG_zero_words, persistent_ws, clear_rows))));
     } else {
       DISPATCH_TT(feat_dtype, DISPATCH_F(F, (bin_count_vride_kernel<kF, true, TT><<<dim3((unsigned)(NB + vblocks)), dim3(kBinThreads), smem, s>>>(
                                   xy2, P, per_block, tile_shift, NB, blockhist, static_cast<const TT*>(tables), vert_idx, vert_w, n_ls, G,
-                                  dG_zero, Ls, T, K, vstride, NV, pow2, vtot, dG_zero_words, persistent_ws))));
+                                  dG_zero, Ls, T, K, vstride, NV, pow2, vtot, dG_zero_words, persistent_ws, nullptr))));
     }
     if (persistent_ws) {       // count -> scatter: the scans ride inside the scatter launch (bin_scatter2_kernel)
       bin_scatter2_kernel<<<dim3(NB), dim3(kBinThreads), smem, s>>>(xy2, P, per_block, tile_shift, NB, chunk, blockhist, persistent_ws,
@@ -1975,11 +1988,11 @@ extern "C" int gngf_encode_tiled_prepare(const float* xy, int64_t P, int tile_sh
   if (mode == GNGF_MODE_HASH) {
     DISPATCH_TT(feat_dtype, DISPATCH_F(F, (bin_scatter_ride_kernel<kF, false, TT><<<dim3((unsigned)(NB + vblocks)), dim3(kBinThreads), smem, s>>>(
                                 xy2, P, per_block, tile_shift, NB, blockhist, tile_off, sorted4, static_cast<const TT*>(tables), nullptr,
-                                nullptr, n_ls, G, dG_zero, Ls, T, 0, 0, 0, pow2, vtot, dG_zero_words))));
+                                nullptr, n_ls, G, dG_zero, Ls, T, 0, 0, 0, pow2, vtot, dG_zero_words, clear_rows))));
   } else {
     DISPATCH_TT(feat_dtype, DISPATCH_F(F, (bin_scatter_ride_kernel<kF, true, TT><<<dim3((unsigned)(NB + vblocks)), dim3(kBinThreads), smem, s>>>(
                                 xy2, P, per_block, tile_shift, NB, blockhist, tile_off, sorted4, static_cast<const TT*>(tables), vert_idx,
-                                vert_w, n_ls, G, dG_zero, Ls, T, K, vstride, NV, pow2, vtot, dG_zero_words))));
+                                vert_w, n_ls, G, dG_zero, Ls, T, K, vstride, NV, pow2, vtot, dG_zero_words, nullptr))));
   }
   GNGF_RETURN_LAUNCH();
 }

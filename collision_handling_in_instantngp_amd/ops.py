@@ -197,11 +197,11 @@ def _direct_bwd(xy, tables, vert_idx, vert_w, n_ls, genc, dtables, dvw, P, L, F,
 # (gradient accumulation over several backward passes, or a caller that keeps the gradients): then the pass gets a zeroed
 # allocation of its own, as before.  `.grad` of consecutive steps aliases, as it does in torch with zero_grad(set_to_none=False).
 PERSISTENT_TABLE_GRAD = True
-PERSISTENT_MIN_BYTES = 1 << 30     # below this a clear hidden inside the training decoder (StepLink.zero_hidden) is cheaper
+PERSISTENT_MIN_BYTES = 1 << 28     # below this a dense clear hidden inside the training decoder (StepLink.zero_hidden) costs next to nothing
 
 
-def _persistent_grad(dp, tables, plan, n_ls):
-    """the model's step-to-step gradient buffer, staged levels' rows cleared — or None (in use / cannot be allocated here)"""
+def _persistent_peek(dp, tables):
+    """the model's step-to-step gradient buffer if it is free right now (no level parameter's gradient lives in it), else None"""
     params = getattr(dp, "level_params", None)
     if not params:
         return None
@@ -211,13 +211,26 @@ def _persistent_grad(dp, tables, plan, n_ls):
         if torch.cuda.is_current_stream_capturing():
             return None                                   # (a buffer born inside a capture belongs to that graph's pool)
         buf = dp.persist_grad = torch.zeros(shape, dtype=_f32, device=tables.device)
+        dp.persist_gen = getattr(dp, "persist_gen", 0) + 1
     base = buf.untyped_storage().data_ptr()
     for w in params:
         for g in (w.grad, getattr(w, "grad_fp32", None)):
             if g is not None and g.is_cuda and g.untyped_storage().data_ptr() == base:
                 return None                               # the previous gradient has not been let go of: it stays intact
-    L, T, F = shape
-    call("gngf_clear_hashed_rows", ptr(buf), ptr(n_ls), plan.Ls, F, T, plan.vtot, stream_ptr())
+    return buf
+
+
+def _persistent_grad(dp, tables, plan, n_ls, cleared=None):
+    """the buffer for a backward pass, staged levels' rows cleared — or None (in use / cannot be allocated here).
+    cleared: the generation at which this pass's FORWARD had the vertex riders clear those rows (TiledWorkspace(clear_rows=)):
+    if no backward pass has taken the buffer since, it is still clean and no clear is launched."""
+    buf = _persistent_peek(dp, tables)
+    if buf is None:
+        return None
+    if cleared is None or cleared != dp.persist_gen:
+        L, T, F = tables.shape
+        call("gngf_clear_hashed_rows", ptr(buf), ptr(n_ls), plan.Ls, F, T, plan.vtot, stream_ptr())
+    dp.persist_gen += 1                                   # handed out: what forward passes cleared before this point is spent
     return buf
 
 
@@ -833,6 +846,7 @@ class DataParallel:
         self.bin_ws = {}                # persistent counters of the two-launch binning (ops._bin_workspace)
         self.level_params = None        # the encoder's level parameters (models.py sets it): whose .grad may live in persist_grad
         self.persist_grad = None        # the step-to-step table-gradient buffer (ops.PERSISTENT_TABLE_GRAD)
+        self.persist_gen = 0            # ... and how often it has been handed to a backward pass (or re-allocated)
         self.pipeline = BinPipeline()   # the next batch's binning riding on this step's pixel-stage launches
         self.world = 1
         self.group = None
@@ -1019,7 +1033,7 @@ def _drop_bin_workspace(dev, ntiles, owner=None):
 class TiledWorkspace:
     """Device buffers of one forward/backward pair (binning result is shared by both)."""
 
-    def __init__(self, plan, xy, vertex=None, zero_dG=None, zero=None, zero_dG_words=1, owner=None, launch=True):
+    def __init__(self, plan, xy, vertex=None, zero_dG=None, zero=None, zero_dG_words=1, owner=None, launch=True, clear_rows=None):
         """vertex = (tables, vert_idx, vert_w, n_ls, vstride, G): also run the vertex stage forward into G (riding on the binning
         launches); zero_dG (same shape as G) and zero (any fp32 buffer, typically the table gradient): cleared on the way.
         launch=False: buffers only (filled by bin2(), or by another step's riders through job())."""
@@ -1052,7 +1066,7 @@ class TiledWorkspace:
                      *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), plan.n_ls_c, ptr(G), ptr(zero_dG), int(zero_dG_words), plan.Ls, F, T,
                      0 if vert_idx is None else vert_idx.shape[1], mode, vstride, 0 if vert_idx is None else vert_idx.shape[0],
                      ptr(zero), 0 if zero is None else zero.numel(), ptr(_bin_workspace(dev, plan.ntiles, owner) if TWO_LAUNCH_BINNING else None),
-                     stream_ptr())
+                     ptr(clear_rows if vert_idx is None else None, _f32, "clear_rows"), stream_ptr())
             except Exception:
                 # the count launch may have run without the scatter launch that puts the persistent counters back to zero: the
                 # next step gets a fresh (zeroed) workspace instead of binning with dirty totals
@@ -1261,6 +1275,8 @@ class EncodeFunction(torch.autograd.Function):
         ctx.next_bin = None
         ctx.fresh_direct = False
         ctx.persist = False
+        ctx.persist_cleared = None
+        clear_now = None
         if plan.Ls > 0 and P > 0:
             dev = tables.device
             pws = _bin_workspace(dev, plan.ntiles, dp, kind="reserve") if (TWO_LAUNCH_BINNING and FUSED_VERTEX_FWD) else None
@@ -1294,15 +1310,19 @@ class EncodeFunction(torch.autograd.Function):
                     ctx.fresh_direct = fresh
                     # ... and with a step-to-step buffer there is no dense clear at all (the backward takes the buffer, or a
                     # zeroed allocation when the buffer is in use)
-                    # (not where the training decoder clears the buffer between its MFMAs — at the 4096^2 shape 448 MB cleared
-                    # there against a sparse-clear launch of 7.3 M rows is a draw: alternating A/B on one box 1.0155-1.0186 vs
-                    # 1.0147-1.0154 ms, tools/ab_persist_cfg4.sh — unless the buffer is larger than that kernel can hide)
+                    # (not for small tables where the training decoder clears the buffer between its MFMAs at next to no cost;
+                    # at the 4096^2 shape that hidden clear of 448 MB costs the decoder 36 us — a draw against a sparse-clear
+                    # LAUNCH of 7.3 M rows, a loss against the same clear riding on the vertex riders: tools/ab_persist_cfg4.sh)
                     hidden = link is not None and link.defer_zero and link.zero_hidden and tables.numel() * 4 <= PERSISTENT_MIN_BYTES
                     ctx.persist = bool(PERSISTENT_TABLE_GRAD and not hidden and mode == MODE_HASH and dp is not None and dp.exchange is None
                                        and getattr(dp, "level_params", None) and (fresh or plan.Ls == L)
                                        and (getattr(dp, "persist_grad", None) is not None or not torch.cuda.is_current_stream_capturing()))
                     if ctx.persist:
                         pre = [None, dgrid, None, None]
+                        # the rows the staged levels can touch are cleared by the vertex riders of the binning launch, if the
+                        # buffer is free now (else the backward pass clears them, or takes an allocation of its own)
+                        clear_now = _persistent_peek(dp, tables)
+                        ctx.persist_cleared = dp.persist_gen if clear_now is not None else None
                     else:
                         dt_ = torch.empty(tables.shape, dtype=_f32, device=dev)
                         pre = [dt_, dgrid, None, dt_[:plan.Ls] if fresh else dt_]
@@ -1346,7 +1366,7 @@ class EncodeFunction(torch.autograd.Function):
                 ws = TiledWorkspace(plan, xy, vertex=(tables, vert_idx, vert_w, n_ls, vstride, G),
                                     zero_dG=(pre[1].view(_f32) if use64 else pre[1]) if pre else None,
                                     zero=(pre[3] if (pre and pre[3] is not None and not defer) else None),
-                                    zero_dG_words=(2 if use64 else 1), owner=dp)
+                                    zero_dG_words=(2 if use64 else 1), owner=dp, clear_rows=clear_now)
                 call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), plan.n_ls_c,
                      ptr(G), ptr(enc), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, stream_ptr())
         if plan.Ls < L:
@@ -1381,7 +1401,8 @@ class EncodeFunction(torch.autograd.Function):
         next_bin, ctx.next_bin = getattr(ctx, "next_bin", None), None
         dtables = pre[0] if pre else None
         if dtables is None and pre and getattr(ctx, "persist", False):
-            dtables = _persistent_grad(dp, tables, plan, n_ls)  # staged levels' rows cleared; the direct levels will be written
+            # staged levels' rows cleared (by this pass's forward, or now); the direct levels will be written
+            dtables = _persistent_grad(dp, tables, plan, n_ls, getattr(ctx, "persist_cleared", None))
         if dtables is None:
             dtables = _grad_buffer(tables)                      # a zeroed allocation of this pass's own
             fresh_direct = False

@@ -114,10 +114,12 @@ int gngf_encode_tiled_prepare(const float* xy, int64_t P, int tile_shift, int NB
                               const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w,
                               const int32_t* n_ls, const int32_t* n_ls_host, float* G, float* dG_zero, int dG_zero_words, int Ls,
                               int F, int64_t T, int K, int mode, int vstride, int64_t NV, float* zero_fill, int64_t zero_floats,
-                              int32_t* persistent_ws, void* stream);
+                              int32_t* persistent_ws, float* clear_rows, void* stream);
 /* persistent_ws (optional): (2 * 4^tile_shift + 1) int32, ZERO before its first use and owned by one stream — with it (and
  * without zero_fill) the binning is TWO launches instead of four: the tile totals meet in global atomics, every scatter
  * workgroup scans them itself, and the last one out puts the workspace back to zero. */
+/* clear_rows (optional, spatial-hash source only): an (L,T,F) fp32 table gradient kept from step to step — the vertex riders zero
+ * row hash(gx, gy) of every staged vertex's level on the way (what gngf_clear_hashed_rows does, without a launch of its own). */
 /* dG_zero_words: 1 = dG_zero is the fp32 vertex-grid gradient (vtot * F floats); 2 = it is the 64-bit fixed-point form of
  * gngf_encode_tiled_bwd's dG64 ((vtot * F + 2) 64-bit words, the two trailing words cleared as well). */
 /* vertex stage: G[(goff_l + gy*(N_l+2) + gx)*F + f] for levels [0, Ls), goff_l = sum_{j<l} (N_j+2)^2.
