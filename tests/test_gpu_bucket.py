@@ -294,3 +294,46 @@ def test_step_to_step_gradient_buffer_equals_a_cleared_allocation_per_step():
     finally:
         ops.PERSISTENT_TABLE_GRAD, ops.PERSISTENT_MIN_BYTES = prev, prev_min
         models.should_use_hash_function = False
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_training_epochs_on_the_step_to_step_buffer_equal_epochs_on_fresh_allocations(graph):
+    """train.train_epoch with the optimizer (eager, and graph=True: cross-replay hipGraphs with FusedAdam inside) on a model whose
+    table gradient takes the step-to-step buffer — generic pixel stage (four features), three direct levels bucketed — against the
+    same epochs with an allocation per step: same losses and outputs up to the order of the float atomics of the staged levels."""
+    from collision_handling_in_instantngp_amd import models, ops, train
+    side, L, T = 512, 8, 2 ** 16
+    g = torch.Generator(device=DEV).manual_seed(3)
+    rows, cols = torch.meshgrid(torch.arange(side, device=DEV), torch.arange(side, device=DEV), indexing="ij")
+    X = (torch.stack([rows, cols], -1).reshape(-1, 2).float() / (side - 1)).contiguous()
+    Y = torch.rand((side * side, 3), device=DEV, generator=g)
+    perm = torch.randperm(side * side, generator=torch.Generator().manual_seed(1)).to(DEV)
+    models.should_use_hash_function = True
+    prev, prev_min = ops.PERSISTENT_TABLE_GRAD, ops.PERSISTENT_MIN_BYTES
+    ops.PERSISTENT_MIN_BYTES = 0
+    try:
+        outs = {}
+        for on in (True, False):
+            ops.PERSISTENT_TABLE_GRAD = on
+            torch.manual_seed(5)
+            net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=T, num_levels=L, n_min=16, n_max=4096,
+                                                  MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
+                                                  HPD_out_features=T, feature_dim=4, topk_k=4)
+            net.return_indices = False
+            loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
+            opt = train.get_optimizer(net, 1e-2, 1e-3, 1e-3, 0.0, 0.0, 1e-6)
+            mses = []
+            for _epoch in range(2):
+                rec = train.train_epoch(net, loss_fn, opt, X, Y, side, side, 1, 1, 1e-3, batch_percentage=1 / 2, should_shuffle=True,
+                                        shuffled_indices=perm, graph=graph)
+                mses += rec["mse"]
+            torch.cuda.synchronize()
+            outs[on] = (rec["outputs"].clone(), torch.stack(mses).clone(), torch.stack([m.weight.detach() for m in net.encoding._hash_tables]).clone())
+            assert (net.dp.persist_grad is not None) == on
+        assert float(outs[False][1][0]) > 0 and float(outs[False][1][-1]) < float(outs[False][1][0])         # it trains
+        assert float((outs[True][1] - outs[False][1]).abs().max()) <= 1e-4 * float(outs[False][1].abs().max())
+        assert float((outs[True][0] - outs[False][0]).abs().max()) <= 2e-3
+        assert float((outs[True][2] - outs[False][2]).abs().max()) <= 1e-3 * float(outs[False][2].abs().max())
+    finally:
+        ops.PERSISTENT_TABLE_GRAD, ops.PERSISTENT_MIN_BYTES = prev, prev_min
+        models.should_use_hash_function = False
