@@ -10,6 +10,7 @@ for pair in frozen:gngf_frozen hash:hash learning:gngf_learning cfg4:cfg4_hash c
 done
 python tools/pmc_summary.py $O/prof_${TAG}_pmc_fetch $O/prof_${TAG}_pmc_write > profiles/${TAG}_pmc_fetch_write.json
 python tools/pmc_summary.py $O/prof_${TAG}_pmc_fetch_cfg4 $O/prof_${TAG}_pmc_write_cfg4 > profiles/${TAG}_pmc_fetch_write_cfg4.json
+if [ -d $O/prof_${TAG}_pmc_fetch_cfg5 ]; then python tools/pmc_summary.py $O/prof_${TAG}_pmc_fetch_cfg5 $O/prof_${TAG}_pmc_write_cfg5 > profiles/${TAG}_pmc_fetch_write_cfg5.json; fi
 python tools/pmc_summary.py $O/prof_${TAG}_pmc_sq1 $O/prof_${TAG}_pmc_sq2 > profiles/${TAG}_pmc_sq_counters.json
 python tools/make_traffic.py $O/prof_${TAG}_pmc_fetch $O/prof_${TAG}_pmc_write > /dev/null
 ls -la profiles | head -30

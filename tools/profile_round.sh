@@ -20,5 +20,9 @@ run sq1      --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_
 run sq2      --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/prof_${TAG}_pmc_sq2 -o p -- python3 $ROOT/bench.py --steps 8 --warmup 1 --ramp-steps 4 --no-extra-modes --no-cpu-baseline --no-full-outputs
 run fetch4   --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG}_pmc_fetch_cfg4 -o p -- python3 $ROOT/bench.py --mode cfg4_hash --steps 8 --warmup 1 --ramp-steps 4 --no-extra-modes --no-cpu-baseline --no-full-outputs
 run write4   --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_${TAG}_pmc_write_cfg4 -o p -- python3 $ROOT/bench.py --mode cfg4_hash --steps 8 --warmup 1 --ramp-steps 4 --no-extra-modes --no-cpu-baseline --no-full-outputs
+if [ "${ONLY_CFG5_PMC:-0}" != "0" ] || [ "${WITH_CFG5_PMC:-1}" != "0" ]; then
+run fetch5   --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG}_pmc_fetch_cfg5 -o p -- python3 $ROOT/bench.py --mode cfg5_hash_fp16 --steps 8 --warmup 1 --ramp-steps 4 --no-extra-modes --no-cpu-baseline --no-full-outputs
+run write5   --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_${TAG}_pmc_write_cfg5 -o p -- python3 $ROOT/bench.py --mode cfg5_hash_fp16 --steps 8 --warmup 1 --ramp-steps 4 --no-extra-modes --no-cpu-baseline --no-full-outputs
+fi
 rm -f $OUT/prof_${TAG}_frozen/*kernel_trace.csv $OUT/prof_${TAG}_hash/*kernel_trace.csv $OUT/prof_${TAG}_cfg4/*kernel_trace.csv $OUT/prof_${TAG}_cfg5/*kernel_trace.csv
 du -sh $OUT/prof_${TAG}_* | cat
