@@ -10,13 +10,16 @@
 // bucket's contributions in a 64-bit fixed-point image of the slice in the LDS and adds the slice to the table gradient with plain
 // coalesced stores.
 //
-//   bucket_count     per (pixel block, level): histogram of the buckets of its 4 corners per pixel        -> matrix
-//   bucket_prefix    per (level, bucket): exclusive prefix over the pixel blocks; totals scanned per group of 64  -> matrix, local, group sums
-//   bucket_scatter   per (pixel block, level): items {slot in bucket, g * c (fp32, rounded as the reference rounds it)}
-//   bucket_sum       per (level, bucket): max |term| and the fullest row's number of terms n -> scale 2^S, S = min(50, 61 - ceil log2 n)
-//                    - exponent - 1 (no overflow; quantum 2^-50 of the bucket's largest term up to 2048 terms per row), integer adds (order-free: the result is bitwise reproducible, which the
-//                    float atomics were not), one rounding to fp32 at the end.  A bucket that holds a non-finite term is summed in
-//                    fp32 (NaN / inf propagate to the rows they belong to, as with atomics).
+//   bucket_count     per (pixel block, level): histogram of the buckets of its 4 corners per pixel            -> matrix
+//   bucket_prefix    per (level, bucket): exclusive prefix over the pixel blocks; the totals scanned per group
+//                    of 64 columns, the group sums left to the readers                                         -> matrix, local, group sums
+//   bucket_scatter   per (pixel block, group of levels): items {slot in bucket, g * c (fp32, rounded as the reference rounds it)}
+//   bucket_sum       per (level, bucket): max |term| and the fullest row's number of terms n -> scale 2^S,
+//                    S = min(50, 61 - ceil log2 n) - exponent - 1 (no overflow; quantum 2^-50 of the bucket's largest term up to
+//                    2048 terms per row); integer adds (order-free: the result is bitwise reproducible, which the float atomics
+//                    were not); one rounding to fp32 at the end.  A bucket that holds a non-finite term is summed in fp32
+//                    (NaN / inf propagate to the rows they belong to, as with atomics).
+// + gngf_clear_hashed_rows: the sparse clear of a table gradient that lives from step to step (ops.PERSISTENT_TABLE_GRAD).
 #include "gngf_common.h"
 
 namespace gngf {
