@@ -416,7 +416,10 @@ def main():
     broken = False
     in_graph_ms = None
     hbm_copy = measure_hbm_copy_gbs(dev)          # this box's streaming-copy bandwidth, same run (fractions against it below)
-    extra = [] if a.no_extra_modes else [m for m in ("gngf_learning", "hash", "gngf_frozen", "cfg4_hash", "cfg5_hash_fp16") if m != a.mode]
+    # the other modes are single-GPU side measurements: at N > 1 only the mode asked for runs (each mode would have to be collective-
+    # matched across the ranks, a failure in any of them would cost the scaling line, and the driver computes scaling from `value`)
+    extra = [] if (a.no_extra_modes or world > 1) else [m for m in ("gngf_learning", "hash", "gngf_frozen", "cfg4_hash", "cfg5_hash_fp16")
+                                                         if m != a.mode]
     kt, kcalls = {}, {}
     batches = {}
     for mode in [a.mode] + extra:
