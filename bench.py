@@ -187,6 +187,7 @@ def eager_step_fn(net, mode, xy, target, world, exchange=True):
     empty = torch.tensor([], device=xy.device)
     one = torch.ones((), device=xy.device)          # the seed of backward(): loss.backward() would fill a fresh one per step
     T = net._hash_table_size
+    net.dp.persist_ok = True      # this loop lets go of every gradient at the top of each step (ops.PERSISTENT_TABLE_GRAD is opt-in)
 
     def step():
         for p in params:
@@ -251,25 +252,27 @@ def measure_hbm_copy_gbs(dev):
     return gbs
 
 
-def exchange_model(net, world):
+def exchange_model(net, world, P=P_PER_GPU):
     """Bytes one rank hands to the gradient exchange per step and the time a ring all-reduce of them takes on the xGMI links
     (2 (n-1)/n x bytes per rank, spread over the 7 links of 153 GB/s each when n = 8, over n-1 links otherwise) — a MODEL, not
-    a measurement: it is printed next to the measured step so that the exchange's share is visible without an 8-GPU node."""
-    dp = net.dp
-    staged = dp.deferred[6].numel() * 4 if dp.deferred is not None else 0
+    a measurement.  The bytes follow from the model's geometry alone (ops.EncodePlan: which levels are staged — their
+    vertex-grid gradient travels — and which run in the direct form — their slice of the fp32 table gradient travels; every
+    other trainable parameter's gradient), so the N = 1 line states the prediction for n = 2, 4, 8 that a later multi-GPU run is
+    read against (`exchange_model`), and the N > 1 line repeats it for its own n (`exchange`)."""
+    from collision_handling_in_instantngp_amd import ops
     enc = net.encoding
-    base = enc._grad_base if enc._grad_base is not None else enc._grad_base_fp32
-    direct = 0
-    if base is not None and dp.tables_reduced < base.shape[0]:
-        direct = base[dp.tables_reduced:].numel() * base.element_size()
-    dense = sum(p.grad.numel() * p.grad.element_size() for n_, p in net.named_parameters()
-                if p.grad is not None and "_hash_tables" not in n_)
+    L, T, F = enc.packed_tables().shape
+    plan = ops.EncodePlan(P, net._n_ls_host, F)
+    staged = plan.vtot * F * 4 if plan.Ls > 0 else 0
+    direct = (L - plan.Ls) * T * F * 4                 # the table gradient is accumulated (and exchanged) in fp32 whatever the storage
+    dense = sum(p.numel() * 4 for n_, p in net.named_parameters() if p.requires_grad and "_hash_tables" not in n_)
     total = staged + direct + dense
     links = min(7, max(1, world - 1))
     t = 2.0 * (world - 1) / world * total / (links * XGMI_LINK_GBS * 1e9) if world > 1 else 0.0
-    return {"vertex_grid_bytes": staged, "direct_level_table_bytes": direct, "decoder_and_hpd_bytes": dense, "exchange_bytes_per_step": total,
-            "modelled_ring_allreduce_ms": t * 1e3, "links_used": links, "link_GBs": XGMI_LINK_GBS,
-            "note": "model: ring all-reduce, 2(n-1)/n x bytes per rank over the point-to-point xGMI links; latency not included"}
+    return {"n": world, "staged_levels": plan.Ls, "vertex_grid_bytes": staged, "direct_level_table_bytes": direct, "decoder_and_hpd_bytes": dense,
+            "exchange_bytes_per_step": total, "modelled_ring_allreduce_ms": t * 1e3, "links_used": links, "link_GBs": XGMI_LINK_GBS,
+            "note": "model: ring all-reduce, 2(n-1)/n x bytes per rank over the point-to-point xGMI links; latency not included; the "
+                    "exchange follows the step's graph on a communication stream and is NOT overlapped with the next step's compute"}
 
 
 ENTRY_NAMES = {"gngf_bin_pixels": "bin_pixels", "gngf_bin_pixels2": "bin_pixels(count+scatter)", "gngf_encode_tiled_fwd_fused": "encode_fwd:tiled", "gngf_encode_tiled_prepare": "prepare(bin+vertex_fwd+clears)", "gngf_vertex_grid_fwd": "vertex_fwd", "gngf_encode_tiled_fwd": "encode_fwd:tiled",
@@ -504,7 +507,13 @@ def main():
             res["roofline_survey"] = {"bytes_per_pixel": sb_f + sb_b, "achieved_GBs": sv, "frac_of_8TBs": sv / HBM_PEAK_GBS,
                                       "frac_of_measured_copy": sv / hbm_copy}
             if world > 1:
-                res["exchange"] = exchange_model(net, world)
+                res["exchange"] = exchange_model(net, world, P)
+            else:
+                # the prediction a multi-GPU run of this mode is to be held against (weak scaling: the same 2^20 px per GPU)
+                res["exchange_model"] = {str(n): exchange_model(net, n, P) for n in (2, 4, 8)}
+                for em in res["exchange_model"].values():
+                    em["predicted_ms_per_step"] = res["ms_per_step"] + em["modelled_ring_allreduce_ms"]
+                    em["predicted_scaling_efficiency"] = res["ms_per_step"] / em["predicted_ms_per_step"]
             if SHAPES[cfg_name]["half"]:
                 res["table_gradient"] = "fp32 accumulation buffer handed over as param.grad_fp32 (ops.FP16_TABLE_GRAD_FP32), no fp16 .grad copy"
             if learning:
@@ -678,7 +687,9 @@ def main():
         line = {
             "metric": "Mpixels/sec fwd+bwd at L=16,F=2,T=2^19", "value": head["mpix_s"], "unit": "Mpixel/s",
             "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"], "ms_per_step": head["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": (f"{c['image']} image's own pixel list (339x508, tests/golden/{c['image']}_rgb.npz) shuffled and repeated to the batch size; "
+                     "random-init weights" if MODES[a.mode] in ("cfg2", "cfg3") else "synthetic (uniform-random coordinates and RGB; random-init weights)"),
             "config": {"workload": f"{MODES[a.mode]}: " + (f"{c['image']} image (339x508) pixel list shuffled+repeated to 2^20 px/GPU, L=16 F=2 T=2^19 K=4 N 16->512"
                                                           if MODES[a.mode] in ("cfg2", "cfg3") else f"synthetic {c['image']}^2 image, L={L} F={F} T={c['T']} N {c['n_min']}->{c['n_max']}")
                                    + f", {a.mode} indexing, random-init weights, MSE loss, fwd+bwd (no optimizer)",

@@ -57,9 +57,18 @@ def table_view(owner):
     return tables, sink
 
 
+STEP_TRACE = None            # tests: a list that receives one (what, {facts}) record per dispatch decision of a backward pass
+
+
+def _trace(what, **facts):
+    if STEP_TRACE is not None:
+        STEP_TRACE.append((what, facts))
+
+
 def _grad_out(dtables, tables, sink=None):
     if tables.dtype == _f32:
         return dtables
+    _trace("grad_out", fp32_handover=sink is not None)
     if sink is None:
         return dtables.to(tables.dtype)
     owner, ws = sink
@@ -175,6 +184,7 @@ def _direct_bwd(xy, tables, vert_idx, vert_w, n_ls, genc, dtables, dvw, P, L, F,
     """d tables of levels [l0, l1) in the direct form.  fresh: those levels of dtables hold NOTHING yet (not even zeros) — the
     bucketed form writes every row of them, the atomics form clears them first."""
     plan = bucketed_plan(P, F, T, l1 - l0, fresh) if (mode == MODE_HASH and dtables.dtype == _f32) else None
+    _trace("direct_bwd", bucketed=plan is not None, write=bool(fresh and plan is not None), levels=(l0, l1))
     if plan is None:
         if fresh:
             dtables[l0:l1].zero_()
@@ -196,6 +206,11 @@ def _direct_bwd(xy, tables, vert_idx, vert_w, n_ls, genc, dtables, dvw, P, L, F,
 # inside the decoder backward) goes.  The buffer is only taken when no level parameter's .grad / .grad_fp32 still lives in it
 # (gradient accumulation over several backward passes, or a caller that keeps the gradients): then the pass gets a zeroed
 # allocation of its own, as before.  `.grad` of consecutive steps aliases, as it does in torch with zero_grad(set_to_none=False).
+# OPT-IN PER MODEL: a tensor a caller still holds (g = p.grad kept for logging, clipping, SAM, manual accumulation)
+# would be overwritten by the next step, which torch never does — so the buffer is only used when the code that OWNS THE LOOP
+# says so (`net.dp.persist_ok = True`: train.GraphedStep, train.train_epoch and bench.py do — they let go of every gradient at
+# the top of each step and hand nothing older than the current step to their caller).  A bare `net(x); loss.backward()` gets an
+# allocation per step, like torch.  This module-level switch turns the mechanism off for everybody (A/B measurements).
 PERSISTENT_TABLE_GRAD = True
 PERSISTENT_MIN_BYTES = 1 << 28     # below this a dense clear hidden inside the training decoder (StepLink.zero_hidden) costs next to nothing
 
@@ -203,7 +218,7 @@ PERSISTENT_MIN_BYTES = 1 << 28     # below this a dense clear hidden inside the 
 def _persistent_peek(dp, tables):
     """the model's step-to-step gradient buffer if it is free right now (no level parameter's gradient lives in it), else None"""
     params = getattr(dp, "level_params", None)
-    if not params:
+    if not params or not getattr(dp, "persist_ok", False):
         return None
     buf = getattr(dp, "persist_grad", None)
     shape = tuple(tables.shape)
@@ -456,16 +471,18 @@ class HpdVertexFunction(torch.autograd.Function):
         zcache, cached = {}, 0
         keep_z = (not keep_probs) and HPD_Z_CACHE_BYTES > 0 and any(ctx.needs_input_grad[7:])
         budget = 0
-        if keep_z:
-            # one query per forward: memory the driver reports free plus what torch's allocator holds in unused cached blocks
-            # (the previous step's kept chunks come back from there), minus the reserve for the backward's own buffers
-            free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-            budget = min(HPD_Z_CACHE_BYTES, free - HPD_Z_CACHE_RESERVE)
         # The hidden layers (2 -> 32 -> 64 -> 128 at the reference's widths) are evaluated for ALL vertices in one go, outside the
         # chunk loop, and kept for the backward pass (0.9 KB per vertex): inside the loop they were ~10 launches per chunk of
         # microseconds of work each, and a small launch that has to find free CUs beside a 5 ms streaming pass on the helper
         # stream takes 0.2-0.4 ms — 108 ms of a 890 ms step at 44 chunks (profiles/r03_kernel_stats_gngf_learning.txt).
         hs_all = HpdVertexFunction._hidden(vertex_coords(0, NV, vstride, dev), params, n_layers)
+        if keep_z:
+            # one query per forward: memory the driver reports free plus what torch's allocator holds in unused cached blocks
+            # (the previous step's kept chunks come back from there), minus the reserve for the backward's own buffers.  Taken
+            # AFTER the hidden layers of all NV vertices are allocated (they live until the backward pass), and less the backward's
+            # dH (NV x last hidden width): ~1.5 GB at a million vertices that the budget used to hand to the logits
+            free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+            budget = min(HPD_Z_CACHE_BYTES, free - HPD_Z_CACHE_RESERVE - NV * W_last.shape[1] * 4)
         parts, parts_free, n_parts = None, None, 0          # row partials of the GEMM epilogue (two buffers when pipelined)
         L = mw.shape[1] if mw is not None else 0
         for u0 in range(0, NV, rows):
@@ -845,6 +862,7 @@ class DataParallel:
         self.comm_done = None
         self.bin_ws = {}                # persistent counters of the two-launch binning (ops._bin_workspace)
         self.level_params = None        # the encoder's level parameters (models.py sets it): whose .grad may live in persist_grad
+        self.persist_ok = False         # the loop's owner vouches that no gradient older than the current step is kept (opt-in)
         self.persist_grad = None        # the step-to-step table-gradient buffer (ops.PERSISTENT_TABLE_GRAD)
         self.persist_gen = 0            # ... and how often it has been handed to a backward pass (or re-allocated)
         self.pipeline = BinPipeline()   # the next batch's binning riding on this step's pixel-stage launches
@@ -1314,7 +1332,8 @@ class EncodeFunction(torch.autograd.Function):
                     # at the 4096^2 shape that hidden clear of 448 MB costs the decoder 36 us — a draw against a sparse-clear
                     # LAUNCH of 7.3 M rows, a loss against the same clear riding on the vertex riders: tools/ab_persist_cfg4.sh)
                     hidden = link is not None and link.defer_zero and link.zero_hidden and tables.numel() * 4 <= PERSISTENT_MIN_BYTES
-                    ctx.persist = bool(PERSISTENT_TABLE_GRAD and not hidden and mode == MODE_HASH and dp is not None and dp.exchange is None
+                    ctx.persist = bool(PERSISTENT_TABLE_GRAD and not hidden and mode == MODE_HASH and dp is not None and dp.persist_ok
+                                       and dp.exchange is None
                                        and getattr(dp, "level_params", None) and (fresh or plan.Ls == L)
                                        and (getattr(dp, "persist_grad", None) is not None or not torch.cuda.is_current_stream_capturing()))
                     if ctx.persist:
@@ -1403,6 +1422,8 @@ class EncodeFunction(torch.autograd.Function):
         if dtables is None and pre and getattr(ctx, "persist", False):
             # staged levels' rows cleared (by this pass's forward, or now); the direct levels will be written
             dtables = _persistent_grad(dp, tables, plan, n_ls, getattr(ctx, "persist_cleared", None))
+        _trace("table_grad", source=("persist" if (dtables is not None and dp is not None and dtables is getattr(dp, "persist_grad", None))
+                                     else ("forward_alloc" if dtables is not None else "zeroed_alloc")))
         if dtables is None:
             dtables = _grad_buffer(tables)                      # a zeroed allocation of this pass's own
             fresh_direct = False

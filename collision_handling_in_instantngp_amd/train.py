@@ -310,6 +310,11 @@ class GraphedStep:
         if coord_bounds is not None:
             net.coord_bounds = (float(coord_bounds[0]), float(coord_bounds[1]))
         self._graphs = {}
+        # A captured step works on static buffers anyway (every replay overwrites the previous replay's results), and _body lets
+        # go of all gradients before the forward pass: the encoder may keep the table gradient in one buffer from step to step
+        # (ops.PERSISTENT_TABLE_GRAD is opt-in per model: an eager loop that may keep old .grad tensors does not get it)
+        if getattr(net, "dp", None) is not None:
+            net.dp.persist_ok = True
 
     def _body(self, st, next_x=None, next_ws=None, binned_in=None):
         """next_x: the coordinate buffer of the step that FOLLOWS this one (inside the same graph, or — cross_replay — the first step
@@ -479,7 +484,7 @@ class GraphedStep:
         next replay's first batch, replays"""
         use = "cold"
         pre = st.get("pre")
-        if "W" in st and pre is not None and batches is not None and pre[1] == self._ident(batches[0][0]):
+        if "W" in st and pre is not None and batches is not None and pre[2] is batches[0][0] and pre[1] == self._ident(batches[0][0]):
             use = "01" if pre[0] == 0 else "10"
         if batches is not None:
             for sub, (bx, by) in zip([st] + st["more"], batches):
@@ -491,7 +496,8 @@ class GraphedStep:
         st["pre"] = None
         if "W" in st and next_first is not None and tuple(next_first.shape) == tuple(st["x"].shape):
             st["x_next"].copy_(next_first)
-            st["pre"] = (self._VARIANTS[use][1], self._ident(next_first))
+            # (the tensor itself is kept: while it is alive no other tensor can take its id and allocator block — ADVICE r4)
+            st["pre"] = (self._VARIANTS[use][1], self._ident(next_first), next_first)
         g, results = self._variant(st, use)
         g.replay()
         return results
@@ -529,7 +535,7 @@ class GraphedStep:
             return self.replay_only(key)
         use = "01" if pre[0] == 0 else "10"
         g, results = self._variant(st, use)
-        st["pre"] = (self._VARIANTS[use][1], pre[1])
+        st["pre"] = (self._VARIANTS[use][1], *pre[1:])
         g.replay()
         return results[0]
 

@@ -270,6 +270,7 @@ def test_step_to_step_gradient_buffer_equals_a_cleared_allocation_per_step():
         for on in (False, True):
             ops.PERSISTENT_TABLE_GRAD = on
             net = build()
+            net.dp.persist_ok = True          # opt-in per model: this loop lets go of the gradients before every step
             res[on] = [step(net, k).clone() for k in range(3)]
             assert (net.dp.persist_grad is not None) == on
             if on:
@@ -293,6 +294,52 @@ def test_step_to_step_gradient_buffer_equals_a_cleared_allocation_per_step():
         assert torch.equal(res[True][2][plan.Ls:], res[False][2][plan.Ls:])
     finally:
         ops.PERSISTENT_TABLE_GRAD, ops.PERSISTENT_MIN_BYTES = prev, prev_min
+        models.should_use_hash_function = False
+
+
+def test_a_gradient_the_caller_keeps_survives_zero_grad_and_the_next_step():
+    """ADVICE r4 (medium).  torch and the reference loop leave a tensor the caller still holds alone: g = p.grad kept for logging,
+    clipping or gradient differences must still hold step 1's values after zero_grad() and step 2.  The step-to-step buffer is
+    therefore opt-in per model (net.dp.persist_ok, set by the code that owns the loop: train.GraphedStep, bench.py): a bare
+    net(x); loss.backward() loop gets an allocation per step — checked here on the shape where the buffer WOULD be taken — and the
+    same loop with the opt-in shows the aliasing the opt-in accepts."""
+    from collision_handling_in_instantngp_amd import models, ops, train
+    P, L, T = 2 ** 17, 8, 2 ** 16
+    models.should_use_hash_function = True
+    prev_min = ops.PERSISTENT_MIN_BYTES
+    ops.PERSISTENT_MIN_BYTES = 0
+    try:
+        g = torch.Generator(device=DEV).manual_seed(21)
+        xs = [torch.rand((P, 2), device=DEV, generator=g) for _ in range(2)]
+        ys = [torch.rand((P, 3), device=DEV, generator=g) for _ in range(2)]
+        for opt_in in (False, True):
+            torch.manual_seed(11)
+            net = models.GeneralNeuralGaugeFields(input_dim=2, hash_table_size=T, num_levels=L, n_min=16, n_max=4096,
+                                                  MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
+                                                  HPD_out_features=T, feature_dim=4, topk_k=4)
+            net.return_indices = False
+            assert net.dp.persist_ok is False           # the default: like torch
+            net.dp.persist_ok = opt_in
+            with torch.no_grad():
+                net.encoding.packed_tables().mul_(100.0)
+            kept, snap = [], []
+            for k in range(2):
+                net.zero_grad()                          # set_to_none: the parameters let go, the caller's references stay
+                with net.fused_mse(ys[k], gloss=1.0):
+                    rgb, _p, _i, _c = net(xs[k], 1.0)
+                ops.mse_loss(rgb, ys[k]).backward()
+                torch.cuda.synchronize()
+                kept.append([m.weight.grad for m in net.encoding._hash_tables])
+                snap.append([t_.clone() for t_ in kept[-1]])
+            same = all(torch.equal(a, b) for a, b in zip(kept[0], snap[0]))
+            assert (net.dp.persist_grad is not None) == opt_in
+            if opt_in:
+                assert not same, "with the opt-in the two steps share one buffer (the aliasing the loop's owner accepted)"
+            else:
+                assert same, "a kept gradient was overwritten by the next step"
+                assert float(torch.stack(kept[0]).abs().max()) > 0
+    finally:
+        ops.PERSISTENT_MIN_BYTES = prev_min
         models.should_use_hash_function = False
 
 
@@ -320,6 +367,7 @@ def test_training_epochs_on_the_step_to_step_buffer_equal_epochs_on_fresh_alloca
                                                   MLP_hidden_layers_widths=[64, 64], HPD_hidden_layers_widths=[32, 64, 128],
                                                   HPD_out_features=T, feature_dim=4, topk_k=4)
             net.return_indices = False
+            net.dp.persist_ok = True          # (graph=True: train.GraphedStep opts in by itself; the eager epoch loop does not)
             loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
             opt = train.get_optimizer(net, 1e-2, 1e-3, 1e-3, 0.0, 0.0, 1e-6)
             mses = []

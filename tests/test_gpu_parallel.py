@@ -137,3 +137,33 @@ def test_decoder_gradients_are_one_flat_buffer():
     flat = parallel._flat_alias([p.grad for p in net.mlp.parameters()])
     assert flat is not None and flat.numel() == sum(p.numel() for p in net.mlp.parameters())
     models.should_use_hash_function = False
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["gngf_frozen", "cfg4_hash"])
+def test_bench_with_two_ranks_runs_as_a_fresh_process(mode, tmp_path):
+    """the N > 1 path of bench.py — one hipGraph per rank with the next batch's binning riding on it
+    (GraphedStep(cross_replay=True), one step per replay), parallel.allreduce_gradients(overlap=True) on the communication stream,
+    the deferred vertex stage behind the exchange, wait_for_gradients at the top of the next replay — started exactly as the driver
+    starts it (`python bench.py --gpus 2 ...` as a child process that spawns its own ranks), with two ranks SHARING this box's one
+    GPU over gloo.  Not a measurement: the first contact with N > 1 hardware must not be the first run of this code."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pixels = 2 ** 18                                  # (two ranks on one card; the exchange is staged through the host)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "4", "--warmup", "1",
+           "--no-cpu-baseline", "--mode", mode, "--pixels", str(pixels), "--ramp-steps", "2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=840, cwd=root)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["collective_ranks"] == 2 and d["backend"] == "gloo" and d["rccl_ranks"] is None
+    assert d["steps"] == 4 and d["config"]["mode"] == mode and d["config"]["pixels_per_gpu"] == pixels
+    assert len(d["ms_per_step_per_rank"]) == 2 and all(np.isfinite(t) and t > 0 for t in d["ms_per_step_per_rank"])
+    assert np.isfinite(d["value"]) and d["value"] > 0 and d["ms_per_step"] >= max(d["ms_per_step_per_rank"]) - 1e-9
+    ex = d["modes"][mode]["exchange"]
+    assert ex["n"] == 2 and ex["exchange_bytes_per_step"] > 0 and ex["vertex_grid_bytes"] > 0
+    assert (ex["direct_level_table_bytes"] > 0) == (mode == "cfg4_hash")
+    assert "hipGraph" in d["config"]["launch"], d["config"]["launch"]

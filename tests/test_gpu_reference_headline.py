@@ -115,7 +115,24 @@ def test_gngf_headline_shape_matches_reference_T19(golden, fused_train, encode_p
     # p = exp(z - max) / sum: a relative error of p IS an absolute error of the logit difference, and the logits of far
     # vertices are in the hundreds (raw integer coordinates up to 512 enter the HPD): 1e-4 relative = 1e-4 absolute on
     # z ~ 3e2, i.e. a few fp32 ulps of a 128-term dot product summed in a different order than the reference's MKL GEMM
-    parity_close(tp.cpu().numpy()[m], ref_tp[m], 2e-4, 0, "G12 top-K probabilities (T=2^19)")
+    # VERDICT r4 item 6 — the one tolerance of the suite that stood above north_star's 1e-5 (rtol 2e-4 until round 4), now pinned
+    # to the reference itself (golden G12_spread, oracle/make_goldens.py::g12s):
+    #   * the reference's own spread over 8 threads / 1 thread / mkldnn off is EXACTLY 0 at this shape (so no slack comes from there);
+    #   * the same forward pass through the reference's modules in float64 gives the exact top-K probabilities for these weights,
+    #     and the fp32 reference is 1.45e-5 (max-abs) away from them: its sequential fp32 accumulation of the 128-term logit
+    #     products, |z| ~ 70, one ulp = 7.6e-6.
+    # So: against the EXACT values the HIP path must meet north_star's 1e-5 outright, and against the fp32 reference it may differ by
+    # what the reference itself differs from exact plus 1e-5 (triangle inequality) — no more.
+    sp = golden("G12_spread")
+    assert float(sp["topk_probs_spread_abs"]) == 0.0 and bool(sp["ordered_topk_identical"])
+    got_tp = tp.cpu().numpy()
+    m64 = m & (sp["fp64_topk_idx"].astype(np.int64) == ref_idx).all(-1)
+    assert m64.mean() > 0.99
+    parity_close(got_tp[m64], sp["fp64_topk_probs"][m64], 0, 1e-5, "G12 top-K probabilities vs the reference evaluated in float64 (T=2^19, atol 1e-5)")
+    own = float(sp["ref_fp32_vs_fp64_topk_probs_abs"])
+    assert own < 3e-5, own
+    parity_close(got_tp[m], ref_tp[m], 0, max(1e-5, 2 * float(sp["topk_probs_spread_abs"]), own + 1e-5),
+                 "G12 top-K probabilities vs the fp32 reference (atol = the reference's own distance from float64 + 1e-5)")
     # --- outputs and loss terms
     parity_close(rgb, g["rgb"], 0, 1e-5, "G12 rgb")
     parity_close(mse, g["mse"], 1e-5, 0, "G12 mse")
