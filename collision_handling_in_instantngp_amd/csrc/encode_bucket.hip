@@ -35,9 +35,21 @@ constexpr int kSumThreads = 512;
 // items per thread kept in registers between the two passes of the summing kernel (F = 4: five registers per item)
 template <int F> constexpr int sum_keep() { return F == 4 ? 4 : 12; }
 
+// `order` (optional): the batch's pixels in TILE order — the binned records {x, y, bits(original index), 0} of the tiled form's
+// workspace (encode_tiled.hip) — instead of xy in the caller's order.  The spatial hash keeps the low bits of gx: the vertices of one
+// grid row (fixed gy) fall into ONE aligned block of table rows as wide as the row, so a workgroup whose 4096 pixels come from a
+// handful of neighbouring tiles sends its contributions to a few hundred buckets instead of to all of them, and its items leave as
+// runs of tens of records — whole lines that the L2 combines — instead of two isolated 16-byte stores per bucket (WRITE_SIZE at the
+// 8192^2 shape: 664 MiB for 320 MiB of items before).  Both passes must walk the pixels in the same order.
+__device__ __forceinline__ float2 bucket_pixel(const float2* __restrict__ xy, const float4* __restrict__ order, int64_t p, int64_t& row) {
+  if (order) { const float4 s = order[p]; row = (int64_t)__float_as_int(s.z); return make_float2(s.x, s.y); }
+  row = p;
+  return xy[p];
+}
+
 __global__ void __launch_bounds__(kBkThreads)
-bucket_count_kernel(const float2* __restrict__ xy, const int32_t* __restrict__ n_ls, int32_t* __restrict__ matrix, int64_t P, int l0,
-                    int64_t T, bool pow2, int bshift, int B, int nblk) {
+bucket_count_kernel(const float2* __restrict__ xy, const float4* __restrict__ order, const int32_t* __restrict__ n_ls,
+                    int32_t* __restrict__ matrix, int64_t P, int l0, int64_t T, bool pow2, int bshift, int B, int nblk) {
   extern __shared__ int bk_hist[];
   const int lv = blockIdx.y;
   const int64_t p0 = (int64_t)blockIdx.x * kBkChunk + threadIdx.x;
@@ -48,7 +60,8 @@ bucket_count_kernel(const float2* __restrict__ xy, const int32_t* __restrict__ n
   for (int j = 0; j < kBkPixels; ++j) {
     const int64_t p = p0 + (int64_t)j * kBkThreads;
     if (p >= P) continue;
-    const float2 c = xy[p];
+    int64_t row_;
+    const float2 c = bucket_pixel(xy, order, p, row_);
     const Cell cell = make_cell(c.x, c.y, n);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -152,7 +165,8 @@ __device__ __forceinline__ unsigned get_item(const void* items, int64_t total, i
 // twice (measured at the 4096^2 shape: 109 us, 52 us without the gradient loads, 44 us without the item stores, 11 us without both).
 template <int F, int LG>
 __global__ void __launch_bounds__(kBkThreads)
-bucket_scatter_kernel(const float2* __restrict__ xy, const int32_t* __restrict__ n_ls, const float* __restrict__ genc,
+bucket_scatter_kernel(const float2* __restrict__ xy, const float4* __restrict__ order, const int32_t* __restrict__ n_ls,
+                      const float* __restrict__ genc,
                       const int32_t* __restrict__ matrix, const int32_t* __restrict__ local, const int32_t* __restrict__ groupsum,
                       int32_t* __restrict__ base, void* __restrict__ items, int64_t total, int64_t P, int L, int l0, int nl, int64_t T,
                       bool pow2, int bshift, int B, int nblk) {
@@ -186,9 +200,10 @@ bucket_scatter_kernel(const float2* __restrict__ xy, const int32_t* __restrict__
   for (int j = 0; j < kBkPixels; ++j) {
     const int64_t p = p0 + (int64_t)j * kBkThreads;
     if (p >= P) continue;
-    const float2 c = xy[p];
+    int64_t row;
+    const float2 c = bucket_pixel(xy, order, p, row);
     float g[LG][F];
-    const float* gp = genc + (p * L + l0 + lv0) * F;
+    const float* gp = genc + (row * L + l0 + lv0) * F;
     if (vec4) {
       const float4 t = *reinterpret_cast<const float4*>(gp);
       const float tt[4] = {t.x, t.y, t.z, t.w};
@@ -244,10 +259,17 @@ bucket_sum_kernel(const void* __restrict__ items, int64_t total, const int32_t* 
   float* out = dtables + ((int64_t)(l0 + lv) * T + slot0) * F;
   const int live = (int)((T - slot0) < slots ? (T - slot0) : slots);            // the last bucket of a table that is no multiple of it
   // the largest |term| of the bucket (bit patterns of absolute values order like the values; NaN and inf sort last) and the
-  // largest number of terms any ROW receives (what bounds a cell's sum: ~10 where the bucket holds thousands)
+  // largest number of terms any ROW receives (what bounds a cell's sum: ~10 where the bucket holds thousands).
+  // Round 5: a bucket of at most 2048 items needs NO count — no row can hold more than the bucket does, and up to 2^11 terms per
+  // row the scale is the same (room = 50 below) — so the usual bucket of the 8192^2 shape (512 items; the ~4000 of the 4096^2 one
+  // keep the count) goes: item loads issued, image cleared WHILE they are in flight, one barrier, adds, one barrier, write-out
+  // (was: five barriers with the loads' round trip exposed between the first two).
+  const bool counted = n > 2048;                                                // (workgroup-uniform)
   unsigned* cnt = reinterpret_cast<unsigned*>(bk_img);
-  for (int k = threadIdx.x; k < slots; k += kSumThreads) cnt[k] = 0u;
-  __syncthreads();
+  if (counted) {
+    for (int k = threadIdx.x; k < slots; k += kSumThreads) cnt[k] = 0u;
+    __syncthreads();
+  }
   unsigned mx = 0;
   // the first kSumKeep items of every thread stay in registers for the second pass (a bucket of the usual size is read once)
   float keep_v[kSumKeep][F];
@@ -258,23 +280,34 @@ bucket_sum_kernel(const void* __restrict__ items, int64_t total, const int32_t* 
     keep_s[j] = 0u;
 #pragma unroll
     for (int f = 0; f < F; ++f) keep_v[j][f] = 0.f;
-    if (k < n) {
-      keep_s[j] = get_item<F>(items, total, (int64_t)beg + k, keep_v[j]);
-      atomicAdd(&cnt[keep_s[j]], 1u);
+    if (k < n) keep_s[j] = get_item<F>(items, total, (int64_t)beg + k, keep_v[j]);
+  }
+  if (!counted) {                                                               // the image is cleared under the loads
+    ulonglong2* z = reinterpret_cast<ulonglong2*>(bk_img);
+    const ulonglong2 zero = {0ull, 0ull};
+    for (int k = threadIdx.x; k < slots * F / 2; k += kSumThreads) z[k] = zero;
+    if ((slots * F) & 1) { if (threadIdx.x == 0) bk_img[slots * F - 1] = 0ull; }
+  }
+#pragma unroll
+  for (int j = 0; j < kSumKeep; ++j) {
+    if (threadIdx.x + j * kSumThreads < n) {
+      if (counted) atomicAdd(&cnt[keep_s[j]], 1u);
 #pragma unroll
       for (int f = 0; f < F; ++f) { const unsigned a = __float_as_uint(keep_v[j][f]) & 0x7fffffffu; mx = a > mx ? a : mx; }
     }
   }
-  for (int k = threadIdx.x + kSumKeep * kSumThreads; k < n; k += kSumThreads) {
-    float v[F];
-    const unsigned s = get_item<F>(items, total, (int64_t)beg + k, v);
-    atomicAdd(&cnt[s], 1u);
+  unsigned mc = counted ? 0u : 2048u;
+  if (counted) {
+    for (int k = threadIdx.x + kSumKeep * kSumThreads; k < n; k += kSumThreads) {
+      float v[F];
+      const unsigned s = get_item<F>(items, total, (int64_t)beg + k, v);
+      atomicAdd(&cnt[s], 1u);
 #pragma unroll
-    for (int f = 0; f < F; ++f) { const unsigned a = __float_as_uint(v[f]) & 0x7fffffffu; mx = a > mx ? a : mx; }
+      for (int f = 0; f < F; ++f) { const unsigned a = __float_as_uint(v[f]) & 0x7fffffffu; mx = a > mx ? a : mx; }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < slots; k += kSumThreads) mc = cnt[k] > mc ? cnt[k] : mc;
   }
-  __syncthreads();
-  unsigned mc = 0;
-  for (int k = threadIdx.x; k < slots; k += kSumThreads) mc = cnt[k] > mc ? cnt[k] : mc;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned t = __shfl_xor(mx, o, 64), u = __shfl_xor(mc, o, 64);
@@ -282,7 +315,7 @@ bucket_sum_kernel(const void* __restrict__ items, int64_t total, const int32_t* 
     mc = u > mc ? u : mc;
   }
   if ((threadIdx.x & 63) == 0) { bk_red[threadIdx.x >> 6] = mx; bk_red[kSumThreads / 64 + (threadIdx.x >> 6)] = mc; }
-  __syncthreads();                                                              // (also: every read of cnt is done before the image is cleared)
+  __syncthreads();                            // (counted: every read of cnt is done before the image is cleared; else: the image IS clear)
   mx = 0; mc = 0;
 #pragma unroll
   for (int w = 0; w < kSumThreads / 64; ++w) {
@@ -308,13 +341,14 @@ bucket_sum_kernel(const void* __restrict__ items, int64_t total, const int32_t* 
     for (int k = threadIdx.x; k < live * F; k += kSumThreads) out[k] = accumulate ? out[k] + img[k] : img[k];
     return;
   }
-  for (int k = threadIdx.x; k < slots * F; k += kSumThreads) bk_img[k] = 0ull;
+  if (counted)
+    for (int k = threadIdx.x; k < slots * F; k += kSumThreads) bk_img[k] = 0ull;
   const int e = (int)(mx >> 23) - 127;                                          // |term| < 2^(e + 1)  (denormals: e = -127, still true)
   const int lg = mc <= 1 ? 0 : 32 - __clz((int)mc - 1);                         // ceil(log2 of the terms of the fullest row)
   const int room = 61 - lg < 50 ? 61 - lg : 50;
   const int S = room - (e + 1);
   const double scale = ldexp(1.0, S), inv = ldexp(1.0, -S);
-  __syncthreads();
+  if (counted) __syncthreads();
 #pragma unroll
   for (int j = 0; j < kSumKeep; ++j) {
     if (threadIdx.x + j * kSumThreads < n) {
@@ -378,6 +412,27 @@ static int bucket_shift_for(int F, int image_bytes) {
   return s;
 }
 
+// levels per scatter workgroup: as many as keep the offsets of the group within 64 KB of LDS
+static int bucket_levels_per_group(int nl, int64_t B) { return (nl >= 4 && 4 * B <= 16384) ? 4 : ((nl >= 2 && 2 * B <= 16384) ? 2 : 1); }
+
+template <int F>
+static bool bucket_lds_grantable_f(int LG, size_t offs, size_t img) {
+  auto ok = [](hipError_t e) {
+    if (e == hipSuccess) return true;
+    (void)hipGetLastError();
+    return e == hipErrorNoDevice || e == hipErrorInsufficientDriver || e == hipErrorNotInitialized || e == hipErrorInvalidDevice;
+  };
+  const void* sc = LG == 4 ? reinterpret_cast<const void*>(bucket_scatter_kernel<F, 4>)
+                           : (LG == 2 ? reinterpret_cast<const void*>(bucket_scatter_kernel<F, 2>) : reinterpret_cast<const void*>(bucket_scatter_kernel<F, 1>));
+  if (offs > 48 * 1024 && !ok(hipFuncSetAttribute(sc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)offs))) return false;
+  if (img > 48 * 1024 && !ok(hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sum_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)img)))
+    return false;
+  return true;
+}
+static bool bucket_lds_grantable(int F, int LG, size_t offs, size_t img) {
+  return F == 1 ? bucket_lds_grantable_f<1>(LG, offs, img) : (F == 2 ? bucket_lds_grantable_f<2>(LG, offs, img) : bucket_lds_grantable_f<4>(LG, offs, img));
+}
+
 }  // namespace gngf
 
 using namespace gngf;
@@ -396,6 +451,15 @@ extern "C" int gngf_encode_bwd_bucketed_plan(int64_t P, int F, int64_t T, int nl
   if (B > kBkMaxBuckets || total >= (1ll << 31) || nl * B > (int64_t)kBkMaxGroups * kBkCols) return 0;
   const int64_t nblk = ceil_div(P, kBkChunk);
   const int64_t ngroups = ceil_div(nl * B, kBkCols);
+  // the dynamic LDS the two big kernels will ask for (the scatter's bucket offsets + scanned group sums, the summing
+  // kernel's 64-bit image) must be grantable on THIS device, or the caller has to be told to take the atomics (0) — not find out
+  // from a failing launch after the answer "1".  Asked of the runtime exactly as the launcher asks (no device visible — the
+  // host-side planning tests — counts as granted: the sizing itself is pure arithmetic).
+  {
+    const int LG = bucket_levels_per_group(nl, B);
+    const size_t offs = sizeof(int) * (size_t)(LG * B + ngroups + 1), img = (size_t)8 * F << bshift;
+    if (!bucket_lds_grantable(F, LG, offs, img)) return 0;
+  }
   plan[0] = bshift; plan[1] = B; plan[2] = nblk; plan[3] = nl * nblk * B;
   plan[4] = (nl * B + 1) + nl * B + ngroups;                  // base | local | group sums
   plan[5] = total * (F == 1 ? 8 : (F == 2 ? 16 : 20));
@@ -405,9 +469,11 @@ extern "C" int gngf_encode_bwd_bucketed_plan(int64_t P, int F, int64_t T, int nl
 // dtables (L,T,F) fp32: levels [l0, l1) receive the gradient of the batch (accumulate = 1: added to what is there — the caller
 // cleared it, or other batches' gradients are in it; 0: every row of those levels is WRITTEN, touched or not — no clear needed).
 // matrix / base / items: scratch sized by gngf_encode_bwd_bucketed_plan (same P, F, T, l1 - l0, image_bytes).
+// pixel_order (optional, P float4 records {x, y, bits(original index), 0}: the binned pixels of the tiled form's workspace):
+// the batch is walked in that order instead of in xy's (same result, bit for bit: the sums are order-free; see bucket_pixel).
 extern "C" int gngf_encode_bwd_bucketed(const float* xy, const int32_t* n_ls, const float* genc, float* dtables, int64_t P, int L, int F,
                                         int64_t T, int l0, int l1, int image_bytes, int accumulate, int32_t* matrix, int32_t* base,
-                                        void* items, void* stream) {
+                                        void* items, const float* pixel_order, void* stream) {
   GNGF_CHECK_ARG(P >= 0 && L > 0 && L <= GNGF_MAX_LEVELS && T > 0 && l0 >= 0 && l0 <= l1 && l1 <= L);
   if (l0 == l1) return 0;
   int64_t plan[6];
@@ -416,7 +482,8 @@ extern "C" int gngf_encode_bwd_bucketed(const float* xy, const int32_t* n_ls, co
     return 0;
   }
   GNGF_CHECK_ARG(gngf_encode_bwd_bucketed_plan(P, F, T, l1 - l0, image_bytes, plan) == 1);
-  GNGF_CHECK_ARG(xy && n_ls && genc && dtables && matrix && base && items);
+  GNGF_CHECK_ARG(xy && n_ls && genc && dtables && matrix && base && items && (reinterpret_cast<uintptr_t>(pixel_order) & 15) == 0);
+  const float4* order = reinterpret_cast<const float4*>(pixel_order);
   // vector accesses: items as 16-byte records, a table row (F floats) as one store, a gradient vector (F floats) as one load
   GNGF_CHECK_ARG((reinterpret_cast<uintptr_t>(items) & 15) == 0 && (reinterpret_cast<uintptr_t>(dtables) & (4 * F - 1)) == 0 &&
                  (reinterpret_cast<uintptr_t>(genc) & (4 * F - 1)) == 0 && (reinterpret_cast<uintptr_t>(xy) & 7) == 0);
@@ -429,11 +496,10 @@ extern "C" int gngf_encode_bwd_bucketed(const float* xy, const int32_t* n_ls, co
   hipStream_t s = as_stream(stream);
   const dim3 grid2((unsigned)nblk, (unsigned)nl);
   bucket_count_kernel<<<grid2, dim3(kBkThreads), sizeof(int) * (size_t)B, s>>>(
-      reinterpret_cast<const float2*>(xy), n_ls, matrix, P, l0, T, pow2, bshift, B, nblk);
+      reinterpret_cast<const float2*>(xy), order, n_ls, matrix, P, l0, T, pow2, bshift, B, nblk);
   bucket_prefix_kernel<<<dim3((unsigned)ngroups), dim3(kBkCols * kBkSegs), 0, s>>>(matrix, local, groupsum, ncols, B, nblk);
   const size_t img = (size_t)8 * F << bshift;
-  // levels per scatter workgroup: as many as keep the offsets of the group within 64 KB of LDS
-  const int LG = (nl >= 4 && 4 * B <= 16384) ? 4 : ((nl >= 2 && 2 * B <= 16384) ? 2 : 1);
+  const int LG = bucket_levels_per_group(nl, B);
   const size_t offs = sizeof(int) * (size_t)(LG * B + ngroups + 1);
   const dim3 grid3((unsigned)nblk, (unsigned)ceil_div(nl, LG));
 #define GNGF_BUCKET_SCATTER(kF, kLG)                                                                                             \
@@ -444,7 +510,7 @@ extern "C" int gngf_encode_bwd_bucketed(const float* xy, const int32_t* n_ls, co
       if (e != hipSuccess) return (int)e;                                                                                       \
     }                                                                                                                           \
     bucket_scatter_kernel<kF, kLG><<<grid3, dim3(kBkThreads), offs, s>>>(                                                       \
-        reinterpret_cast<const float2*>(xy), n_ls, genc, matrix, local, groupsum, base, items, total, P, L, l0, nl, T, pow2,    \
+        reinterpret_cast<const float2*>(xy), order, n_ls, genc, matrix, local, groupsum, base, items, total, P, L, l0, nl, T, pow2, \
         bshift, B, nblk);                                                                                                       \
   }
 #define GNGF_BUCKET_F(kF)                                                                                                       \

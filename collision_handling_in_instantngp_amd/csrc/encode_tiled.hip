@@ -1271,13 +1271,21 @@ tiled_fwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
 // No task waits for another one (the totals were completed by the previous launch); NB = 0: none.
 typedef BinJobDev BinScatterRide;   // (bin_scatter3_body)
 
-template <bool L16>
+// HDT (spatial-hash index source on a single rank, bound on |genc| given: round 5): the vertex stage backward is GONE.  The store
+// pass converts the item's exact 64-bit sums to fp32 (one rounding) and adds them straight to row hash(gx, gy) of the level's
+// table gradient with fire-and-forget float atomics — the same number of memory-side atomic requests as the adds into the
+// fixed-point vertex grid they replace (one per non-zero vertex of the item's sub-grids), no fixed-point grid to clear, no
+// vertex_bwd_hash64 launch behind the kernel (10.7 us of a 396 us step).  What is given up: a vertex shared by several items (tile
+// borders; every vertex of the coarse levels, whose cells span several tiles) now receives one fp32 add per item instead of one
+// exact sum, so a table row is an fp32 sum of up to ~16 exactly rounded partial sums (was: one per vertex that hashes to it).
+template <bool L16, bool HDT = false>
 __global__ void __launch_bounds__(kTB)
 tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ items, const int32_t* __restrict__ n_items,
                     int32_t* __restrict__ counter, const int32_t* __restrict__ n_ls, const float* __restrict__ genc,
                     float* __restrict__ dG, float* __restrict__ partials, const float* __restrict__ gmax_hint, int hint_count,
                     int hint_stride, int L, int Ls, int tile_shift, int lds_floats, int rows2, int log2_chunk, int nwork,
-                    RideAlong ride, MseRide mride, unsigned long long* __restrict__ dG64, const BinScatterRide bride) {
+                    RideAlong ride, MseRide mride, unsigned long long* __restrict__ dG64, const BinScatterRide bride,
+                    float* __restrict__ hash_dt = nullptr, int64_t hash_T = 0, bool hash_pow2 = false) {
   constexpr int F = 2;
   extern __shared__ unsigned long long accil[];   // [rows2][kIL], then the compact fp32 image of the store pass
   __shared__ ILMeta m;
@@ -1434,7 +1442,11 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
             int vx = gx + (q & 1), vy = gy + (q >> 1);
             vx = vx < 0 ? 0 : (vx > n + 1 ? n + 1 : vx);
             vy = vy < 0 ? 0 : (vy > n + 1 ? n + 1 : vy);
-            if (dG64) {
+            if constexpr (HDT) {
+              float* d = hash_dt + ((int64_t)l * hash_T + spatial_hash(vx, vy, hash_T, hash_pow2)) * F;
+              atomicAdd(d, gv.x * cq[q]);
+              atomicAdd(d + 1, gv.y * cq[q]);
+            } else if (dG64) {
               unsigned long long* d = dG64 + (m.goff[l] + (int64_t)vy * gw + vx) * F;
               atomicAdd(d, term(gv.x * scale, cq[q]));
               atomicAdd(d + 1, term(gv.y * scale, cq[q]));
@@ -1499,6 +1511,30 @@ tiled_bwd_il_kernel(const float4* __restrict__ sorted, const int4* __restrict__ 
     // consecutive lanes read 16 different columns, no bank conflicts — and drops the fp32 value into a COMPACT image (levels
     // back to back, the format tiled_bwd_kernel writes and gather_partials reads) behind the accumulators; that image then
     // leaves with coalesced 16-byte stores.
+    if constexpr (HDT) {
+      // Straight into the table gradient (see the kernel's header): flattened over the compact image as below; a non-finite
+      // gradient (or a broken promise) poisons every row the item's sub-grids reach
+      const double inv = finite ? ldexp(1.0, -S) : 0.0;
+      for (int e = tid; e < used; e += kTB) {
+        int q = (8 < Ls && e >= m.loff[8]) ? 8 : 0;
+        if (q + 4 < Ls && e >= m.loff[q + 4]) q += 4;
+        if (q + 2 < Ls && e >= m.loff[q + 2]) q += 2;
+        if (q + 1 < Ls && e >= m.loff[q + 1]) q += 1;
+        const int i = e - m.loff[q];
+        const int wx = m.wx[q], rows_l = wx * m.wy[q] * F, copies = m.copies[q];
+        unsigned long long sum = accil[i * kIL + q];
+        for (int c = 1; c < copies; ++c) sum += accil[(c * rows_l + i) * kIL + q];
+        if (sum != 0ull || !finite) {
+          const int v = i >> 1;
+          const int iy = (int)(((float)v + 0.5f) * (1.0f / (float)wx)), ix = v - iy * wx;
+          float* r = hash_dt + ((int64_t)q * hash_T + spatial_hash(m.cx[q] + ix, m.cy[q] + iy, hash_T, hash_pow2)) * F + (i & 1);
+          atomicAdd(r, finite ? (float)((double)(long long)sum * inv) : __int_as_float(0x7fc00000));
+        }
+      }
+      IL_STAMP(5);
+      IL_STAMP_ITEM(it.y);
+      continue;
+    }
     if (dG64) {
       // Straight into the fixed-point vertex grid, FLATTENED over the compact image (element e = row i of level lv: feature
       // i & 1 of vertex i >> 1 of the level's sub-grid): two to three elements per thread instead of up to eleven trips in
@@ -2259,8 +2295,11 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
   if (max_items == 0 && ride_blocks == 0) return 0;
   GNGF_CHECK_ARG(max_items == 0 || (sorted && items && n_items && tile_item_base && n_ls && n_ls_host && genc && partials));
   // dG may be NULL only when the launch is going to fill dG64 and nothing else (the caller reads the fixed-point grid itself)
-  GNGF_CHECK_ARG(max_items == 0 || dG || (genc_absmax && dG64 && log2_pixels > 0 && log2_pixels <= 40 && !hash_dtables &&
-                                          interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, true)));
+  // ... or, spatial-hash source, when the interleaved kernel adds to the table gradient itself (bound given, no fixed-point grid)
+  GNGF_CHECK_ARG(max_items == 0 || dG ||
+                 (genc_absmax && dG64 && log2_pixels > 0 && log2_pixels <= 40 && !hash_dtables &&
+                  interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, true)) ||
+                 (genc_absmax && !dG64 && hash_dtables && interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, true)));
   // a fixed-point grid (with the bound that makes it usable) is only ever filled by the interleaved kernel: a caller that
   // passes one for a shape the generic kernels take has sized / initialised dG for the wrong path (it would read an
   // uninitialised dG) — rejected instead of computed (callers ask gngf_tiled_interleaved_applies first)
@@ -2277,7 +2316,10 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
       const size_t need = (sizeof(int) << (2 * next_bin->tile_shift)) + sizeof(int);
       smem = smem < need ? need : smem;
     }
-    auto fn = (L == 16) ? tiled_bwd_il_kernel<true> : tiled_bwd_il_kernel<false>;
+    // spatial-hash source with a bound on |genc| and NO fixed-point grid handed in: the store pass adds to the table gradient itself
+    const bool hdt = hash_dtables && genc_absmax && !dG64;
+    auto fn = hdt ? ((L == 16) ? tiled_bwd_il_kernel<true, true> : tiled_bwd_il_kernel<false, true>)
+                  : ((L == 16) ? tiled_bwd_il_kernel<true> : tiled_bwd_il_kernel<false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     const int per_cu = (int)((150 * 1024) / (smem + 2048)) < 1 ? 1 : (int)((150 * 1024) / (smem + 2048));
@@ -2290,7 +2332,8 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
     fn<<<dim3((unsigned)(nwork + ride_blocks)), dim3(kTB), smem, as_stream(stream)>>>(
         reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, const_cast<int32_t*>(n_items) + 2, n_ls,
         genc, dG, partials, genc_absmax, absmax_count, absmax_stride, L, Ls, tile_shift, lds_bytes / 4, rows2,
-        g64 ? log2_pixels : log2_chunk, nwork, ride, mride, g64, bride);
+        g64 ? log2_pixels : log2_chunk, nwork, ride, mride, g64, bride, hdt ? hash_dtables : nullptr, hash_T, hpow2);
+    if (hdt) GNGF_RETURN_LAUNCH();
     if (g64) {
       if (hash_dtables)
         vertex_bwd_hash64_kernel<2><<<dim3((unsigned)ceil_div(vtot_h, 256)), dim3(256), 0, as_stream(stream)>>>(

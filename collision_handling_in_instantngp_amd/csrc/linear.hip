@@ -474,11 +474,9 @@ gemm128_split_kernel(const float* __restrict__ A, const float* __restrict__ B, f
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
           f32x16 c = acc[ta][tb];                              // small terms first
-#ifndef GNGF_SPLIT_TIMING_THREE_TERMS      // (timing experiment only — wrong numerics: what would half the matrix work buy? DESIGN section 9)
           c = mfma_bf16(fa[ta].lo, fb[tb].hi, c);
           c = mfma_bf16(fa[ta].hi, fb[tb].lo, c);
           c = mfma_bf16(fa[ta].mid, fb[tb].mid, c);
-#endif
           c = mfma_bf16(fa[ta].mid, fb[tb].hi, c);
           c = mfma_bf16(fa[ta].hi, fb[tb].mid, c);
           c = mfma_bf16(fa[ta].hi, fb[tb].hi, c);

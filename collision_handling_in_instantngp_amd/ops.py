@@ -1175,10 +1175,15 @@ HASH_VERTEX_FUSION = True    # hash indexing, single rank: the vertex stage back
 
 # The kernel chain of one training step at the headline shape, as a string that changes whenever the chain does: PMC traffic
 # figures (profiles/traffic.json) are stamped with it and bench.py reports them only for the chain they were measured on.
-STEP_CHAIN_SIGNATURE = "r4: [bin_count_ride+bin_scatter2 | riders of the previous step] > tiled_fwd_il<SRC tables>(+count riders) > decoder_train > tiled_bwd_il(+scatter tasks, reduce, mse) > vertex_bwd_hash64|vertex_bwd_sorted<FROM64>"
+STEP_CHAIN_SIGNATURE = "r5: [bin_count_ride+bin_scatter2 | riders of the previous step] > tiled_fwd_il<SRC tables>(+count riders) > decoder_train > tiled_bwd_il(+scatter tasks, reduce, mse)<hash: HDT, table rows added by the store pass> [> vertex_bwd_sorted<FROM64> (vertex-table source)]"
 FUSED_VERTEX_FWD = True      # fp32 tables on the interleaved forward kernel: the vertex stage forward runs inside its staging loop
 BIN_PIPELINE = True          # ... and an announced next batch (BinPipeline) is binned by riders of this step's pixel-stage launches
 DG64 = True                  # F = 2, <= 16 staged levels, bounded |genc|: 64-bit fixed-point vertex grid fed by global integer atomics
+# Round 5, spatial-hash source on a single rank (no exchange): the interleaved pixel-stage backward adds its items' exact sums —
+# rounded to fp32 once per item and vertex — straight to the table-gradient rows hash(gx, gy): no fixed-point vertex grid (nothing to
+# clear, nothing to convert) and no vertex-stage launch behind the kernel (vertex_bwd_hash64: 10.7 us of the 396 us hash step).  Same
+# number of memory-side atomic requests as the adds into the fixed-point grid.  False: fixed-point grid + vertex_bwd_hash64 (round 4).
+HASH_DIRECT_SCATTER = True
 VERTEX_READS_DG64 = True     # ... and the slot-ordered vertex backward converts it on the fly (False: dg64_to_float first)
 
 
@@ -1191,6 +1196,7 @@ def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None, link=None, hash_fuse
     if PIXEL_BWD_TRACE is not None:
         PIXEL_BWD_TRACE.append({"P": plan.P, "Ls": plan.Ls, "bound": absmax is not None, "dG64": dG64 is not None and absmax is not None,
                                 "hash_fuse": hash_fuse is not None, "fp32_grid": dG is not None,
+                                "direct_hash": hash_fuse is not None and dG is None and dG64 is None and absmax is not None,
                                 "interleaved": plan.interleaved(backward=True)})
     partials = torch.empty((plan.max_items * (plan.lds_bytes // 4),), dtype=_f32, device=genc.device)
     am, am_count, am_stride = absmax if absmax is not None else (None, 0, 0)
@@ -1292,6 +1298,7 @@ class EncodeFunction(torch.autograd.Function):
         pre = None
         ctx.next_bin = None
         ctx.fresh_direct = False
+        ctx.direct_hash = False
         ctx.persist = False
         ctx.persist_cleared = None
         clear_now = None
@@ -1311,16 +1318,21 @@ class EncodeFunction(torch.autograd.Function):
                 # (the launcher decides whether that kernel runs — e.g. not at the 4096^2 shape, whose interleaved image exceeds
                 # the LDS: the generic kernels accumulate into a ZEROED fp32 grid instead)
                 use64 = DG64 and F == 2 and plan.Ls <= 16 and plan.interleaved(backward=True)
+                # hash source, single rank: no vertex-grid gradient at all when the interleaved backward adds to the table gradient
+                # itself (decided again in backward: it needs the bound on |d enc| that only the backward pass can see)
+                ctx.direct_hash = bool(HASH_DIRECT_SCATTER and HASH_VERTEX_FUSION and use64 and mode == MODE_HASH and link is not None
+                                       and (dp is None or dp.exchange is None))
                 nt = tables.numel()
                 if fused and nt % 4 == 0:
                     # ONE allocation [table gradient | vertex-grid gradient]: whoever clears the table gradient — the fused
                     # training decoder between its MFMAs, or rider workgroups of the count launch — clears both
-                    ng = (plan.vtot * F + 2) * 2 if use64 else plan.vtot * F
+                    ng = 0 if ctx.direct_hash else ((plan.vtot * F + 2) * 2 if use64 else plan.vtot * F)
                     big = torch.empty((nt + ((ng + 3) & ~3),), dtype=_f32, device=dev)
-                    dgrid = big[nt:nt + ng].view(_i64) if use64 else big[nt:nt + ng].view(plan.vtot, F)
+                    dgrid = None if ctx.direct_hash else (big[nt:nt + ng].view(_i64) if use64 else big[nt:nt + ng].view(plan.vtot, F))
                     pre = [big[:nt].view(tables.shape), dgrid, big, big]
                 else:
                     fused = False
+                    ctx.direct_hash = False
                     dgrid = (torch.empty((plan.vtot * F + 2,), dtype=_i64, device=dev) if use64
                              else torch.empty((plan.vtot, F), dtype=_f32, device=dev))
                     # direct levels whose backward WRITES every row (the bucketed form) are left out of the clear
@@ -1383,7 +1395,7 @@ class EncodeFunction(torch.autograd.Function):
                 # and the clears ride on the binning kernels as extra workgroups: ops.TiledWorkspace)
                 G = torch.empty((plan.vtot, F), dtype=_f32, device=dev)
                 ws = TiledWorkspace(plan, xy, vertex=(tables, vert_idx, vert_w, n_ls, vstride, G),
-                                    zero_dG=(pre[1].view(_f32) if use64 else pre[1]) if pre else None,
+                                    zero_dG=(pre[1].view(_f32) if use64 else pre[1]) if (pre and pre[1] is not None) else None,
                                     zero=(pre[3] if (pre and pre[3] is not None and not defer) else None),
                                     zero_dG_words=(2 if use64 else 1), owner=dp, clear_rows=clear_now)
                 call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), plan.n_ls_c,
@@ -1429,18 +1441,23 @@ class EncodeFunction(torch.autograd.Function):
             fresh_direct = False
         dvw = torch.zeros_like(vert_w) if (vert_w is not None and ctx.needs_input_grad[5]) else None
         if plan.Ls > 0 and P > 0:
-            dG64 = pre[1] if (pre and pre[1].dtype == _i64) else None
+            dG64 = pre[1] if (pre and pre[1] is not None and pre[1].dtype == _i64) else None
             if dG64 is not None and absmax is None:            # no bound on |genc| from its producer: the per-item scales need the fp32 path
                 dG64 = None
             if dG64 is not None and not plan.interleaved(backward=True):
                 dG64 = None                                     # gngf_set_tiled_interleaved changed since the forward pass: fp32 path
             fuse = (dtables, T) if (HASH_VERTEX_FUSION and vert_idx is None and exchange is None) else None
+            # the forward pass planned for it (no vertex-grid gradient was allocated) and the conditions still hold: the pixel stage
+            # adds to the table gradient itself.  Otherwise (no bound arrived, the interleaved switch changed): partial images +
+            # gather pass with the hash fused in, on a vertex grid allocated here
+            direct_hash = bool(getattr(ctx, "direct_hash", False) and pre and fuse is not None and absmax is not None
+                               and plan.interleaved(backward=True))
             # vertex-table source in slot order, single rank, no d w: the vertex stage reads the fixed-point grid itself (no
             # fp32 copy of the vertex-grid gradient, no conversion launch)
             direct64 = (dG64 is not None and VERTEX_READS_DG64 and vert_idx is not None and order is not None and exchange is None
                         and dvw is None)
-            dG = None if direct64 else (pre[1] if (pre and pre[1].dtype == _f32) else
-                                        (torch.empty if dG64 is not None else torch.zeros)((plan.vtot, F), dtype=_f32, device=tables.device))
+            dG = None if (direct64 or direct_hash) else (pre[1] if (pre and pre[1] is not None and pre[1].dtype == _f32) else
+                                                         (torch.empty if dG64 is not None else torch.zeros)((plan.vtot, F), dtype=_f32, device=tables.device))
             job_next = None
             if next_bin is not None and plan.interleaved(backward=True):
                 job_next = next_bin[1]

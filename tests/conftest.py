@@ -57,8 +57,8 @@ class _EncodePath:
         assert len(self.trace) >= min_launches, f"expected >= {min_launches} tiled pixel-stage backward launches, saw {len(self.trace)}"
         for r in self.trace:
             assert r["Ls"] > 0 and r["interleaved"], r
-            if fixed_point:
-                assert r["bound"] and r["dG64"], r
+            if fixed_point:        # (hash source since round 5: the same fixed-point sums, added to the table rows by the store pass itself)
+                assert r["bound"] and (r["dG64"] or r.get("direct_hash")), r
 
 
 @pytest.fixture(params=["auto", "tiled"])

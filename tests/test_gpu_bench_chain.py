@@ -79,10 +79,11 @@ def test_bench_step_at_full_size_matches_the_oracle(mode):
         res = gs.run_many([(xy, target)] * 2)
         torch.cuda.synchronize()
         r = res[-1]
-        assert len(trace) >= 2 and all(t_["dG64"] and t_["interleaved"] and t_["Ls"] == L and t_["P"] == P for t_ in trace), trace[:2]
-        assert all(t_["hash_fuse"] == (mode == "hash") and t_["fp32_grid"] == (mode == "hash") for t_ in trace) or mode != "hash", trace[:2]
-        if mode == "gngf_frozen":
-            assert all(not t_["fp32_grid"] for t_ in trace), trace[:2]                # vertex_bwd_sorted reads the fixed-point grid itself
+        assert len(trace) >= 2 and all(t_["bound"] and t_["interleaved"] and t_["Ls"] == L and t_["P"] == P for t_ in trace), trace[:2]
+        if mode == "hash":      # round 5: the store pass of tiled_bwd_il adds to the table-gradient rows itself (no fixed-point grid, no vertex launch)
+            assert all(t_["direct_hash"] and t_["hash_fuse"] and not t_["dG64"] and not t_["fp32_grid"] for t_ in trace), trace[:2]
+        else:                   # vertex_bwd_sorted reads the fixed-point grid itself
+            assert all(t_["dG64"] and not t_["fp32_grid"] and not t_["direct_hash"] for t_ in trace), trace[:2]
         tables, dw, db = _numpy_state(net, L)
         n_ls = np.array(net._n_ls_host, np.int32)
         vidx = vw = None
@@ -145,7 +146,8 @@ def test_fixed_point_chain_on_the_steps_own_gradient_keeps_small_rows(mode):
         ops.decoder_apply = real_decoder_apply
         ops.PIXEL_BWD_TRACE = prev_trace
         models.should_use_hash_function = False
-    assert len(captured) == 1 and len(trace) == 1 and trace[0]["dG64"] and trace[0]["interleaved"], trace
+    assert len(captured) == 1 and len(trace) == 1 and trace[0]["interleaved"] and trace[0]["bound"], trace
+    assert trace[0]["direct_hash"] if mode == "hash" else trace[0]["dG64"], trace
     genc = np.ascontiguousarray(captured[0].cpu().numpy())
     n_ls = np.array(net._n_ls_host, np.int32)
     vidx = vw = None

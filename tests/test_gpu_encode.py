@@ -445,6 +445,37 @@ def test_fixed_point_vertex_grid_is_exact_and_order_free(ops, P, coords):
     dt_b = torch.zeros_like(dt_a)
     ops._vertex_bwd(plan, tables, None, None, n_t, 0, grids[0][0], dt_b, None)
     close(dt_a, dt_b.cpu().numpy(), 1e-5, 1e-6 * float(dt_b.abs().max()), "hash table gradient from the fixed-point grid")
+    # (3a) round 5, hash source: NO grid at all — the store pass of the interleaved backward adds each item's exact sums (rounded to
+    # fp32 once) to the table-gradient rows hash(gx, gy) itself (tiled_bwd_il_kernel<., HDT>); incl. the pixels outside the staged
+    # sub-grids ("outside"), which go to their rows one float atomic per term.  Against the table gradient formed from the exact
+    # per-vertex sums: the two differ only in how many fp32 roundings a row's partial sums meet (one per item that reaches the
+    # vertex instead of one per vertex) — a few ulp of the row's absolute mass
+    dt_h = torch.zeros((L, T, Fd), dtype=torch.float32, device=DEV)
+    trace = []
+    prev_trace, ops.PIXEL_BWD_TRACE = ops.PIXEL_BWD_TRACE, trace
+    try:
+        ops._pixel_bwd(plan, ws, n_t, genc, None, L, Fd, (am, 1, 0), None, (dt_h, T), None)
+    finally:
+        ops.PIXEL_BWD_TRACE = prev_trace
+    assert trace and trace[0]["direct_hash"] and trace[0]["interleaved"], trace
+    gabs = torch.zeros((plan.vtot, Fd), dtype=torch.float32, device=DEV)
+    ops._pixel_bwd(plan, ws, n_t, genc.abs(), gabs, L, Fd, (am, 1, 0), None)                 # per-vertex absolute mass (c >= 0)
+    mass = torch.zeros((L, T, Fd), dtype=torch.float32, device=DEV)
+    ops._vertex_bwd(plan, tables, None, None, n_t, 0, gabs, mass, None)
+    err = (dt_h.double() - dt_a.double()).abs()
+    assert bool(((mass == 0) <= (dt_h == 0)).all()), "a row no pixel reaches received something"
+    worst = float((err[mass > 0] / mass[mass > 0].double()).max())
+    print(f"[direct hash scatter {P} {coords}] worst |err| / row mass vs the exact per-vertex sums: {worst:.2e}")
+    assert worst <= 2e-6, worst
+    close(dt_h, dt_a.cpu().numpy(), 1e-5, 2e-6 * float(dt_a.abs().max()), "hash table gradient added by the store pass (no vertex grid) vs from the fixed-point grid")
+    dt_n = torch.zeros((L, T, Fd), dtype=torch.float32, device=DEV)
+    ops._pixel_bwd(plan, ws, n_t, genc, None, L, Fd, (torch.full((1,), float("nan"), device=DEV), 1, 0), None, (dt_n, T), None)
+    hit = dt_a != 0
+    assert bool(hit.any())
+    if coords == "outside":      # (rows reached ONLY by pixels outside every staged sub-grid — never for in-domain coordinates — are not poisoned)
+        assert float(torch.isnan(dt_n[hit]).float().mean()) > 0.9
+    else:
+        assert bool(torch.isnan(dt_n[hit]).all()), "a NaN bound poisons every row the batch reaches"
     # (3b) vertex-table source in slot order: the vertex stage reading the fixed-point grid itself (no fp32 grid at all)
     vstride = max(n_host) + 2
     NV, K = vstride * vstride, 3
