@@ -25,10 +25,10 @@ SIGNATURES = {
     "gngf_mrhe_bwd": [_P, _I, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _P],
     "gngf_bilinear_fwd": [_P, _P, _P, _P, _L, _I, _I, _P],
     "gngf_bilinear_bwd": [_P, _P, _P, _P, _L, _I, _I, _P],
-    "gngf_encode_fwd": [_P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _L, _I, _I, _P],
+    "gngf_encode_fwd": [_P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _L, _I, _I, _P, _P],
     "gngf_encode_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _L, _I, _I, _P],
     "gngf_encode_bwd_bucketed_plan": [_L, _I, _L, _I, _I, _P],
-    "gngf_encode_bwd_bucketed": [_P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _I, _P, _P, _P, _P],
+    "gngf_encode_bwd_bucketed": [_P, _P, _P, _P, _L, _I, _I, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "gngf_clear_hashed_rows": [_P, _P, _I, _I, _L, _L, _P],
     "gngf_bin_pixels": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "gngf_encode_tiled_prepare": [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _I, _L,
@@ -88,7 +88,7 @@ SIGNATURES = {
     "gngf_adam_step": [_P, _I, _L, _P, _P, _P, _I, _F, _F, _F, _F, _P],
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class BinJob(ctypes.Structure):

@@ -194,12 +194,18 @@ __global__ void __launch_bounds__(kBlock)
 encode_fwd_kernel(const float2* __restrict__ xy, const TT* __restrict__ tables,
                   const int32_t* __restrict__ vert_idx, const float* __restrict__ vert_w,
                   const int32_t* __restrict__ n_ls, float* __restrict__ enc,
-                  int64_t total, int L, int l0, int nl, int64_t T, int K, int vstride, int64_t NV, bool pow2) {
+                  int64_t total, int L, int l0, int nl, int64_t T, int K, int vstride, int64_t NV, bool pow2,
+                  const float4* __restrict__ order = nullptr) {
   const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (gid >= total) return;
-  const int64_t p = gid / nl;
+  int64_t p = gid / nl;
   const int l = l0 + (int)(gid - p * nl);
-  const float2 c = xy[p];
+  // order (optional): the pixels in TILE order (binned records {x, y, bits(original index), 0} of the tiled form) — neighbouring
+  // lanes then gather from the same few aligned blocks of table rows (the spatial hash keeps the low bits of gx: one grid row =
+  // one block) instead of from anywhere in the table; the result lands in the pixel's own row of enc either way
+  float2 c;
+  if (order) { const float4 s = order[p]; c = make_float2(s.x, s.y); p = (int64_t)__float_as_int(s.z); }
+  else c = xy[p];
   const Cell cell = make_cell(c.x, c.y, n_ls[l]);
   const TT* tab = tables + (int64_t)l * T * F;
   float feat[4][F];
@@ -355,11 +361,12 @@ extern "C" int gngf_bilinear_bwd(const float* xy, const int32_t* n_ls, const flo
 
 extern "C" int gngf_encode_fwd(const float* xy, const void* tables_v, int feat_dtype, const int32_t* vert_idx, const float* vert_w,
                                const int32_t* n_ls, float* enc, int64_t P, int L, int F, int64_t T, int K,
-                               int mode, int vstride, int64_t NV, int l0, int l1, void* stream) {
+                               int mode, int vstride, int64_t NV, int l0, int l1, const float* pixel_order, void* stream) {
   GNGF_CHECK_ARG(P >= 0 && L > 0 && L <= GNGF_MAX_LEVELS && T > 0 && l0 >= 0 && l0 <= l1 && l1 <= L);
   GNGF_CHECK_ARG(mode == GNGF_MODE_HASH || mode == GNGF_MODE_VERTEX_TABLE);
   if (P == 0 || l0 == l1) return 0;
-  GNGF_CHECK_ARG(xy && tables_v && n_ls && enc);
+  GNGF_CHECK_ARG(xy && tables_v && n_ls && enc && (reinterpret_cast<uintptr_t>(pixel_order) & 15) == 0);
+  const float4* order = reinterpret_cast<const float4*>(pixel_order);
   const int nl = l1 - l0;
   const int64_t total = P * nl;
   const dim3 grid((unsigned)ceil_div(total, kBlock)), block(kBlock);
@@ -367,12 +374,12 @@ extern "C" int gngf_encode_fwd(const float* xy, const void* tables_v, int feat_d
   if (mode == GNGF_MODE_HASH) {
     DISPATCH_TT(feat_dtype, DISPATCH_F(F, (encode_fwd_kernel<kF, false, TT><<<grid, block, 0, as_stream(stream)>>>(
                       reinterpret_cast<const float2*>(xy), static_cast<const TT*>(tables_v), nullptr, nullptr, n_ls, enc, total, L, l0,
-                      nl, T, 0, 0, 0, pow2))));
+                      nl, T, 0, 0, 0, pow2, order))));
   } else {
     GNGF_CHECK_ARG(vert_idx && vert_w && K > 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0);
     DISPATCH_TT(feat_dtype, DISPATCH_F(F, (encode_fwd_kernel<kF, true, TT><<<grid, block, 0, as_stream(stream)>>>(
                       reinterpret_cast<const float2*>(xy), static_cast<const TT*>(tables_v), vert_idx, vert_w, n_ls, enc, total, L,
-                      l0, nl, T, K, vstride, NV, pow2))));
+                      l0, nl, T, K, vstride, NV, pow2, order))));
   }
   GNGF_RETURN_LAUNCH();
 }

@@ -802,12 +802,16 @@ __device__ __forceinline__ unsigned long long to_fixed_fma(double g, double c) {
 // reference) is scaled by 2^S, S = 61 - ceil(log2(chunk)) - exponent(max |g| over the item's pixels), which makes
 // overflow impossible and the quantisation (2^-S per term, ~2^-49 of the item's largest gradient) far below one fp32
 // ulp of any partial sum.  Integer adds commute: the per-item image is bitwise reproducible.
-template <int F>
+// HDT (round 5; spatial-hash source on a single rank): as in tiled_bwd_il_kernel, the store pass adds the item's sums — rounded to
+// fp32 once — straight to row hash(gx, gy) of the level's table gradient: no partial images, no gather pass (245 us at the 8192^2
+// shape, 121 us at the 4096^2 one), no vertex grid.
+template <int F, bool HDT = false>
 __global__ void __launch_bounds__(kTB)
 tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ items, const int32_t* __restrict__ n_items,
                  const int32_t* __restrict__ n_ls, const float* __restrict__ genc, float* __restrict__ dG,
                  float* __restrict__ partials, const float* __restrict__ gmax_hint, int hint_count, int hint_stride, int L,
-                 int Ls, int tile_shift, int lds_floats, int log2_chunk, RideAlong ride, MseRide mride) {
+                 int Ls, int tile_shift, int lds_floats, int log2_chunk, RideAlong ride, MseRide mride,
+                 float* __restrict__ hash_dt = nullptr, int64_t hash_T = 0, bool hash_pow2 = false) {
   extern __shared__ unsigned long long acc64[];
   __shared__ TileMeta m;
   __shared__ float wmax[kTB / 64];
@@ -915,18 +919,39 @@ tiled_bwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
             int gx = c.gx + (q & 1), gy = c.gy + (q >> 1);
             gx = gx < 0 ? 0 : (gx > n + 1 ? n + 1 : gx);
             gy = gy < 0 ? 0 : (gy > n + 1 ? n + 1 : gy);
+            if constexpr (HDT) {
+              float* r = hash_dt + ((int64_t)l * hash_T + spatial_hash(gx, gy, hash_T, hash_pow2)) * F;
 #pragma unroll
-            for (int f = 0; f < F; ++f) atomicAdd(dGl + ((int64_t)gy * gw + gx) * F + f, g[f] * c.c[q]);
+              for (int f = 0; f < F; ++f) atomicAdd(r + f, g[f] * c.c[q]);
+            } else {
+#pragma unroll
+              for (int f = 0; f < F; ++f) atomicAdd(dGl + ((int64_t)gy * gw + gx) * F + f, g[f] * c.c[q]);
+            }
           }
         }
       }
     }
   }
   __syncthreads();
+  const double inv = finite ? ldexp(1.0, -S) : 0.0;
+  if constexpr (HDT) {
+    // element i of the image = feature f of vertex v of the q-th level that fits (the levels are placed back to back in order)
+    for (int i = tid; i < used; i += kTB) {
+      int q = 0, lo = 0, sz = 0;
+      for (; q < Ls; ++q) { sz = m.wx[q] * m.wy[q] * F; if (i < lo + sz) break; lo += sz; }
+      const long long sum = (long long)acc64[i];
+      if (sum != 0 || !finite) {
+        const int j = i - lo, v = j / F, f = j - v * F;
+        const int wxq = m.wx[q], iy = v / wxq, ix = v - iy * wxq;
+        atomicAdd(hash_dt + ((int64_t)q * hash_T + spatial_hash(m.cx[q] + ix, m.cy[q] + iy, hash_T, hash_pow2)) * F + f,
+                  finite ? (float)((double)sum * inv) : __int_as_float(0x7fc00000));
+      }
+    }
+    return;
+  }
   // store pass: the item's privatised sub-grid image goes out as fp32 with plain coalesced stores; the gather pass
   // sums, per destination vertex, the images of the (few) items that cover it — no global float atomics at all.
   float* part = partials + (int64_t)blockIdx.x * lds_floats;
-  const double inv = finite ? ldexp(1.0, -S) : 0.0;
   for (int i = tid; i < used; i += kTB)
     part[i] = finite ? (float)((double)(long long)acc64[i] * inv) : __int_as_float(0x7fc00000);
 }
@@ -2299,7 +2324,7 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
   GNGF_CHECK_ARG(max_items == 0 || dG ||
                  (genc_absmax && dG64 && log2_pixels > 0 && log2_pixels <= 40 && !hash_dtables &&
                   interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, true)) ||
-                 (genc_absmax && !dG64 && hash_dtables && interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, true)));
+                 (!dG64 && hash_dtables));
   // a fixed-point grid (with the bound that makes it usable) is only ever filled by the interleaved kernel: a caller that
   // passes one for a shape the generic kernels take has sized / initialised dG for the wrong path (it would read an
   // uninitialised dG) — rejected instead of computed (callers ask gngf_tiled_interleaved_applies first)
@@ -2316,8 +2341,8 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
       const size_t need = (sizeof(int) << (2 * next_bin->tile_shift)) + sizeof(int);
       smem = smem < need ? need : smem;
     }
-    // spatial-hash source with a bound on |genc| and NO fixed-point grid handed in: the store pass adds to the table gradient itself
-    const bool hdt = hash_dtables && genc_absmax && !dG64;
+    // spatial-hash source and neither vertex grid handed in: the store pass adds to the table gradient itself
+    const bool hdt = hash_dtables && !dG && !dG64;
     auto fn = hdt ? ((L == 16) ? tiled_bwd_il_kernel<true, true> : tiled_bwd_il_kernel<false, true>)
                   : ((L == 16) ? tiled_bwd_il_kernel<true> : tiled_bwd_il_kernel<false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -2350,16 +2375,18 @@ extern "C" int gngf_encode_tiled_bwd(const float* sorted, const int32_t* items, 
           partials, tile_item_base, tile_level_off, n_ls, dG, Ls, tile_shift, lds_bytes / 4);
     GNGF_RETURN_LAUNCH();
   }
+  const bool hdt_g = hash_dtables && !dG && !dG64;       // (generic kernels: see tiled_bwd_kernel<F, HDT>)
   DISPATCH_F(F, {
+    auto fn = hdt_g ? tiled_bwd_kernel<kF, true> : tiled_bwd_kernel<kF, false>;
     if (2 * lds_bytes > 48 * 1024) {       // 64-bit accumulators: twice the forward image
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiled_bwd_kernel<kF>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * lds_bytes);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * lds_bytes);
       if (e != hipSuccess) return (int)e;
     }
-    tiled_bwd_kernel<kF><<<dim3((unsigned)(max_items + ride_blocks)), dim3(kTB), (size_t)2 * lds_bytes, as_stream(stream)>>>(
+    fn<<<dim3((unsigned)(max_items + ride_blocks)), dim3(kTB), (size_t)2 * lds_bytes, as_stream(stream)>>>(
         reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, n_ls, genc, dG, partials,
-        genc_absmax, absmax_count, absmax_stride, L, Ls, tile_shift, lds_bytes / 4, log2_chunk, ride, mride);
-    if (max_items > 0) {
+        genc_absmax, absmax_count, absmax_stride, L, Ls, tile_shift, lds_bytes / 4, log2_chunk, ride, mride,
+        hdt_g ? hash_dtables : nullptr, hash_T, hpow2);
+    if (max_items > 0 && !hdt_g) {
       if (hash_dtables)
         gather_partials_kernel<kF, true><<<dim3((unsigned)ceil_div(vtot_h, 256)), dim3(256), 0, as_stream(stream)>>>(
             partials, tile_item_base, tile_level_off, n_ls, dG, Ls, tile_shift, lds_bytes / 4, hash_dtables, hash_T, hpow2);

@@ -167,6 +167,8 @@ BUCKETED_MIN_DENSITY = 0.5
 # ... when the bucketed form WRITES the levels (a fresh gradient buffer: those levels then need no clear — a quarter of the 4 GiB
 # clear at the 8192^2 shape): step 2.83 -> 2.63 ms there although the kernels themselves only draw with the atomics
 BUCKETED_MIN_DENSITY_FRESH = 0.2
+DIRECT_FWD_TILE_ORDER = True   # ... and so does the direct levels' forward gather (gngf_encode_fwd(..., pixel_order))
+BUCKETED_TILE_ORDER = True     # walk the pixels in the tiled form's binned order when a workspace exists (round 5; see bucket_pixel)
 
 
 def bucketed_plan(P, F, T, nl, fresh=False):
@@ -180,9 +182,10 @@ def bucketed_plan(P, F, T, nl, fresh=False):
     return tuple(int(v) for v in plan)
 
 
-def _direct_bwd(xy, tables, vert_idx, vert_w, n_ls, genc, dtables, dvw, P, L, F, T, K, mode, vstride, NV, l0, l1, fresh=False):
+def _direct_bwd(xy, tables, vert_idx, vert_w, n_ls, genc, dtables, dvw, P, L, F, T, K, mode, vstride, NV, l0, l1, fresh=False, order=None):
     """d tables of levels [l0, l1) in the direct form.  fresh: those levels of dtables hold NOTHING yet (not even zeros) — the
-    bucketed form writes every row of them, the atomics form clears them first."""
+    bucketed form writes every row of them, the atomics form clears them first.  order: the batch's binned pixel records (P,4) of
+    the tiled form's workspace, if there is one: the bucketed form walks the pixels tile by tile (whole-line item runs)."""
     plan = bucketed_plan(P, F, T, l1 - l0, fresh) if (mode == MODE_HASH and dtables.dtype == _f32) else None
     _trace("direct_bwd", bucketed=plan is not None, write=bool(fresh and plan is not None), levels=(l0, l1))
     if plan is None:
@@ -196,7 +199,8 @@ def _direct_bwd(xy, tables, vert_idx, vert_w, n_ls, genc, dtables, dvw, P, L, F,
     base = torch.empty((plan[4],), dtype=_i32, device=dev)
     items = torch.empty((plan[5],), dtype=torch.uint8, device=dev)
     call("gngf_encode_bwd_bucketed", ptr(xy), ptr(n_ls), ptr(genc, _f32, "grad"), ptr(dtables), P, L, F, T, l0, l1,
-         int(BUCKET_IMAGE_BYTES), 0 if fresh else 1, ptr(matrix), ptr(base), ptr(items), stream_ptr())
+         int(BUCKET_IMAGE_BYTES), 0 if fresh else 1, ptr(matrix), ptr(base), ptr(items),
+         ptr(order if (BUCKETED_TILE_ORDER and order is not None and order.shape[0] == P) else None, _f32, "pixel_order"), stream_ptr())
 
 
 # Hash source, staged levels on the generic pixel-stage kernels (the big shapes): the table gradient lives in ONE buffer per model
@@ -265,7 +269,7 @@ class EncodeDirectFunction(torch.autograd.Function):
         NV = 0 if vert_idx is None else vert_idx.shape[0]
         enc = torch.empty((P, L * F), dtype=_f32, device=tables.device)
         call("gngf_encode_fwd", ptr(xy, _f32, "xy"), *_tab(tables), ptr(vert_idx, _i32, "vert_idx"),
-             ptr(vert_w, _f32, "vert_w"), ptr(n_ls, _i32, "n_ls"), ptr(enc), P, L, F, T, K, mode, vstride, NV, 0, L,
+             ptr(vert_w, _f32, "vert_w"), ptr(n_ls, _i32, "n_ls"), ptr(enc), P, L, F, T, K, mode, vstride, NV, 0, L, ptr(None),
              stream_ptr())
         ctx.save_for_backward(xy, n_ls, tables, vert_idx, vert_w)
         ctx.cfg = (P, L, F, T, K, mode, vstride, NV)
@@ -1403,7 +1407,7 @@ class EncodeFunction(torch.autograd.Function):
         if plan.Ls < L:
             call("gngf_encode_fwd", ptr(xy, _f32, "xy"), *_tab(tables), ptr(vert_idx, _i32, "vert_idx"),
                  ptr(vert_w, _f32, "vert_w"), ptr(n_ls, _i32, "n_ls"), ptr(enc), P, L, F, T, K, mode, vstride, NV, plan.Ls, L,
-                 stream_ptr())
+                 ptr(ws.sorted if (DIRECT_FWD_TILE_ORDER and ws is not None) else None, _f32, "pixel_order"), stream_ptr())
         ctx.save_for_backward(xy, n_ls, tables, vert_idx, vert_w, order)
         ctx.cfg = (P, L, F, T, K, mode, vstride, NV, plan, ws)
         ctx.pre = pre                                           # zero-filled (dtables, dG), consumed by the first backward
@@ -1472,7 +1476,7 @@ class EncodeFunction(torch.autograd.Function):
                 # the caller exchanges dG and runs the vertex stage after backward (parallel.allreduce_gradients)
                 if plan.Ls < L:
                     _direct_bwd(xy, tables, vert_idx, vert_w, n_ls, genc, dtables, dvw, P, L, F, T, K, mode, vstride, NV, plan.Ls, L,
-                                fresh=fresh_direct)
+                                fresh=fresh_direct, order=(ws.sorted if ws is not None else None))
                 gout = _grad_out(dtables, tables, sink)
                 dp.deferred = (plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, order, gout)
                 dp.tables_reduced = plan.Ls
@@ -1493,7 +1497,7 @@ class EncodeFunction(torch.autograd.Function):
             dvw_t = None
         if plan.Ls < L:
             _direct_bwd(xy, tables, vert_idx, vert_w, n_ls, genc, dtables, dvw, P, L, F, T, K, mode, vstride, NV, plan.Ls, L,
-                        fresh=fresh_direct)
+                        fresh=fresh_direct, order=(ws.sorted if ws is not None else None))
         if dvw_t is not None:
             dvw = dvw + dvw_t
         return (None, None, None, _grad_out(dtables, tables, sink), None, dvw, *NONE)
@@ -1867,7 +1871,7 @@ def encode_kernels(xy, n_ls, n_ls_host, tables, vert_idx, vert_w, vstride, genc,
         out["vertex_bwd"] = lambda: _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, None, order)
     if plan.Ls < L:
         out["encode_fwd:direct"] = lambda: call("gngf_encode_fwd", ptr(xy), *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls),
-                                                ptr(enc), P, L, F, T, K, mode, vstride, NV, plan.Ls, L, s())
+                                                ptr(enc), P, L, F, T, K, mode, vstride, NV, plan.Ls, L, ptr(None), s())
         out["encode_bwd:direct"] = lambda: call("gngf_encode_bwd", ptr(xy), *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls),
                                                 ptr(genc), ptr(dtables), ptr(None), P, L, F, T, K, mode, vstride, NV, plan.Ls,
                                                 L, s())

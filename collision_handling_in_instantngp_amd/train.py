@@ -426,18 +426,30 @@ class GraphedStep:
             pipe.reset()
         g = torch.cuda.CUDAGraph()
         results = []
-        # thread_local: other threads of the process (the RCCL watchdog at world > 1) may query events while we capture
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            subs = [st] + st["more"]
-            for j, sub in enumerate(subs):
-                last = j + 1 == len(subs)
-                # step j's pixel-stage launches bin step j + 1's batch (its own static buffer: refilled before every replay); the
-                # last step's bin the first batch of the NEXT replay (cross_replay: the caller puts it into x_next beforehand)
-                nx = subs[j + 1]["x"] if not last else (st["x_next"] if W is not None else None)
-                results.append(self._body(sub, next_x=nx, next_ws=(W[fills] if (last and W is not None) else None),
-                                          binned_in=(W[reads] if (j == 0 and W is not None and reads is not None) else None)))
-                if self.optimizer is not None:
-                    self.optimizer.step()
+        # No garbage collection while the stream captures: a collection that happens to run inside the body finalises whatever
+        # cyclic garbage earlier work left behind (other models' graphs, events, blocks last used on other streams), and a
+        # finaliser that touches the runtime during a capture aborts the process (seen once in round 5: "Fatal Python error:
+        # Aborted ... Garbage-collecting" in the middle of a captured forward pass).  torch.cuda.graph() collects once on entry;
+        # what the body itself leaves behind is collected after the capture has ended.
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            # thread_local: other threads of the process (the RCCL watchdog at world > 1) may query events while we capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                subs = [st] + st["more"]
+                for j, sub in enumerate(subs):
+                    last = j + 1 == len(subs)
+                    # step j's pixel-stage launches bin step j + 1's batch (its own static buffer: refilled before every replay);
+                    # the last step's bin the first batch of the NEXT replay (cross_replay: the caller puts it into x_next beforehand)
+                    nx = subs[j + 1]["x"] if not last else (st["x_next"] if W is not None else None)
+                    results.append(self._body(sub, next_x=nx, next_ws=(W[fills] if (last and W is not None) else None),
+                                              binned_in=(W[reads] if (j == 0 and W is not None and reads is not None) else None)))
+                    if self.optimizer is not None:
+                        self.optimizer.step()
+        finally:
+            if gc_was_on:
+                gc.enable()
         if pipe is not None:
             pipe.reset()
         st["variants"][name] = (g, results, self._handover(st))

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNGF_ABI_VERSION 11
+#define GNGF_ABI_VERSION 12
 #define GNGF_MAX_LEVELS 32
 #define GNGF_MAX_TOPK 32
 
@@ -65,10 +65,12 @@ int gngf_bilinear_bwd(const float* xy, const int32_t* n_ls, const float* genc, f
  * Only levels [l0, l1) are produced / consumed (enc rows stay (P, L*F)); the tiled form below covers the others.
  * mode HASH: vert_idx/vert_w NULL, K ignored.
  * mode VERTEX_TABLE: vert_idx (NV,K) int32 slots and vert_w (NV,K) blend weights per grid vertex
- *   (vid = gy*vstride + gx), i.e. HPD(top-K) evaluated once per DISTINCT vertex instead of per instance. */
+ *   (vid = gy*vstride + gx), i.e. HPD(top-K) evaluated once per DISTINCT vertex instead of per instance.
+ * pixel_order (ABI 12, may be NULL): as in gngf_encode_bwd_bucketed — the pixels walked in the tiled form's binned order (the
+ *   gathers of neighbouring lanes then fall into the same aligned blocks of table rows); enc is written by original index. */
 int gngf_encode_fwd(const float* xy, const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w,
                     const int32_t* n_ls, float* enc, int64_t P, int L, int F, int64_t T, int K,
-                    int mode, int vstride, int64_t NV, int l0, int l1, void* stream);
+                    int mode, int vstride, int64_t NV, int l0, int l1, const float* pixel_order, void* stream);
 /* backward: dtables (L,T,F) accumulated (caller zero-fills); dvert_w (NV,K) accumulated (caller zero-fills),
  * = sum over instances of c_v * <g, E_l[idx_k]>  (gradient w.r.t. the blend WEIGHT, before the blend's own backward). */
 int gngf_encode_bwd(const float* xy, const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w,
@@ -84,11 +86,14 @@ int gngf_encode_bwd(const float* xy, const void* tables, int feat_dtype, const i
  *   the item buffer — or 0 when the shape is not served (F not in {1,2,4}, > 8192 buckets per level, >= 2^31 contributions);
  *   image_bytes: LDS bytes of a bucket's image (1 KiB .. 128 KiB).
  * gngf_encode_bwd_bucketed: accumulate = 1 adds to dtables (L,T,F) fp32; 0 WRITES every row of levels [l0, l1) (no clear needed).
- *   matrix / base / items: scratch of the sizes the plan names. */
+ *   matrix / base / items: scratch of the sizes the plan names.
+ *   pixel_order (ABI 12, may be NULL): the batch's pixels as P records {x, y, bits(original index), 0} in TILE order (the `sorted`
+ *   output of gngf_bin_pixels / gngf_bin_pixels2 for the same xy): walked in that order, a workgroup's contributions fall into a few
+ *   hundred buckets instead of all of them (the hash keeps the low bits of gx) and leave as whole lines.  Same result bit for bit. */
 int gngf_encode_bwd_bucketed_plan(int64_t P, int F, int64_t T, int nl, int image_bytes, int64_t* plan);
 int gngf_encode_bwd_bucketed(const float* xy, const int32_t* n_ls, const float* genc, float* dtables, int64_t P, int L, int F,
                              int64_t T, int l0, int l1, int image_bytes, int accumulate, int32_t* matrix, int32_t* base,
-                             void* items, void* stream);
+                             void* items, const float* pixel_order, void* stream);
 
 /* zeroes, in dtables (L,T,F) fp32, row hash(gx, gy) of level l for every vertex of levels [0, Ls): all the rows the staged levels
  * of a hash-indexed encoder can touch, whatever the batch (a gradient buffer kept from step to step needs no dense clear).

@@ -25,7 +25,7 @@ def _case(P, n_min, n_max, L, T, F, seed):
     return x, n_ls, g
 
 
-def _bucketed(ops, _lib, x, n_ls, g, L, T, F, l0, l1, image, accumulate, into=None):
+def _bucketed(ops, _lib, x, n_ls, g, L, T, F, l0, l1, image, accumulate, into=None, order=None):
     P = x.shape[0]
     plan = (ctypes.c_int64 * 6)()
     assert _lib.query("gngf_encode_bwd_bucketed_plan", P, F, T, l1 - l0, image, plan) == 1
@@ -34,9 +34,33 @@ def _bucketed(ops, _lib, x, n_ls, g, L, T, F, l0, l1, image, accumulate, into=No
     base = torch.empty((plan[4],), dtype=torch.int32, device=DEV)
     items = torch.empty((plan[5],), dtype=torch.uint8, device=DEV)
     _lib.call("gngf_encode_bwd_bucketed", _lib.ptr(x), _lib.ptr(n_ls), _lib.ptr(g), _lib.ptr(dt), P, L, F, T, l0, l1, image, accumulate,
-              _lib.ptr(matrix), _lib.ptr(base), _lib.ptr(items), _lib.stream_ptr())
+              _lib.ptr(matrix), _lib.ptr(base), _lib.ptr(items), _lib.ptr(order), _lib.stream_ptr())
     torch.cuda.synchronize()
     return dt, tuple(plan)
+
+
+@pytest.mark.parametrize("F,T,image", [(2, 2 ** 18, 65536), (4, 2 ** 20, 65536), (1, 1000, 1024)])
+def test_bucketed_backward_walking_the_pixels_in_tile_order_is_bit_identical(F, T, image):
+    """gngf_encode_bwd_bucketed(..., pixel_order): the batch walked in the tiled form's binned order (records {x, y, bits(original
+    index), 0}: the `sorted` output of the binning for the same xy) instead of in the caller's order — the sums are integer sums of
+    the same terms, so the table gradient is the same bit for bit; both store modes; a ragged batch (P no multiple of the block)."""
+    from collision_handling_in_instantngp_amd import ops, _lib
+    P, L, l0, l1 = 2 ** 17 + 1001, 6, 3, 6
+    x, n_ls, g = _case(P, 16, 4096, L, T, F, seed=F)
+    xt, nt, gt = torch.from_numpy(x).to(DEV), torch.from_numpy(n_ls).to(DEV), torch.from_numpy(g).to(DEV)
+    n_host = [int(n) for n in n_ls]
+    plan = ops.EncodePlan(P, n_host, F, "tiled")
+    assert plan.Ls > 0
+    ws = ops.TiledWorkspace(plan, xt)                           # binning only: ws.sorted = the pixels in tile order
+    torch.cuda.synchronize()
+    idx = ws.sorted[:, 2].contiguous().view(torch.int32).long()
+    assert torch.equal(torch.sort(idx).values, torch.arange(P, device=DEV)), "the binned records are a permutation of the batch"
+    assert torch.equal(ws.sorted[:, :2], xt[idx])
+    for accumulate in (0, 1):
+        a, _ = _bucketed(ops, _lib, xt, nt, gt, L, T, F, l0, l1, image, accumulate)
+        b, _ = _bucketed(ops, _lib, xt, nt, gt, L, T, F, l0, l1, image, accumulate, order=ws.sorted)
+        assert float(a[l0:l1].abs().max()) > 0
+        assert torch.equal(a, b), f"accumulate={accumulate}: the tile-ordered walk changed the table gradient"
 
 
 @pytest.mark.parametrize("shape", [

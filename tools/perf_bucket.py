@@ -26,6 +26,7 @@ def timed(fn, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+ORDER = None
 IMAGES = tuple(int(v) for v in os.environ.get("IMAGES", "16384,32768,65536,131072").split(","))
 
 
@@ -38,6 +39,11 @@ def run(tag, P, L, F, T, levels):
     dt = torch.zeros((L, T, F), device=DEV)
     tables = torch.zeros((1,), device=DEV)
     l0, l1 = L - len(levels), L
+    global ORDER
+    ORDER = None
+    if os.environ.get("TILE_ORDER", "0") == "1":      # walk the pixels in the tiled form's binned order (64 x 64 tiles)
+        plan = ops.EncodePlan(P, [16, 1024], F, "tiled")
+        ORDER = ops.TiledWorkspace(plan, xy).sorted
     us = timed(lambda: _lib.call("gngf_encode_bwd", _lib.ptr(xy), _lib.ptr(tables), 0, _lib.ptr(None), _lib.ptr(None), _lib.ptr(n_ls),
                                  _lib.ptr(genc), _lib.ptr(dt), _lib.ptr(None), P, L, F, T, 0, ops.MODE_HASH, 0, 0, l0, l1, _lib.stream_ptr()))
     print(f"{tag}: atomics {us:8.1f} us", flush=True)
@@ -52,13 +58,13 @@ def run(tag, P, L, F, T, levels):
         items = torch.empty((plan[5],), dtype=torch.uint8, device=DEV)
         for acc in (1, 0):
             fn = lambda: _lib.call("gngf_encode_bwd_bucketed", _lib.ptr(xy), _lib.ptr(n_ls), _lib.ptr(genc), _lib.ptr(dt), P, L, F, T, l0, l1,
-                                   image, acc, _lib.ptr(matrix), _lib.ptr(base), _lib.ptr(items), _lib.stream_ptr())
+                                   image, acc, _lib.ptr(matrix), _lib.ptr(base), _lib.ptr(items), _lib.ptr(ORDER), _lib.stream_ptr())
             us = timed(fn)
             print(f"{tag}: image {image:6d} B ({plan[1]} buckets/level, matrix {plan[3] * 4 / 2**20:.1f} MiB, items {plan[5] / 2**20:.0f} MiB) "
                   f"accumulate={acc}: {us:8.1f} us", flush=True)
         dt.zero_()
         fn = lambda: _lib.call("gngf_encode_bwd_bucketed", _lib.ptr(xy), _lib.ptr(n_ls), _lib.ptr(genc), _lib.ptr(dt), P, L, F, T, l0, l1,
-                               image, 0, _lib.ptr(matrix), _lib.ptr(base), _lib.ptr(items), _lib.stream_ptr())
+                               image, 0, _lib.ptr(matrix), _lib.ptr(base), _lib.ptr(items), _lib.ptr(ORDER), _lib.stream_ptr())
         fn()
         torch.cuda.synchronize()
         if ref is None:

@@ -25,16 +25,16 @@ genc = torch.randn((P, L * F), device=dev, generator=g)
 from collision_handling_in_instantngp_amd._lib import call, ptr, stream_ptr
 enc = torch.empty((P, L * F), device=dev)
 dt = torch.zeros_like(tables)
-def fwd_hash(): call("gngf_encode_fwd", ptr(xy), ptr(tables), 0, ptr(None), ptr(None), ptr(n_ls), ptr(enc), P, L, F, T, 0, 0, 0, 0, 0, L, stream_ptr())
-def bwd_hash(): call("gngf_encode_bwd", ptr(xy), ptr(tables), 0, ptr(None), ptr(None), ptr(n_ls), ptr(genc), ptr(dt), ptr(None), P, L, F, T, 0, 0, 0, 0, 0, L, stream_ptr())
+def fwd_hash(): call("gngf_encode_fwd", ptr(xy), ptr(tables), 0, ptr(None), ptr(None), ptr(n_ls), ptr(enc), P, L, F, T, 0, 0, 0, 0, 0, L, ptr(None), stream_ptr())
+def bwd_hash(): call("gngf_encode_bwd", ptr(xy), ptr(tables), 0, ptr(None), ptr(None), ptr(n_ls), ptr(genc), ptr(dt), ptr(None), P, L, F, T, 0, 0, 0, 0, 0, L, ptr(None), stream_ptr())
 t = timeit(fwd_hash); print(f"direct hash fwd  {t:.3f} ms  {P/t/1e3:.1f} Mpx/s")
 t = timeit(bwd_hash); print(f"direct hash bwd  {t:.3f} ms  {P/t/1e3:.1f} Mpx/s")
 vs = 514; NV = vs * vs
 vidx = torch.randint(0, T, (NV, K), device=dev, dtype=torch.int32, generator=g)
 vw = torch.rand((NV, K), device=dev, generator=g)
 dvw = torch.zeros_like(vw)
-def fwd_vt(): call("gngf_encode_fwd", ptr(xy), ptr(tables), 0, ptr(vidx), ptr(vw), ptr(n_ls), ptr(enc), P, L, F, T, K, 1, vs, NV, 0, L, stream_ptr())
-def bwd_vt(): call("gngf_encode_bwd", ptr(xy), ptr(tables), 0, ptr(vidx), ptr(vw), ptr(n_ls), ptr(genc), ptr(dt), ptr(dvw), P, L, F, T, K, 1, vs, NV, 0, L, stream_ptr())
+def fwd_vt(): call("gngf_encode_fwd", ptr(xy), ptr(tables), 0, ptr(vidx), ptr(vw), ptr(n_ls), ptr(enc), P, L, F, T, K, 1, vs, NV, 0, L, ptr(None), stream_ptr())
+def bwd_vt(): call("gngf_encode_bwd", ptr(xy), ptr(tables), 0, ptr(vidx), ptr(vw), ptr(n_ls), ptr(genc), ptr(dt), ptr(dvw), P, L, F, T, K, 1, vs, NV, 0, L, ptr(None), stream_ptr())
 t = timeit(fwd_vt); print(f"direct VT fwd    {t:.3f} ms  {P/t/1e3:.1f} Mpx/s")
 t = timeit(bwd_vt); print(f"direct VT bwd    {t:.3f} ms  {P/t/1e3:.1f} Mpx/s")
 t = timeit(lambda: dt.zero_()); print(f"zero 64MiB       {t:.3f} ms")
