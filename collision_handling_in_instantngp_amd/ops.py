@@ -1,8 +1,11 @@
 """torch.autograd.Function wrappers over the C-ABI (include/gngf.h).  Device memory + stream plumbing only;
 all arithmetic happens in the HIP kernels.  CPU tensors raise (no fallback)."""
 import ctypes as _ct
+import dataclasses as _dc
 import math as _math
 import os
+import sys as _sys
+import types as _types
 
 import torch
 
@@ -13,6 +16,72 @@ BLEND_CODES = {True: 0, None: 1, False: 2}   # should_softmax_topk_features -> G
 MODE_HASH, MODE_VERTEX_TABLE = 0, 1
 
 _f32, _i32, _i64 = torch.float32, torch.int32, torch.int64
+
+
+# ------------------------------------------------------------------------------------------------ tuning: ONE frozen object
+# Every measured threshold and A/B switch of the dispatch lives in ops.TUNING (round 5; they were ~35 module globals).  The object is
+# frozen: a change replaces it as a whole — `ops.TUNING = dataclasses.replace(ops.TUNING, dg64=False)` — and, for the tests, tools
+# and `bench.py --set NAME=VALUE` written against the old names, `ops.DG64 = False` / `ops.DG64` still work (the module forwards
+# upper-case names of fields to the object).  The comments that explain each field stand where the mechanism is implemented
+# ("# TUNING.<name> (default ...)" lines below).  Which kernel chain a step takes is decided ONCE per forward pass from this
+# object, the plan and the model's state: StepConfig.choose().
+@_dc.dataclass(frozen=True)
+class Tuning:
+    fp16_table_grad_fp32: object = False
+    bucketed_direct_bwd: object = True
+    bucketed_min_pixels: object = 1 << 16
+    bucket_image_bytes: object = 64 * 1024
+    bucketed_min_density: object = 0.5
+    bucketed_min_density_fresh: object = 0.2
+    direct_fwd_tile_order: object = True
+    bucketed_tile_order: object = True
+    persistent_table_grad: object = True
+    persistent_min_bytes: object = 1 << 28
+    hpd_z_cache_bytes: object = 216 << 30
+    hpd_z_cache_reserve: object = 40 << 30
+    hpd_pipeline: object = True
+    hpd_gemm_split_bf16: object = True
+    hpd_epilogue_stats: object = True
+    encode_path: object = "auto"
+    tiled_chunk: object = None
+    tiled_min_pixels: object = 1 << 14
+    tiled_cells_per_pixel: object = 4.0
+    tiled_lds_limit: object = 48 * 1024
+    tiled_tile_shift_bias: object = 0
+    bin_blocks_max: object = 128
+    bin_pixels_per_block: object = 8192
+    two_launch_binning: object = True
+    hash_vertex_fusion: object = True
+    fused_vertex_fwd: object = True
+    bin_pipeline: object = True
+    dg64: object = True
+    hash_direct_scatter: object = True
+    vertex_reads_dg64: object = True
+    use_side_stream: object = True
+    decoder_save_hidden: object = True
+    decoder_reduce_rides: object = True
+    decoder_train_fusion: object = True
+    decoder_bwd_clears: object = True
+
+
+TUNING = Tuning()
+_TUNING_FIELDS = {f.name for f in _dc.fields(Tuning)}
+
+
+class _OpsModule(_types.ModuleType):
+    def __getattr__(self, name):                      # (only reached when the module has no such attribute)
+        if name.isupper() and name.lower() in _TUNING_FIELDS:
+            return getattr(self.TUNING, name.lower())
+        raise AttributeError(f"module {self.__name__!r} has no attribute {name!r}")
+
+    def __setattr__(self, name, value):
+        if name.isupper() and name.lower() in _TUNING_FIELDS:
+            _types.ModuleType.__setattr__(self, "TUNING", _dc.replace(self.TUNING, **{name.lower(): value}))
+        else:
+            _types.ModuleType.__setattr__(self, name, value)
+
+
+_sys.modules[__name__].__class__ = _OpsModule
 
 
 def _c(t):
@@ -40,7 +109,7 @@ def _grad_buffer(tables):
 # the parameter's type, so by default that buffer is cast to fp16 (6 GiB of traffic at T = 2^24, F = 4: a quarter of the
 # step).  With FP16_TABLE_GRAD_FP32 the buffer itself is handed over instead: level l's parameter gets `grad_fp32` (a view of
 # it) and no `.grad`; train.FusedAdam — which updates an fp32 master copy anyway — consumes it directly.
-FP16_TABLE_GRAD_FP32 = False     # default of MultiResHashEncoding.grad_fp32_handover (None there = this switch)
+# TUNING.fp16_table_grad_fp32 (default False)     — default of MultiResHashEncoding.grad_fp32_handover (None there = this switch)
 
 
 def table_view(owner):
@@ -52,7 +121,7 @@ def table_view(owner):
     ws = tuple(m.weight for m in owner._hash_tables)
     tables = TableViewFunction.apply(base, owner, *ws)
     handover = getattr(owner, "grad_fp32_handover", None)
-    handover = FP16_TABLE_GRAD_FP32 if handover is None else handover
+    handover = TUNING.fp16_table_grad_fp32 if handover is None else handover
     sink = (owner, ws) if (base.dtype != _f32 and handover) else None
     return tables, sink
 
@@ -157,27 +226,27 @@ class BilinearFunction(torch.autograd.Function):
 # Backward of the direct levels, hash source: above BUCKETED_MIN_PIXELS the contributions are counting-sorted by table slice and summed
 # in LDS images (csrc/encode_bucket.hip) instead of one memory-side atomic each (20.6 G row updates/s on this chip wherever the rows
 # lie: tools/micro/atomic_window.cpp).  Bitwise reproducible; the terms are the same fp32 products, summed exactly, rounded once.
-BUCKETED_DIRECT_BWD = True
-BUCKETED_MIN_PIXELS = 1 << 16
-BUCKET_IMAGE_BYTES = 64 * 1024
+# TUNING.bucketed_direct_bwd (default True)
+# TUNING.bucketed_min_pixels (default 1 << 16)
+# TUNING.bucket_image_bytes (default 64 * 1024)
 # contributions per table row of a level below which the atomics win: every bucket costs its image's clear and its slice's
 # write-out whatever it holds (measured, tools/perf_bucket.py: 1.0 per row at the 4096^2 shape: 407 -> 188 us; 0.25 per row at
 # the 8192^2 one: 817 -> 822 us)
-BUCKETED_MIN_DENSITY = 0.5
+# TUNING.bucketed_min_density (default 0.5)
 # ... when the bucketed form WRITES the levels (a fresh gradient buffer: those levels then need no clear — a quarter of the 4 GiB
 # clear at the 8192^2 shape): step 2.83 -> 2.63 ms there although the kernels themselves only draw with the atomics
-BUCKETED_MIN_DENSITY_FRESH = 0.2
-DIRECT_FWD_TILE_ORDER = True   # ... and so does the direct levels' forward gather (gngf_encode_fwd(..., pixel_order))
-BUCKETED_TILE_ORDER = True     # walk the pixels in the tiled form's binned order when a workspace exists (round 5; see bucket_pixel)
+# TUNING.bucketed_min_density_fresh (default 0.2)
+# TUNING.direct_fwd_tile_order (default True)   — ... and so does the direct levels' forward gather (gngf_encode_fwd(..., pixel_order))
+# TUNING.bucketed_tile_order (default True)     — walk the pixels in the tiled form's binned order when a workspace exists (round 5; see bucket_pixel)
 
 
 def bucketed_plan(P, F, T, nl, fresh=False):
     """(bucket_shift, buckets per level, pixel blocks, matrix ints, base ints, item bytes) or None — the library's own decision"""
-    density = BUCKETED_MIN_DENSITY_FRESH if fresh else BUCKETED_MIN_DENSITY
-    if not BUCKETED_DIRECT_BWD or P < BUCKETED_MIN_PIXELS or nl <= 0 or 4.0 * P < density * T:
+    density = TUNING.bucketed_min_density_fresh if fresh else TUNING.bucketed_min_density
+    if not TUNING.bucketed_direct_bwd or P < TUNING.bucketed_min_pixels or nl <= 0 or 4.0 * P < density * T:
         return None
     plan = (_ct.c_int64 * 6)()
-    if query("gngf_encode_bwd_bucketed_plan", int(P), int(F), int(T), int(nl), int(BUCKET_IMAGE_BYTES), plan) != 1:
+    if query("gngf_encode_bwd_bucketed_plan", int(P), int(F), int(T), int(nl), int(TUNING.bucket_image_bytes), plan) != 1:
         return None
     return tuple(int(v) for v in plan)
 
@@ -199,8 +268,8 @@ def _direct_bwd(xy, tables, vert_idx, vert_w, n_ls, genc, dtables, dvw, P, L, F,
     base = torch.empty((plan[4],), dtype=_i32, device=dev)
     items = torch.empty((plan[5],), dtype=torch.uint8, device=dev)
     call("gngf_encode_bwd_bucketed", ptr(xy), ptr(n_ls), ptr(genc, _f32, "grad"), ptr(dtables), P, L, F, T, l0, l1,
-         int(BUCKET_IMAGE_BYTES), 0 if fresh else 1, ptr(matrix), ptr(base), ptr(items),
-         ptr(order if (BUCKETED_TILE_ORDER and order is not None and order.shape[0] == P) else None, _f32, "pixel_order"), stream_ptr())
+         int(TUNING.bucket_image_bytes), 0 if fresh else 1, ptr(matrix), ptr(base), ptr(items),
+         ptr(order if (TUNING.bucketed_tile_order and order is not None and order.shape[0] == P) else None, _f32, "pixel_order"), stream_ptr())
 
 
 # Hash source, staged levels on the generic pixel-stage kernels (the big shapes): the table gradient lives in ONE buffer per model
@@ -215,8 +284,8 @@ def _direct_bwd(xy, tables, vert_idx, vert_w, n_ls, genc, dtables, dvw, P, L, F,
 # says so (`net.dp.persist_ok = True`: train.GraphedStep, train.train_epoch and bench.py do — they let go of every gradient at
 # the top of each step and hand nothing older than the current step to their caller).  A bare `net(x); loss.backward()` gets an
 # allocation per step, like torch.  This module-level switch turns the mechanism off for everybody (A/B measurements).
-PERSISTENT_TABLE_GRAD = True
-PERSISTENT_MIN_BYTES = 1 << 28     # below this a dense clear hidden inside the training decoder (StepLink.zero_hidden) costs next to nothing
+# TUNING.persistent_table_grad (default True)
+# TUNING.persistent_min_bytes (default 1 << 28)     — below this a dense clear hidden inside the training decoder (StepLink.zero_hidden) costs next to nothing
 
 
 def _persistent_peek(dp, tables):
@@ -383,8 +452,8 @@ def expand_vertex_table(xy, n_ls, vstride, NV, src_idx=None, src_val=None, want_
 
 # Logits kept from the forward to the backward of the chunked HPD (see HpdVertexFunction.forward): budget, and the free
 # device memory that must remain after keeping a chunk.
-HPD_Z_CACHE_BYTES = 216 << 30
-HPD_Z_CACHE_RESERVE = 40 << 30
+# TUNING.hpd_z_cache_bytes (default 216 << 30)
+# TUNING.hpd_z_cache_reserve (default 40 << 30)
 
 
 class HpdAux:
@@ -398,26 +467,26 @@ class HpdAux:
 
 # Chunks are software-pipelined over two streams: the T-wide GEMMs (matrix-pipe bound) of one chunk run beside the streaming
 # softmax / top-K / batch-mean passes (HBM bound) of its neighbour.  False: everything in line on the current stream.
-HPD_PIPELINE = True
+# TUNING.hpd_pipeline (default True)
 
 
 # The three T-wide products of the HPD's last layer (logits, dW, dh: 3 x 2 U 128 T FLOP per training step) run on the
 # split-bf16 GEMM (csrc/linear.hip: every fp32 value split exactly into three bf16 terms, six cross products accumulated in
 # fp32; measured error against float64 equal to or below the exact-fp32 MFMA kernel's, 1.2-1.3x its speed).  False: exact
 # fp32 MFMA for these as well.
-HPD_GEMM_SPLIT_BF16 = True
+# TUNING.hpd_gemm_split_bf16 (default True)
 # The logits GEMM leaves per-row (max, sum exp) partials per 64-column block in its epilogue and the row statistics + top-K come
 # out of a merge over them (1/32 of the logits' bytes) instead of a pass over the logits: one of the step's ~8.4 passes over the
 # (U, T) logit matrix less (learning mode is HBM-bound as a whole).  Needs the split-bf16 GEMM and whole 128 x 128 tiles; other
 # chunks (the ragged last one) take the separate statistics pass as before.
-HPD_EPILOGUE_STATS = True
+# TUNING.hpd_epilogue_stats (default True)
 
 
 class _split_gemm:
     """scope in which large aligned GEMMs of this process use the split-bf16 kernel (when HPD_GEMM_SPLIT_BF16)"""
 
     def __enter__(self):
-        self.prev = query("gngf_set_gemm_split_bf16", 1) if HPD_GEMM_SPLIT_BF16 else None
+        self.prev = query("gngf_set_gemm_split_bf16", 1) if TUNING.hpd_gemm_split_bf16 else None
         return self
 
     def __exit__(self, *exc):
@@ -461,7 +530,7 @@ class HpdVertexFunction(torch.autograd.Function):
             mw = _c(mw)
             L = mw.shape[1]
             pbar = torch.zeros((L, T), dtype=_f32, device=dev)
-        pipelined = (HPD_PIPELINE and not keep_probs and NV > rows and not torch.cuda.is_current_stream_capturing())
+        pipelined = (TUNING.hpd_pipeline and not keep_probs and NV > rows and not torch.cuda.is_current_stream_capturing())
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if pipelined else None
         pipelined = pipelined and side is not main and side.stream_id != main.stream_id
@@ -473,7 +542,7 @@ class HpdVertexFunction(torch.autograd.Function):
         # Checkpointing policy sized for 288 GB of HBM: the backward needs every chunk's logits again; the chunks that fit
         # HPD_Z_CACHE_BYTES (and leave HPD_Z_CACHE_RESERVE free on the device) keep theirs, the rest are recomputed.
         zcache, cached = {}, 0
-        keep_z = (not keep_probs) and HPD_Z_CACHE_BYTES > 0 and any(ctx.needs_input_grad[7:])
+        keep_z = (not keep_probs) and TUNING.hpd_z_cache_bytes > 0 and any(ctx.needs_input_grad[7:])
         budget = 0
         # The hidden layers (2 -> 32 -> 64 -> 128 at the reference's widths) are evaluated for ALL vertices in one go, outside the
         # chunk loop, and kept for the backward pass (0.9 KB per vertex): inside the loop they were ~10 launches per chunk of
@@ -486,7 +555,7 @@ class HpdVertexFunction(torch.autograd.Function):
             # AFTER the hidden layers of all NV vertices are allocated (they live until the backward pass), and less the backward's
             # dH (NV x last hidden width): ~1.5 GB at a million vertices that the budget used to hand to the logits
             free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-            budget = min(HPD_Z_CACHE_BYTES, free - HPD_Z_CACHE_RESERVE - NV * W_last.shape[1] * 4)
+            budget = min(TUNING.hpd_z_cache_bytes, free - TUNING.hpd_z_cache_reserve - NV * W_last.shape[1] * 4)
         parts, parts_free, n_parts = None, None, 0          # row partials of the GEMM epilogue (two buffers when pipelined)
         L = mw.shape[1] if mw is not None else 0
         for u0 in range(0, NV, rows):
@@ -509,7 +578,7 @@ class HpdVertexFunction(torch.autograd.Function):
                 if scratch_free[sb] is not None:
                     main.wait_event(scratch_free[sb])
             # statistics in the GEMM's epilogue when the chunk is whole 128 x 128 tiles on the split-bf16 kernel
-            epi = (HPD_EPILOGUE_STATS and HPD_GEMM_SPLIT_BF16 and not keep_probs and n % 128 == 0 and T % 128 == 0
+            epi = (TUNING.hpd_epilogue_stats and TUNING.hpd_gemm_split_bf16 and not keep_probs and n % 128 == 0 and T % 128 == 0
                    and W_last.shape[1] % 32 == 0 and K * 64 <= T and T < (1 << 22))
             if epi:
                 if parts is None:
@@ -589,7 +658,7 @@ class HpdVertexFunction(torch.autograd.Function):
         dz_buf = None
         if lowrank:
             scratch = torch.empty((min(rows, NV) * (1 + K),), dtype=_f32, device=dev)
-        pipelined = HPD_PIPELINE and lowrank and NV > rows and not torch.cuda.is_current_stream_capturing()
+        pipelined = TUNING.hpd_pipeline and lowrank and NV > rows and not torch.cuda.is_current_stream_capturing()
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if pipelined else None
         pipelined = pipelined and side.stream_id != main.stream_id
@@ -792,7 +861,7 @@ class TableViewFunction(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ tiled encoder
-ENCODE_PATH = "auto"        # "auto" | "direct" | "tiled"  (tests force a path; auto = tiled when it pays)
+# TUNING.encode_path (default "auto")        — "auto" | "direct" | "tiled"  (tests force a path; auto = tiled when it pays)
 
 
 class BinPipeline:
@@ -941,14 +1010,14 @@ class StepLink:
             return
         with torch.cuda.stream(r["stream_obj"]):
             call("gngf_mse_fwd", ptr(r["pred"]), ptr(r["label"]), ptr(r["loss"]), ptr(r["ws"]), r["pred"].numel(), stream_ptr())
-TILED_CHUNK = None          # max pixels per (tile, chunk) work item; None: about two average tiles' worth (see EncodePlan)
-TILED_MIN_PIXELS = 1 << 14  # below this the binning overhead is not worth it
+# TUNING.tiled_chunk (default None)          — max pixels per (tile, chunk) work item; None: about two average tiles' worth (see EncodePlan)
+# TUNING.tiled_min_pixels (default 1 << 14)  — below this the binning overhead is not worth it
 # a level is staged while N_l^2 <= this * P (sparser levels: direct form).  Measured at the cfg4 shape (2^20 px, N -> 4095):
 # 8 also stages the level with 7.6 cells per pixel — its direct backward drops 412 -> 210 us but the vertex stage and the dense
 # per-item images of that level cost more (step 1.43 -> 1.58 ms)
-TILED_CELLS_PER_PIXEL = 4.0
-TILED_LDS_LIMIT = 48 * 1024    # forward image; the backward image (64-bit accumulators) is twice this
-TILED_TILE_SHIFT_BIAS = 0      # +1: four times as many (smaller) spatial tiles as "<= 16 cells of the finest staged level per tile side"
+# TUNING.tiled_cells_per_pixel (default 4.0)
+# TUNING.tiled_lds_limit (default 48 * 1024)    — forward image; the backward image (64-bit accumulators) is twice this
+# TUNING.tiled_tile_shift_bias (default 0)      — +1: four times as many (smaller) spatial tiles as "<= 16 cells of the finest staged level per tile side"
 
 
 class EncodePlan:
@@ -956,15 +1025,15 @@ class EncodePlan:
     grid, LDS budget, workspace sizes.  Pure integer arithmetic (unit-tested on CPU)."""
 
     def __init__(self, P, n_ls_host, F, path=None):
-        path = path or ENCODE_PATH
+        path = path or TUNING.encode_path
         self.P, self.F = int(P), int(F)
         self.n_ls_host = [int(n) for n in n_ls_host]
         L = len(self.n_ls_host)
         self.L = L
         Ls = 0
-        if path != "direct" and (path == "tiled" or P >= TILED_MIN_PIXELS):
+        if path != "direct" and (path == "tiled" or P >= TUNING.tiled_min_pixels):
             for n in self.n_ls_host:          # resolutions ascend: stage the leading levels that are dense enough
-                dense_enough = n * n <= TILED_CELLS_PER_PIXEL * max(P, 1)
+                dense_enough = n * n <= TUNING.tiled_cells_per_pixel * max(P, 1)
                 small_enough = (n + 2) * (n + 2) * F * 4 <= (64 << 20)
                 if dense_enough and small_enough:
                     Ls += 1
@@ -974,15 +1043,15 @@ class EncodePlan:
         if Ls == 0:
             return
         nmax = max(self.n_ls_host[:Ls])
-        shift = max(0, min(6, int(_math.ceil(_math.log2(max(nmax / 16.0, 1.0)))) + TILED_TILE_SHIFT_BIAS))
+        shift = max(0, min(6, int(_math.ceil(_math.log2(max(nmax / 16.0, 1.0)))) + TUNING.tiled_tile_shift_bias))
         while True:
             TS = 1 << shift
             lds = sum((n // TS + 3) ** 2 for n in self.n_ls_host[:Ls]) * F * 4
-            if lds <= TILED_LDS_LIMIT or shift == 6:
+            if lds <= TUNING.tiled_lds_limit or shift == 6:
                 break
             shift += 1
-        if lds > TILED_LDS_LIMIT:      # drop the finest staged levels until the sub-grids fit
-            while Ls > 0 and sum((n // TS + 3) ** 2 for n in self.n_ls_host[:Ls]) * F * 4 > TILED_LDS_LIMIT:
+        if lds > TUNING.tiled_lds_limit:      # drop the finest staged levels until the sub-grids fit
+            while Ls > 0 and sum((n // TS + 3) ** 2 for n in self.n_ls_host[:Ls]) * F * 4 > TUNING.tiled_lds_limit:
                 Ls -= 1
             self.Ls = Ls
             if Ls == 0:
@@ -994,12 +1063,12 @@ class EncodePlan:
         # one work item per tile for the typical tile (an item that is a sliver of a split tile still stages every
         # sub-grid): twice the mean pixels per tile, as a power of two in [1024, 4096].  Measured at 2^20 px / 1024 tiles:
         # chunk 1024 -> 0.70 ms per step, 2048..4096 -> 0.67 ms (tools/ab_chunk.py).
-        if TILED_CHUNK is not None:
-            self.chunk = int(TILED_CHUNK)
+        if TUNING.tiled_chunk is not None:
+            self.chunk = int(TUNING.tiled_chunk)
         else:
             want = 2 * max(1, -(-P // self.ntiles))
             self.chunk = min(4096, max(1024, 1 << (want - 1).bit_length()))
-        self.NB = max(1, min(BIN_BLOCKS_MAX, -(-P // BIN_PIXELS_PER_BLOCK)))        # more binning workgroups do not help (measured: tools/perf_bin.py)
+        self.NB = max(1, min(TUNING.bin_blocks_max, -(-P // TUNING.bin_pixels_per_block)))        # more binning workgroups do not help (measured: tools/perf_bin.py)
         self.max_items = -(-P // self.chunk) + self.ntiles
         self.vtot = sum((n + 2) ** 2 for n in self.n_ls_host[:Ls])
         self.n_ls_c = (_ct.c_int32 * L)(*self.n_ls_host)
@@ -1018,9 +1087,9 @@ class EncodePlan:
                           int(bool(backward))))
 
 
-BIN_BLOCKS_MAX = 128            # binning workgroups: more do not help (measured: tools/perf_bin.py, tools/perf_overlap.py)
-BIN_PIXELS_PER_BLOCK = 8192
-TWO_LAUNCH_BINNING = True     # count -> scatter (the scans ride inside the scatter launch) when the launch carries no gradient clear
+# TUNING.bin_blocks_max (default 128)            — binning workgroups: more do not help (measured: tools/perf_bin.py, tools/perf_overlap.py)
+# TUNING.bin_pixels_per_block (default 8192)
+# TUNING.two_launch_binning (default True)     — count -> scatter (the scans ride inside the scatter launch) when the launch carries no gradient clear
 _BIN_WORKSPACES = {}
 
 
@@ -1087,7 +1156,7 @@ class TiledWorkspace:
                      ptr(self.tile_off), ptr(self.tile_item_base), ptr(self.items), ptr(self.n_items), ptr(self.sorted),
                      *_tab(tables), ptr(vert_idx), ptr(vert_w), ptr(n_ls), plan.n_ls_c, ptr(G), ptr(zero_dG), int(zero_dG_words), plan.Ls, F, T,
                      0 if vert_idx is None else vert_idx.shape[1], mode, vstride, 0 if vert_idx is None else vert_idx.shape[0],
-                     ptr(zero), 0 if zero is None else zero.numel(), ptr(_bin_workspace(dev, plan.ntiles, owner) if TWO_LAUNCH_BINNING else None),
+                     ptr(zero), 0 if zero is None else zero.numel(), ptr(_bin_workspace(dev, plan.ntiles, owner) if TUNING.two_launch_binning else None),
                      ptr(clear_rows if vert_idx is None else None, _f32, "clear_rows"), stream_ptr())
             except Exception:
                 # the count launch may have run without the scatter launch that puts the persistent counters back to zero: the
@@ -1174,21 +1243,22 @@ def tile_level_offsets(plan, device):
     return hit
 
 
-HASH_VERTEX_FUSION = True    # hash indexing, single rank: the vertex stage backward rides on the gather pass of the pixel stage
+# TUNING.hash_vertex_fusion (default True)    — hash indexing, single rank: the vertex stage backward rides on the gather pass of the pixel stage
 
 
 # The kernel chain of one training step at the headline shape, as a string that changes whenever the chain does: PMC traffic
 # figures (profiles/traffic.json) are stamped with it and bench.py reports them only for the chain they were measured on.
 STEP_CHAIN_SIGNATURE = "r5: [bin_count_ride+bin_scatter2 | riders of the previous step] > tiled_fwd_il<SRC tables>(+count riders) > decoder_train > tiled_bwd_il(+scatter tasks, reduce, mse)<hash: HDT, table rows added by the store pass> [> vertex_bwd_sorted<FROM64> (vertex-table source)]"
-FUSED_VERTEX_FWD = True      # fp32 tables on the interleaved forward kernel: the vertex stage forward runs inside its staging loop
-BIN_PIPELINE = True          # ... and an announced next batch (BinPipeline) is binned by riders of this step's pixel-stage launches
-DG64 = True                  # F = 2, <= 16 staged levels, bounded |genc|: 64-bit fixed-point vertex grid fed by global integer atomics
-# Round 5, spatial-hash source on a single rank (no exchange): the interleaved pixel-stage backward adds its items' exact sums —
-# rounded to fp32 once per item and vertex — straight to the table-gradient rows hash(gx, gy): no fixed-point vertex grid (nothing to
-# clear, nothing to convert) and no vertex-stage launch behind the kernel (vertex_bwd_hash64: 10.7 us of the 396 us hash step).  Same
-# number of memory-side atomic requests as the adds into the fixed-point grid.  False: fixed-point grid + vertex_bwd_hash64 (round 4).
-HASH_DIRECT_SCATTER = True
-VERTEX_READS_DG64 = True     # ... and the slot-ordered vertex backward converts it on the fly (False: dg64_to_float first)
+# TUNING.fused_vertex_fwd (default True)      — fp32 tables on the interleaved forward kernel: the vertex stage forward runs inside its staging loop
+# TUNING.bin_pipeline (default True)          — ... and an announced next batch (BinPipeline) is binned by riders of this step's pixel-stage launches
+# TUNING.dg64 (default True)                  — F = 2, <= 16 staged levels, bounded |genc|: 64-bit fixed-point vertex grid fed by global integer atomics
+# Round 5, spatial-hash source on a single rank (no exchange): the pixel-stage backward (level-interleaved AND generic kernels) adds
+# its items' exact sums — rounded to fp32 once per item and vertex — straight to the table-gradient rows hash(gx, gy): no vertex grid
+# (nothing to clear, nothing to convert), no vertex-stage launch behind the interleaved kernel (vertex_bwd_hash64: 10.7 us of the
+# 396 us hash step) and no partial images + gather pass behind the generic one (gather_partials: 121 / 245 us at the 4096^2 / 8192^2
+# shapes).  False: round 4's chains (fixed-point grid + vertex_bwd_hash64; partial images + gather_partials<HASHFUSE>).
+# TUNING.hash_direct_scatter (default True)
+# TUNING.vertex_reads_dg64 (default True)     — ... and the slot-ordered vertex backward converts it on the fly (False: dg64_to_float first)
 
 
 PIXEL_BWD_TRACE = None       # tests: a list that receives one record per pixel-stage backward launch (which chain ran)
@@ -1200,7 +1270,7 @@ def _pixel_bwd(plan, ws, n_ls, genc, dG, L, F, absmax=None, link=None, hash_fuse
     if PIXEL_BWD_TRACE is not None:
         PIXEL_BWD_TRACE.append({"P": plan.P, "Ls": plan.Ls, "bound": absmax is not None, "dG64": dG64 is not None and absmax is not None,
                                 "hash_fuse": hash_fuse is not None, "fp32_grid": dG is not None,
-                                "direct_hash": hash_fuse is not None and dG is None and dG64 is None and absmax is not None,
+                                "direct_hash": hash_fuse is not None and dG is None and dG64 is None,
                                 "interleaved": plan.interleaved(backward=True)})
     partials = torch.empty((plan.max_items * (plan.lds_bytes // 4),), dtype=_f32, device=genc.device)
     am, am_count, am_stride = absmax if absmax is not None else (None, 0, 0)
@@ -1264,7 +1334,7 @@ def _vertex_bwd(plan, tables, vert_idx, vert_w, n_ls, vstride, dG, dtables, dvw,
 
 
 _SIDE_STREAMS = {}
-USE_SIDE_STREAM = True      # False: helper-stream work is issued in line on the current stream (measurement)
+# TUNING.use_side_stream (default True)      — False: helper-stream work is issued in line on the current stream (measurement)
 
 
 def _side_stream(device):
@@ -1273,7 +1343,7 @@ def _side_stream(device):
     # one helper per (device, main stream): a helper that has exchanged events with the legacy default stream must not
     # later join a hipGraph capture started on another stream (hipStreamEndCapture crashed on exactly that history:
     # tools/dbg_graphed.py), and two main streams must not serialise through one shared helper anyway
-    if not USE_SIDE_STREAM:
+    if not TUNING.use_side_stream:
         return torch.cuda.current_stream(device)
     key = (device.type, device.index, torch.cuda.current_stream(device).stream_id)
     if key not in _SIDE_STREAMS:
@@ -1308,11 +1378,11 @@ class EncodeFunction(torch.autograd.Function):
         clear_now = None
         if plan.Ls > 0 and P > 0:
             dev = tables.device
-            pws = _bin_workspace(dev, plan.ntiles, dp, kind="reserve") if (TWO_LAUNCH_BINNING and FUSED_VERTEX_FWD) else None
+            pws = _bin_workspace(dev, plan.ntiles, dp, kind="reserve") if (TUNING.two_launch_binning and TUNING.fused_vertex_fwd) else None
             # fp32 tables on the level-interleaved kernel: the vertex stage forward runs INSIDE the pixel stage's staging loop (no
             # vertex grid G, no vertex riders) and the binning is two launches of its own — or none, when the previous step's
             # launches carried it (BinPipeline)
-            fused = (FUSED_VERTEX_FWD and pws is not None and pws.numel() >= 2 * plan.ntiles + 3 and tables.dtype == _f32
+            fused = (TUNING.fused_vertex_fwd and pws is not None and pws.numel() >= 2 * plan.ntiles + 3 and tables.dtype == _f32
                      and F == 2 and plan.interleaved(backward=False))
             use64 = False
             big = None
@@ -1321,11 +1391,10 @@ class EncodeFunction(torch.autograd.Function):
                 # fixed-point sums straight into a 64-bit vertex grid (cleared here; + scale and poison words), no gather pass
                 # (the launcher decides whether that kernel runs — e.g. not at the 4096^2 shape, whose interleaved image exceeds
                 # the LDS: the generic kernels accumulate into a ZEROED fp32 grid instead)
-                use64 = DG64 and F == 2 and plan.Ls <= 16 and plan.interleaved(backward=True)
+                use64 = TUNING.dg64 and F == 2 and plan.Ls <= 16 and plan.interleaved(backward=True)
                 # hash source, single rank: no vertex-grid gradient at all when the interleaved backward adds to the table gradient
                 # itself (decided again in backward: it needs the bound on |d enc| that only the backward pass can see)
-                ctx.direct_hash = bool(HASH_DIRECT_SCATTER and HASH_VERTEX_FUSION and use64 and mode == MODE_HASH and link is not None
-                                       and (dp is None or dp.exchange is None))
+                ctx.direct_hash = bool(TUNING.hash_direct_scatter and TUNING.hash_vertex_fusion and mode == MODE_HASH and (dp is None or dp.exchange is None))
                 nt = tables.numel()
                 if fused and nt % 4 == 0:
                     # ONE allocation [table gradient | vertex-grid gradient]: whoever clears the table gradient — the fused
@@ -1336,9 +1405,8 @@ class EncodeFunction(torch.autograd.Function):
                     pre = [big[:nt].view(tables.shape), dgrid, big, big]
                 else:
                     fused = False
-                    ctx.direct_hash = False
-                    dgrid = (torch.empty((plan.vtot * F + 2,), dtype=_i64, device=dev) if use64
-                             else torch.empty((plan.vtot, F), dtype=_f32, device=dev))
+                    dgrid = None if ctx.direct_hash else (torch.empty((plan.vtot * F + 2,), dtype=_i64, device=dev) if use64
+                                                          else torch.empty((plan.vtot, F), dtype=_f32, device=dev))
                     # direct levels whose backward WRITES every row (the bucketed form) are left out of the clear
                     fresh = plan.Ls < L and mode == MODE_HASH and bucketed_plan(P, F, T, L - plan.Ls, True) is not None
                     ctx.fresh_direct = fresh
@@ -1347,8 +1415,8 @@ class EncodeFunction(torch.autograd.Function):
                     # (not for small tables where the training decoder clears the buffer between its MFMAs at next to no cost;
                     # at the 4096^2 shape that hidden clear of 448 MB costs the decoder 36 us — a draw against a sparse-clear
                     # LAUNCH of 7.3 M rows, a loss against the same clear riding on the vertex riders: tools/ab_persist_cfg4.sh)
-                    hidden = link is not None and link.defer_zero and link.zero_hidden and tables.numel() * 4 <= PERSISTENT_MIN_BYTES
-                    ctx.persist = bool(PERSISTENT_TABLE_GRAD and not hidden and mode == MODE_HASH and dp is not None and dp.persist_ok
+                    hidden = link is not None and link.defer_zero and link.zero_hidden and tables.numel() * 4 <= TUNING.persistent_min_bytes
+                    ctx.persist = bool(TUNING.persistent_table_grad and not hidden and mode == MODE_HASH and dp is not None and dp.persist_ok
                                        and dp.exchange is None
                                        and getattr(dp, "level_params", None) and (fresh or plan.Ls == L)
                                        and (getattr(dp, "persist_grad", None) is not None or not torch.cuda.is_current_stream_capturing()))
@@ -1367,7 +1435,7 @@ class EncodeFunction(torch.autograd.Function):
             if defer:
                 link.zero_request = zbuf
             if fused:
-                pipe = dp.pipeline if (dp is not None and BIN_PIPELINE) else None
+                pipe = dp.pipeline if (dp is not None and TUNING.bin_pipeline) else None
                 if pipe is not None and pipe.pending is not None:
                     # a count half whose scatter half never ran (a forward pass without its backward pass): nothing to repair —
                     # the cursors run on from job to job and the abandoned job noted where its successor starts
@@ -1399,7 +1467,7 @@ class EncodeFunction(torch.autograd.Function):
                 # and the clears ride on the binning kernels as extra workgroups: ops.TiledWorkspace)
                 G = torch.empty((plan.vtot, F), dtype=_f32, device=dev)
                 ws = TiledWorkspace(plan, xy, vertex=(tables, vert_idx, vert_w, n_ls, vstride, G),
-                                    zero_dG=(pre[1].view(_f32) if use64 else pre[1]) if (pre and pre[1] is not None) else None,
+                                    zero_dG=(pre[1].view(_f32) if pre[1].dtype == _i64 else pre[1]) if (pre and pre[1] is not None) else None,
                                     zero=(pre[3] if (pre and pre[3] is not None and not defer) else None),
                                     zero_dG_words=(2 if use64 else 1), owner=dp, clear_rows=clear_now)
                 call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), plan.n_ls_c,
@@ -1407,7 +1475,7 @@ class EncodeFunction(torch.autograd.Function):
         if plan.Ls < L:
             call("gngf_encode_fwd", ptr(xy, _f32, "xy"), *_tab(tables), ptr(vert_idx, _i32, "vert_idx"),
                  ptr(vert_w, _f32, "vert_w"), ptr(n_ls, _i32, "n_ls"), ptr(enc), P, L, F, T, K, mode, vstride, NV, plan.Ls, L,
-                 ptr(ws.sorted if (DIRECT_FWD_TILE_ORDER and ws is not None) else None, _f32, "pixel_order"), stream_ptr())
+                 ptr(ws.sorted if (TUNING.direct_fwd_tile_order and ws is not None) else None, _f32, "pixel_order"), stream_ptr())
         ctx.save_for_backward(xy, n_ls, tables, vert_idx, vert_w, order)
         ctx.cfg = (P, L, F, T, K, mode, vstride, NV, plan, ws)
         ctx.pre = pre                                           # zero-filled (dtables, dG), consumed by the first backward
@@ -1450,15 +1518,15 @@ class EncodeFunction(torch.autograd.Function):
                 dG64 = None
             if dG64 is not None and not plan.interleaved(backward=True):
                 dG64 = None                                     # gngf_set_tiled_interleaved changed since the forward pass: fp32 path
-            fuse = (dtables, T) if (HASH_VERTEX_FUSION and vert_idx is None and exchange is None) else None
+            fuse = (dtables, T) if (TUNING.hash_vertex_fusion and vert_idx is None and exchange is None) else None
             # the forward pass planned for it (no vertex-grid gradient was allocated) and the conditions still hold: the pixel stage
-            # adds to the table gradient itself.  Otherwise (no bound arrived, the interleaved switch changed): partial images +
-            # gather pass with the hash fused in, on a vertex grid allocated here
-            direct_hash = bool(getattr(ctx, "direct_hash", False) and pre and fuse is not None and absmax is not None
-                               and plan.interleaved(backward=True))
+            # — level-interleaved or generic kernel, with or without a bound on |d enc| — adds to the table gradient itself.
+            # Otherwise (a second backward pass through the same graph): partial images + gather pass with the hash fused in, on a
+            # vertex grid allocated here
+            direct_hash = bool(getattr(ctx, "direct_hash", False) and pre and fuse is not None)
             # vertex-table source in slot order, single rank, no d w: the vertex stage reads the fixed-point grid itself (no
             # fp32 copy of the vertex-grid gradient, no conversion launch)
-            direct64 = (dG64 is not None and VERTEX_READS_DG64 and vert_idx is not None and order is not None and exchange is None
+            direct64 = (dG64 is not None and TUNING.vertex_reads_dg64 and vert_idx is not None and order is not None and exchange is None
                         and dvw is None)
             dG = None if (direct64 or direct_hash) else (pre[1] if (pre and pre[1] is not None and pre[1].dtype == _f32) else
                                                          (torch.empty if dG64 is not None else torch.zeros)((plan.vtot, F), dtype=_f32, device=tables.device))
@@ -1586,12 +1654,12 @@ def js_kl_rows(pbar, gamma, eps):
 # Keep the decoder's activated hidden layers (512 B / pixel) from forward to backward instead of recomputing them: the
 # stores and loads ride under the MFMAs of kernels that leave most of the HBM bandwidth unused (decoder backward 345 -> ~230 us
 # at 2^20 px).  False: recompute (no extra memory).
-DECODER_SAVE_HIDDEN = True
+# TUNING.decoder_save_hidden (default True)
 # The slab reduction of the decoder backward (8 us + a launch gap of ~6 us inside a replayed step) rides on the NEXT launch of
 # the backward pass — the tiled encoder backward, which comes right behind it and only needs max |d enc| (taken from the
 # slabs' last words) — as extra workgroups of that kernel.  If no tiled encoder backward follows, the reduction is launched
 # on its own when the backward pass ends.
-DECODER_REDUCE_RIDES = True
+# TUNING.decoder_reduce_rides (default True)
 
 def _at_end_of_backward(fn):
     """Runs fn when the running backward pass ends (autograd engine callback); outside a backward pass (a Function's
@@ -1607,10 +1675,10 @@ def _at_end_of_backward(fn):
 # The promise is CHECKED ON THE DEVICE by the consumers of the results (csrc/gngf_common.h::promise_broken: the slab reduction
 # and the tiled encoder backward compare the promised scalar with the gradient autograd delivers, no synchronisation, always
 # on): a broken promise turns every gradient of the step into NaN instead of handing over gradients for the wrong value.
-DECODER_TRAIN_FUSION = True
+# TUNING.decoder_train_fusion (default True)
 # Without the training kernel (64 input features) the BACKWARD kernel of the two-kernel path clears the encoder's table-gradient
 # buffer on the way, instead of rider workgroups of the binning launch (4 GiB at BASELINE config 5: 0.69 ms of a 2.9 ms step there)
-DECODER_BWD_CLEARS = True
+# TUNING.decoder_bwd_clears (default True)
 _GLOSS_SCALARS = {}
 
 
@@ -1638,9 +1706,9 @@ def _decoder_fwd(ctx, enc, leaky, ws, target, gloss_known=None, link=None):
     rgb = torch.empty((P, out_dim), dtype=_f32, device=dev)
     hidden = None
     ctx.train = None
-    train = (DECODER_TRAIN_FUSION and gloss_known is not None and target is not None and in_dim == 32 and P > 0
-             and DECODER_REDUCE_RIDES and any(ctx.needs_input_grad))
-    if DECODER_SAVE_HIDDEN and P > 0 and any(ctx.needs_input_grad) and not train:
+    train = (TUNING.decoder_train_fusion and gloss_known is not None and target is not None and in_dim == 32 and P > 0
+             and TUNING.decoder_reduce_rides and any(ctx.needs_input_grad))
+    if TUNING.decoder_save_hidden and P > 0 and any(ctx.needs_input_grad) and not train:
         hidden = torch.empty((_lib.query("gngf_decoder_hidden_floats", P),), dtype=_f32, device=dev)
     if target is not None:
         if P == 0:
@@ -1753,10 +1821,10 @@ def _decoder_bwd(ctx, drgb, gloss):
     # the encoder's table-gradient buffer, if it was left for a decoder kernel to clear (StepLink.defer_zero) and the training
     # kernel did not run (64 input features: BASELINE config 5): this launch clears it between its MFMAs
     zr = None
-    if DECODER_BWD_CLEARS and link.zero_request is not None and link.zero_request.numel() % 4 == 0:
+    if TUNING.decoder_bwd_clears and link.zero_request is not None and link.zero_request.numel() % 4 == 0:
         zr, link.zero_request = link.zero_request, None
     zargs = (ptr(zr), 0 if zr is None else zr.numel())
-    if DECODER_REDUCE_RIDES and P > 0:
+    if TUNING.decoder_reduce_rides and P > 0:
         call("gngf_decoder_bwd", *common, *[ptr(None)] * 6, ptr(slabs), ptr(None), ptr(ctx.hidden), *zargs, P, in_dim, out_dim, leaky, stream_ptr())
         _schedule_reduce(ctx, link, dev, slabs, flat, grads, P, in_dim, out_dim)
         hint = (slabs[nslab - 1:], nslabs, nslab)         # the per-slab maxima: all the encoder backward needs from the slabs

@@ -468,6 +468,26 @@ def test_fixed_point_vertex_grid_is_exact_and_order_free(ops, P, coords):
     print(f"[direct hash scatter {P} {coords}] worst |err| / row mass vs the exact per-vertex sums: {worst:.2e}")
     assert worst <= 2e-6, worst
     close(dt_h, dt_a.cpu().numpy(), 1e-5, 2e-6 * float(dt_a.abs().max()), "hash table gradient added by the store pass (no vertex grid) vs from the fixed-point grid")
+    # ... and the same through the GENERIC pixel-stage kernel (tiled_bwd_kernel<F, HDT>: what the 4096^2 / 8192^2 shapes run), with
+    # and without a bound on |genc| (per-item scales: float adds need no common one)
+    from collision_handling_in_instantngp_amd import _lib
+    prev_il = _lib.query("gngf_set_tiled_interleaved", 0)
+    try:
+        for bound in ((am, 1, 0), None):
+            dt_g = torch.zeros((L, T, Fd), dtype=torch.float32, device=DEV)
+            trace = []
+            prev_trace, ops.PIXEL_BWD_TRACE = ops.PIXEL_BWD_TRACE, trace
+            try:
+                ops._pixel_bwd(plan, ws, n_t, genc, None, L, Fd, bound, None, (dt_g, T), None)
+            finally:
+                ops.PIXEL_BWD_TRACE = prev_trace
+            assert trace and trace[0]["direct_hash"] and not trace[0]["interleaved"], trace
+            errg = (dt_g.double() - dt_a.double()).abs()
+            assert bool(((mass == 0) <= (dt_g == 0)).all())
+            worst_g = float((errg[mass > 0] / mass[mass > 0].double()).max())
+            assert worst_g <= 2e-6, (worst_g, bound is not None)
+    finally:
+        _lib.query("gngf_set_tiled_interleaved", prev_il)
     dt_n = torch.zeros((L, T, Fd), dtype=torch.float32, device=DEV)
     ops._pixel_bwd(plan, ws, n_t, genc, None, L, Fd, (torch.full((1,), float("nan"), device=DEV), 1, 0), None, (dt_n, T), None)
     hit = dt_a != 0
