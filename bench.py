@@ -493,6 +493,9 @@ def main():
             dt = timed(step, steps // per, -(-warmup // per), world)       # exactly `steps` steps: steps / per replays of `per` steps each
             res = results[mode] = {"mpix_s": P * world * steps / dt / 1e6, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                                    "launch": launch, "shape": {k: v for k, v in SHAPES[cfg_name].items()}}
+            sc_ = getattr(net.dp, "step_config", None)
+            res["step_config"] = sc_.signature() if sc_ is not None else None      # the kernel chain this mode's steps took (ops.StepConfig)
+            res["step_chain"] = sc_.chain() if sc_ is not None else None
             if world > 1:
                 res["ms_per_step_per_rank"] = [t_ / steps * 1e3 for t_ in LAST_PER_RANK]
             if not learning:
@@ -664,6 +667,10 @@ def main():
                                           "(DESIGN.md section 3)"}
                 return {"bound": "mfma", "kernel": name, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc(name),
+                        # matrix pipes busy (SQ_VALU_MFMA_BUSY_CYCLES / 4 SQ_BUSY_CU_CYCLES, the round's SQ pass through
+                        # profiles/traffic.json): `frac` prices fp32-ACCURATE arithmetic, part of which runs on the 16x faster bf16
+                        # pipe — it is not "the matrix pipes are frac busy"
+                        "mfma_busy": (traffic.get(name) or {}).get("mfma_busy"),
                         "avg_launch_ms": t * 1e3, "algorithmic_flops_per_pixel": fl, "pixels_per_launch": P, "note": notes[base]}
             return None
 
@@ -694,7 +701,7 @@ def main():
                                                           if MODES[a.mode] in ("cfg2", "cfg3") else f"synthetic {c['image']}^2 image, L={L} F={F} T={c['T']} N {c['n_min']}->{c['n_max']}")
                                    + f", {a.mode} indexing, random-init weights, MSE loss, fwd+bwd (no optimizer)",
                        "mode": a.mode, "pixels_per_gpu": P, "parallelism": f"dp{world}",
-                       "untimed_ramp_steps_before_warmup": a.ramp_steps, "launch": head["launch"]},
+                       "untimed_ramp_steps_before_warmup": a.ramp_steps, "launch": head["launch"], "step_config": head.get("step_config")},
             "collective_ranks": collective_ranks, "rccl_ranks": (collective_ranks if (world > 1 and a.backend == "nccl") else None),
             "backend": (a.backend if world > 1 else None),
             "modes": results, "kernel_ms": {k: (v * 1e3 if isinstance(v, float) else v) for k, v in kt.items()},

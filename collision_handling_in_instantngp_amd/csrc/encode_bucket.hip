@@ -17,7 +17,14 @@
 //   bucket_sum       per (level, bucket): max |term| and the fullest row's number of terms n -> scale 2^S,
 //                    S = min(50, 61 - ceil log2 n) - exponent - 1 (no overflow; quantum 2^-50 of the bucket's largest term up to
 //                    2048 terms per row); integer adds (order-free: the result is bitwise reproducible, which the float atomics
-//                    were not); one rounding to fp32 at the end.  A bucket that holds a non-finite term is summed in fp32
+//                    were not); one rounding to fp32 at the end.
+//                    ACCURACY, stated as what it is: the bound is ABSOLUTE per bucket — every term is rounded to a
+//                    multiple of q = 2^-50 (2^-(61 - ceil log2 n) above 2048 terms per row) of the bucket's LARGEST |term|, so a
+//                    row's error is <= (its terms) * q / 2 + half an fp32 ulp of its sum.  A row whose terms are all below q / 2
+//                    of a term elsewhere in the same 4096-row (F = 2) bucket comes out as 0, where fp32 atomics would have kept it
+//                    at fp32 relative precision: 15 decimal orders below the bucket's largest term (tests/test_gpu_bucket.py::
+//                    test_a_tiny_row_next_to_a_large_one_in_the_same_bucket).  Against the double-precision sum of the same
+//                    terms the result is within half an fp32 ulp + that quantum.  A bucket that holds a non-finite term is summed in fp32
 //                    (NaN / inf propagate to the rows they belong to, as with atomics).
 // + gngf_clear_hashed_rows: the sparse clear of a table gradient that lives from step to step (ops.PERSISTENT_TABLE_GRAD).
 #include "gngf_common.h"
@@ -368,14 +375,25 @@ bucket_sum_kernel(const void* __restrict__ items, int64_t total, const int32_t* 
 #pragma unroll
     for (int f = 0; f < F; ++f) r[f] = (float)((double)(long long)bk_img[k * F + f] * inv);
     float* o = out + (int64_t)k * F;
+    // (write mode: the slice is written once and read next by the optimizer, a whole step later — streamed past the caches)
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef float f4v __attribute__((ext_vector_type(4)));
     if constexpr (F == 2) {
-      float2 t = accumulate ? *reinterpret_cast<float2*>(o) : make_float2(0.f, 0.f);
-      t.x += r[0]; t.y += r[1];
-      *reinterpret_cast<float2*>(o) = t;
+      if (accumulate) {
+        float2 t = *reinterpret_cast<float2*>(o);
+        t.x += r[0]; t.y += r[1];
+        *reinterpret_cast<float2*>(o) = t;
+      } else {
+        __builtin_nontemporal_store((f2v){r[0], r[1]}, reinterpret_cast<f2v*>(o));
+      }
     } else if constexpr (F == 4) {
-      float4 t = accumulate ? *reinterpret_cast<float4*>(o) : make_float4(0.f, 0.f, 0.f, 0.f);
-      t.x += r[0]; t.y += r[1]; t.z += r[2]; t.w += r[3];
-      *reinterpret_cast<float4*>(o) = t;
+      if (accumulate) {
+        float4 t = *reinterpret_cast<float4*>(o);
+        t.x += r[0]; t.y += r[1]; t.z += r[2]; t.w += r[3];
+        *reinterpret_cast<float4*>(o) = t;
+      } else {
+        __builtin_nontemporal_store((f4v){r[0], r[1], r[2], r[3]}, reinterpret_cast<f4v*>(o));
+      }
     } else {
       o[0] = (accumulate ? o[0] : 0.f) + r[0];
     }

@@ -127,6 +127,7 @@ def table_view(owner):
 
 
 STEP_TRACE = None            # tests: a list that receives one (what, {facts}) record per dispatch decision of a backward pass
+SEEN_STEP_CONFIGS = None     # tests: a set that receives StepConfig.chain() of every forward pass (tests/conftest.py records it per test)
 
 
 def _trace(what, **facts):
@@ -225,7 +226,9 @@ class BilinearFunction(torch.autograd.Function):
 
 # Backward of the direct levels, hash source: above BUCKETED_MIN_PIXELS the contributions are counting-sorted by table slice and summed
 # in LDS images (csrc/encode_bucket.hip) instead of one memory-side atomic each (20.6 G row updates/s on this chip wherever the rows
-# lie: tools/micro/atomic_window.cpp).  Bitwise reproducible; the terms are the same fp32 products, summed exactly, rounded once.
+# lie: tools/micro/atomic_window.cpp).  Bitwise reproducible; the terms are the same fp32 products, summed
+# in 64-bit fixed point whose quantum is 2^-50 of the BUCKET's largest |term| (an absolute bound per bucket: a row 15 decimal orders
+# below a neighbour in the same bucket is flushed — csrc/encode_bucket.hip's header), rounded to fp32 once.
 # TUNING.bucketed_direct_bwd (default True)
 # TUNING.bucketed_min_pixels (default 1 << 16)
 # TUNING.bucket_image_bytes (default 64 * 1024)
@@ -939,6 +942,8 @@ class DataParallel:
         self.persist_grad = None        # the step-to-step table-gradient buffer (ops.PERSISTENT_TABLE_GRAD)
         self.persist_gen = 0            # ... and how often it has been handed to a backward pass (or re-allocated)
         self.pipeline = BinPipeline()   # the next batch's binning riding on this step's pixel-stage launches
+        self.step_config = None         # the StepConfig of the model's most recent forward pass through the fused encoder
+        self.zero = None                # parallel.shard_direct_levels: this rank's share of the direct levels' rows
         self.world = 1
         self.group = None
 
@@ -1351,6 +1356,74 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+@_dc.dataclass(frozen=True)
+class StepConfig:
+    """The kernel chain ONE forward / backward pair of the fused encoder takes — decided ONCE, at the top of the forward pass
+    (StepConfig.choose: a pure function of the plan, the index source, the table dtype, what the decoder of the same pass will do
+    with the gradient buffer, the model's data-parallel state and ops.TUNING), recorded on the model (`net.dp.step_config`), in
+    ops.STEP_TRACE and in bench.py's line (`config.step_config`).  forward() and backward() read it instead of re-deriving it.
+    What only the backward pass can know (did a bound on |d enc| arrive? is this a second backward through the same graph?) can
+    DEMOTE the planned chain to the general one (partial images + gather pass, zeroed allocations); that is traced too
+    ("pixel_bwd" records of PIXEL_BWD_TRACE).  tests/test_step_config_cpu.py enumerates the reachable configurations and names
+    the GPU parity test that runs each."""
+    source: str            # "hash" | "vertex_table"
+    staged: int            # levels in the tiled form (plan.Ls); 0: direct form only
+    direct: int            # levels in the direct form
+    binning: str           # "pipeline": two launches of its own or none (the previous step's riders) | "prepare": rides with the vertex stage | "none"
+    vertex_fwd: str        # "fused" into the pixel stage's staging loop | "riders" of the binning launches | "none"
+    pixel: str             # "interleaved" | "generic" | "none"        (forward and backward kernels of the staged levels)
+    grad_sink: str         # where the staged levels' backward puts its sums: "table_rows" | "dG64" | "fp32_grid" | "none" (no gradient)
+    table_grad: str        # "block" ([dE | grid]: ONE allocation) | "persist" (step-to-step buffer) | "alloc" | "none"
+    clear: str             # who clears it: "decoder" (between its MFMAs) | "riders" (of the binning launch) | "rows" (sparse, persist) | "none"
+    direct_bwd: str        # "bucketed_write" | "bucketed_or_atomics" (decided per call on the density) | "none"
+    exchange: bool         # a data-parallel exchange of the vertex-grid gradient is set up
+
+    def signature(self):
+        return (f"{self.source} L{self.staged}+{self.direct} bin={self.binning} vfwd={self.vertex_fwd} px={self.pixel} sink={self.grad_sink} "
+                f"dE={self.table_grad}/{self.clear} direct={self.direct_bwd}" + (" xchg" if self.exchange else ""))
+
+    def chain(self):
+        """the signature without the level COUNTS (the same kernels run whether 4 or 16 levels are staged): the key the test
+        coverage table of tests/test_step_config_cpu.py is written in"""
+        lv = ("tiled" if self.staged else "") + ("+" if self.staged and self.direct else "") + ("direct" if self.direct else "")
+        return (f"{self.source} {lv} bin={self.binning} vfwd={self.vertex_fwd} px={self.pixel} sink={self.grad_sink} "
+                f"dE={self.table_grad}/{self.clear} direct={self.direct_bwd}" + (" xchg" if self.exchange else ""))
+
+    @staticmethod
+    def choose(plan, L, T, F, P, mode, fp32_tables, needs_grad, link_defer_zero, link_zero_hidden, exchange, persist_ok, persist_alloc_ok,
+               have_reserve_ws):
+        """link_defer_zero / link_zero_hidden: the StepLink of the pass says a fused decoder kernel will clear the buffer it is left
+        (zero_hidden: the one-launch training kernel, which clears for free).  persist_alloc_ok: the step-to-step buffer exists or may
+        be allocated now (not inside a capture).  have_reserve_ws: the persistent counters of the two-launch binning exist."""
+        t = TUNING
+        src = "hash" if mode == MODE_HASH else "vertex_table"
+        tiled = plan.Ls > 0 and P > 0
+        nd = L - plan.Ls
+        if not tiled:       # (direct form only: a data-parallel exchange changes nothing in the encoder's own chain)
+            return StepConfig(src, 0, L, "none", "none", "none", "none", "alloc" if needs_grad else "none", "none",
+                              "bucketed_or_atomics" if (needs_grad and nd > 0) else "none", False)
+        il_f, il_b = plan.interleaved(backward=False), plan.interleaved(backward=True)
+        fused = bool(t.fused_vertex_fwd and t.two_launch_binning and have_reserve_ws and fp32_tables and F == 2 and il_f)
+        if needs_grad and (L * T * F) % 4 != 0:
+            fused = False                                    # (the one-block gradient allocation wants whole 16-byte vectors)
+        if not needs_grad:
+            return StepConfig(src, plan.Ls, nd, "pipeline" if fused else "prepare", "fused" if fused else "riders",
+                              "interleaved" if il_f else "generic", "none", "none", "none", "none", bool(exchange))
+        direct_hash = bool(t.hash_direct_scatter and t.hash_vertex_fusion and mode == MODE_HASH and not exchange)
+        use64 = bool(t.dg64 and F == 2 and plan.Ls <= 16 and il_b)
+        sink = "table_rows" if direct_hash else ("dG64" if use64 else "fp32_grid")
+        if fused:
+            return StepConfig(src, plan.Ls, nd, "pipeline", "fused", "interleaved", sink, "block", "decoder" if link_defer_zero else "riders",
+                              "bucketed_or_atomics" if nd > 0 else "none", bool(exchange))
+        fresh = nd > 0 and mode == MODE_HASH and bucketed_plan(P, F, T, nd, True) is not None
+        hidden = link_defer_zero and link_zero_hidden and L * T * F * 4 <= t.persistent_min_bytes
+        persist = bool(t.persistent_table_grad and not hidden and mode == MODE_HASH and persist_ok and not exchange and (fresh or nd == 0)
+                       and persist_alloc_ok)
+        return StepConfig(src, plan.Ls, nd, "prepare", "riders", "interleaved" if il_b else "generic", sink,
+                          "persist" if persist else "alloc", "rows" if persist else ("decoder" if link_defer_zero else "riders"),
+                          "bucketed_write" if fresh else ("bucketed_or_atomics" if nd > 0 else "none"), bool(exchange))
+
+
 class EncodeFunction(torch.autograd.Function):
     """Fused coords -> (P, L*F) encoder.  Levels [0, plan.Ls) run through the tiled form (vertex stage + binned,
     LDS-privatised pixel stage), levels [plan.Ls, L) through the direct form.  Same inputs / gradients as
@@ -1376,27 +1449,37 @@ class EncodeFunction(torch.autograd.Function):
         ctx.persist = False
         ctx.persist_cleared = None
         clear_now = None
-        if plan.Ls > 0 and P > 0:
-            dev = tables.device
-            pws = _bin_workspace(dev, plan.ntiles, dp, kind="reserve") if (TUNING.two_launch_binning and TUNING.fused_vertex_fwd) else None
+        dev = tables.device
+        tiled = plan.Ls > 0 and P > 0
+        pws = _bin_workspace(dev, plan.ntiles, dp, kind="reserve") if (tiled and TUNING.two_launch_binning and TUNING.fused_vertex_fwd) else None
+        # ONE decision per pass (see StepConfig): which kernels, which buffers, who clears them
+        sc = ctx.step_config = StepConfig.choose(
+            plan, L, T, F, P, mode, tables.dtype == _f32, bool(ctx.needs_input_grad[3]),
+            bool(link is not None and link.defer_zero), bool(link is not None and link.zero_hidden),
+            bool(dp is not None and dp.exchange is not None), bool(dp is not None and dp.persist_ok and getattr(dp, "level_params", None)),
+            bool(dp is not None and (getattr(dp, "persist_grad", None) is not None or not torch.cuda.is_current_stream_capturing())),
+            bool(pws is not None and pws.numel() >= 2 * plan.ntiles + 3))
+        if dp is not None:
+            dp.step_config = sc
+        _trace("step_config", signature=sc.signature())
+        if SEEN_STEP_CONFIGS is not None:
+            SEEN_STEP_CONFIGS.add(sc.chain())
+        if tiled:
             # fp32 tables on the level-interleaved kernel: the vertex stage forward runs INSIDE the pixel stage's staging loop (no
             # vertex grid G, no vertex riders) and the binning is two launches of its own — or none, when the previous step's
             # launches carried it (BinPipeline)
-            fused = (TUNING.fused_vertex_fwd and pws is not None and pws.numel() >= 2 * plan.ntiles + 3 and tables.dtype == _f32
-                     and F == 2 and plan.interleaved(backward=False))
-            use64 = False
+            fused = sc.vertex_fwd == "fused"
+            use64 = sc.grad_sink == "dG64"
             big = None
             if ctx.needs_input_grad[3]:
-                # F = 2, <= 16 staged levels (the level-interleaved kernels): the pixel stage of the backward adds its exact
-                # fixed-point sums straight into a 64-bit vertex grid (cleared here; + scale and poison words), no gather pass
-                # (the launcher decides whether that kernel runs — e.g. not at the 4096^2 shape, whose interleaved image exceeds
-                # the LDS: the generic kernels accumulate into a ZEROED fp32 grid instead)
-                use64 = TUNING.dg64 and F == 2 and plan.Ls <= 16 and plan.interleaved(backward=True)
-                # hash source, single rank: no vertex-grid gradient at all when the interleaved backward adds to the table gradient
-                # itself (decided again in backward: it needs the bound on |d enc| that only the backward pass can see)
-                ctx.direct_hash = bool(TUNING.hash_direct_scatter and TUNING.hash_vertex_fusion and mode == MODE_HASH and (dp is None or dp.exchange is None))
+                # grad_sink "dG64" (F = 2, <= 16 staged levels: the level-interleaved kernels): the pixel stage of the backward adds
+                # its exact fixed-point sums straight into a 64-bit vertex grid (cleared here; + scale and poison words), no gather
+                # pass; "fp32_grid": the generic kernels (e.g. the 4096^2 shape, whose interleaved image exceeds the LDS) accumulate
+                # into a ZEROED fp32 grid; "table_rows" (hash source, single rank): no vertex-grid gradient at all — the pixel stage
+                # adds to the table gradient itself
+                ctx.direct_hash = sc.grad_sink == "table_rows"
                 nt = tables.numel()
-                if fused and nt % 4 == 0:
+                if fused:
                     # ONE allocation [table gradient | vertex-grid gradient]: whoever clears the table gradient — the fused
                     # training decoder between its MFMAs, or rider workgroups of the count launch — clears both
                     ng = 0 if ctx.direct_hash else ((plan.vtot * F + 2) * 2 if use64 else plan.vtot * F)
@@ -1404,22 +1487,17 @@ class EncodeFunction(torch.autograd.Function):
                     dgrid = None if ctx.direct_hash else (big[nt:nt + ng].view(_i64) if use64 else big[nt:nt + ng].view(plan.vtot, F))
                     pre = [big[:nt].view(tables.shape), dgrid, big, big]
                 else:
-                    fused = False
                     dgrid = None if ctx.direct_hash else (torch.empty((plan.vtot * F + 2,), dtype=_i64, device=dev) if use64
                                                           else torch.empty((plan.vtot, F), dtype=_f32, device=dev))
-                    # direct levels whose backward WRITES every row (the bucketed form) are left out of the clear
-                    fresh = plan.Ls < L and mode == MODE_HASH and bucketed_plan(P, F, T, L - plan.Ls, True) is not None
+                    # direct_bwd "bucketed_write": direct levels whose backward WRITES every row are left out of the clear
+                    fresh = sc.direct_bwd == "bucketed_write"
                     ctx.fresh_direct = fresh
-                    # ... and with a step-to-step buffer there is no dense clear at all (the backward takes the buffer, or a
-                    # zeroed allocation when the buffer is in use)
-                    # (not for small tables where the training decoder clears the buffer between its MFMAs at next to no cost;
-                    # at the 4096^2 shape that hidden clear of 448 MB costs the decoder 36 us — a draw against a sparse-clear
-                    # LAUNCH of 7.3 M rows, a loss against the same clear riding on the vertex riders: tools/ab_persist_cfg4.sh)
-                    hidden = link is not None and link.defer_zero and link.zero_hidden and tables.numel() * 4 <= TUNING.persistent_min_bytes
-                    ctx.persist = bool(TUNING.persistent_table_grad and not hidden and mode == MODE_HASH and dp is not None and dp.persist_ok
-                                       and dp.exchange is None
-                                       and getattr(dp, "level_params", None) and (fresh or plan.Ls == L)
-                                       and (getattr(dp, "persist_grad", None) is not None or not torch.cuda.is_current_stream_capturing()))
+                    # table_grad "persist": with a step-to-step buffer there is no dense clear at all (the backward takes the buffer,
+                    # or a zeroed allocation when the buffer is in use) — not for small tables where the training decoder clears
+                    # the buffer between its MFMAs at next to no cost (at the 4096^2 shape that hidden clear of 448 MB costs the
+                    # decoder 36 us — a draw against a sparse-clear LAUNCH of 7.3 M rows, a loss against the same clear riding on
+                    # the vertex riders: tools/ab_persist_cfg4.sh)
+                    ctx.persist = sc.table_grad == "persist"
                     if ctx.persist:
                         pre = [None, dgrid, None, None]
                         # the rows the staged levels can touch are cleared by the vertex riders of the binning launch, if the

@@ -171,10 +171,15 @@ def allreduce_gradients(net, world: int, group=None, keep_tables_flag: bool = Fa
     tables_done = int(dp.tables_reduced) if dp is not None else 0     # leading levels already reduced through dG by the encoder backward
     if dp is not None and not keep_tables_flag:
         dp.tables_reduced = 0
+    zero = getattr(dp, "zero", None) if dp is not None else None
+    scatter = None
     if base is not None:
         handled = {id(m.weight) for m in enc._hash_tables}
         if tables_done < base.shape[0]:
-            tensors.append(base[tables_done:])   # (L,T,F): the direct-form levels only
+            if zero and zero["Ls"] == tables_done and base.is_contiguous():
+                scatter = base[tables_done:].reshape(-1)          # sharded update: reduce-scatter instead of all-reduce (below)
+            else:
+                tensors.append(base[tables_done:])   # (L,T,F): the direct-form levels only
     rest = [p for p in net.parameters() if p.requires_grad and p.grad is not None and id(p) not in handled]
     flat = None
     in_place = False
@@ -185,6 +190,8 @@ def allreduce_gradients(net, world: int, group=None, keep_tables_flag: bool = Fa
             flat = torch.cat([p.grad.reshape(-1) for p in rest])
         tensors.append(flat)
     average_tensors(tensors, world, group)
+    if scatter is not None:
+        _reduce_scatter_mean(scatter, zero, world, group)
     if deferred is not None:
         ops.run_deferred_vertex_stage(dp, exchanged=True)
     if flat is not None and not in_place:
@@ -193,6 +200,75 @@ def allreduce_gradients(net, world: int, group=None, keep_tables_flag: bool = Fa
             n = p.grad.numel()
             p.grad.copy_(flat[off:off + n].view_as(p.grad))
             off += n
+
+
+# ------------------------------------------------------------------------------------------------ sharded update of the direct levels
+def shard_direct_levels(net, world: int, rank: int, pixels_per_rank: int, group=None):
+    """Round 5 — the answer to "exchange ~ step" at BASELINE config 5 (8 GPUs, F = 4, T = 2^24, fp16 tables:
+    the four direct levels' slice of the fp32 table gradient is 1 GiB, its ring all-reduce ~1.75 ms beside a ~1.75 ms step, and
+    the dense Adam over all 2 GiB of tables 5.5 ms on EVERY rank).  ZeRO-1 restricted to the levels that need it:
+
+      * the staged levels stay as they are (their gradient travels as the small vertex-grid gradient and every rank updates them);
+      * the direct levels' gradient slice is REDUCE-SCATTERED (each rank receives the mean of its 1/n of the rows: (n-1)/n x S on the
+        links instead of 2 (n-1)/n x S), each rank's optimizer updates only those rows (`_adam_range` on the level parameters:
+        train.FusedAdam offsets its segment records; moments and the fp32 master copy of the other rows are never touched), and
+        the updated PARAMETER rows are all-gathered (fp16 storage: half the bytes of the gradient) — gather_direct_levels(),
+        after optimizer.step().
+    Bytes per rank and step at config 5, n = 8: 0.875 x 1 GiB + 0.875 x 0.5 GiB = 1.31 GiB instead of 1.75 GiB, and the Adam launch
+    covers 1/8 of the direct levels (+ the staged ones) instead of all of them.  Which levels are direct follows from the plan of
+    a `pixels_per_rank` batch (ops.EncodePlan), as in the encoder.  Returns (first direct level, lo, hi): this rank's element range
+    inside the flat direct slice.  Undo: shard_direct_levels(net, 1, 0, pixels_per_rank)."""
+    enc = net.encoding
+    L, T, F = enc.packed_tables().shape
+    Ls = ops.EncodePlan(int(pixels_per_rank), net._n_ls_host, F).Ls
+    dp = net.dp
+    levels = list(enc._hash_tables)
+    for m in levels:
+        m.weight._adam_range = None
+    dp.zero = None
+    n_d = (L - Ls) * T * F
+    if world <= 1 or n_d == 0:
+        return Ls, 0, n_d
+    per = -(-n_d // world)
+    per = -(-per // 1024) * 1024                                  # whole 4 KiB blocks: every shard starts 16-byte aligned in every dtype
+    lo, hi = min(n_d, rank * per), min(n_d, (rank + 1) * per)
+    for l in range(Ls, L):
+        a, b = (l - Ls) * T * F, (l - Ls + 1) * T * F             # this level inside the flat direct slice
+        levels[l].weight._adam_range = (max(lo, a) - a, max(min(hi, b), max(lo, a)) - a)
+    dp.zero = {"Ls": Ls, "lo": lo, "hi": hi, "per": per, "n": n_d, "world": int(world), "rank": int(rank), "group": group}
+    return Ls, lo, hi
+
+
+def _reduce_scatter_mean(flat, z, world, group):
+    """mean over the ranks of `flat` (the direct levels' gradient slice), delivered to this rank's [lo, hi) only"""
+    if dist.get_backend(group) == "nccl" and flat.is_cuda and z["per"] * world == z["n"]:
+        dist.reduce_scatter_tensor(flat[z["lo"]:z["hi"]], flat, op=dist.ReduceOp.AVG, group=group)     # in place: RCCL's own layout
+        return
+    # gloo rehearsal (ranks sharing a GPU in tests), or a slice that does not divide evenly: the same values by all-reduce
+    all_reduce_sum(flat, group)
+    flat.mul_(1.0 / world)
+
+
+def gather_direct_levels(net, group=None):
+    """after optimizer.step() with shard_direct_levels(): every rank receives the parameter rows the others updated"""
+    z = getattr(net.dp, "zero", None)
+    if not z:
+        return
+    world = z["world"]
+    flat = net.encoding.packed_tables()[z["Ls"]:].reshape(-1)
+    with torch.no_grad():
+        if dist.get_backend(group) == "nccl" and flat.is_cuda and z["per"] * world == z["n"]:
+            dist.all_gather_into_tensor(flat, flat[z["lo"]:z["hi"]].clone(), group=group)
+            return
+        mine = flat[z["lo"]:z["hi"]].detach()
+        pad = torch.zeros((z["per"],), dtype=flat.dtype, device="cpu")
+        pad[:mine.numel()] = mine.cpu()
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad, group=group)
+        for r, part in enumerate(parts):
+            a, b = min(z["n"], r * z["per"]), min(z["n"], (r + 1) * z["per"])
+            if b > a and r != z["rank"]:
+                flat[a:b].copy_(part[:b - a].to(flat.device))
 
 
 def broadcast_parameters(net, src: int = 0, group=None):

@@ -124,8 +124,14 @@ class FusedAdam(torch.optim.Optimizer):
                 for t_ in (p, st["exp_avg"], st["exp_avg_sq"]):
                     if not t_.is_contiguous():
                         raise RuntimeError("FusedAdam needs contiguous parameters and moments")
-                segs.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                             st["master"].data_ptr() if half else 0, p.numel(), gi, int(half) | (2 if g32 is not None else 0), g))
+                # data parallel, sharded optimizer state (parallel.shard_direct_levels): this rank updates elements [lo, hi) of the
+                # parameter only — the others' rows arrive with the all-gather that follows the step
+                lo, hi = getattr(p, "_adam_range", None) or (0, p.numel())
+                if hi <= lo:
+                    continue
+                segs.append((p.data_ptr() + lo * p.element_size(), g.data_ptr() + lo * g.element_size(), st["exp_avg"].data_ptr() + lo * 4,
+                             st["exp_avg_sq"].data_ptr() + lo * 4, (st["master"].data_ptr() + lo * 4) if half else 0, hi - lo, gi,
+                             int(half) | (2 if g32 is not None else 0), g))
         return segs
 
     def zero_grad(self, set_to_none=True):

@@ -79,6 +79,46 @@ def encode_path(request):
         ops.ENCODE_PATH, ops.TILED_CELLS_PER_PIXEL, ops.PIXEL_BWD_TRACE = prev
 
 
+# ------------------------------------------------------------------------------------------------ which kernel chain did each test run?
+STEP_CHAINS_BY_TEST = {}       # nodeid -> sorted list of ops.StepConfig.chain() strings its forward passes took (this process + reported children)
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_call(item):
+    """Every GPU test runs with ops.SEEN_STEP_CONFIGS collecting the kernel chains (ops.StepConfig) of its forward passes; the
+    session writes gpurun_out/step_configs_gpu.json = {chain: [tests that ran it]} — the evidence behind the coverage table
+    tests/step_config_coverage.json that tests/test_step_config_cpu.py checks the reachable configurations against."""
+    ops = None
+    if "gpu" in item.keywords:
+        try:
+            from collision_handling_in_instantngp_amd import ops
+            ops.SEEN_STEP_CONFIGS = set()
+        except Exception:  # pragma: no cover
+            ops = None
+    yield
+    if ops is not None:
+        seen, ops.SEEN_STEP_CONFIGS = ops.SEEN_STEP_CONFIGS, None
+        if seen:
+            STEP_CHAINS_BY_TEST[item.nodeid] = sorted(seen)
+
+
+def _write_step_chains():
+    if not STEP_CHAINS_BY_TEST:
+        return
+    import json
+    by_chain = {}
+    for nodeid, chains in STEP_CHAINS_BY_TEST.items():
+        for c in chains:
+            by_chain.setdefault(c, []).append(nodeid)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "step_configs_gpu.json"), "w") as f:
+            json.dump({c: sorted(v) for c, v in sorted(by_chain.items())}, f, indent=1)
+    except OSError:  # pragma: no cover
+        pass
+
+
 # ------------------------------------------------------------------------------------------------ achieved-error report
 class ParityRecorder:
     """Every tolerance check of the parity tests also records the ACHIEVED error, so that the numbers behind
@@ -125,6 +165,7 @@ def parity_close(got, want, rtol, atol, quantity=""):
 
 
 def pytest_sessionfinish(session, exitstatus):
+    _write_step_chains()
     if not PARITY.rows:
         return
     import json

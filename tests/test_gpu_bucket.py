@@ -177,6 +177,43 @@ def test_a_batch_that_lands_in_four_rows_is_still_exact():
     assert float(np.abs(want).max()) > 100
 
 
+def test_a_tiny_row_next_to_a_large_one_in_the_same_bucket():
+    """the bucket's fixed-point scale comes from its LARGEST |term| — the error bound is absolute per bucket, not
+    relative per row.  Two pixels in different cells whose rows share one bucket (T = one bucket): one with gradient ~1, one with
+    ~1e-20.  The large rows are within half an fp32 ulp of the double-precision sum; the tiny row's error is bounded by the quantum
+    2^-50 (2^-45 here: 65 535 terms on the fullest row) of the bucket's largest term per term — which here means it is FLUSHED to zero, where float atomics would have kept
+    1e-20 at fp32 relative precision.  Stated in csrc/encode_bucket.hip's header; this test pins it."""
+    from collision_handling_in_instantngp_amd import _lib, ops
+    P, L, T, F = 2 ** 16, 1, 2048, 2
+    rng = np.random.default_rng(3)
+    x = np.zeros((P, 2), np.float32)
+    x[:] = [0.26, 0.26]                                    # every pixel on one cell ...
+    x[0] = [0.74, 0.74]                                    # ... except the tiny one
+    n_ls = np.array([64], np.int32)
+    g = rng.standard_normal((P, L * F)).astype(np.float32)
+    g[0] = 1e-20
+    tx, tn, tg = torch.from_numpy(x).to(DEV), torch.from_numpy(n_ls).to(DEV), torch.from_numpy(g).to(DEV)
+    got, plan = _bucketed(ops, _lib, tx, tn, tg, L, T, F, 0, L, 65536, 0)
+    assert plan[1] == 1, plan                             # ONE bucket holds the whole level: both cells' rows share its scale
+    got = got.double().cpu().numpy()
+    want = c_oracle.encode_bwd_f64(x, (L, T, F), n_ls, g) if c_oracle.available() else None
+    _, grid = orc.scale_to_grid(x[[0, 1]], n_ls)
+    idx = orc.spatial_hash(grid.astype(np.int32), T)                     # (2, L, 4)
+    tiny_rows, big_rows = idx[0, 0], idx[1, 0]
+    assert not set(tiny_rows.tolist()) & set(big_rows.tolist())
+    if want is not None:
+        big = np.zeros((L, T, F), bool)
+        big[0, big_rows] = True
+        ulp = np.spacing(np.abs(want[big]).astype(np.float32)).astype(np.float64)
+        # 65 535 terms on the fullest row: room = 61 - 16 = 45 bits, |term| < 2^(e + 1) <= 2 max |g|  ->  quantum q <= 2^-44 max |g|
+        q = 2.0 ** -44 * float(np.abs(g).max())
+        assert np.all(np.abs(got[big] - want[big]) <= 0.5 * ulp + 0.5 * q * P)
+        # the absolute bound on the tiny rows: one quantum (of the bucket's largest term) per term, one term per row here
+        assert np.all(np.abs(got[0, tiny_rows] - want[0, tiny_rows]) <= q)
+        assert np.all(want[0, tiny_rows] > 0)
+    assert np.all(got[0, tiny_rows] == 0.0), "documented behaviour: 1e-20 next to 1 in one bucket is below the bucket's quantum"
+
+
 def test_non_finite_terms_reach_their_rows_only():
     from collision_handling_in_instantngp_amd import _lib, ops
     P, L, T, F = 2 ** 16, 2, 2 ** 14, 2

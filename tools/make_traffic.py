@@ -9,7 +9,7 @@ groups = {     # round 3 kernel names (the round-2 names stay listed: general sh
     "prepare(bin+vertex_fwd+clears)": ["gngf::bin_count_vride_kernel", "gngf::bin_rowscan_kernel", "gngf::bin_scan_kernel",
                                        "gngf::bin_scatter_ride_kernel<2", "gngf::bin_scatter_kernel"],
     "encode_fwd:tiled": ["gngf::tiled_fwd_kernel<2>", "gngf::tiled_fwd_il_kernel"],
-    "encode_bwd:tiled": ["gngf::tiled_bwd_kernel<2>", "gngf::gather_partials_kernel<2", "gngf::tiled_bwd_il_kernel", "gngf::dg64_to_float_kernel",
+    "encode_bwd:tiled": ["gngf::tiled_bwd_kernel<2", "gngf::gather_partials_kernel<2", "gngf::tiled_bwd_il_kernel", "gngf::dg64_to_float_kernel",
                          "gngf::vertex_bwd_hash64_kernel"],
     "decoder_train": ["gngf::decoder_bwd_kernel<32, false, true, false, true, true>"],     # forward + backward in one launch
     "vertex_bwd": ["gngf::vertex_bwd_sorted_kernel<2", "gngf::vertex_bwd_kernel<2"],
@@ -33,6 +33,20 @@ for name, ks in groups.items():
         ff = fetch_factor.get(name, 2.0)
         out[name] = {"hbm_bytes_per_launch": (ff * f + w) * 1024, "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB": w, "fetch_factor": ff,
                      "note": "bytes = (fetch_factor*FETCH_SIZE + WRITE_SIZE)*1024; gfx950 FETCH_SIZE counts wide (16 B/lane) reads at half"}
+# matrix-pipe occupancy of the dominant kernel from the SQ pass of the same round (profiles/<tag>_pmc_sq_counters.json, optional third
+# argument): SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES) — what bench.py prints as roofline.mfma_busy next to `frac`,
+# so that "0.9 of the fp32 MFMA peak" (144 of a tile's 244 fp32-MFMA equivalents run on the 16x faster bf16 pipe) is not read as
+# "matrix pipes 90 % busy" 
+sq_path = os.environ.get("GNGF_SQ_COUNTERS")
+if sq_path and os.path.isfile(sq_path):
+    sq = json.load(open(sq_path))
+    for name, ks in groups.items():
+        busy = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for k, v in sq.items() if any(k.startswith(p_) for p_ in ks))
+        cu = sum(v.get("SQ_BUSY_CU_CYCLES", 0.0) for k, v in sq.items() if any(k.startswith(p_) for p_ in ks))
+        valu = sum(v.get("SQ_INSTS_VALU", 0.0) for k, v in sq.items() if any(k.startswith(p_) for p_ in ks))
+        if name in out and cu > 0:
+            out[name]["mfma_busy"] = busy / (4.0 * cu)
+            out[name]["valu_insts_per_dispatch"] = valu
 # stamp: the kernel chain the passes were taken on (bench.py reports the figures only for that chain), commit, kernel names
 sys.path.insert(0, os.getcwd())
 from collision_handling_in_instantngp_amd import ops as _ops   # noqa: E402

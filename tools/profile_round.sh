@@ -3,7 +3,7 @@
 # PMC passes (FETCH_SIZE, WRITE_SIZE — each in its own run, with --kernel-trace only) of the headline mode.
 # Usage: bash tools/profile_round.sh r02      -> gpurun_out/prof_<tag>_*/
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
