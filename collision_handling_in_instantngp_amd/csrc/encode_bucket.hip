@@ -251,16 +251,28 @@ __device__ __forceinline__ unsigned long long bucket_fixed(float v, double scale
   return (unsigned long long)__double_as_longlong(r) - 0x4338000000000000ull;
 }
 
+// the first sum_keep<F>() items of every thread, kept in registers from the pass that finds the scale to the pass that adds
 template <int F>
-__global__ void __launch_bounds__(kSumThreads)
-bucket_sum_kernel(const void* __restrict__ items, int64_t total, const int32_t* __restrict__ base, float* __restrict__ dtables, int l0,
-                  int64_t T, int bshift, int B, int accumulate) {
-  extern __shared__ unsigned long long bk_img[];
-  __shared__ unsigned bk_red[2 * (kSumThreads / 64)];
+__device__ __forceinline__ void bucket_load(const void* __restrict__ items, int64_t total, int beg, int n,
+                                            float (&keep_v)[sum_keep<F>()][F], unsigned (&keep_s)[sum_keep<F>()]) {
+#pragma unroll
+  for (int j = 0; j < sum_keep<F>(); ++j) {
+    const int k = threadIdx.x + j * kSumThreads;
+    keep_s[j] = 0u;
+#pragma unroll
+    for (int f = 0; f < F; ++f) keep_v[j][f] = 0.f;
+    if (k < n) keep_s[j] = get_item<F>(items, total, (int64_t)beg + k, keep_v[j]);
+  }
+}
+
+// one (level, bucket): items in registers (bucket_load) -> 64-bit image in the LDS -> the slice of the table gradient
+template <int F>
+__device__ __forceinline__ void bucket_sum_one(const void* __restrict__ items, int64_t total, float* __restrict__ dtables, int l0, int64_t T,
+                                               int bshift, int B, int accumulate, int i, int beg, int n,
+                                               float (&keep_v)[sum_keep<F>()][F], unsigned (&keep_s)[sum_keep<F>()],
+                                               unsigned long long* bk_img, unsigned* bk_red) {
   constexpr int kSumKeep = sum_keep<F>();
-  const int i = blockIdx.x;
   const int lv = i / B, b = i - lv * B;
-  const int beg = base[i], n = base[i + 1] - beg;
   const int slots = 1 << bshift;
   const int64_t slot0 = (int64_t)b << bshift;
   float* out = dtables + ((int64_t)(l0 + lv) * T + slot0) * F;
@@ -269,7 +281,7 @@ bucket_sum_kernel(const void* __restrict__ items, int64_t total, const int32_t* 
   // largest number of terms any ROW receives (what bounds a cell's sum: ~10 where the bucket holds thousands).
   // Round 5: a bucket of at most 2048 items needs NO count — no row can hold more than the bucket does, and up to 2^11 terms per
   // row the scale is the same (room = 50 below) — so the usual bucket of the 8192^2 shape (512 items; the ~4000 of the 4096^2 one
-  // keep the count) goes: item loads issued, image cleared WHILE they are in flight, one barrier, adds, one barrier, write-out
+  // keep the count) goes: image cleared (the item loads were issued a whole bucket ago), one barrier, adds, one barrier, write-out
   // (was: five barriers with the loads' round trip exposed between the first two).
   const bool counted = n > 2048;                                                // (workgroup-uniform)
   unsigned* cnt = reinterpret_cast<unsigned*>(bk_img);
@@ -278,17 +290,6 @@ bucket_sum_kernel(const void* __restrict__ items, int64_t total, const int32_t* 
     __syncthreads();
   }
   unsigned mx = 0;
-  // the first kSumKeep items of every thread stay in registers for the second pass (a bucket of the usual size is read once)
-  float keep_v[kSumKeep][F];
-  unsigned keep_s[kSumKeep];
-#pragma unroll
-  for (int j = 0; j < kSumKeep; ++j) {
-    const int k = threadIdx.x + j * kSumThreads;
-    keep_s[j] = 0u;
-#pragma unroll
-    for (int f = 0; f < F; ++f) keep_v[j][f] = 0.f;
-    if (k < n) keep_s[j] = get_item<F>(items, total, (int64_t)beg + k, keep_v[j]);
-  }
   if (!counted) {                                                               // the image is cleared under the loads
     ulonglong2* z = reinterpret_cast<ulonglong2*>(bk_img);
     const ulonglong2 zero = {0ull, 0ull};
@@ -400,6 +401,44 @@ bucket_sum_kernel(const void* __restrict__ items, int64_t total, const int32_t* 
   }
 }
 
+
+// Workgroups are PERSISTENT (two per CU: the image is 64 KB) and walk the (level, bucket) list with their stride; the items of
+// the NEXT bucket are requested before the current one is processed, so that their round trip — a third of a bucket's 6 us when
+// every bucket started with it — runs under the current bucket's LDS work and write-out.
+template <int F>
+__global__ void __launch_bounds__(kSumThreads)
+bucket_sum_kernel(const void* __restrict__ items, int64_t total, const int32_t* __restrict__ base, float* __restrict__ dtables, int l0,
+                  int64_t T, int bshift, int B, int accumulate, int nbuckets) {
+  extern __shared__ unsigned long long bk_img[];
+  __shared__ unsigned bk_red[2 * (kSumThreads / 64)];
+  constexpr int kSumKeep = sum_keep<F>();
+  int i = blockIdx.x;
+  if (i >= nbuckets) return;
+  float cur_v[kSumKeep][F], nxt_v[kSumKeep][F];
+  unsigned cur_s[kSumKeep], nxt_s[kSumKeep];
+  int beg = base[i], n = base[i + 1] - beg;
+  bucket_load<F>(items, total, beg, n, cur_v, cur_s);
+  for (;;) {
+    const int inext = i + (int)gridDim.x;
+    const bool more = inext < nbuckets;
+    int nbeg = 0, nn = 0;
+    if (more) {
+      nbeg = base[inext]; nn = base[inext + 1] - nbeg;
+      bucket_load<F>(items, total, nbeg, nn, nxt_v, nxt_s);
+    }
+    bucket_sum_one<F>(items, total, dtables, l0, T, bshift, B, accumulate, i, beg, n, cur_v, cur_s, bk_img, bk_red);
+    if (!more) break;
+    __syncthreads();                                   // every read of this bucket's image is done before the next one's clear
+#pragma unroll
+    for (int j = 0; j < kSumKeep; ++j) {
+      cur_s[j] = nxt_s[j];
+#pragma unroll
+      for (int f = 0; f < F; ++f) cur_v[j][f] = nxt_v[j][f];
+    }
+    i = inext; beg = nbeg; n = nn;
+  }
+}
+
 // Rows of the table gradient that the STAGED levels of a spatial-hash encoder can ever touch: hash(gx, gy) of every vertex of
 // every staged level — a set that depends on the level resolutions only, not on the batch.  A gradient buffer that lives from
 // step to step (ops.PERSISTENT_TABLE_GRAD) needs only these rows cleared before the next backward adds into it: 4.6 M rows of
@@ -428,6 +467,16 @@ static int bucket_shift_for(int F, int image_bytes) {
   int s = 0;
   while ((8ll * F << (s + 1)) <= image_bytes) ++s;
   return s;
+}
+
+static int bucket_compute_units() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    else { (void)hipGetLastError(); cus = 256; }
+  }
+  return cus;
 }
 
 // levels per scatter workgroup: as many as keep the offsets of the group within 64 KB of LDS
@@ -539,8 +588,13 @@ extern "C" int gngf_encode_bwd_bucketed(const float* xy, const int32_t* n_ls, co
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)img);                                 \
       if (e != hipSuccess) return (int)e;                                                                                       \
     }                                                                                                                           \
-    bucket_sum_kernel<kF><<<dim3((unsigned)(nl * B)), dim3(kSumThreads), img, s>>>(items, total, base, dtables, l0, T, bshift,  \
-                                                                                  B, accumulate);                             \
+    /* persistent + prefetching workgroups where the buckets are small (<= 2048 items on average: the 8192^2 shape, 552 vs 612 us);   \
+       one workgroup per bucket where they are big (the 4096^2 shape: ~4000 items, 130 vs 157 us — the hardware's own dispatch       \
+       balances unequal buckets better than a stride does) */                                                                   \
+    const int nbk = nl * B, fit = 2 * bucket_compute_units();                                                                  \
+    const bool persistent = total <= (int64_t)2048 * nbk;                                                                      \
+    bucket_sum_kernel<kF><<<dim3((unsigned)((persistent && fit < nbk) ? fit : nbk)), dim3(kSumThreads), img, s>>>(items, total, base, dtables, l0, T, \
+                                                                                                 bshift, B, accumulate, nbk);  \
   }
   if (F == 1) GNGF_BUCKET_F(1) else if (F == 2) GNGF_BUCKET_F(2) else GNGF_BUCKET_F(4)
 #undef GNGF_BUCKET_F

@@ -1,0 +1,13 @@
+#!/bin/bash
+set -o pipefail
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_gpu_bucket.py tests/test_gpu_big_shapes.py -m gpu -q -x > gpurun_out/r5_i_test.log 2>&1; rc=$?
+tail -n 4 gpurun_out/r5_i_test.log
+if [ $rc -ne 0 ]; then exit $rc; fi
+IMAGES=65536 TILE_ORDER=1 timeout -k 10 300 python tools/perf_bucket.py 2>&1 | grep "us"
+for m in cfg5_hash_fp16 cfg4_hash; do
+  timeout -k 10 300 python bench.py --mode $m --no-extra-modes --no-cpu-baseline --no-full-outputs > gpurun_out/r5_i_${m}.json 2> gpurun_out/r5_i_${m}.err || exit 1
+  python -c "
+import json
+d=json.loads(open('gpurun_out/r5_i_${m}.json').read().strip().splitlines()[-1]); print('$m', d['ms_per_step'], d['ms_per_step_windows'], {k: round(x,3) for k,x in d['kernel_ms'].items()})"
+done
