@@ -405,6 +405,7 @@ __device__ __forceinline__ void bucket_sum_one(const void* __restrict__ items, i
 // Workgroups are PERSISTENT (two per CU: the image is 64 KB) and walk the (level, bucket) list with their stride; the items of
 // the NEXT bucket are requested before the current one is processed, so that their round trip — a third of a bucket's 6 us when
 // every bucket started with it — runs under the current bucket's LDS work and write-out.
+// (F = 4 only: with the twelve kept items of the F <= 2 item formats the second register set costs a workgroup per CU.)
 template <int F>
 __global__ void __launch_bounds__(kSumThreads)
 bucket_sum_kernel(const void* __restrict__ items, int64_t total, const int32_t* __restrict__ base, float* __restrict__ dtables, int l0,
@@ -436,6 +437,158 @@ bucket_sum_kernel(const void* __restrict__ items, int64_t total, const int32_t* 
       for (int f = 0; f < F; ++f) cur_v[j][f] = nxt_v[j][f];
     }
     i = inext; beg = nbeg; n = nn;
+  }
+}
+
+// ONE workgroup per (level, bucket) — the kernel of rounds 4 / 5 before the persistent form, kept for the shapes whose buckets are
+// big (the 4096^2 one: ~4000 items, unequal: the hardware's dispatch balances them better than a stride) and for F <= 2 (restated
+// through bucket_sum_one the F = 2 instance took 255 VGPRs against this one's 74: one workgroup per CU, 43 -> 90 us).
+template <int F>
+__global__ void __launch_bounds__(kSumThreads)
+bucket_sum_single_kernel(const void* __restrict__ items, int64_t total, const int32_t* __restrict__ base, float* __restrict__ dtables, int l0,
+                  int64_t T, int bshift, int B, int accumulate) {
+  extern __shared__ unsigned long long bk_img[];
+  __shared__ unsigned bk_red[2 * (kSumThreads / 64)];
+  constexpr int kSumKeep = sum_keep<F>();
+  const int i = blockIdx.x;
+  const int lv = i / B, b = i - lv * B;
+  const int beg = base[i], n = base[i + 1] - beg;
+  const int slots = 1 << bshift;
+  const int64_t slot0 = (int64_t)b << bshift;
+  float* out = dtables + ((int64_t)(l0 + lv) * T + slot0) * F;
+  const int live = (int)((T - slot0) < slots ? (T - slot0) : slots);            // the last bucket of a table that is no multiple of it
+  // the largest |term| of the bucket (bit patterns of absolute values order like the values; NaN and inf sort last) and the
+  // largest number of terms any ROW receives (what bounds a cell's sum: ~10 where the bucket holds thousands).
+  // Round 5: a bucket of at most 2048 items needs NO count — no row can hold more than the bucket does, and up to 2^11 terms per
+  // row the scale is the same (room = 50 below) — so the usual bucket of the 8192^2 shape (512 items; the ~4000 of the 4096^2 one
+  // keep the count) goes: item loads issued, image cleared WHILE they are in flight, one barrier, adds, one barrier, write-out
+  // (was: five barriers with the loads' round trip exposed between the first two).
+  const bool counted = n > 2048;                                                // (workgroup-uniform)
+  unsigned* cnt = reinterpret_cast<unsigned*>(bk_img);
+  if (counted) {
+    for (int k = threadIdx.x; k < slots; k += kSumThreads) cnt[k] = 0u;
+    __syncthreads();
+  }
+  unsigned mx = 0;
+  // the first kSumKeep items of every thread stay in registers for the second pass (a bucket of the usual size is read once)
+  float keep_v[kSumKeep][F];
+  unsigned keep_s[kSumKeep];
+#pragma unroll
+  for (int j = 0; j < kSumKeep; ++j) {
+    const int k = threadIdx.x + j * kSumThreads;
+    keep_s[j] = 0u;
+#pragma unroll
+    for (int f = 0; f < F; ++f) keep_v[j][f] = 0.f;
+    if (k < n) keep_s[j] = get_item<F>(items, total, (int64_t)beg + k, keep_v[j]);
+  }
+  if (!counted) {                                                               // the image is cleared under the loads
+    ulonglong2* z = reinterpret_cast<ulonglong2*>(bk_img);
+    const ulonglong2 zero = {0ull, 0ull};
+    for (int k = threadIdx.x; k < slots * F / 2; k += kSumThreads) z[k] = zero;
+    if ((slots * F) & 1) { if (threadIdx.x == 0) bk_img[slots * F - 1] = 0ull; }
+  }
+#pragma unroll
+  for (int j = 0; j < kSumKeep; ++j) {
+    if (threadIdx.x + j * kSumThreads < n) {
+      if (counted) atomicAdd(&cnt[keep_s[j]], 1u);
+#pragma unroll
+      for (int f = 0; f < F; ++f) { const unsigned a = __float_as_uint(keep_v[j][f]) & 0x7fffffffu; mx = a > mx ? a : mx; }
+    }
+  }
+  unsigned mc = counted ? 0u : 2048u;
+  if (counted) {
+    for (int k = threadIdx.x + kSumKeep * kSumThreads; k < n; k += kSumThreads) {
+      float v[F];
+      const unsigned s = get_item<F>(items, total, (int64_t)beg + k, v);
+      atomicAdd(&cnt[s], 1u);
+#pragma unroll
+      for (int f = 0; f < F; ++f) { const unsigned a = __float_as_uint(v[f]) & 0x7fffffffu; mx = a > mx ? a : mx; }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < slots; k += kSumThreads) mc = cnt[k] > mc ? cnt[k] : mc;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned t = __shfl_xor(mx, o, 64), u = __shfl_xor(mc, o, 64);
+    mx = t > mx ? t : mx;
+    mc = u > mc ? u : mc;
+  }
+  if ((threadIdx.x & 63) == 0) { bk_red[threadIdx.x >> 6] = mx; bk_red[kSumThreads / 64 + (threadIdx.x >> 6)] = mc; }
+  __syncthreads();                            // (counted: every read of cnt is done before the image is cleared; else: the image IS clear)
+  mx = 0; mc = 0;
+#pragma unroll
+  for (int w = 0; w < kSumThreads / 64; ++w) {
+    mx = bk_red[w] > mx ? bk_red[w] : mx;
+    mc = bk_red[kSumThreads / 64 + w] > mc ? bk_red[kSumThreads / 64 + w] : mc;
+  }
+  if (mx == 0) {                                                                // no contribution, or only zeros
+    if (!accumulate)
+      for (int k = threadIdx.x; k < live * F; k += kSumThreads) out[k] = 0.f;
+    return;
+  }
+  if (mx >= 0x7f800000u) {                                                      // a non-finite term: fp32 sums, as the atomics formed them
+    float* img = reinterpret_cast<float*>(bk_img);
+    for (int k = threadIdx.x; k < slots * F; k += kSumThreads) img[k] = 0.f;
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += kSumThreads) {
+      float v[F];
+      const unsigned s = get_item<F>(items, total, (int64_t)beg + k, v);
+#pragma unroll
+      for (int f = 0; f < F; ++f) atomicAdd(&img[s * F + f], v[f]);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < live * F; k += kSumThreads) out[k] = accumulate ? out[k] + img[k] : img[k];
+    return;
+  }
+  if (counted)
+    for (int k = threadIdx.x; k < slots * F; k += kSumThreads) bk_img[k] = 0ull;
+  const int e = (int)(mx >> 23) - 127;                                          // |term| < 2^(e + 1)  (denormals: e = -127, still true)
+  const int lg = mc <= 1 ? 0 : 32 - __clz((int)mc - 1);                         // ceil(log2 of the terms of the fullest row)
+  const int room = 61 - lg < 50 ? 61 - lg : 50;
+  const int S = room - (e + 1);
+  const double scale = ldexp(1.0, S), inv = ldexp(1.0, -S);
+  if (counted) __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kSumKeep; ++j) {
+    if (threadIdx.x + j * kSumThreads < n) {
+#pragma unroll
+      for (int f = 0; f < F; ++f) atomicAdd(&bk_img[keep_s[j] * F + f], bucket_fixed(keep_v[j][f], scale));
+    }
+  }
+  for (int k = threadIdx.x + kSumKeep * kSumThreads; k < n; k += kSumThreads) {
+    float v[F];
+    const unsigned s = get_item<F>(items, total, (int64_t)beg + k, v);
+#pragma unroll
+    for (int f = 0; f < F; ++f) atomicAdd(&bk_img[s * F + f], bucket_fixed(v[f], scale));
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < live; k += kSumThreads) {
+    float r[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) r[f] = (float)((double)(long long)bk_img[k * F + f] * inv);
+    float* o = out + (int64_t)k * F;
+    // (write mode: the slice is written once and read next by the optimizer, a whole step later — streamed past the caches)
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    if constexpr (F == 2) {
+      if (accumulate) {
+        float2 t = *reinterpret_cast<float2*>(o);
+        t.x += r[0]; t.y += r[1];
+        *reinterpret_cast<float2*>(o) = t;
+      } else {
+        __builtin_nontemporal_store((f2v){r[0], r[1]}, reinterpret_cast<f2v*>(o));
+      }
+    } else if constexpr (F == 4) {
+      if (accumulate) {
+        float4 t = *reinterpret_cast<float4*>(o);
+        t.x += r[0]; t.y += r[1]; t.z += r[2]; t.w += r[3];
+        *reinterpret_cast<float4*>(o) = t;
+      } else {
+        __builtin_nontemporal_store((f4v){r[0], r[1], r[2], r[3]}, reinterpret_cast<f4v*>(o));
+      }
+    } else {
+      o[0] = (accumulate ? o[0] : 0.f) + r[0];
+    }
   }
 }
 
@@ -492,7 +645,8 @@ static bool bucket_lds_grantable_f(int LG, size_t offs, size_t img) {
   const void* sc = LG == 4 ? reinterpret_cast<const void*>(bucket_scatter_kernel<F, 4>)
                            : (LG == 2 ? reinterpret_cast<const void*>(bucket_scatter_kernel<F, 2>) : reinterpret_cast<const void*>(bucket_scatter_kernel<F, 1>));
   if (offs > 48 * 1024 && !ok(hipFuncSetAttribute(sc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)offs))) return false;
-  if (img > 48 * 1024 && !ok(hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sum_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)img)))
+  if (img > 48 * 1024 && !(ok(hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sum_single_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)img)) &&
+                           ok(hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sum_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)img))))
     return false;
   return true;
 }
@@ -584,17 +738,23 @@ extern "C" int gngf_encode_bwd_bucketed(const float* xy, const int32_t* n_ls, co
   {                                                                                                                             \
     if (LG == 4) GNGF_BUCKET_SCATTER(kF, 4) else if (LG == 2) GNGF_BUCKET_SCATTER(kF, 2) else GNGF_BUCKET_SCATTER(kF, 1)        \
     if (img > 48 * 1024) {                                                                                                      \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sum_kernel<kF>),                                  \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sum_single_kernel<kF>),                           \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)img);                                 \
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sum_kernel<kF>),                  \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)img);                       \
       if (e != hipSuccess) return (int)e;                                                                                       \
     }                                                                                                                           \
     /* persistent + prefetching workgroups where the buckets are small (<= 2048 items on average: the 8192^2 shape, 552 vs 612 us);   \
        one workgroup per bucket where they are big (the 4096^2 shape: ~4000 items, 130 vs 157 us — the hardware's own dispatch       \
        balances unequal buckets better than a stride does) */                                                                   \
     const int nbk = nl * B, fit = 2 * bucket_compute_units();                                                                  \
-    const bool persistent = total <= (int64_t)2048 * nbk;                                                                      \
-    bucket_sum_kernel<kF><<<dim3((unsigned)((persistent && fit < nbk) ? fit : nbk)), dim3(kSumThreads), img, s>>>(items, total, base, dtables, l0, T, \
-                                                                                                 bshift, B, accumulate, nbk);  \
+    const bool persistent = kF == 4 && total <= (int64_t)2048 * nbk && fit < nbk;                                              \
+    if (persistent)                                                                                                             \
+      bucket_sum_kernel<kF><<<dim3((unsigned)fit), dim3(kSumThreads), img, s>>>(items, total, base, dtables, l0, T, bshift, B,   \
+                                                                               accumulate, nbk);                               \
+    else                                                                                                                        \
+      bucket_sum_single_kernel<kF><<<dim3((unsigned)nbk), dim3(kSumThreads), img, s>>>(items, total, base, dtables, l0, T, bshift, \
+                                                                                      B, accumulate);                          \
   }
   if (F == 1) GNGF_BUCKET_F(1) else if (F == 2) GNGF_BUCKET_F(2) else GNGF_BUCKET_F(4)
 #undef GNGF_BUCKET_F
