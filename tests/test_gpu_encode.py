@@ -468,8 +468,13 @@ def test_fixed_point_vertex_grid_is_exact_and_order_free(ops, P, coords):
     print(f"[direct hash scatter {P} {coords}] worst |err| / row mass vs the exact per-vertex sums: {worst:.2e}")
     assert worst <= 2e-6, worst
     close(dt_h, dt_a.cpu().numpy(), 1e-5, 2e-6 * float(dt_a.abs().max()), "hash table gradient added by the store pass (no vertex grid) vs from the fixed-point grid")
+    # ... without a bound on |genc| (a decoder that hands none over): per-item scales — float adds need no common one
+    dt_u = torch.zeros((L, T, Fd), dtype=torch.float32, device=DEV)
+    ops._pixel_bwd(plan, ws, n_t, genc, None, L, Fd, None, None, (dt_u, T), None)
+    err_u = (dt_u.double() - dt_a.double()).abs()
+    assert float((err_u[mass > 0] / mass[mass > 0].double()).max()) <= 2e-6
     # ... and the same through the GENERIC pixel-stage kernel (tiled_bwd_kernel<F, HDT>: what the 4096^2 / 8192^2 shapes run), with
-    # and without a bound on |genc| (per-item scales: float adds need no common one)
+    # and without a bound on |genc|
     from collision_handling_in_instantngp_amd import _lib
     prev_il = _lib.query("gngf_set_tiled_interleaved", 0)
     try:
