@@ -27,42 +27,47 @@ _f32, _i32, _i64 = torch.float32, torch.int32, torch.int64
 # object, the plan and the model's state: StepConfig.choose().
 @_dc.dataclass(frozen=True)
 class Tuning:
-    fp16_table_grad_fp32: object = False
-    bucketed_direct_bwd: object = True
-    bucketed_min_pixels: object = 1 << 16
-    bucket_image_bytes: object = 64 * 1024
-    bucketed_min_density: object = 0.5
-    bucketed_min_density_fresh: object = 0.2
-    direct_fwd_tile_order: object = True
-    bucketed_tile_order: object = True
-    persistent_table_grad: object = True
-    persistent_min_bytes: object = 1 << 28
-    hpd_z_cache_bytes: object = 216 << 30
-    hpd_z_cache_reserve: object = 40 << 30
-    hpd_pipeline: object = True
-    hpd_gemm_split_bf16: object = True
-    hpd_epilogue_stats: object = True
-    encode_path: object = "auto"
-    tiled_chunk: object = None
-    tiled_min_pixels: object = 1 << 14
-    tiled_cells_per_pixel: object = 4.0
-    tiled_lds_limit: object = 48 * 1024
-    tiled_tile_shift_bias: object = 0
-    bin_blocks_max: object = 128
-    bin_pixels_per_block: object = 8192
-    two_launch_binning: object = True
-    hash_vertex_fusion: object = True
-    fused_vertex_fwd: object = True
-    bin_pipeline: object = True
-    dg64: object = True
-    hash_direct_scatter: object = True
-    vertex_reads_dg64: object = True
-    use_side_stream: object = True
-    decoder_save_hidden: object = True
-    decoder_reduce_rides: object = True
-    decoder_train_fusion: object = True
-    decoder_bwd_clears: object = True
-
+    # ---- table gradient
+    fp16_table_grad_fp32: bool = False        # fp16 tables: hand the fp32 accumulation buffer over (param.grad_fp32) instead of an fp16 .grad copy
+    persistent_table_grad: bool = True        # a model whose loop opted in (dp.persist_ok) keeps ONE gradient buffer from step to step
+    persistent_min_bytes: int = 1 << 28       # ... above this size (below, the training decoder's hidden dense clear is cheaper)
+    # ---- direct levels (csrc/encode_direct.hip, encode_bucket.hip)
+    bucketed_direct_bwd: bool = True          # counting sort by table slice + LDS sums instead of one memory-side atomic per contribution
+    bucketed_min_pixels: int = 1 << 16
+    bucket_image_bytes: int = 64 * 1024       # LDS image of one bucket (= table slice)
+    bucketed_min_density: float = 0.5         # contributions per table row below which the atomics win ...
+    bucketed_min_density_fresh: float = 0.2   # ... when the bucketed form WRITES the levels (no clear needed)
+    direct_fwd_tile_order: bool = True        # the forward gather walks the pixels in the tiled form's binned order
+    bucketed_tile_order: bool = True          # ... and so does the bucketed backward (whole-line item runs)
+    # ---- HPD per distinct vertex (learning mode)
+    hpd_z_cache_bytes: int = 216 << 30        # logits kept from forward to backward (the rest is recomputed)
+    hpd_z_cache_reserve: int = 40 << 30       # device memory that must stay free beside them
+    hpd_pipeline: bool = True                 # chunks software-pipelined over two streams (GEMMs beside streaming passes)
+    hpd_gemm_split_bf16: bool = True          # the three T-wide GEMMs on the exact three-way bf16 split
+    hpd_epilogue_stats: bool = True           # row statistics in the logits GEMM's epilogue
+    # ---- tiled form: plan (EncodePlan)
+    encode_path: str = "auto"                 # "auto" | "direct" | "tiled" (tests force a path)
+    tiled_chunk: object = None                # max pixels per work item (None: about two average tiles' worth)
+    tiled_min_pixels: int = 1 << 14           # below this the binning is not worth it
+    tiled_cells_per_pixel: float = 4.0        # a level is staged while N_l^2 <= this * P
+    tiled_lds_limit: int = 48 * 1024          # forward image of the generic kernels
+    tiled_tile_shift_bias: int = 0
+    bin_blocks_max: int = 128
+    bin_pixels_per_block: int = 8192
+    # ---- tiled form: which kernels (StepConfig.choose reads these)
+    two_launch_binning: bool = True           # count -> scatter with the scans riding inside (else four launches)
+    fused_vertex_fwd: bool = True             # vertex stage forward inside the interleaved pixel stage's staging loop
+    bin_pipeline: bool = True                 # an announced next batch is binned by riders of this step's pixel-stage launches
+    dg64: bool = True                         # interleaved backward: 64-bit fixed-point vertex grid fed by integer atomics
+    hash_vertex_fusion: bool = True           # hash source, single rank: no vertex-stage launch of its own
+    hash_direct_scatter: bool = True          # ... and no vertex grid at all: the pixel stage adds to the hashed table rows (round 5)
+    vertex_reads_dg64: bool = True            # slot-ordered vertex backward converts the fixed-point grid on the fly
+    use_side_stream: bool = True              # False: helper-stream work in line on the current stream (measurement)
+    # ---- decoder (csrc/decoder.hip)
+    decoder_save_hidden: bool = True          # two-kernel path: hidden layers travel forward -> backward through HBM instead of being recomputed
+    decoder_reduce_rides: bool = True         # the slab reduction rides on the encoder backward's launch
+    decoder_train_fusion: bool = True         # forward + loss gradient + backward in ONE launch when the loss gradient is promised
+    decoder_bwd_clears: bool = True           # 64-feature backward clears the encoder's gradient buffer on the way
 
 TUNING = Tuning()
 _TUNING_FIELDS = {f.name for f in _dc.fields(Tuning)}
