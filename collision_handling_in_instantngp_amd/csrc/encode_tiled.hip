@@ -465,9 +465,11 @@ __device__ __forceinline__ void vertex_fwd_lane(const TT* __restrict__ tables, c
   for (int f = 0; f < F; ++f) acc[f] = 0.f;
   if constexpr (!VT) {
     const int64_t row = spatial_hash(gx, gy, T, pow2);
-    const TT* r = tab + row * F;
+    if (G) {                                      // (G == nullptr: the pixel stage gathers from the tables itself — this lane only clears)
+      const TT* r = tab + row * F;
 #pragma unroll
-    for (int f = 0; f < F; ++f) acc[f] = tload(r + f);
+      for (int f = 0; f < F; ++f) acc[f] = tload(r + f);
+    }
     if (clear_rows) {                             // a step-to-step table gradient: the row this vertex can add to starts from zero
       float* z = clear_rows + ((int64_t)l * T + row) * F;       // (as gngf_clear_hashed_rows, without a launch of its own)
 #pragma unroll
@@ -484,9 +486,11 @@ __device__ __forceinline__ void vertex_fwd_lane(const TT* __restrict__ tables, c
       }
     }
   }
-  float* o = G + (goff + i) * F;
+  if (G) {
+    float* o = G + (goff + i) * F;
 #pragma unroll
-  for (int f = 0; f < F; ++f) o[f] = acc[f];
+    for (int f = 0; f < F; ++f) o[f] = acc[f];
+  }
   if (dG_zero) {                                  // the vertex-grid gradient of the coming backward pass starts from zero
     float* z = dG_zero + (goff + i) * F * zero_words;          // (zero_words = 2: the 64-bit fixed-point form, see tiled_bwd_il_kernel)
     for (int f = 0; f < F * zero_words; ++f) z[f] = 0.f;
@@ -664,11 +668,14 @@ __device__ __forceinline__ void setup_tile(TileMeta& m, const int32_t* n_ls, int
   __syncthreads();
 }
 
-template <int F>
+// HSRC (round 5, spatial-hash source): the sub-grids are staged from the level tables themselves — G_l[v] = E_l[hash(v)], the value
+// vertex_fwd_lane would have put into the vertex grid G, so enc is bit-identical — and the vertex grid (69 MB written and read
+// back at the 4096^2 shape, 90 MB at the 8192^2 one) and the vertex riders' gathers disappear, as on the interleaved kernel.
+template <int F, bool HSRC = false, typename TT = float>
 __global__ void __launch_bounds__(kTBF)
 tiled_fwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ items, const int32_t* __restrict__ n_items,
                  const int32_t* __restrict__ n_ls, const float* __restrict__ G, float* __restrict__ enc, int L, int Ls,
-                 int tile_shift, int lds_floats) {
+                 int tile_shift, int lds_floats, const TT* __restrict__ tables = nullptr, int64_t T = 0, bool pow2 = false) {
   extern __shared__ float lds[];
   __shared__ TileMeta m;
   if ((int)blockIdx.x >= *n_items) return;
@@ -692,10 +699,16 @@ tiled_fwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
       }
       const int i = e - base, wx = m.wx[l];
       const int iy = i / wx, ix = i - iy * wx;
-      const float* sp = G + (m.goff[l] + (int64_t)(m.cy[l] + iy) * m.gw[l] + m.cx[l] + ix) * F;
       float* dst = lds + m.loff[l] + i * F;
+      if constexpr (HSRC) {
+        const TT* sp = tables + ((int64_t)l * T + spatial_hash(m.cx[l] + ix, m.cy[l] + iy, T, pow2)) * F;
 #pragma unroll
-      for (int f = 0; f < F; ++f) dst[f] = sp[f];
+        for (int f = 0; f < F; ++f) dst[f] = tload(sp + f);
+      } else {
+        const float* sp = G + (m.goff[l] + (int64_t)(m.cy[l] + iy) * m.gw[l] + m.cx[l] + ix) * F;
+#pragma unroll
+        for (int f = 0; f < F; ++f) dst[f] = sp[f];
+      }
     }
   }
   __syncthreads();
@@ -761,8 +774,14 @@ tiled_fwd_kernel(const float4* __restrict__ sorted, const int4* __restrict__ ite
           int gx = c.gx + (q & 1), gy = c.gy + (q >> 1);
           gx = gx < 0 ? 0 : (gx > n + 1 ? n + 1 : gx);
           gy = gy < 0 ? 0 : (gy > n + 1 ? n + 1 : gy);
+          if constexpr (HSRC) {
+            const TT* sp = tables + ((int64_t)l * T + spatial_hash(gx, gy, T, pow2)) * F;
 #pragma unroll
-          for (int f = 0; f < F; ++f) v[q][f] = Gl[((int64_t)gy * gw + gx) * F + f];
+            for (int f = 0; f < F; ++f) v[q][f] = tload(sp + f);
+          } else {
+#pragma unroll
+            for (int f = 0; f < F; ++f) v[q][f] = Gl[((int64_t)gy * gw + gx) * F + f];
+          }
         }
       }
       float* o = enc + p * LF + l * F;
@@ -2001,7 +2020,9 @@ extern "C" int gngf_encode_tiled_prepare(const float* xy, int64_t P, int tile_sh
   GNGF_CHECK_ARG(!clear_rows || (mode == GNGF_MODE_HASH && (reinterpret_cast<uintptr_t>(clear_rows) & 3) == 0));
   GNGF_CHECK_ARG(P >= 0 && P < (1ll << 31) && tile_shift >= 0 && tile_shift <= 6 && NB > 0 && NB <= kBinMaxBlocks && chunk > 0);
   GNGF_CHECK_ARG(xy && blockhist && tile_off && tile_item_base && items && n_items && sorted);
-  GNGF_CHECK_ARG(Ls > 0 && Ls <= GNGF_MAX_LEVELS && T > 0 && tables && n_ls && n_ls_host && G);
+  // G == NULL (spatial-hash source only): no vertex grid is wanted — the pixel stage gathers from the level tables itself
+  // (gngf_encode_tiled_fwd_fused) — and the riders only clear (dG_zero / clear_rows), or do not run at all
+  GNGF_CHECK_ARG(Ls > 0 && Ls <= GNGF_MAX_LEVELS && T > 0 && tables && n_ls && n_ls_host && (G || mode == GNGF_MODE_HASH));
   GNGF_CHECK_ARG(mode == GNGF_MODE_HASH || (vert_idx && vert_w && K > 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0));
   GNGF_CHECK_ARG(!zero_fill || (zero_floats >= 0 && (zero_floats & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_fill) & 15) == 0));
   const int ntiles = 1 << (2 * tile_shift);
@@ -2010,7 +2031,7 @@ extern "C" int gngf_encode_tiled_prepare(const float* xy, int64_t P, int tile_sh
   const size_t smem = (size_t)ntiles * sizeof(int);
   int64_t vtot = 0;
   for (int l = 0; l < Ls; ++l) vtot += (int64_t)(n_ls_host[l] + 2) * (n_ls_host[l] + 2);
-  const int vblocks = (int)ceil_div(vtot, kBinThreads);
+  const int vblocks = (G || dG_zero || clear_rows) ? (int)ceil_div(vtot, kBinThreads) : 0;
   const bool pow2 = (T & (T - 1)) == 0;
   const float2* xy2 = reinterpret_cast<const float2*>(xy);
   const int64_t nvec = zero_fill ? zero_floats / 4 : 0;
@@ -2251,9 +2272,26 @@ extern "C" int gngf_encode_tiled_fwd_fused(const float* sorted, const int32_t* i
   GNGF_CHECK_ARG(max_items >= 0 && L > 0 && Ls > 0 && Ls <= L && L <= GNGF_MAX_LEVELS && lds_bytes >= 0 && lds_bytes <= 128 * 1024);
   GNGF_CHECK_ARG(!next_count || bin_job_ok(next_count));
   if (max_items == 0 && !next_count) return 0;
-  GNGF_CHECK_ARG(sorted && items && n_items && n_ls && n_ls_host && tables && enc && T > 0 && feat_dtype == GNGF_FEAT_F32);
+  GNGF_CHECK_ARG(sorted && items && n_items && n_ls && n_ls_host && tables && enc && T > 0);
   GNGF_CHECK_ARG(mode == GNGF_MODE_HASH || (vert_idx && vert_w && K > 0 && K <= GNGF_MAX_TOPK && vstride > 0 && NV > 0));
-  GNGF_CHECK_ARG(interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, false));
+  if (!interleaved_applies(n_ls_host, Ls, F, tile_shift, lds_bytes / 4, false)) {
+    // generic pixel-stage kernel (shapes whose level-interleaved image does not fit, F != 2): spatial-hash source, fp32 or fp16 tables
+    GNGF_CHECK_ARG(mode == GNGF_MODE_HASH && !next_count);
+    if (max_items == 0) return 0;
+    const bool hp2 = (T & (T - 1)) == 0;
+    DISPATCH_TT(feat_dtype, DISPATCH_F(F, {
+      auto fn = tiled_fwd_kernel<kF, true, TT>;
+      if (lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return (int)e;
+      }
+      fn<<<dim3((unsigned)max_items), dim3(kTBF), (size_t)lds_bytes, as_stream(stream)>>>(
+          reinterpret_cast<const float4*>(sorted), reinterpret_cast<const int4*>(items), n_items, n_ls, nullptr, enc, L, Ls, tile_shift,
+          lds_bytes / 4, static_cast<const TT*>(tables), T, hp2);
+    }));
+    GNGF_RETURN_LAUNCH();
+  }
+  GNGF_CHECK_ARG(feat_dtype == GNGF_FEAT_F32);
   size_t smem = (size_t)interleaved_rows(n_ls_host, Ls, tile_shift) * kIL * 8;
   BinCountRide cride = bin_job_none();
   if (next_count) {

@@ -1412,7 +1412,8 @@ class StepConfig:
         if needs_grad and (L * T * F) % 4 != 0:
             fused = False                                    # (the one-block gradient allocation wants whole 16-byte vectors)
         if not needs_grad:
-            return StepConfig(src, plan.Ls, nd, "pipeline" if fused else "prepare", "fused" if fused else "riders",
+            vf0 = "fused" if (fused or (t.fused_vertex_fwd and mode == MODE_HASH and not il_f)) else "riders"
+            return StepConfig(src, plan.Ls, nd, "pipeline" if fused else "prepare", vf0,
                               "interleaved" if il_f else "generic", "none", "none", "none", "none", bool(exchange))
         direct_hash = bool(t.hash_direct_scatter and t.hash_vertex_fusion and mode == MODE_HASH and not exchange)
         use64 = bool(t.dg64 and F == 2 and plan.Ls <= 16 and il_b)
@@ -1424,7 +1425,10 @@ class StepConfig:
         hidden = link_defer_zero and link_zero_hidden and L * T * F * 4 <= t.persistent_min_bytes
         persist = bool(t.persistent_table_grad and not hidden and mode == MODE_HASH and persist_ok and not exchange and (fresh or nd == 0)
                        and persist_alloc_ok)
-        return StepConfig(src, plan.Ls, nd, "prepare", "riders", "interleaved" if il_b else "generic", sink,
+        # generic kernels (or the interleaved one on fp16 tables): hash source — the pixel stage gathers from the tables itself too
+        # (no vertex grid; the riders of the binning launch only clear), vertex-table source — vertex riders build the grid
+        vf = "fused" if (t.fused_vertex_fwd and mode == MODE_HASH and not il_f) else "riders"
+        return StepConfig(src, plan.Ls, nd, "prepare", vf, "interleaved" if il_b else "generic", sink,
                           "persist" if persist else "alloc", "rows" if persist else ("decoder" if link_defer_zero else "riders"),
                           "bucketed_write" if fresh else ("bucketed_or_atomics" if nd > 0 else "none"), bool(exchange))
 
@@ -1473,7 +1477,7 @@ class EncodeFunction(torch.autograd.Function):
             # fp32 tables on the level-interleaved kernel: the vertex stage forward runs INSIDE the pixel stage's staging loop (no
             # vertex grid G, no vertex riders) and the binning is two launches of its own — or none, when the previous step's
             # launches carried it (BinPipeline)
-            fused = sc.vertex_fwd == "fused"
+            fused = sc.vertex_fwd == "fused" and sc.binning == "pipeline"      # (the interleaved kernel's own binning: two launches or riders)
             use64 = sc.grad_sink == "dG64"
             big = None
             if ctx.needs_input_grad[3]:
@@ -1548,13 +1552,19 @@ class EncodeFunction(torch.autograd.Function):
             else:
                 # binning, vertex stage and the clears of the backward's gradient buffers: ONE chain of launches (the vertex stage
                 # and the clears ride on the binning kernels as extra workgroups: ops.TiledWorkspace)
-                G = torch.empty((plan.vtot, F), dtype=_f32, device=dev)
+                gather = sc.vertex_fwd == "fused"             # hash source on the generic kernels: no vertex grid (riders only clear)
+                G = None if gather else torch.empty((plan.vtot, F), dtype=_f32, device=dev)
                 ws = TiledWorkspace(plan, xy, vertex=(tables, vert_idx, vert_w, n_ls, vstride, G),
                                     zero_dG=(pre[1].view(_f32) if pre[1].dtype == _i64 else pre[1]) if (pre and pre[1] is not None) else None,
                                     zero=(pre[3] if (pre and pre[3] is not None and not defer) else None),
                                     zero_dG_words=(2 if use64 else 1), owner=dp, clear_rows=clear_now)
-                call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), plan.n_ls_c,
-                     ptr(G), ptr(enc), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, stream_ptr())
+                if gather:
+                    call("gngf_encode_tiled_fwd_fused", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), plan.n_ls_c,
+                         *_tab(tables), ptr(None), ptr(None), ptr(enc), L, plan.Ls, F, T, 0, mode, 0, 0, plan.tile_shift, plan.lds_bytes, None,
+                         stream_ptr())
+                else:
+                    call("gngf_encode_tiled_fwd", ptr(ws.sorted), ptr(ws.items), ptr(ws.n_items), plan.max_items, ptr(n_ls), plan.n_ls_c,
+                         ptr(G), ptr(enc), L, plan.Ls, F, plan.tile_shift, plan.lds_bytes, stream_ptr())
         if plan.Ls < L:
             call("gngf_encode_fwd", ptr(xy, _f32, "xy"), *_tab(tables), ptr(vert_idx, _i32, "vert_idx"),
                  ptr(vert_w, _f32, "vert_w"), ptr(n_ls, _i32, "n_ls"), ptr(enc), P, L, F, T, K, mode, vstride, NV, plan.Ls, L,

@@ -113,7 +113,9 @@ int gngf_bin_pixels(const float* xy, int64_t P, int tile_shift, int NB, int chun
  *   gngf_vertex_grid_fwd (levels [0, Ls), riding on the count launch as extra workgroups) plus two buffer clears:
  *   dG_zero (same shape as G; NULL: none) and zero_fill (zero_floats floats, a multiple of 4, 16-byte aligned — the table
  *   gradient buffer; NULL: none; riding on the scatter launch).  Parallel branches of a replayed hipGraph cost ~10 us per
- *   cross-queue dependency on this stack; riders on one chain cost nothing. */
+ *   cross-queue dependency on this stack; riders on one chain cost nothing.
+ *   G may be NULL for the spatial-hash source (round 5): no vertex grid is built — the pixel stage gathers from the level tables
+ *   itself (gngf_encode_tiled_fwd_fused) — and the riders only clear (dG_zero / clear_rows), or do not run at all. */
 int gngf_encode_tiled_prepare(const float* xy, int64_t P, int tile_shift, int NB, int chunk, int32_t* blockhist,
                               int32_t* tile_off, int32_t* tile_item_base, int32_t* items, int32_t* n_items, float* sorted,
                               const void* tables, int feat_dtype, const int32_t* vert_idx, const float* vert_w,
@@ -171,7 +173,8 @@ typedef struct gngf_bin_job {
  * aligned) is cleared by rider workgroups of the count launch */
 int gngf_bin_pixels2(const gngf_bin_job* job, float* zero_fill, int64_t zero_floats, void* stream);
 /* pixel stage forward with the vertex stage forward fused into its staging loop (bit-identical to gngf_vertex_grid_fwd +
- * gngf_encode_tiled_fwd; interleaved kernel only: F = 2, fp32 tables — see gngf_tiled_interleaved_applies — else rejected).
+ * gngf_encode_tiled_fwd).  Level-interleaved kernel (F = 2, fp32 tables — see gngf_tiled_interleaved_applies): both index sources;
+ * generic kernel (any other shape; round 5): spatial-hash source, fp32 or fp16 tables, next_count must be NULL.
  * next_count (optional): the count half of another batch's binning runs in extra workgroups at the head of the launch; its
  * scatter half rides on gngf_encode_tiled_bwd(..., next_bin) of the same step. */
 int gngf_encode_tiled_fwd_fused(const float* sorted, const int32_t* items, const int32_t* n_items, int max_items,

@@ -8,7 +8,7 @@ groups = {     # round 3 kernel names (the round-2 names stay listed: general sh
     "bin_pixels(count+scatter)": ["gngf::bin_count_reserve_kernel", "gngf::bin_scatter3_kernel"],
     "prepare(bin+vertex_fwd+clears)": ["gngf::bin_count_vride_kernel", "gngf::bin_rowscan_kernel", "gngf::bin_scan_kernel",
                                        "gngf::bin_scatter_ride_kernel<2", "gngf::bin_scatter_kernel"],
-    "encode_fwd:tiled": ["gngf::tiled_fwd_kernel<2>", "gngf::tiled_fwd_il_kernel"],
+    "encode_fwd:tiled": ["gngf::tiled_fwd_kernel<2", "gngf::tiled_fwd_il_kernel"],
     "encode_bwd:tiled": ["gngf::tiled_bwd_kernel<2", "gngf::gather_partials_kernel<2", "gngf::tiled_bwd_il_kernel", "gngf::dg64_to_float_kernel",
                          "gngf::vertex_bwd_hash64_kernel"],
     "decoder_train": ["gngf::decoder_bwd_kernel<32, false, true, false, true, true>"],     # forward + backward in one launch
