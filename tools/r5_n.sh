@@ -4,7 +4,7 @@
 mkdir -p gpurun_out
 for rep in 1 2; do
   for lib in build/libgngf_dev.so ""; do
-    for m in cfg4_hash; do
+    for m in cfg4_hash cfg5_hash_fp16; do
       GNGF_LIB_PATH=$lib timeout -k 10 300 python bench.py --mode $m --no-extra-modes --no-cpu-baseline --no-full-outputs > gpurun_out/r5_n.json 2> gpurun_out/r5_n.err || { tail -3 gpurun_out/r5_n.err; exit 1; }
       python -c "
 import json
