@@ -392,6 +392,71 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+// Epilogue of the 128 x 128 split kernels: wave (wm, wn) holds rows wm * 64 .. + 63, columns wn * 64 .. + 63 of the tile as 2 x 2
+// MFMA accumulators; bias, activation / atomic accumulation, and (rowparts) the row statistics of the tile.
+__device__ __forceinline__ void split_epilogue(f32x16 (&acc)[2][2], float* __restrict__ C, int64_t ldc, const float* __restrict__ bias,
+                                               int act, int atomic_out, int64_t m0, int64_t n0, int wm, int wn, int i, int h,
+                                               float2* __restrict__ rowparts, int nparts) {
+  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(C + m0 * ldc + n0, 0, 0x7fffffff, 0x00020000);
+  const unsigned oc = 4u * ((unsigned)(wm * 64 + 4 * h) * (unsigned)ldc + wn * 64 + i);
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const float bv = (bias && blockIdx.y == 0) ? bias[n0 + wn * 64 + tn * 32 + i] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned so = 4u * ((unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)ldc + tn * 32);
+        const float v = acc[tm][tn][r] + bv;
+        if (atomic_out) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rsc, oc, so, 0);
+        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(act_fwd(v, act)), rsc, oc, so, 0);
+        if (rowparts) acc[tm][tn][r] = v;                        // (the statistics below are taken on the stored values)
+      }
+  }
+  if (rowparts) {
+    // ROW STATISTICS OF THE TILE IN THE EPILOGUE (the logits product of the chunked HashProbDistribution, reference
+    // models.py:85,105-116): for every row of the tile and each 64-column half (this wave's columns) the maximum and
+    // sum exp(z - max) — 8 bytes per 256 bytes of logits — so that the row maxima / normalisers and the top-K (which lies inside
+    // the K half-tiles with the largest maxima) come out of a merge over these partials instead of a second pass over the logits
+    // (hpd.hip: rowstats_topk_kernel).  Reduction over the 32 lanes that share a row: four DPP steps inside each 16-lane row
+    // (quad_perm, half mirror, mirror: every lane of the row ends up with the row's result) and row_bcast15 into rows 1 / 3;
+    // lanes 16 (h = 0) and 48 (h = 1) store.  A NaN logit makes the half's sum NaN (the maximum ignores it, as fmaxf does).
+    constexpr float kLog2e = 1.4426950408889634f;
+    const int64_t part = (n0 >> 6) + wn;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float a = acc[tm][0][r], b = acc[tm][1][r];
+        float m = fmaxf(a, b);
+        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0xB1, 0xF, 0xF, false)));
+        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x4E, 0xF, 0xF, false)));
+        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x141, 0xF, 0xF, false)));
+        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x140, 0xF, 0xF, false)));
+        // rows 1 and 3 take lane 15 of rows 0 and 2; rows 0 and 2 keep their own value (it is not used)
+        const float mo = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x142, 0xA, 0xF, false));
+        m = fmaxf(m, mo);
+        // every lane needs the maximum of ALL 32 lanes for its exponentials: lane 16 holds it for h = 0, lane 48 for h = 1
+        const float m_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 16));
+        const float m_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 48));
+        const float mall = h ? m_hi : m_lo;
+        float sx = (mall == -INFINITY) ? 0.f
+                                       : __builtin_amdgcn_exp2f((a - mall) * kLog2e) + __builtin_amdgcn_exp2f((b - mall) * kLog2e);
+        if (a != a || b != b) sx = __int_as_float(0x7fc00000);
+        sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0xB1, 0xF, 0xF, false));
+        sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x4E, 0xF, 0xF, false));
+        sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x141, 0xF, 0xF, false));
+        sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x140, 0xF, 0xF, false));
+        const float so2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x142, 0xA, 0xF, true));
+        sx += so2;                                               // (rows 0 / 2 receive 0: bound_ctrl; their sums are not used)
+        if (i == 16) {
+          const int64_t row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          rowparts[row * nparts + part] = make_float2(mall, sx);
+        }
+      }
+  }
+}
+
 // Same staging and tile order as gemm128_fast_kernel (fp32 K-blocks in LDS, k-major); every wave splits the fragments it
 // reads.  (A variant that splits once per workgroup on the way into LDS — bf16 planes, 16-byte fragment reads — was not
 // faster on any of the three shapes, and slower where both operands are staged transposed: the kernel is bound by its
@@ -485,64 +550,185 @@ gemm128_split_kernel(const float* __restrict__ A, const float* __restrict__ B, f
     });
     __syncthreads();
   }
-  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(C + m0 * ldc + n0, 0, 0x7fffffff, 0x00020000);
-  const unsigned oc = 4u * ((unsigned)(wm * 64 + 4 * h) * (unsigned)ldc + wn * 64 + i);
-#pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const float bv = (bias && blockIdx.y == 0) ? bias[n0 + wn * 64 + tn * 32 + i] : 0.f;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned so = 4u * ((unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)ldc + tn * 32);
-        const float v = acc[tm][tn][r] + bv;
-        if (atomic_out) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rsc, oc, so, 0);
-        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(act_fwd(v, act)), rsc, oc, so, 0);
-        if (rowparts) acc[tm][tn][r] = v;                        // (the statistics below are taken on the stored values)
-      }
+  split_epilogue(acc, C, ldc, bias, act, atomic_out, m0, n0, wm, wn, i, h, rowparts, nparts);
+}
+
+// ---------------------------------------------------------------------------------- split once, bf16 planes in LDS
+// The split kernel above splits every fragment a wave reads — each operand value is split twice (two waves share a tile row /
+// column) by 5.5 VALU instructions, and the K loop is bound by vector issue (SQ counters, dW shape: vector issue 65 % busy + MFMA
+// issue 15 %, matrix pipe 60 %, the chip holding ~1.6 GHz under that load).  Here a value is split ONCE, by the thread that loaded
+// it, on the way into LDS: the K-block of an operand is kept as NP planes of bf16 (hi, mid, lo — or hi, lo), 8 KB each, and a
+// fragment is one 16-byte read per plane.  Two images, both without padding and conflict-free for their writes and reads:
+//  * [row][k] for an operand whose k runs contiguously in memory: 64-byte rows, the four 16-byte chunks of a row XOR-ed with
+//    (row >> 2) & 3; lane (i, h) reads chunk 2 s + h of row i with ds_read_b128;
+//  * [k][row] for an operand stored k-major: 256-byte rows (four 64-byte segments of 32 rows, segment XOR-ed with k & 3), written
+//    as loaded (four rows of one k: 8 bytes per plane) and read through the hardware transposition (ds_read_b64_tr_b16: a group of
+//    16 lanes reads 4 k-rows x 16 columns and every lane receives its column's four k).
+// NP = 3: x = hi + mid + lo exactly, six products, the numbers of the kernel above bit for bit (same terms, same order).
+// NP = 2: x ~= hi + lo (16 significant bits), three products hi hi + hi lo + lo hi: |error| <= 3 * 2^-18 |a b| per product — inside
+// what an fp32 dot product of >= 200 terms may lose by its own a-priori bound (n 2^-24), and in the measured error against float64 at
+// the level of the exact-fp32 kernel (tools/perf_gemm_split.py); for the two accumulating GEMMs of the backward pass (dW, dh).
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+
+template <int NP> __device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[NP]) {
+  const unsigned h = cvt_pk_bf16(a, b);
+  const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);          // exact
+  out[0] = h;
+  const unsigned m = cvt_pk_bf16(ra, rb);
+  out[1] = m;
+  if constexpr (NP == 3) {
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);      // exact
+    out[2] = cvt_pk_bf16(sa, sb);
   }
-  if (rowparts) {
-    // ROW STATISTICS OF THE TILE IN THE EPILOGUE (the logits product of the chunked HashProbDistribution, reference
-    // models.py:85,105-116): for every row of the tile and each 64-column half (this wave's columns) the maximum and
-    // sum exp(z - max) — 8 bytes per 256 bytes of logits — so that the row maxima / normalisers and the top-K (which lies inside
-    // the K half-tiles with the largest maxima) come out of a merge over these partials instead of a second pass over the logits
-    // (hpd.hip: rowstats_topk_kernel).  Reduction over the 32 lanes that share a row: four DPP steps inside each 16-lane row
-    // (quad_perm, half mirror, mirror: every lane of the row ends up with the row's result) and row_bcast15 into rows 1 / 3;
-    // lanes 16 (h = 0) and 48 (h = 1) store.  A NaN logit makes the half's sum NaN (the maximum ignores it, as fmaxf does).
-    constexpr float kLog2e = 1.4426950408889634f;
-    const int64_t part = (n0 >> 6) + wn;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float a = acc[tm][0][r], b = acc[tm][1][r];
-        float m = fmaxf(a, b);
-        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0xB1, 0xF, 0xF, false)));
-        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x4E, 0xF, 0xF, false)));
-        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x141, 0xF, 0xF, false)));
-        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x140, 0xF, 0xF, false)));
-        // rows 1 and 3 take lane 15 of rows 0 and 2; rows 0 and 2 keep their own value (it is not used)
-        const float mo = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x142, 0xA, 0xF, false));
-        m = fmaxf(m, mo);
-        // every lane needs the maximum of ALL 32 lanes for its exponentials: lane 16 holds it for h = 0, lane 48 for h = 1
-        const float m_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 16));
-        const float m_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 48));
-        const float mall = h ? m_hi : m_lo;
-        float sx = (mall == -INFINITY) ? 0.f
-                                       : __builtin_amdgcn_exp2f((a - mall) * kLog2e) + __builtin_amdgcn_exp2f((b - mall) * kLog2e);
-        if (a != a || b != b) sx = __int_as_float(0x7fc00000);
-        sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0xB1, 0xF, 0xF, false));
-        sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x4E, 0xF, 0xF, false));
-        sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x141, 0xF, 0xF, false));
-        sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x140, 0xF, 0xF, false));
-        const float so2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x142, 0xA, 0xF, true));
-        sx += so2;                                               // (rows 0 / 2 receive 0: bound_ctrl; their sums are not used)
-        if (i == 16) {
-          const int64_t row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          rowparts[row * nparts + part] = make_float2(mall, sx);
-        }
-      }
+}
+
+// byte offset (inside one 8 KB plane) of the 8 bytes thread `li` of the staging pass writes: KM = the operand is k-major in memory
+// (thread li holds rows 4 (li & 31) .. + 3 of k = li >> 5), else k-contiguous (row li >> 3, k = 4 (li & 7) .. + 3)
+template <bool KM> __device__ __forceinline__ unsigned plane_write_offset(int li) {
+  if (KM) {
+    const int k = li >> 5, mq = li & 31;
+    return 256u * k + 64u * ((mq >> 3) ^ (k & 3)) + 8u * (mq & 7);
   }
+  const int row = li >> 3, kq = li & 7;
+  return 64u * row + 16u * ((kq >> 1) ^ ((row >> 2) & 3)) + 8u * (kq & 1);
+}
+
+template <int NP> struct Frag { u32x4 p[NP]; };
+
+// fragment (rows w64 + 32 t .. + 31, k = 16 s + 8 h .. + 7) of one operand: lane-dependent part of the address in a0 / a1
+//   k-contiguous image: a_s  = 64 (w64 + i) + 16 ((2 s + h) ^ ((i >> 2) & 3))      (s = 0, 1);  + 2048 t + 8192 plane
+//   k-major image:      a_t  = 256 (8 h + q) + 64 ((w64 / 32 + t) ^ q) + 32 ((lane >> 4) & 1) + 8 p  (q = (lane >> 2) & 3, p = lane & 3);
+//                              + 4096 s + 1024 (second four k) + 8192 plane
+template <bool KM, int NP, int S, int TT>
+__device__ __forceinline__ Frag<NP> read_frag(const lds_byte* base, unsigned a0, unsigned a1) {
+  Frag<NP> f;
+#pragma unroll
+  for (int pl = 0; pl < NP; ++pl) {
+    if constexpr (KM) {
+      const lds_byte* q = base + (TT ? a1 : a0) + 4096 * S + 8192 * pl;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)q);
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q + 1024));
+      const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+      f.p[pl] = u32x4{l2.x, l2.y, h2.x, h2.y};
+    } else {
+      const lds_byte* q = base + (S ? a1 : a0) + 2048 * TT + 8192 * pl;
+      f.p[pl] = *(const lds_u32x4*)q;
+    }
+  }
+  return f;
+}
+
+template <int NP> __device__ __forceinline__ f32x16 split_products(const Frag<NP>& a, const Frag<NP>& b, f32x16 c) {
+  if constexpr (NP == 3) {                                     // small terms first (the order of gemm128_split_kernel)
+    c = mfma_bf16(a.p[2], b.p[0], c);
+    c = mfma_bf16(a.p[0], b.p[2], c);
+    c = mfma_bf16(a.p[1], b.p[1], c);
+    c = mfma_bf16(a.p[1], b.p[0], c);
+    c = mfma_bf16(a.p[0], b.p[1], c);
+    c = mfma_bf16(a.p[0], b.p[0], c);
+  } else {
+    c = mfma_bf16(a.p[1], b.p[0], c);
+    c = mfma_bf16(a.p[0], b.p[1], c);
+    c = mfma_bf16(a.p[0], b.p[0], c);
+  }
+  return c;
+}
+
+template <bool TA, bool TB, int NP>
+__global__ void __launch_bounds__(256, 3)
+gemm128_planes_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                      int64_t lda, int64_t ldb, int64_t ldc, const float* __restrict__ bias, int act, int64_t K,
+                      int64_t kchunk, int atomic_out, int tiles_m, int tiles_n, float2* __restrict__ rowparts = nullptr,
+                      int nparts = 0) {
+  constexpr int BKF = 32;
+  constexpr int NV4 = BKF / 8;
+  constexpr bool AKM = TA, BKM = !TB;                           // which operands are k-major in memory
+  __shared__ __attribute__((aligned(16))) unsigned char img[2 * NP * 8192];          // planes of A, then planes of B
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
+  int64_t t = blockIdx.x;
+  const int64_t ntiles = (int64_t)tiles_m * tiles_n;
+  if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);
+  const int64_t m0 = (tiles_m <= tiles_n ? t % tiles_m : t / tiles_n) * BM2;
+  const int64_t n0 = (tiles_m <= tiles_n ? t / tiles_m : t % tiles_n) * BN2;
+  const int64_t kbeg = (int64_t)blockIdx.y * kchunk;
+  const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+  const int nkb = (int)((kend - kbeg) / BKF);
+  const float* Aw = TA ? A + kbeg * lda + m0 : A + m0 * lda + kbeg;
+  const float* Bw = !TB ? B + kbeg * ldb + n0 : B + n0 * ldb + kbeg;
+  const int64_t sa = TA ? (int64_t)BKF * lda : BKF, sb = !TB ? (int64_t)BKF * ldb : BKF;
+  unsigned oa[NV4], ob[NV4];
+#pragma unroll
+  for (int e = 0; e < NV4; ++e) {
+    const int li = tid + e * 256;
+    oa[e] = 4u * (TA ? (unsigned)(li >> 5) * (unsigned)lda + (li & 31) * 4 : (unsigned)(li / (BKF / 4)) * (unsigned)lda + (li % (BKF / 4)) * 4);
+    ob[e] = 4u * (!TB ? (unsigned)(li >> 5) * (unsigned)ldb + (li & 31) * 4 : (unsigned)(li / (BKF / 4)) * (unsigned)ldb + (li % (BKF / 4)) * 4);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = 0;
+  u32x4 va[NV4], vb[NV4];
+  auto fetch = [&](int kb) {
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Aw + kb * sa), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bw + kb * sb), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int e = 0; e < NV4; ++e) {
+      va[e] = __builtin_amdgcn_raw_buffer_load_b128(rsa, oa[e], 0, 0);
+      vb[e] = __builtin_amdgcn_raw_buffer_load_b128(rsb, ob[e], 0, 0);
+    }
+  };
+  fetch(0);
+  lds_byte* const imgA = (lds_byte*)img;
+  lds_byte* const imgB = imgA + NP * 8192;
+  // this thread's staging offsets are the same every K-block: one base each, the four passes 2048 bytes apart in either image
+  const unsigned wa0 = plane_write_offset<AKM>(tid), wb0 = plane_write_offset<BKM>(tid);
+  // lane-dependent parts of the fragment addresses
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+  const unsigned ra0 = AKM ? 256u * (8 * h + q4) + 64u * ((2 * wm) ^ q4) + 32u * g1 + 8u * p4
+                           : 64u * (wm * 64 + i) + 16u * ((unsigned)h ^ ((i >> 2) & 3));
+  const unsigned ra1 = AKM ? 256u * (8 * h + q4) + 64u * ((2 * wm + 1) ^ q4) + 32u * g1 + 8u * p4
+                           : 64u * (wm * 64 + i) + 16u * ((unsigned)(2 + h) ^ ((i >> 2) & 3));
+  const unsigned rb0 = BKM ? 256u * (8 * h + q4) + 64u * ((2 * wn) ^ q4) + 32u * g1 + 8u * p4
+                           : 64u * (wn * 64 + i) + 16u * ((unsigned)h ^ ((i >> 2) & 3));
+  const unsigned rb1 = BKM ? 256u * (8 * h + q4) + 64u * ((2 * wn + 1) ^ q4) + 32u * g1 + 8u * p4
+                           : 64u * (wn * 64 + i) + 16u * ((unsigned)(2 + h) ^ ((i >> 2) & 3));
+  for (int kb = 0; kb < nkb; ++kb) {
+#pragma unroll
+    for (int e = 0; e < NV4; ++e) {
+      // pass e: li = tid + 256 e  ->  k + 8 e (k-major: 8 rows of 256 bytes) or row + 32 e (32 rows of 64 bytes): + 2048 e bytes;
+      // the XOR terms do not change (k & 3, (row >> 2) & 3 are those of pass 0: 8 e and 32 e leave them alone)
+      unsigned pa[2][NP], pb[2][NP];
+      split_pair<NP>(__uint_as_float(va[e].x), __uint_as_float(va[e].y), pa[0]);
+      split_pair<NP>(__uint_as_float(va[e].z), __uint_as_float(va[e].w), pa[1]);
+      split_pair<NP>(__uint_as_float(vb[e].x), __uint_as_float(vb[e].y), pb[0]);
+      split_pair<NP>(__uint_as_float(vb[e].z), __uint_as_float(vb[e].w), pb[1]);
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) {
+        *(lds_u32x2*)(imgA + wa0 + 2048 * e + 8192 * pl) = u32x2{pa[0][pl], pa[1][pl]};
+        *(lds_u32x2*)(imgB + wb0 + 2048 * e + 8192 * pl) = u32x2{pb[0][pl], pb[1][pl]};
+      }
+    }
+    __syncthreads();
+    if (kb + 1 < nkb) fetch(kb + 1);
+    unrolled<2>([&](auto S_) {
+      constexpr int ks = S_.value;
+      const Frag<NP> fa0 = read_frag<AKM, NP, ks, 0>(imgA, ra0, ra1), fa1 = read_frag<AKM, NP, ks, 1>(imgA, ra0, ra1);
+      const Frag<NP> fb0 = read_frag<BKM, NP, ks, 0>(imgB, rb0, rb1), fb1 = read_frag<BKM, NP, ks, 1>(imgB, rb0, rb1);
+      acc[0][0] = split_products<NP>(fa0, fb0, acc[0][0]);
+      acc[0][1] = split_products<NP>(fa0, fb1, acc[0][1]);
+      acc[1][0] = split_products<NP>(fa1, fb0, acc[1][0]);
+      acc[1][1] = split_products<NP>(fa1, fb1, acc[1][1]);
+    });
+    __syncthreads();
+  }
+  split_epilogue(acc, C, ldc, bias, act, atomic_out, m0, n0, wm, wn, i, h, rowparts, nparts);
 }
 
 static int g_split_bf16 = 0;       // see gngf_set_gemm_split_bf16
@@ -579,8 +765,12 @@ static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int6
     if (!(M % BM2 == 0 && N % BN2 == 0 && K % 32 == 0 && !amask && aligned && windows32 && splitk <= 1 && !force_atomic && act == 0))
       return (int)hipErrorInvalidValue;
     const unsigned tm_ = (unsigned)(M / BM2), tn_ = (unsigned)(N / BN2);
-    gemm128_split_kernel<TA, TB><<<dim3(tm_ * tn_, 1), dim3(256), 0, s>>>(A, B, C, lda, ldb, ldc, bias, act, K, K, 0, (int)tm_, (int)tn_,
-                                                                       rowparts, (int)(N / 64));
+    if (g_split_bf16 == 17)
+      gemm128_split_kernel<TA, TB><<<dim3(tm_ * tn_, 1), dim3(256), 0, s>>>(A, B, C, lda, ldb, ldc, bias, act, K, K, 0, (int)tm_, (int)tn_,
+                                                                         rowparts, (int)(N / 64));
+    else
+      gemm128_planes_kernel<TA, TB, 3><<<dim3(tm_ * tn_, 1), dim3(256), 0, s>>>(A, B, C, lda, ldb, ldc, bias, act, K, K, 0, (int)tm_, (int)tn_,
+                                                                             rowparts, (int)(N / 64));
     return (int)hipGetLastError();
   }
   int64_t kchunk = K;
@@ -597,8 +787,14 @@ static int launch_gemm(const float* A, const float* B, float* C, int64_t M, int6
     if (M % BM2 == 0 && N % BN2 == 0 && !amask && aligned && windows32) {
       const dim3 gridf(grid2.x * grid2.y, (unsigned)splitk);
       if (g_split_bf16 && K % 32 == 0 && kchunk % 32 == 0) {
-        gemm128_split_kernel<TA, TB><<<gridf, dim3(256), 0, s>>>(A, B, C, lda, ldb, ldc, bias, act, K, kchunk,
-                                                                    (splitk > 1 || force_atomic) ? 1 : 0, (int)grid2.y, (int)grid2.x);
+        const int ato = (splitk > 1 || force_atomic) ? 1 : 0;
+        // two planes only where the result is ACCUMULATED over a long contraction (the backward pass's dW and dh: force_atomic)
+        if (g_split_bf16 == 2 && force_atomic)
+          gemm128_planes_kernel<TA, TB, 2><<<gridf, dim3(256), 0, s>>>(A, B, C, lda, ldb, ldc, bias, act, K, kchunk, ato, (int)grid2.y, (int)grid2.x);
+        else if (g_split_bf16 == 17)
+          gemm128_split_kernel<TA, TB><<<gridf, dim3(256), 0, s>>>(A, B, C, lda, ldb, ldc, bias, act, K, kchunk, ato, (int)grid2.y, (int)grid2.x);
+        else
+          gemm128_planes_kernel<TA, TB, 3><<<gridf, dim3(256), 0, s>>>(A, B, C, lda, ldb, ldc, bias, act, K, kchunk, ato, (int)grid2.y, (int)grid2.x);
         return (int)hipGetLastError();
       }
       if (K % kFastBK == 0 && kchunk % kFastBK == 0) {
@@ -630,7 +826,7 @@ using namespace gngf;
 // is on (process-wide switch; returns the previous setting).  Off by default.
 extern "C" int gngf_set_gemm_split_bf16(int on) {
   const int prev = g_split_bf16;
-  g_split_bf16 = on ? 1 : 0;
+  g_split_bf16 = (on == 2 || on == 17) ? on : (on ? 1 : 0);
   return prev;
 }
 

@@ -44,6 +44,8 @@ class Tuning:
     hpd_z_cache_reserve: int = 40 << 30       # device memory that must stay free beside them
     hpd_pipeline: bool = True                 # chunks software-pipelined over two streams (GEMMs beside streaming passes)
     hpd_gemm_split_bf16: bool = True          # the three T-wide GEMMs on the exact three-way bf16 split
+    hpd_gemm_kernel: int = 1                  # 1: values split once into bf16 planes in LDS (round 5) | 17: every wave splits what it reads
+    hpd_bwd_two_planes: bool = True           # dW and dh (accumulated over >= 4096 terms) on two planes, three products
     hpd_epilogue_stats: bool = True           # row statistics in the logits GEMM's epilogue
     # ---- tiled form: plan (EncodePlan)
     encode_path: str = "auto"                 # "auto" | "direct" | "tiled" (tests force a path)
@@ -493,8 +495,11 @@ class HpdAux:
 class _split_gemm:
     """scope in which large aligned GEMMs of this process use the split-bf16 kernel (when HPD_GEMM_SPLIT_BF16)"""
 
+    def __init__(self, accumulating=False):
+        self.mode = 2 if (accumulating and TUNING.hpd_bwd_two_planes and TUNING.hpd_gemm_kernel == 1) else TUNING.hpd_gemm_kernel
+
     def __enter__(self):
-        self.prev = query("gngf_set_gemm_split_bf16", 1) if TUNING.hpd_gemm_split_bf16 else None
+        self.prev = query("gngf_set_gemm_split_bf16", self.mode) if TUNING.hpd_gemm_split_bf16 else None
         return self
 
     def __exit__(self, *exc):
@@ -706,7 +711,7 @@ class HpdVertexFunction(torch.autograd.Function):
                      ptr(mw[u0:u0 + n] if g_pbar is not None else None), ptr(g_pbar), L if g_pbar is not None else 0,
                      ptr(grads[-1]), ptr(scratch), ptr(tv[u0:u0 + n] if g_tv is not None else None), n, T,
                      K if g_tv is not None else 0, stream_ptr())
-                with _split_gemm():
+                with _split_gemm(accumulating=True):
                     linear_bwd_weight(dz, None, hs[-1], grads[-2], None, ACT_NONE)
             else:
                 if keep_probs:
@@ -721,7 +726,7 @@ class HpdVertexFunction(torch.autograd.Function):
                      ptr(g_probs[u0:u0 + n]), ptr(mw[u0:u0 + n] if g_pbar is not None else None), ptr(g_pbar), L, ptr(dz), n, T,
                      K if g_tv is not None else 0, stream_ptr())
                 linear_bwd_weight(dz, None, hs[-1], grads[-2], grads[-1], ACT_NONE)
-            with _split_gemm():
+            with _split_gemm(accumulating=lowrank):
                 gemm_acc(dz, W_last, dH[u0:u0 + n], n, W_last.shape[1], T, ta=False, tb=False)     # dh = dz @ W_last, split over T
         HpdVertexFunction._hidden_backward(hs_all, dH, params, grads, n_layers)
         return (None, None, None, None, None, None, None, *grads)
@@ -749,7 +754,7 @@ class HpdVertexFunction(torch.autograd.Function):
 
         def stage_c(dz, hs, done_b, n, u0):
             main.wait_event(done_b)
-            with _split_gemm():
+            with _split_gemm(accumulating=True):
                 linear_bwd_weight(dz, None, hs[-1], grads[-2], None, ACT_NONE)
                 gemm_acc(dz, W_last, dH[u0:u0 + n], n, W_last.shape[1], T, ta=False, tb=False)     # dh = dz @ W_last, split over T
 

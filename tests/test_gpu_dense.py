@@ -867,3 +867,53 @@ def test_logits_gemm_with_epilogue_statistics_equals_the_separate_pass(ops, M, T
     import pytest as _pt
     with _pt.raises(RuntimeError):
         call("gngf_linear_fwd_rowstats", ptr(xx[:100].contiguous()), ptr(Wt), ptr(bt), ptr(z1), ptr(parts), 100, T, Kc, stream_ptr())
+
+
+@pytest.mark.parametrize("mode", [1, 2, 17])
+def test_split_gemms_with_bf16_planes_in_lds(ops, mode):
+    """Round 5: the three T-wide GEMMs of the HashProbDistribution's last layer (reference models.py:84-85 and its autograd
+    backward) with every operand value split ONCE into bf16 planes on the way into LDS (mode 1: three planes, six products;
+    mode 2: two planes, three products, accumulating GEMMs only) against float64 and against the per-wave split kernel (mode 17):
+    the three-plane kernel computes the same six terms in the same order — logits bit-identical; error over sum |a b| at the
+    fp32 level for modes 1 / 17 and <= 3 * 2^-18 (its a-priori bound) for mode 2."""
+    from collision_handling_in_instantngp_amd._lib import query
+    rng = np.random.default_rng(5)
+    n, T, H = 512, 2048, 128
+    h = t((rng.standard_normal((n, H)) * 50).astype(np.float32))
+    W = t(((rng.random((T, H)) * 2 - 1) / H ** 0.5).astype(np.float32))
+    b = t(((rng.random(T) * 2 - 1) / H ** 0.5).astype(np.float32))
+    # gradients with 30 decades between the columns, as softmax gradients have
+    dz = t((rng.standard_normal((n, T)) * np.exp(rng.uniform(-60, 0, size=(1, T)))).astype(np.float32))
+
+    def run(md):
+        prev = query("gngf_set_gemm_split_bf16", md)
+        try:
+            z = ops.linear_fwd(h, W, b, ops.ACT_NONE)
+            dW = torch.zeros_like(W)
+            ops.linear_bwd_weight(dz, None, h, dW, None, ops.ACT_NONE)
+            dh = torch.zeros((n, H), device=DEV)
+            ops.gemm_acc(dz, W, dh, n, H, T, ta=False, tb=False)
+            torch.cuda.synchronize()
+        finally:
+            query("gngf_set_gemm_split_bf16", prev)
+        return z, dW, dh
+
+    z, dW, dh = run(mode)
+    z17, dW17, dh17 = run(17)
+    hd, Wd, dzd = h.double(), W.double(), dz.double()
+    zr, sz = hd @ Wd.T + b.double(), hd.abs() @ Wd.abs().T
+    dWr, sW = dzd.T @ hd, dzd.abs().T @ hd.abs()
+    dhr, sH = dzd @ Wd, dzd.abs() @ Wd.abs()
+    ez = float(((z.double() - zr).abs() / sz).max())
+    eW = float(((dW.double() - dWr).abs() / sW.clamp_min(1e-300)).max())
+    eH = float(((dh.double() - dhr).abs() / sH).max())
+    print(f"mode {mode}: |err| / sum|a b|  logits {ez:.2e}  dW {eW:.2e}  dh {eH:.2e}")
+    assert ez <= 6e-7                                              # the logits keep the exact three-way split in every mode
+    if mode != 17:
+        assert torch.equal(z, z17)
+    tol = 3 * 2.0 ** -18 if mode == 2 else 6e-7
+    assert eW <= tol and eH <= tol, (eW, eH, tol)
+    # every column of dW keeps its own leading digits (Adam normalises per element: a column 1e-20 of the largest must not come out as zero)
+    small = dWr.abs().amax(dim=1) > 0
+    rel_col = ((dW.double() - dWr).abs().amax(dim=1) / dWr.abs().amax(dim=1).clamp_min(1e-300))[small]
+    assert float(rel_col.max()) <= (2e-4 if mode == 2 else 2e-5), float(rel_col.max())

@@ -18,7 +18,8 @@ def timeit(fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 res = {}
-for split in (0, 1, 0, 1):
+MODES = (0, 17, 1, 2)      # exact fp32 MFMA | per-wave three-way split | three bf16 planes in LDS | two planes (accumulating GEMMs)
+for split in MODES + MODES:
     _lib.query("gngf_set_gemm_split_bf16", split)
     z = ops.linear_fwd(h, W, b, ops.ACT_NONE)
     t1 = timeit(lambda: ops.linear_fwd(h, W, b, ops.ACT_NONE))
@@ -45,9 +46,14 @@ cols = torch.arange(0, T, 4096, device=dev)
 dWr = dz[:, cols].double().T @ h.double()
 dhr = dz[rows].double() @ W.double()
 scale_z = (h[rows].double().abs() @ W.double().abs().T)          # sum |a_k b_k|
-for split in (0, 1):
+for split in MODES:
     z, dW, dh = res[split]
     ez = (z[rows].double() - zr).abs()
+    sW = dz[:, cols].double().abs().T @ h.double().abs()
+    sH = dz[rows].double().abs() @ W.double().abs()
     print(f"split={split}: logits max abs err {ez.max():.3e} (max |z| {zr.abs().max():.1f}), err / sum|ab| {float((ez / scale_z).max()):.3e};"
-          f"  dW max err / max {float((dW[cols].double() - dWr).abs().max() / dWr.abs().max()):.3e};"
-          f"  dh max err / max {float((dh[rows].double() - dhr).abs().max() / dhr.abs().max()):.3e}")
+          f"  dW max err / max {float((dW[cols].double() - dWr).abs().max() / dWr.abs().max()):.3e}, err / sum|ab| {float(((dW[cols].double() - dWr).abs() / sW).max()):.3e};"
+          f"  dh max err / max {float((dh[rows].double() - dhr).abs().max() / dhr.abs().max()):.3e}, err / sum|ab| {float(((dh[rows].double() - dhr).abs() / sH).max()):.3e}")
+z1, z17 = res[1][0], res[17][0]
+print("three planes vs per-wave split, logits bit-identical:", bool(torch.equal(z1, z17)),
+      " dW:", float((res[1][1] - res[17][1]).abs().max()), " dh:", float((res[1][2] - res[17][2]).abs().max()))
