@@ -61,6 +61,9 @@ SIGNATURES = {
     "gngf_gemm_acc": [_P, _P, _P, _L, _L, _L, _I, _I, _P],
     "gngf_softmax_topk": [_P, _P, _P, _P, _L, _L, _I, _P],
     "gngf_softmax_bwd_lowrank": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _L, _I, _P],
+    "gngf_hpd_bwd_dot": [_P, _P, _P, _P, _P, _P, _I, _P, _L, _L, _I, _P],
+    "gngf_hpd_bwd_fused_applies": [_L, _L, _I, _I, _I],
+    "gngf_hpd_bwd_fused": [_P] * 8 + [_I, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _P],
     "gngf_logits_topk_pbar": [_P, _P, _P, _P, _P, _I, _P, _L, _L, _I, _P],
     "gngf_linear_fwd_rowstats": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
     "gngf_rowstats_topk": [_P, _P, _P, _P, _P, _L, _L, _I, _P],
@@ -88,7 +91,7 @@ SIGNATURES = {
     "gngf_adam_step": [_P, _I, _L, _P, _P, _P, _I, _F, _F, _F, _F, _P],
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class BinJob(ctypes.Structure):

@@ -1014,6 +1014,30 @@ extern "C" int gngf_softmax_bwd_lowrank(float* logits_dz, const float* rowstat, 
   GNGF_RETURN_LAUNCH();
 }
 
+// The row dots of that backward alone, for gngf_hpd_bwd_fused (linear.hip), which forms dz in the loaders of the dW / dh GEMMs:
+//   dot[r] = sum_k topk_p[r,k] dq[r,k] + sum_t p[r,t] (mw G)[r,t]          one read of the logits, nothing written but dot (U)
+extern "C" int gngf_hpd_bwd_dot(const float* logits, const float* rowstat, const float* dq, const float* topk_p, const float* mw,
+                                const float* G, int L, float* dot, int64_t U, int64_t T, int K, void* stream) {
+  GNGF_CHECK_ARG(U >= 0 && T > 0 && T % 32 == 0 && T < (1 << 24) && K >= 0 && K <= GNGF_MAX_TOPK && L >= 0 && L <= 32);
+  if (U == 0) return 0;
+  GNGF_CHECK_ARG(logits && rowstat && dot && (K == 0 || (dq && topk_p)) && (L == 0 || (mw && G)));
+  hipStream_t s = as_stream(stream);
+  if (K > 0) {
+    softmax_bwd_dot_init_kernel<<<dim3((unsigned)ceil_div(U, 256)), dim3(256), 0, s>>>(topk_p, dq, dot, U, K);
+  } else {
+    hipError_t e = zero_async(dot, sizeof(float) * (size_t)U, s);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (L > 0) {
+    const dim3 grid((unsigned)ceil_div(T, kLrCols), (unsigned)ceil_div(U, kLrRows));
+    float* z = const_cast<float*>(logits);                                         // (the <false> instance only reads)
+    if (L <= 4) softmax_bwd_mfma_kernel<false, 4><<<grid, dim3(256), 0, s>>>(z, rowstat, mw, G, L, dot, nullptr, U, T);
+    else if (L <= 16) softmax_bwd_mfma_kernel<false, 16><<<grid, dim3(256), 0, s>>>(z, rowstat, mw, G, L, dot, nullptr, U, T);
+    else softmax_bwd_mfma_kernel<false, 32><<<grid, dim3(256), 0, s>>>(z, rowstat, mw, G, L, dot, nullptr, U, T);
+  }
+  GNGF_RETURN_LAUNCH();
+}
+
 extern "C" int gngf_vertex_coords(float* verts, int64_t u0, int64_t count, int vstride, void* stream) {
   GNGF_CHECK_ARG(count >= 0 && u0 >= 0 && vstride > 0);
   if (count == 0) return 0;

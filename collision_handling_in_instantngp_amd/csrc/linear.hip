@@ -731,6 +731,376 @@ gemm128_planes_kernel(const float* __restrict__ A, const float* __restrict__ B, 
   split_epilogue(acc, C, ldc, bias, act, atomic_out, m0, n0, wm, wn, i, h, rowparts, nparts);
 }
 
+// ------------------------------------------------------------ softmax backward formed in the operand loaders of dW and dh
+// Backward of the T-wide last layer of the HashProbDistribution from the LOGITS (reference models.py:84-85,105-116 and the batch-mean
+// loss utils.py:138,159 through autograd), without the d-logits matrix ever existing:
+//     dz[r,t] = p[r,t] (g[r,t] - dot_r),   p = exp(z - m_r) / s_r,   g = mw (U x L) G (L x T),   dot_r = <p_r, g_r> + top-K part
+//     dW[t,:] += sum_r dz[r,t] h[r,:]      db[t] += sum_r dz[r,t]      dh[r,:] += sum_t dz[r,t] W[t,:]
+// (the K top-K slots of a row add p_k dq_k to dz: two sparse side products, hpd_topk_side_kernel).  Both GEMMs read z where they
+// read dz before: the apply pass of the softmax backward (a read and a write of the (U, T) matrix) and the dz round trip are gone.
+// The loader works in the accumulator layout of the small product g^T = G^T mw^T (one 32x32x16 MFMA per product term, L <= 16):
+// lane (i, h) holds ROW r = i of the block — its (m, 1/s, dot) are three registers — and the sixteen t = 8 j + 4 h + 0..3 of it:
+// four 16-byte loads of z, four packed 8-byte stores per plane into the image of the GEMM proper (bf16 planes as above; g keeps the
+// exact three-way split: six MFMAs per 32 x 32 block, against 12-24 of the GEMM).
+// Loads of the fused kernels' K loops go through inline asm and are waited for by hand: hipcc sizes the vmcnt wait in front of the
+// first use of a prefetched register for the worst predecessor of the loop header (coming from the prologue nothing follows the
+// loads), i.e. it drains the whole prefetch ring at the top of every step (decoder.hip has the same note).  The compiler neither
+// sees these loads nor waits for them: every step waits itself (s_waitcnt vmcnt) and pins the registers behind that wait.
+template <bool ASM, int OFF> __device__ __forceinline__ u32x4 fused_load_b128(unsigned voff, __amdgpu_buffer_rsrc_t rs) {
+  if constexpr (ASM) {
+    u32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(v) : "v"(voff), "s"(rs), "n"(OFF) : "memory");
+    return v;
+  } else {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, OFF, 0);
+  }
+}
+// A descriptor the scalar ALU has just written must be 5 wait states old when a vector-memory instruction reads it; the hazard
+// recognizer inserts them for instructions it can see — not for the text of an asm statement.  (Without this a load can go out with
+// a descriptor that is half the previous block's: harmless-looking on small shapes, a memory fault once the base crosses 4 GiB.)
+template <bool ASM> __device__ __forceinline__ __amdgpu_buffer_rsrc_t settled(__amdgpu_buffer_rsrc_t rs) {
+  if constexpr (ASM) asm volatile("s_nop 4" : "+s"(rs));
+  return rs;
+}
+template <bool ASM> __device__ __forceinline__ float fused_load_f32(const float* p) {
+  if constexpr (ASM) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+  } else {
+    return *p;
+  }
+}
+template <bool ASM> __device__ __forceinline__ u32x2 fused_load_b64(const float* p) {
+  if constexpr (ASM) {
+    u32x2 v;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+  } else {
+    return *reinterpret_cast<const u32x2*>(p);
+  }
+}
+// (the asm form is verified for the dW kernel only: in the dH kernel it faulted on grids of >= 512 workgroups for a reason not found,
+// and that kernel keeps the compiler's loads and waits)
+constexpr bool kDwAsmLoads = true, kDhAsmLoads = false;
+
+template <int NP> __device__ __forceinline__ void fused_dz_block(const u32x4 (&zv)[4], const f32x16& g, float m, float rs, float dot,
+                                                                 unsigned (&pk)[4][2][NP], float (*dacc)[16]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float d[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float q = __builtin_amdgcn_exp2f((__uint_as_float(zv[j][c]) - m) * 1.4426950408889634f) * rs;
+      const float p = __builtin_amdgcn_fmed3f(q, 0.f, 3.4028234663852886e38f);            // nan_to_num: NaN -> 0, inf -> max
+      d[c] = p * (g[4 * j + c] - dot);
+      if (dacc) (*dacc)[4 * j + c] += d[c];
+    }
+    split_pair<NP>(d[0], d[1], pk[j][0]);
+    split_pair<NP>(d[2], d[3], pk[j][1]);
+  }
+}
+
+// g^T block (32 t x 32 r) = G^T (t x l) mw^T (l x r), both operands split exactly three ways: fp32-accurate
+__device__ __forceinline__ f32x16 fused_g_block(const Split3& Gs, const Split3& Ms) {
+  f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  c = mfma_bf16(Gs.lo, Ms.hi, c);
+  c = mfma_bf16(Gs.hi, Ms.lo, c);
+  c = mfma_bf16(Gs.mid, Ms.mid, c);
+  c = mfma_bf16(Gs.mid, Ms.hi, c);
+  c = mfma_bf16(Gs.hi, Ms.mid, c);
+  c = mfma_bf16(Gs.hi, Ms.hi, c);
+  return c;
+}
+
+// dW (T x 128) += dz^T h, db (T) += column sums of dz.  A workgroup owns 128 columns t for ALL U rows (U % 32 == 0): wave w stages the
+// 32 columns t0 + 32 w .. + 31 of every 32-row block (A image k-major: [r][t]), the block's h rows are staged as in the planes kernel.
+template <int NP>
+__global__ void __launch_bounds__(256, 2)
+hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowstat, const float* __restrict__ dot,
+                    const float* __restrict__ mw, const float* __restrict__ G, int L, const float* __restrict__ Hh,
+                    float* __restrict__ dW, float* __restrict__ db, int64_t U, int64_t T) {
+  __shared__ __attribute__((aligned(16))) unsigned char img[2 * NP * 8192];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
+  int64_t tile = blockIdx.x;
+  const int64_t ntiles = T / 128;
+  if ((ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
+  const int64_t t0 = tile * 128;
+  const int nkb = (int)(U / 32);
+  // G^T fragment of this wave's 32 columns: lane (i, h) holds G[8 h + j][t0 + 32 wave + i]  (constant over the K loop)
+  Split3 Gs;
+  {
+    float gx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gx[j] = (8 * h + j < L) ? G[(int64_t)(8 * h + j) * T + t0 + 32 * wave + i] : 0.f;   // (once per workgroup)
+    Gs = split8(gx);
+  }
+  const unsigned zo = 4u * ((unsigned)i * (unsigned)T + 32u * wave + 4u * h);             // + 32 j bytes; window: 32 rows x T
+  unsigned ob[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int li = tid + e * 256;
+    ob[e] = 4u * ((unsigned)(li >> 5) * 128u + (li & 31) * 4);
+  }
+  // The logits are the HBM stream: TWO K-blocks of them are in flight per workgroup (register ring zv0 / zv1, the loop unrolled by
+  // two) — with one, a workgroup holds 16 KB in flight, two workgroups per CU 8 MB over the chip, and the kernel ran at 2 TB/s
+  // (bytes in flight / latency).  The small operands (h rows, row constants, multiplicity weights: L2 hits) stay one block ahead.
+  u32x4 zv0[4], zv1[4], vb[4];
+  u32x2 rc_ms;
+  float rc_d, mwx[8];
+  const int Ls = L > 0 ? L : 1;                             // (L = 0: the caller passes readable dummies for mw / G, every term is masked)
+  const int lsel = (8 * h < Ls) ? 8 * h : 0;                // lanes whose eight l are all >= L read the first eight (masked at use)
+  int mwo[8];                                               // (clamped index; the mask l < L is applied where the value is used)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) mwo[j] = (lsel + j < Ls) ? lsel + j : Ls - 1;
+  auto fetch_z = [&](int kb, u32x4 (&zv)[4]) {              // 4 loads
+    const __amdgpu_buffer_rsrc_t rz = settled<kDwAsmLoads>(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z + (int64_t)kb * 32 * T + t0), 0, 0x7fffffff, 0x00020000));
+    zv[0] = fused_load_b128<kDwAsmLoads, 0>(zo, rz); zv[1] = fused_load_b128<kDwAsmLoads, 32>(zo, rz);
+    zv[2] = fused_load_b128<kDwAsmLoads, 64>(zo, rz); zv[3] = fused_load_b128<kDwAsmLoads, 96>(zo, rz);
+  };
+  auto fetch_small = [&](int kb) {                          // 4 + 2 + 8 loads
+    const int64_t r = (int64_t)kb * 32 + i;
+    const __amdgpu_buffer_rsrc_t rh = settled<kDwAsmLoads>(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Hh + (int64_t)kb * 32 * 128), 0, 0x7fffffff, 0x00020000));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vb[e] = fused_load_b128<kDwAsmLoads, 0>(ob[e], rh);
+    rc_ms = fused_load_b64<kDwAsmLoads>(rowstat + 2 * r);
+    rc_d = fused_load_f32<kDwAsmLoads>(dot + r);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mwx[j] = fused_load_f32<kDwAsmLoads>(mw + r * Ls + mwo[j]);
+  };
+  // at the top of a step the loads in flight are, oldest first: logits of this block (4), small operands of this block (14), logits of
+  // the next block (4): wait for all but the newest four, then pin what the step reads behind that wait
+  auto landed = [&](u32x4 (&zv)[4]) {
+    if constexpr (!kDwAsmLoads) return;
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("" : "+v"(zv[0]), "+v"(zv[1]), "+v"(zv[2]), "+v"(zv[3]), "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]), "+v"(rc_ms), "+v"(rc_d),
+                      "+v"(mwx[0]), "+v"(mwx[1]), "+v"(mwx[2]), "+v"(mwx[3]), "+v"(mwx[4]), "+v"(mwx[5]), "+v"(mwx[6]), "+v"(mwx[7]));
+  };
+  fetch_z(0, zv0);
+  fetch_small(0);
+  fetch_z(nkb > 1 ? 1 : 0, zv1);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = 0;
+  float dacc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
+  lds_byte* const imgA = (lds_byte*)img;
+  lds_byte* const imgB = imgA + NP * 8192;
+  const unsigned wa0 = 256u * i + 64u * ((unsigned)wave ^ (i & 3)) + 8u * h;              // + 16 j
+  const unsigned wb0 = plane_write_offset<true>(tid);
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+  const unsigned ra0 = 256u * (8 * h + q4) + 64u * ((2 * wm) ^ q4) + 32u * g1 + 8u * p4;
+  const unsigned ra1 = 256u * (8 * h + q4) + 64u * ((2 * wm + 1) ^ q4) + 32u * g1 + 8u * p4;
+  const unsigned rb0 = 256u * (8 * h + q4) + 64u * ((2 * wn) ^ q4) + 32u * g1 + 8u * p4;
+  const unsigned rb1 = 256u * (8 * h + q4) + 64u * ((2 * wn + 1) ^ q4) + 32u * g1 + 8u * p4;
+  auto step = [&](int kb, u32x4 (&zv)[4]) {
+    landed(zv);
+    {
+      unsigned pk[4][2][NP];
+      float mx[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mx[j] = (8 * h + j < L) ? mwx[j] : 0.f;
+      const f32x16 g = fused_g_block(Gs, split8(mx));
+      fused_dz_block<NP>(zv, g, __uint_as_float(rc_ms.x), 1.0f / __uint_as_float(rc_ms.y), rc_d, pk, &dacc);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) *(lds_u32x2*)(imgA + wa0 + 16 * j + 8192 * pl) = u32x2{pk[j][0][pl], pk[j][1][pl]};
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned pb[2][NP];
+      split_pair<NP>(__uint_as_float(vb[e].x), __uint_as_float(vb[e].y), pb[0]);
+      split_pair<NP>(__uint_as_float(vb[e].z), __uint_as_float(vb[e].w), pb[1]);
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) *(lds_u32x2*)(imgB + wb0 + 2048 * e + 8192 * pl) = u32x2{pb[0][pl], pb[1][pl]};
+    }
+    // loads return in order: the small operands of block kb + 1 are issued BEFORE the logits of block kb + 2, so that the next step
+    // can wait for them (and for the logits of kb + 1, issued a step ago) with the newest four loads still in flight
+    // ... and UNCONDITIONALLY (the last blocks are fetched again, in bounds, and dropped): behind a branch the compiler's wait counts
+    // must hold for the path that issued nothing, i.e. they drain every load in flight at the top of each step
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_small(kb + 1 < nkb ? kb + 1 : nkb - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_z(kb + 2 < nkb ? kb + 2 : nkb - 1, zv);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    unrolled<2>([&](auto S_) {
+      constexpr int ks = S_.value;
+      const Frag<NP> fa0 = read_frag<true, NP, ks, 0>(imgA, ra0, ra1), fa1 = read_frag<true, NP, ks, 1>(imgA, ra0, ra1);
+      const Frag<NP> fb0 = read_frag<true, NP, ks, 0>(imgB, rb0, rb1), fb1 = read_frag<true, NP, ks, 1>(imgB, rb0, rb1);
+      acc[0][0] = split_products<NP>(fa0, fb0, acc[0][0]);
+      acc[0][1] = split_products<NP>(fa0, fb1, acc[0][1]);
+      acc[1][0] = split_products<NP>(fa1, fb0, acc[1][0]);
+      acc[1][1] = split_products<NP>(fa1, fb1, acc[1][1]);
+    });
+    __syncthreads();
+  };
+  for (int kb = 0; kb < nkb; kb += 2) {                       // (nkb = U / 32 is even: U % 128 == 0)
+    step(kb, zv0);
+    step(kb + 1, zv1);
+  }
+  if constexpr (kDwAsmLoads) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the tail's redundant loads: landed before their registers are reused
+  split_epilogue(acc, dW, 128, nullptr, 0, 1, t0, 0, wm, wn, i, h, nullptr, 0);
+  if (db) {
+    // column sums: register r of lane (i, h) is column 32 wave + (r & 3) + 8 (r >> 2) + 4 h summed over this lane's rows; add the 32 lanes of a half
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = dacc[r];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (i == 0) atomicAdd(db + t0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h, v);
+    }
+  }
+}
+
+// dH (U x 128) += dz W over the columns [blockIdx.y * kchunk, + kchunk) (kchunk % 64 == 0), rows blockIdx.x * 128 .. + 127: wave w stages
+// rows 32 w .. + 31 (A image [r][t]: k contiguous), W's rows t are staged as in the planes kernel (k-major).  Float atomics into dH.
+template <int NP>
+__global__ void __launch_bounds__(256, 2)
+hpd_dh_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowstat, const float* __restrict__ dot,
+                    const float* __restrict__ mw, const float* __restrict__ G, int L, const float* __restrict__ W,
+                    float* __restrict__ dH, int64_t U, int64_t T, int64_t kchunk) {
+  __shared__ __attribute__((aligned(16))) unsigned char img[2 * NP * 8192];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
+  const int64_t r0 = (int64_t)blockIdx.x * 128;
+  const int64_t kbeg = (int64_t)blockIdx.y * kchunk;
+  const int64_t kend = (kbeg + kchunk < T) ? kbeg + kchunk : T;
+  const int nkb = (int)((kend - kbeg) / 32);
+  const int64_t r = r0 + 32 * wave + i;                                                  // this lane's row, for the whole kernel
+  const float rc_m = rowstat[2 * r], rc_rs = 1.0f / rowstat[2 * r + 1], rc_d = dot[r];
+  Split3 Ms;
+  {
+    float mx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mx[j] = (8 * h + j < L) ? mw[r * L + 8 * h + j] : 0.f;
+    Ms = split8(mx);
+  }
+  const unsigned zo = 4u * ((unsigned)(32 * wave + i) * (unsigned)T + 4u * h);            // + 32 j bytes; window: 128 rows x T
+  unsigned ob[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int li = tid + e * 256;
+    ob[e] = 4u * ((unsigned)(li >> 5) * 128u + (li & 31) * 4);
+  }
+  u32x4 zv0[4], zv1[4], vb[4];                                // (two K-blocks of logits in flight: see hpd_dw_fused_kernel)
+  float gx[8];
+  const int Ls = L > 0 ? L : 1;
+  const int lsel = (8 * h < Ls) ? 8 * h : 0;
+  int64_t go[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) go[j] = (int64_t)((lsel + j < Ls) ? lsel + j : Ls - 1) * T + i;      // (masked at use: see hpd_dw_fused_kernel)
+  auto fetch_z = [&](int kb, u32x4 (&zv)[4]) {              // 4 loads
+    const __amdgpu_buffer_rsrc_t rz = settled<kDhAsmLoads>(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z + r0 * T + kbeg + (int64_t)kb * 32), 0, 0x7fffffff, 0x00020000));
+    zv[0] = fused_load_b128<kDhAsmLoads, 0>(zo, rz); zv[1] = fused_load_b128<kDhAsmLoads, 32>(zo, rz);
+    zv[2] = fused_load_b128<kDhAsmLoads, 64>(zo, rz); zv[3] = fused_load_b128<kDhAsmLoads, 96>(zo, rz);
+  };
+  auto fetch_small = [&](int kb) {                          // 4 + 8 loads
+    const int64_t tb = kbeg + (int64_t)kb * 32;
+    const __amdgpu_buffer_rsrc_t rw = settled<kDhAsmLoads>(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + tb * 128), 0, 0x7fffffff, 0x00020000));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vb[e] = fused_load_b128<kDhAsmLoads, 0>(ob[e], rw);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gx[j] = fused_load_f32<kDhAsmLoads>(G + tb + go[j]);
+  };
+  auto landed = [&](u32x4 (&zv)[4]) {                         // (see hpd_dw_fused_kernel)
+    if constexpr (!kDhAsmLoads) return;
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("" : "+v"(zv[0]), "+v"(zv[1]), "+v"(zv[2]), "+v"(zv[3]), "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]),
+                      "+v"(gx[0]), "+v"(gx[1]), "+v"(gx[2]), "+v"(gx[3]), "+v"(gx[4]), "+v"(gx[5]), "+v"(gx[6]), "+v"(gx[7]));
+  };
+  fetch_z(0, zv0);
+  fetch_small(0);
+  fetch_z(nkb > 1 ? 1 : 0, zv1);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = 0;
+  lds_byte* const imgA = (lds_byte*)img;
+  lds_byte* const imgB = imgA + NP * 8192;
+  const unsigned swz = (i >> 2) & 3;
+  unsigned wa[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wa[j] = 64u * (32 * wave + i) + 16u * ((unsigned)j ^ swz) + 8u * h;
+  const unsigned wb0 = plane_write_offset<true>(tid);
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+  const unsigned ra0 = 64u * (wm * 64 + i) + 16u * ((unsigned)h ^ swz);
+  const unsigned ra1 = 64u * (wm * 64 + i) + 16u * ((unsigned)(2 + h) ^ swz);
+  const unsigned rb0 = 256u * (8 * h + q4) + 64u * ((2 * wn) ^ q4) + 32u * g1 + 8u * p4;
+  const unsigned rb1 = 256u * (8 * h + q4) + 64u * ((2 * wn + 1) ^ q4) + 32u * g1 + 8u * p4;
+  auto step = [&](int kb, u32x4 (&zv)[4]) {
+    landed(zv);
+    {
+      unsigned pk[4][2][NP];
+      float gm[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gm[j] = (8 * h + j < L) ? gx[j] : 0.f;
+      const f32x16 g = fused_g_block(split8(gm), Ms);
+      fused_dz_block<NP>(zv, g, rc_m, rc_rs, rc_d, pk, nullptr);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) *(lds_u32x2*)(imgA + wa[j] + 8192 * pl) = u32x2{pk[j][0][pl], pk[j][1][pl]};
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned pb[2][NP];
+      split_pair<NP>(__uint_as_float(vb[e].x), __uint_as_float(vb[e].y), pb[0]);
+      split_pair<NP>(__uint_as_float(vb[e].z), __uint_as_float(vb[e].w), pb[1]);
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) *(lds_u32x2*)(imgB + wb0 + 2048 * e + 8192 * pl) = u32x2{pb[0][pl], pb[1][pl]};
+    }
+    // loads return in order: the small operands of block kb + 1 are issued BEFORE the logits of block kb + 2, so that the next step
+    // can wait for them (and for the logits of kb + 1, issued a step ago) with the newest four loads still in flight
+    // ... and UNCONDITIONALLY (the last blocks are fetched again, in bounds, and dropped): behind a branch the compiler's wait counts
+    // must hold for the path that issued nothing, i.e. they drain every load in flight at the top of each step
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_small(kb + 1 < nkb ? kb + 1 : nkb - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_z(kb + 2 < nkb ? kb + 2 : nkb - 1, zv);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    unrolled<2>([&](auto S_) {
+      constexpr int ks = S_.value;
+      const Frag<NP> fa0 = read_frag<false, NP, ks, 0>(imgA, ra0, ra1), fa1 = read_frag<false, NP, ks, 1>(imgA, ra0, ra1);
+      const Frag<NP> fb0 = read_frag<true, NP, ks, 0>(imgB, rb0, rb1), fb1 = read_frag<true, NP, ks, 1>(imgB, rb0, rb1);
+      acc[0][0] = split_products<NP>(fa0, fb0, acc[0][0]);
+      acc[0][1] = split_products<NP>(fa0, fb1, acc[0][1]);
+      acc[1][0] = split_products<NP>(fa1, fb0, acc[1][0]);
+      acc[1][1] = split_products<NP>(fa1, fb1, acc[1][1]);
+    });
+    __syncthreads();
+  };
+  for (int kb = 0; kb < nkb; kb += 2) {                       // (nkb is even: kchunk % 64 == 0 and T % 64 == 0)
+    step(kb, zv0);
+    step(kb + 1, zv1);
+  }
+  if constexpr (kDhAsmLoads) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  split_epilogue(acc, dH, 128, nullptr, 0, 1, r0, 0, wm, wn, i, h, nullptr, 0);
+}
+
+// the K top-K slots of a row add a = p_k dq_k to dz[r, topk_idx]: dW[slot,:] += a h[r,:], dH[r,:] += a W[slot,:], db[slot] += a.
+// One block of 128 threads per (row, k).
+__global__ void __launch_bounds__(128)
+hpd_topk_side_kernel(const float* __restrict__ pk, const float* __restrict__ dq, const int32_t* __restrict__ topi,
+                     const float* __restrict__ Hh, const float* __restrict__ W, float* __restrict__ dW, float* __restrict__ db,
+                     float* __restrict__ dH, int K) {
+  const int64_t e = blockIdx.x, r = e / K;
+  const float a = pk[e] * dq[e];
+  if (a == 0.f) return;
+  const int64_t slot = topi[e];
+  const int c = threadIdx.x;
+  atomicAdd(dW + slot * 128 + c, a * Hh[r * 128 + c]);
+  atomicAdd(dH + r * 128 + c, a * W[slot * 128 + c]);
+  if (c == 0 && db) atomicAdd(db + slot, a);
+}
+
 static int g_split_bf16 = 0;       // see gngf_set_gemm_split_bf16
 
 // column sums of dZ = dY * act'(Y):  db[n] = sum_m dZ[m][n].  grid.x = ceil(N/64), grid.y = row slices; atomics.
@@ -907,4 +1277,41 @@ extern "C" int gngf_gemm_acc(const float* A, const float* B, float* C, int64_t M
   if (!ta && tb) return launch_gemm<false, true>(A, B, C, M, N, Kc, lda, ldb, N, nullptr, 0, nullptr, 0, splitk, s, true);
   if (ta && !tb) return launch_gemm<true, false>(A, B, C, M, N, Kc, lda, ldb, N, nullptr, 0, nullptr, 0, splitk, s, true);
   return launch_gemm<true, true>(A, B, C, M, N, Kc, lda, ldb, N, nullptr, 0, nullptr, 0, splitk, s, true);
+}
+
+// Does gngf_hpd_bwd_fused take this shape?  (whole 128-row / 128-column tiles, last hidden width 128, L <= 16, 32-bit windows)
+extern "C" int gngf_hpd_bwd_fused_applies(int64_t U, int64_t T, int L, int K, int hidden) {
+  return (U > 0 && U % 128 == 0 && T % 128 == 0 && T < (1 << 22) && hidden == 128 && L >= 0 && L <= 16 && K >= 0 && K <= GNGF_MAX_TOPK) ? 1 : 0;
+}
+
+// Backward of the HashProbDistribution's last layer from the logits of one chunk (see hpd_dw_fused_kernel):
+//   dW (T,128) += dz^T h,  db (T) += colsum dz,  dH (U,128) += dz W      with dz = p (mw G - dot) + [top-K slots] p_k dq_k
+// logits (U,T), rowstat (U,2) = (max, sum exp), dot (U) from gngf_hpd_bwd_dot, dq / topk_p / topk_idx (U,K) or K = 0, mw (U,L),
+// G (L,T) or L = 0, h (U,128), W (T,128).  planes: 3 = exact three-way split, 2 = two planes (three products).
+extern "C" int gngf_hpd_bwd_fused(const float* logits, const float* rowstat, const float* dot, const float* dq, const float* topk_p,
+                                  const int32_t* topk_idx, const float* mw, const float* G, int L, const float* h, const float* W,
+                                  float* dW, float* db, float* dH, int64_t U, int64_t T, int K, int hidden, int planes, void* stream) {
+  const int only = planes >> 4;                             // diagnostic: + 16 = dW / db only, + 32 = dH only, + 48 = the top-K terms only
+  planes &= 15;
+  GNGF_CHECK_ARG(gngf_hpd_bwd_fused_applies(U, T, L, K, hidden) && (planes == 2 || planes == 3));
+  GNGF_CHECK_ARG(logits && rowstat && dot && h && W && dW && dH && (L == 0 || (mw && G)) && (K == 0 || (dq && topk_p && topk_idx)));
+  hipStream_t s = as_stream(stream);
+  if (L == 0) { mw = rowstat; G = logits; }                  // read (clamped index 0) and masked: never used
+  const dim3 gw((unsigned)(T / 128));
+  // dh: enough column slices for ~1024 workgroups, each a multiple of 32 columns
+  const int64_t rtiles = U / 128;
+  int64_t slices = ceil_div(1024, rtiles);
+  int64_t kchunk = ceil_div(ceil_div(T, slices), 64) * 64;      // (an even number of 32-column K-blocks per slice)
+  slices = ceil_div(T, kchunk);
+  const dim3 gh((unsigned)rtiles, (unsigned)slices);
+  if (planes == 2) {
+    if (only == 0 || only == 1) hpd_dw_fused_kernel<2><<<gw, dim3(256), 0, s>>>(logits, rowstat, dot, mw, G, L, h, dW, db, U, T);
+    if (only == 0 || only == 2) hpd_dh_fused_kernel<2><<<gh, dim3(256), 0, s>>>(logits, rowstat, dot, mw, G, L, W, dH, U, T, kchunk);
+  } else {
+    if (only == 0 || only == 1) hpd_dw_fused_kernel<3><<<gw, dim3(256), 0, s>>>(logits, rowstat, dot, mw, G, L, h, dW, db, U, T);
+    if (only == 0 || only == 2) hpd_dh_fused_kernel<3><<<gh, dim3(256), 0, s>>>(logits, rowstat, dot, mw, G, L, W, dH, U, T, kchunk);
+  }
+  if (K > 0 && (only == 0 || only == 3))
+    hpd_topk_side_kernel<<<dim3((unsigned)(U * K)), dim3(128), 0, s>>>(topk_p, dq, topk_idx, h, W, dW, db, dH, K);
+  GNGF_RETURN_LAUNCH();
 }

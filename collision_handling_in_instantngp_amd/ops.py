@@ -46,6 +46,7 @@ class Tuning:
     hpd_gemm_split_bf16: bool = True          # the three T-wide GEMMs on the exact three-way bf16 split
     hpd_gemm_kernel: int = 1                  # 1: values split once into bf16 planes in LDS (round 5) | 17: every wave splits what it reads
     hpd_bwd_two_planes: bool = True           # dW and dh (accumulated over >= 4096 terms) on two planes, three products
+    hpd_bwd_fused: bool = True                # dz formed in the loaders of the dW / dh GEMMs (no apply pass, no d-logits matrix)
     hpd_epilogue_stats: bool = True           # row statistics in the logits GEMM's epilogue
     # ---- tiled form: plan (EncodePlan)
     encode_path: str = "auto"                 # "auto" | "direct" | "tiled" (tests force a path)
@@ -706,6 +707,18 @@ class HpdVertexFunction(torch.autograd.Function):
                 if not have_z:
                     with _split_gemm():
                         call("gngf_linear_fwd", ptr(hs[-1]), ptr(W_last), ptr(b_last), ptr(dz), n, T, W_last.shape[1], ACT_NONE, stream_ptr())
+                Lq, Kq = (L if g_pbar is not None else 0), (K if g_tv is not None else 0)
+                if (TUNING.hpd_bwd_fused and TUNING.hpd_gemm_split_bf16
+                        and query("gngf_hpd_bwd_fused_applies", n, T, Lq, Kq, W_last.shape[1]) == 1):
+                    dotv = scratch[:n]
+                    call("gngf_hpd_bwd_dot", ptr(dz), ptr(rowstat[u0:u0 + n]), ptr(g_tv[u0:u0 + n] if Kq else None),
+                         ptr(tv[u0:u0 + n] if Kq else None), ptr(mw[u0:u0 + n] if Lq else None), ptr(g_pbar if Lq else None), Lq,
+                         ptr(dotv), n, T, Kq, stream_ptr())
+                    call("gngf_hpd_bwd_fused", ptr(dz), ptr(rowstat[u0:u0 + n]), ptr(dotv), ptr(g_tv[u0:u0 + n] if Kq else None),
+                         ptr(tv[u0:u0 + n] if Kq else None), ptr(ti[u0:u0 + n] if Kq else None), ptr(mw[u0:u0 + n] if Lq else None),
+                         ptr(g_pbar if Lq else None), Lq, ptr(hs[-1]), ptr(W_last), ptr(grads[-2]), ptr(grads[-1]), ptr(dH[u0:u0 + n]),
+                         n, T, Kq, W_last.shape[1], 2 if TUNING.hpd_bwd_two_planes else 3, stream_ptr())
+                    continue
                 call("gngf_softmax_bwd_lowrank", ptr(dz), ptr(rowstat[u0:u0 + n]),
                      ptr(g_tv[u0:u0 + n] if g_tv is not None else None), ptr(ti[u0:u0 + n]),
                      ptr(mw[u0:u0 + n] if g_pbar is not None else None), ptr(g_pbar), L if g_pbar is not None else 0,
@@ -751,9 +764,36 @@ class HpdVertexFunction(torch.autograd.Function):
         W_last, b_last = params[-2], params[-1]
         dev = W_last.device
         n_unkept, alive, pending = 0, [], None
+        Lq = L if g_pbar is not None else 0
+        Kq = K if g_tv is not None else 0
+        planes = 2 if TUNING.hpd_bwd_two_planes else 3
+        dots = torch.empty((NV,), dtype=_f32, device=dev) if TUNING.hpd_bwd_fused else None    # row dots of every chunk (the GEMMs of chunk i read
+        #                                                                                       them while the dot pass of chunk i + 1 writes its own)
+
+        def fused(n):
+            return (TUNING.hpd_bwd_fused and TUNING.hpd_gemm_split_bf16
+                    and query("gngf_hpd_bwd_fused_applies", n, T, Lq, Kq, W_last.shape[1]) == 1)
+
+        def stage_b(dz, n, u0):
+            if fused(n):          # one read of the logits: the row dots only
+                call("gngf_hpd_bwd_dot", ptr(dz), ptr(rowstat[u0:u0 + n]), ptr(g_tv[u0:u0 + n] if Kq else None),
+                     ptr(tv[u0:u0 + n] if Kq else None), ptr(mw[u0:u0 + n] if Lq else None), ptr(g_pbar if Lq else None), Lq,
+                     ptr(dots[u0:u0 + n]), n, T, Kq, stream_ptr())
+                return
+            call("gngf_softmax_bwd_lowrank", ptr(dz), ptr(rowstat[u0:u0 + n]),
+                 ptr(g_tv[u0:u0 + n] if g_tv is not None else None), ptr(ti[u0:u0 + n]),
+                 ptr(mw[u0:u0 + n] if g_pbar is not None else None), ptr(g_pbar), L if g_pbar is not None else 0,
+                 ptr(grads[-1]), ptr(scratch), ptr(tv[u0:u0 + n] if g_tv is not None else None), n, T,
+                 K if g_tv is not None else 0, stream_ptr())
 
         def stage_c(dz, hs, done_b, n, u0):
             main.wait_event(done_b)
+            if fused(n):          # dz formed in the loaders of both GEMMs, which read the logits (dz IS the logits here)
+                call("gngf_hpd_bwd_fused", ptr(dz), ptr(rowstat[u0:u0 + n]), ptr(dots[u0:u0 + n]), ptr(g_tv[u0:u0 + n] if Kq else None),
+                     ptr(tv[u0:u0 + n] if Kq else None), ptr(ti[u0:u0 + n] if Kq else None), ptr(mw[u0:u0 + n] if Lq else None),
+                     ptr(g_pbar if Lq else None), Lq, ptr(hs[-1]), ptr(W_last), ptr(grads[-2]), ptr(grads[-1]), ptr(dH[u0:u0 + n]),
+                     n, T, Kq, W_last.shape[1], planes, stream_ptr())
+                return
             with _split_gemm(accumulating=True):
                 linear_bwd_weight(dz, None, hs[-1], grads[-2], None, ACT_NONE)
                 gemm_acc(dz, W_last, dH[u0:u0 + n], n, W_last.shape[1], T, ta=False, tb=False)     # dh = dz @ W_last, split over T
@@ -772,11 +812,7 @@ class HpdVertexFunction(torch.autograd.Function):
             ready.record(main)
             with torch.cuda.stream(side):                      # B
                 side.wait_event(ready)
-                call("gngf_softmax_bwd_lowrank", ptr(dz), ptr(rowstat[u0:u0 + n]),
-                     ptr(g_tv[u0:u0 + n] if g_tv is not None else None), ptr(ti[u0:u0 + n]),
-                     ptr(mw[u0:u0 + n] if g_pbar is not None else None), ptr(g_pbar), L if g_pbar is not None else 0,
-                     ptr(grads[-1]), ptr(scratch), ptr(tv[u0:u0 + n] if g_tv is not None else None), n, T,
-                     K if g_tv is not None else 0, stream_ptr())
+                stage_b(dz, n, u0)
                 done_b = torch.cuda.Event()
                 done_b.record(side)
             if pending is not None:                            # C of the previous chunk, beside this chunk's B
@@ -786,6 +822,8 @@ class HpdVertexFunction(torch.autograd.Function):
             stage_c(*pending)
         main.wait_stream(side)
         side.wait_stream(main)       # the helper's next use starts behind everything issued here
+        if dots is not None:
+            dots.record_stream(side)
         del alive[:]
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNGF_ABI_VERSION 12
+#define GNGF_ABI_VERSION 13
 #define GNGF_MAX_LEVELS 32
 #define GNGF_MAX_TOPK 32
 
@@ -349,6 +349,23 @@ int gngf_pbar_accumulate(const float* logits, const float* rowstat, const float*
 int gngf_softmax_bwd_lowrank(float* logits_dz, const float* rowstat, const float* dq, const int32_t* topk_idx, const float* mw,
                              const float* G, int L, float* db, float* scratch, const float* topk_p, int64_t U, int64_t T, int K,
                              void* stream);
+/* The same backward WITHOUT the d-logits matrix (round 5): gngf_hpd_bwd_dot leaves the row dots
+ *   dot[r] = sum_k topk_p[r,k] dq[r,k] + sum_t p[r,t] (mw G)[r,t]
+ * (one read of the logits), and gngf_hpd_bwd_fused forms dz = p .* (mw G - dot) (+ p_k dq_k at the K top-K slots of a row) inside
+ * the operand loaders of the last layer's two backward GEMMs, which read the LOGITS:
+ *   dW (T,hidden) += dz^T h,  db (T) += column sums of dz (NULL: skipped),  dH (U,hidden) += dz W        (all three accumulate)
+ * — what gngf_softmax_bwd_lowrank + gngf_linear_bwd_weight + gngf_gemm_acc compute (the autograd backward of models.py:84-85,
+ * 105-116 under the batch-mean loss utils.py:138,159), with two passes over the (U,T) matrix instead of five.
+ * h (U,hidden) = the last hidden layer, W (T,hidden) = the last layer's weight.  planes: 3 = every fp32 operand split exactly into
+ * three bf16 terms (six products, fp32 accumulation), 2 = two terms, three products (|error| <= 3 * 2^-18 |a b| per product).
+ * Shapes: gngf_hpd_bwd_fused_applies(U, T, L, K, hidden) != 0 (U % 128 == 0, T % 128 == 0, T < 2^22, hidden == 128, L <= 16);
+ * anything else is rejected (hipErrorInvalidValue) — the caller then takes the three separate entry points. */
+int gngf_hpd_bwd_dot(const float* logits, const float* rowstat, const float* dq, const float* topk_p, const float* mw,
+                     const float* G, int L, float* dot, int64_t U, int64_t T, int K, void* stream);
+int gngf_hpd_bwd_fused_applies(int64_t U, int64_t T, int L, int K, int hidden);
+int gngf_hpd_bwd_fused(const float* logits, const float* rowstat, const float* dot, const float* dq, const float* topk_p,
+                       const int32_t* topk_idx, const float* mw, const float* G, int L, const float* h, const float* W,
+                       float* dW, float* db, float* dH, int64_t U, int64_t T, int K, int hidden, int planes, void* stream);
 /* topk_p (optional; (U,K)): the top-K probabilities gngf_logits_topk_pbar / gngf_softmax_topk returned for these logits — the
  * backward then takes p at the top-K slots from them instead of reading the logits again at random. */
 

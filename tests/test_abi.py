@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert len(decl) >= 8
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in include/gngf.h but not exported"
-    assert lib.gngf_abi_version() == _lib.ABI_VERSION == 12
+    assert lib.gngf_abi_version() == _lib.ABI_VERSION == 13
 
 
 def test_bindings_mirror_header_arity_and_kinds():

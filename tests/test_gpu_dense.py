@@ -917,3 +917,66 @@ def test_split_gemms_with_bf16_planes_in_lds(ops, mode):
     small = dWr.abs().amax(dim=1) > 0
     rel_col = ((dW.double() - dWr).abs().amax(dim=1) / dWr.abs().amax(dim=1).clamp_min(1e-300))[small]
     assert float(rel_col.max()) <= (2e-4 if mode == 2 else 2e-5), float(rel_col.max())
+
+
+@pytest.mark.parametrize("planes", [3, 2])
+@pytest.mark.parametrize("U,T,L,K", [(256, 2048, 16, 4), (128, 1024, 5, 1), (384, 4096, 16, 0), (128, 512, 0, 3), (1024, 131072, 16, 4)])
+def test_softmax_backward_formed_in_the_gemm_loaders(ops, U, T, L, K, planes):
+    """Round 5: gngf_hpd_bwd_dot + gngf_hpd_bwd_fused (dz = p (mw G - dot) + top-K terms formed inside the dW / dh GEMMs, which read
+    the logits) against float64 autograd-equivalent algebra (reference models.py:84-85,105-116; utils.py:138,159) and against the
+    three separate entry points they replace (gngf_softmax_bwd_lowrank + gngf_linear_bwd_weight + gngf_gemm_acc)."""
+    from collision_handling_in_instantngp_amd._lib import call, ptr, stream_ptr, query
+    rng = np.random.default_rng(U + T + L + K)
+    Hd = 128
+    z = t((rng.standard_normal((U, T)) * 4).astype(np.float32))
+    h = t(np.maximum(rng.standard_normal((U, Hd)) * 30, 0).astype(np.float32))
+    W = t(((rng.random((T, Hd)) * 2 - 1) / Hd ** 0.5).astype(np.float32))
+    mw = t((rng.random((U, max(L, 1))) / (4 * U)).astype(np.float32)) if L else None
+    G = t((rng.standard_normal((max(L, 1), T)) * 3).astype(np.float32)) if L else None
+    zd = z.double()
+    m = zd.max(dim=1, keepdim=True).values
+    ssum = torch.exp(zd - m).sum(dim=1, keepdim=True)
+    p = torch.exp(zd - m) / ssum
+    rowstat = torch.cat([m, ssum], dim=1).float().contiguous()
+    g = (mw.double() @ G.double()) if L else torch.zeros_like(zd)
+    if K:
+        tp, ti = torch.topk(p, K, dim=1)
+        ti32 = ti.to(torch.int32).contiguous()
+        pk = tp.float().contiguous()
+        dq = t(rng.standard_normal((U, K)).astype(np.float32) * 1e-3)
+        g = g.scatter_add(1, ti, dq.double())
+    else:
+        ti32 = pk = dq = None
+    dot = (p * g).sum(dim=1, keepdim=True)
+    dz = p * (g - dot)
+    dWr, dbr, dHr = dz.T @ h.double(), dz.sum(dim=0), dz @ W.double()
+
+    dotv = torch.empty((U,), device=DEV)
+    dW, db, dH = torch.zeros((T, Hd), device=DEV), torch.zeros((T,), device=DEV), torch.zeros((U, Hd), device=DEV)
+    assert query("gngf_hpd_bwd_fused_applies", U, T, L, K, Hd) == 1
+    call("gngf_hpd_bwd_dot", ptr(z), ptr(rowstat), ptr(dq), ptr(pk), ptr(mw), ptr(G), L, ptr(dotv), U, T, K, stream_ptr())
+    call("gngf_hpd_bwd_fused", ptr(z), ptr(rowstat), ptr(dotv), ptr(dq), ptr(pk), ptr(ti32), ptr(mw), ptr(G), L, ptr(h), ptr(W),
+         ptr(dW), ptr(db), ptr(dH), U, T, K, Hd, planes, stream_ptr())
+    # the three entry points it replaces
+    dz1 = z.clone()
+    scratch = torch.empty((U * (1 + max(K, 1)),), device=DEV)
+    dW1, db1, dH1 = torch.zeros_like(dW), torch.zeros_like(db), torch.zeros_like(dH)
+    call("gngf_softmax_bwd_lowrank", ptr(dz1), ptr(rowstat), ptr(dq), ptr(ti32), ptr(mw), ptr(G), L, ptr(db1), ptr(scratch), ptr(pk),
+         U, T, K, stream_ptr())
+    ops.linear_bwd_weight(dz1, None, h, dW1, None, ops.ACT_NONE)
+    ops.gemm_acc(dz1, W, dH1, U, Hd, T, ta=False, tb=False)
+    torch.cuda.synchronize()
+
+    def rel(a, ref):
+        return float((a.double() - ref).abs().max() / ref.abs().max())
+    close(dotv, dot[:, 0].float(), 2e-5, 1e-9, "row dots")
+    e = {"dW": rel(dW, dWr), "db": rel(db, dbr), "dH": rel(dH, dHr)}
+    e1 = {"dW": rel(dW1, dWr), "db": rel(db1, dbr), "dH": rel(dH1, dHr)}
+    print(f"U={U} T={T} L={L} K={K} planes={planes}: fused |err|/max {e}   separate {e1}")
+    for k in e:
+        assert e[k] <= max(2e-5, 4 * e1[k]), (k, e, e1)
+    # shapes the fused form does not take are rejected, never computed wrongly
+    assert query("gngf_hpd_bwd_fused_applies", U + 3, T, L, K, Hd) == 0 and query("gngf_hpd_bwd_fused_applies", U, T, 17, K, Hd) == 0
+    with pytest.raises(RuntimeError):
+        call("gngf_hpd_bwd_fused", ptr(z), ptr(rowstat), ptr(dotv), ptr(dq), ptr(pk), ptr(ti32), ptr(mw), ptr(G), L, ptr(h), ptr(W),
+             ptr(dW), ptr(db), ptr(dH), U, T, K, 64, planes, stream_ptr())
