@@ -623,6 +623,22 @@ __device__ __forceinline__ Frag<NP> read_frag(const lds_byte* base, unsigned a0,
   return f;
 }
 
+// k-major image whose 8-byte units are ALSO permuted inside their 64-byte segment (unit ^ ((k >> 1) & 7)): for a writer that holds
+// one k per lane and 8-byte runs of rows (the fused dW loader: 16 lanes = 16 k of one unit, which without this are 8-way conflicts on
+// every store).  The transposed read's lane address picks up (4 h + (q >> 1)) ^ 2 r2 on its unit: a[TT][r2], r2 = the second four k.
+template <int NP, int S, int TT>
+__device__ __forceinline__ Frag<NP> read_frag_km8(const lds_byte* base, const unsigned (&a)[2][2]) {
+  Frag<NP> f;
+#pragma unroll
+  for (int pl = 0; pl < NP; ++pl) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + a[TT][0] + 4096 * S + 8192 * pl));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + a[TT][1] + 4096 * S + 1024 + 8192 * pl));
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    f.p[pl] = u32x4{l2.x, l2.y, h2.x, h2.y};
+  }
+  return f;
+}
+
 template <int NP> __device__ __forceinline__ f32x16 split_products(const Frag<NP>& a, const Frag<NP>& b, f32x16 c) {
   if constexpr (NP == 3) {                                     // small terms first (the order of gemm128_split_kernel)
     c = mfma_bf16(a.p[2], b.p[0], c);
@@ -890,11 +906,17 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
   for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
   lds_byte* const imgA = (lds_byte*)img;
   lds_byte* const imgB = imgA + NP * 8192;
-  const unsigned wa0 = 256u * i + 64u * ((unsigned)wave ^ (i & 3)) + 8u * h;              // + 16 j
+  unsigned wa[4];                                                                         // run j: unit 2 j + h of segment `wave`, row k = i
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wa[j] = 256u * i + 64u * ((unsigned)wave ^ (i & 3)) + 8u * ((unsigned)(2 * j + h) ^ ((i >> 1) & 7));
   const unsigned wb0 = plane_write_offset<true>(tid);
   const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
-  const unsigned ra0 = 256u * (8 * h + q4) + 64u * ((2 * wm) ^ q4) + 32u * g1 + 8u * p4;
-  const unsigned ra1 = 256u * (8 * h + q4) + 64u * ((2 * wm + 1) ^ q4) + 32u * g1 + 8u * p4;
+  unsigned ra[2][2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2)
+      ra[tt][r2] = 256u * (8 * h + q4) + 64u * ((unsigned)(2 * wm + tt) ^ q4) + 8u * ((unsigned)(4 * g1 + p4) ^ (unsigned)((4 * h + (q4 >> 1)) ^ (2 * r2)));
   const unsigned rb0 = 256u * (8 * h + q4) + 64u * ((2 * wn) ^ q4) + 32u * g1 + 8u * p4;
   const unsigned rb1 = 256u * (8 * h + q4) + 64u * ((2 * wn + 1) ^ q4) + 32u * g1 + 8u * p4;
   auto step = [&](int kb, u32x4 (&zv)[4]) {
@@ -909,7 +931,7 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) *(lds_u32x2*)(imgA + wa0 + 16 * j + 8192 * pl) = u32x2{pk[j][0][pl], pk[j][1][pl]};
+        for (int pl = 0; pl < NP; ++pl) *(lds_u32x2*)(imgA + wa[j] + 8192 * pl) = u32x2{pk[j][0][pl], pk[j][1][pl]};
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -931,7 +953,7 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
     __syncthreads();
     unrolled<2>([&](auto S_) {
       constexpr int ks = S_.value;
-      const Frag<NP> fa0 = read_frag<true, NP, ks, 0>(imgA, ra0, ra1), fa1 = read_frag<true, NP, ks, 1>(imgA, ra0, ra1);
+      const Frag<NP> fa0 = read_frag_km8<NP, ks, 0>(imgA, ra), fa1 = read_frag_km8<NP, ks, 1>(imgA, ra);
       const Frag<NP> fb0 = read_frag<true, NP, ks, 0>(imgB, rb0, rb1), fb1 = read_frag<true, NP, ks, 1>(imgB, rb0, rb1);
       acc[0][0] = split_products<NP>(fa0, fb0, acc[0][0]);
       acc[0][1] = split_products<NP>(fa0, fb1, acc[0][1]);

@@ -43,6 +43,7 @@ class Tuning:
     hpd_z_cache_bytes: int = 216 << 30        # logits kept from forward to backward (the rest is recomputed)
     hpd_z_cache_reserve: int = 40 << 30       # device memory that must stay free beside them
     hpd_pipeline: bool = True                 # chunks software-pipelined over two streams (GEMMs beside streaming passes)
+    hpd_pipeline_fwd: bool = True             # ... in the forward pass too (False: only the backward pass is pipelined)
     hpd_gemm_split_bf16: bool = True          # the three T-wide GEMMs on the exact three-way bf16 split
     hpd_gemm_kernel: int = 1                  # 1: values split once into bf16 planes in LDS (round 5) | 17: every wave splits what it reads
     hpd_bwd_two_planes: bool = True           # dW and dh (accumulated over >= 4096 terms) on two planes, three products
@@ -544,7 +545,8 @@ class HpdVertexFunction(torch.autograd.Function):
             mw = _c(mw)
             L = mw.shape[1]
             pbar = torch.zeros((L, T), dtype=_f32, device=dev)
-        pipelined = (TUNING.hpd_pipeline and not keep_probs and NV > rows and not torch.cuda.is_current_stream_capturing())
+        pipelined = (TUNING.hpd_pipeline and TUNING.hpd_pipeline_fwd and not keep_probs and NV > rows
+                     and not torch.cuda.is_current_stream_capturing())
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if pipelined else None
         pipelined = pipelined and side is not main and side.stream_id != main.stream_id
