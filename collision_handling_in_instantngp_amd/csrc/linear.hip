@@ -796,9 +796,11 @@ template <bool ASM> __device__ __forceinline__ u32x2 fused_load_b64(const float*
     return *reinterpret_cast<const u32x2*>(p);
   }
 }
-// (the asm form is verified for the dW kernel only: in the dH kernel it faulted on grids of >= 512 workgroups for a reason not found,
-// and that kernel keeps the compiler's loads and waits)
-constexpr bool kDwAsmLoads = true, kDhAsmLoads = false;
+// NOT USED (both false): with the asm form the dH kernel faulted on grids of >= 512 workgroups and the dW kernel returned wrong
+// columns once in three runs at (1024, 131072) — most likely a register copy of a loop-carried asm output ahead of the data (the outputs
+// would have to be tied "+v" operands so that each ring slot keeps ONE register) — and measured no faster than the compiler's loads
+// (3.87 vs 3.88 ms): what bounds these kernels is not the depth of the prefetch.  Kept as the record of the experiment.
+constexpr bool kDwAsmLoads = false, kDhAsmLoads = false;
 
 template <int NP> __device__ __forceinline__ void fused_dz_block(const u32x4 (&zv)[4], const f32x16& g, float m, float rs, float dot,
                                                                  unsigned (&pk)[4][2][NP], float (*dacc)[16]) {
