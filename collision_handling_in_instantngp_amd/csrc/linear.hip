@@ -804,6 +804,8 @@ constexpr bool kDwAsmLoads = false, kDhAsmLoads = false;
 
 template <int NP> __device__ __forceinline__ void fused_dz_block(const u32x4 (&zv)[4], const f32x16& g, float m, float rs, float dot,
                                                                  unsigned (&pk)[4][2][NP], float (*dacc)[16]) {
+  // the expression of the streaming passes (hpd.hip: prob_fast), so that the dots of gngf_hpd_bwd_dot and these dz are of one piece:
+  //   p = nan_to_num(exp2((z - m) log2 e) / s),  dz = p (g - dot)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float d[4];
