@@ -63,7 +63,8 @@ SIGNATURES = {
     "gngf_softmax_bwd_lowrank": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _L, _I, _P],
     "gngf_hpd_bwd_dot": [_P, _P, _P, _P, _P, _P, _I, _P, _L, _L, _I, _P],
     "gngf_hpd_bwd_fused_applies": [_L, _L, _I, _I, _I],
-    "gngf_hpd_bwd_fused": [_P] * 8 + [_I, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _P],
+    "gngf_hpd_bwd_prepare": [_P, _P, _L, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _P],
+    "gngf_hpd_bwd_fused": [_P] * 8 + [_L, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _P],
     "gngf_logits_topk_pbar": [_P, _P, _P, _P, _P, _I, _P, _L, _L, _I, _P],
     "gngf_linear_fwd_rowstats": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
     "gngf_rowstats_topk": [_P, _P, _P, _P, _P, _L, _L, _I, _P],

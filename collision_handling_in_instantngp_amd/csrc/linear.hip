@@ -758,50 +758,6 @@ gemm128_planes_kernel(const float* __restrict__ A, const float* __restrict__ B, 
 // lane (i, h) holds ROW r = i of the block — its (m, 1/s, dot) are three registers — and the sixteen t = 8 j + 4 h + 0..3 of it:
 // four 16-byte loads of z, four packed 8-byte stores per plane into the image of the GEMM proper (bf16 planes as above; g keeps the
 // exact three-way split: six MFMAs per 32 x 32 block, against 12-24 of the GEMM).
-// Loads of the fused kernels' K loops go through inline asm and are waited for by hand: hipcc sizes the vmcnt wait in front of the
-// first use of a prefetched register for the worst predecessor of the loop header (coming from the prologue nothing follows the
-// loads), i.e. it drains the whole prefetch ring at the top of every step (decoder.hip has the same note).  The compiler neither
-// sees these loads nor waits for them: every step waits itself (s_waitcnt vmcnt) and pins the registers behind that wait.
-template <bool ASM, int OFF> __device__ __forceinline__ u32x4 fused_load_b128(unsigned voff, __amdgpu_buffer_rsrc_t rs) {
-  if constexpr (ASM) {
-    u32x4 v;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(v) : "v"(voff), "s"(rs), "n"(OFF) : "memory");
-    return v;
-  } else {
-    return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, OFF, 0);
-  }
-}
-// A descriptor the scalar ALU has just written must be 5 wait states old when a vector-memory instruction reads it; the hazard
-// recognizer inserts them for instructions it can see — not for the text of an asm statement.  (Without this a load can go out with
-// a descriptor that is half the previous block's: harmless-looking on small shapes, a memory fault once the base crosses 4 GiB.)
-template <bool ASM> __device__ __forceinline__ __amdgpu_buffer_rsrc_t settled(__amdgpu_buffer_rsrc_t rs) {
-  if constexpr (ASM) asm volatile("s_nop 4" : "+s"(rs));
-  return rs;
-}
-template <bool ASM> __device__ __forceinline__ float fused_load_f32(const float* p) {
-  if constexpr (ASM) {
-    float v;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-  } else {
-    return *p;
-  }
-}
-template <bool ASM> __device__ __forceinline__ u32x2 fused_load_b64(const float* p) {
-  if constexpr (ASM) {
-    u32x2 v;
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-  } else {
-    return *reinterpret_cast<const u32x2*>(p);
-  }
-}
-// NOT USED (both false): with the asm form the dH kernel faulted on grids of >= 512 workgroups and the dW kernel returned wrong
-// columns once in three runs at (1024, 131072) — most likely a register copy of a loop-carried asm output ahead of the data (the outputs
-// would have to be tied "+v" operands so that each ring slot keeps ONE register) — and measured no faster than the compiler's loads
-// (3.87 vs 3.88 ms): what bounds these kernels is not the depth of the prefetch.  Kept as the record of the experiment.
-constexpr bool kDwAsmLoads = false, kDhAsmLoads = false;
-
 template <int NP> __device__ __forceinline__ void fused_dz_block(const u32x4 (&zv)[4], const f32x16& g, float m, float rs, float dot,
                                                                  unsigned (&pk)[4][2][NP], float (*dacc)[16]) {
   // the expression of the streaming passes (hpd.hip: prob_fast), so that the dots of gngf_hpd_bwd_dot and these dz are of one piece:
@@ -833,13 +789,30 @@ __device__ __forceinline__ f32x16 fused_g_block(const Split3& Gs, const Split3& 
   return c;
 }
 
-// dW (T x 128) += dz^T h, db (T) += column sums of dz.  A workgroup owns 128 columns t for ALL U rows (U % 32 == 0): wave w stages the
-// 32 columns t0 + 32 w .. + 31 of every 32-row block (A image k-major: [r][t]), the block's h rows are staged as in the planes kernel.
+// The small operands of both kernels arrive SPLIT (gngf_hpd_bwd_prepare, once per backward pass): bf16 planes
+//   hp  (NP, rows_total, 128)  the last hidden layer  (B operand of dW)         Wp  (NP, T, 128)  the last layer's weight (B operand of dH)
+//   mwp (3, rows_total, 16)    multiplicity weights, zero-padded to 16 levels   Gtp (3, T, 16)    G transposed, zero-padded
+// so a K-block's B tile is four 16-byte loads and four 16-byte LDS stores per thread and an operand of the small product g is
+// three 16-byte loads — no split instruction outside the dz values themselves (per wave and K-block: 213 vector instructions where the
+// first form, which split h / W / mw / G from fp32 in the loop, had 313).
+// (Measured on the way and dropped: the K loop's loads through inline asm with a hand-counted s_waitcnt and a two-deep register ring
+// — hipcc sizes the loop-header wait for its worst predecessor and drains the ring in every other step —: exactly as fast, 3.87 vs 3.88
+// ms, and unsafe as written: loop-carried asm outputs must be tied operands.  A select on a freshly loaded value makes hipcc wait for
+// that load, and every load in flight, on the spot: nothing is selected in the fetch.)
+template <bool KM> __device__ __forceinline__ unsigned plane_tile_write_offset(int tid);
+// a [32 k][128 n] bf16 tile of a plane, k-major image: thread -> k = tid >> 4 (+ 16 in the second pass: + 4096 bytes), 16-byte chunk tid & 15
+template <> __device__ __forceinline__ unsigned plane_tile_write_offset<true>(int tid) {
+  const int k = tid >> 4, c16 = tid & 15;
+  return 256u * k + 64u * ((unsigned)(c16 >> 2) ^ (k & 3)) + 16u * (c16 & 3);
+}
+
+// dW (T x 128) += dz^T h, db (T) += column sums of dz.  A workgroup owns 128 columns t for ALL U rows (U % 64 == 0): wave w stages the
+// 32 columns t0 + 32 w .. + 31 of every 32-row block (A image k-major: [r][t], 8-byte units permuted: read_frag_km8).
 template <int NP>
 __global__ void __launch_bounds__(256, 2)
 hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowstat, const float* __restrict__ dot,
-                    const float* __restrict__ mw, const float* __restrict__ G, int L, const float* __restrict__ Hh,
-                    float* __restrict__ dW, float* __restrict__ db, int64_t U, int64_t T) {
+                    const unsigned short* __restrict__ mwp, const unsigned short* __restrict__ Gtp, const unsigned short* __restrict__ hp,
+                    int64_t rows_total, float* __restrict__ dW, float* __restrict__ db, int64_t U, int64_t T) {
   __shared__ __attribute__((aligned(16))) unsigned char img[2 * NP * 8192];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
@@ -848,54 +821,45 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
   if ((ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
   const int64_t t0 = tile * 128;
   const int nkb = (int)(U / 32);
-  // G^T fragment of this wave's 32 columns: lane (i, h) holds G[8 h + j][t0 + 32 wave + i]  (constant over the K loop)
+  // G^T fragment of this wave's 32 columns, constant over the K loop: lane (i, h) holds G[8 h .. 8 h + 7][t0 + 32 wave + i]
   Split3 Gs;
   {
-    float gx[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) gx[j] = (8 * h + j < L) ? G[(int64_t)(8 * h + j) * T + t0 + 32 * wave + i] : 0.f;   // (once per workgroup)
-    Gs = split8(gx);
+    const unsigned short* g0 = Gtp + (t0 + 32 * wave + i) * 16 + 8 * h;
+    Gs.hi = *reinterpret_cast<const u32x4*>(g0);
+    Gs.mid = *reinterpret_cast<const u32x4*>(g0 + T * 16);
+    Gs.lo = *reinterpret_cast<const u32x4*>(g0 + 2 * T * 16);
   }
   const unsigned zo = 4u * ((unsigned)i * (unsigned)T + 32u * wave + 4u * h);             // + 32 j bytes; window: 32 rows x T
-  unsigned ob[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int li = tid + e * 256;
-    ob[e] = 4u * ((unsigned)(li >> 5) * 128u + (li & 31) * 4);
-  }
-  // The logits are the HBM stream: TWO K-blocks of them are in flight per workgroup (register ring zv0 / zv1, the loop unrolled by
-  // two) — with one, a workgroup holds 16 KB in flight, two workgroups per CU 8 MB over the chip, and the kernel ran at 2 TB/s
-  // (bytes in flight / latency).  The small operands (h rows, row constants, multiplicity weights: L2 hits) stay one block ahead.
-  u32x4 zv0[4], zv1[4], vb[4];
+  const unsigned bo = 2u * ((unsigned)(tid >> 4) * 128u + 8u * (tid & 15));               // + 4096 in the second pass; window: 32 rows x 128
+  const unsigned mo = 2u * ((unsigned)i * 16u + 8u * h);                                  // window: 32 rows x 16
+  // two K-blocks of logits in flight per workgroup (register ring zv0 / zv1, the loop unrolled by two); the small operands (L2 hits)
+  // one block ahead, issued BEFORE the logits of the block after it (loads return in order) and unconditionally (the last blocks are
+  // fetched again, in bounds: behind a branch the compiler's wait counts would have to hold for the path that issued nothing)
+  u32x4 zv0[4], zv1[4], vb[NP][2];
+  Split3 Ms;
   u32x2 rc_ms;
-  float rc_d, mwx[8];
-  const int Ls = L > 0 ? L : 1;                             // (L = 0: the caller passes readable dummies for mw / G, every term is masked)
-  const int lsel = (8 * h < Ls) ? 8 * h : 0;                // lanes whose eight l are all >= L read the first eight (masked at use)
-  int mwo[8];                                               // (clamped index; the mask l < L is applied where the value is used)
+  float rc_d;
+  auto fetch_z = [&](int kb, u32x4 (&zv)[4]) {
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z + (int64_t)kb * 32 * T + t0), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) mwo[j] = (lsel + j < Ls) ? lsel + j : Ls - 1;
-  auto fetch_z = [&](int kb, u32x4 (&zv)[4]) {              // 4 loads
-    const __amdgpu_buffer_rsrc_t rz = settled<kDwAsmLoads>(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z + (int64_t)kb * 32 * T + t0), 0, 0x7fffffff, 0x00020000));
-    zv[0] = fused_load_b128<kDwAsmLoads, 0>(zo, rz); zv[1] = fused_load_b128<kDwAsmLoads, 32>(zo, rz);
-    zv[2] = fused_load_b128<kDwAsmLoads, 64>(zo, rz); zv[3] = fused_load_b128<kDwAsmLoads, 96>(zo, rz);
+    for (int j = 0; j < 4; ++j) zv[j] = __builtin_amdgcn_raw_buffer_load_b128(rz, zo, 32 * j, 0);
   };
-  auto fetch_small = [&](int kb) {                          // 4 + 2 + 8 loads
-    const int64_t r = (int64_t)kb * 32 + i;
-    const __amdgpu_buffer_rsrc_t rh = settled<kDwAsmLoads>(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Hh + (int64_t)kb * 32 * 128), 0, 0x7fffffff, 0x00020000));
+  auto fetch_small = [&](int kb) {
+    const int64_t r0 = (int64_t)kb * 32;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) vb[e] = fused_load_b128<kDwAsmLoads, 0>(ob[e], rh);
-    rc_ms = fused_load_b64<kDwAsmLoads>(rowstat + 2 * r);
-    rc_d = fused_load_f32<kDwAsmLoads>(dot + r);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) mwx[j] = fused_load_f32<kDwAsmLoads>(mw + r * Ls + mwo[j]);
-  };
-  // at the top of a step the loads in flight are, oldest first: logits of this block (4), small operands of this block (14), logits of
-  // the next block (4): wait for all but the newest four, then pin what the step reads behind that wait
-  auto landed = [&](u32x4 (&zv)[4]) {
-    if constexpr (!kDwAsmLoads) return;
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    asm volatile("" : "+v"(zv[0]), "+v"(zv[1]), "+v"(zv[2]), "+v"(zv[3]), "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]), "+v"(rc_ms), "+v"(rc_d),
-                      "+v"(mwx[0]), "+v"(mwx[1]), "+v"(mwx[2]), "+v"(mwx[3]), "+v"(mwx[4]), "+v"(mwx[5]), "+v"(mwx[6]), "+v"(mwx[7]));
+    for (int pl = 0; pl < NP; ++pl) {
+      const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(hp + (pl * rows_total + r0) * 128), 0, 0x7fffffff, 0x00020000);
+      vb[pl][0] = __builtin_amdgcn_raw_buffer_load_b128(rh, bo, 0, 0);
+      vb[pl][1] = __builtin_amdgcn_raw_buffer_load_b128(rh, bo, 4096, 0);
+    }
+    const __amdgpu_buffer_rsrc_t rm0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(mwp + r0 * 16), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(mwp + (rows_total + r0) * 16), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(mwp + (2 * rows_total + r0) * 16), 0, 0x7fffffff, 0x00020000);
+    Ms.hi = __builtin_amdgcn_raw_buffer_load_b128(rm0, mo, 0, 0);
+    Ms.mid = __builtin_amdgcn_raw_buffer_load_b128(rm1, mo, 0, 0);
+    Ms.lo = __builtin_amdgcn_raw_buffer_load_b128(rm2, mo, 0, 0);
+    rc_ms = *reinterpret_cast<const u32x2*>(rowstat + 2 * (r0 + i));
+    rc_d = dot[r0 + i];
   };
   fetch_z(0, zv0);
   fetch_small(0);
@@ -913,7 +877,7 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
   unsigned wa[4];                                                                         // run j: unit 2 j + h of segment `wave`, row k = i
 #pragma unroll
   for (int j = 0; j < 4; ++j) wa[j] = 256u * i + 64u * ((unsigned)wave ^ (i & 3)) + 8u * ((unsigned)(2 * j + h) ^ ((i >> 1) & 7));
-  const unsigned wb0 = plane_write_offset<true>(tid);
+  const unsigned wb0 = plane_tile_write_offset<true>(tid);
   const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
   unsigned ra[2][2];
 #pragma unroll
@@ -924,13 +888,9 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
   const unsigned rb0 = 256u * (8 * h + q4) + 64u * ((2 * wn) ^ q4) + 32u * g1 + 8u * p4;
   const unsigned rb1 = 256u * (8 * h + q4) + 64u * ((2 * wn + 1) ^ q4) + 32u * g1 + 8u * p4;
   auto step = [&](int kb, u32x4 (&zv)[4]) {
-    landed(zv);
     {
       unsigned pk[4][2][NP];
-      float mx[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) mx[j] = (8 * h + j < L) ? mwx[j] : 0.f;
-      const f32x16 g = fused_g_block(Gs, split8(mx));
+      const f32x16 g = fused_g_block(Gs, Ms);
       fused_dz_block<NP>(zv, g, __uint_as_float(rc_ms.x), 1.0f / __uint_as_float(rc_ms.y), rc_d, pk, &dacc);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -938,17 +898,10 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
         for (int pl = 0; pl < NP; ++pl) *(lds_u32x2*)(imgA + wa[j] + 8192 * pl) = u32x2{pk[j][0][pl], pk[j][1][pl]};
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      unsigned pb[2][NP];
-      split_pair<NP>(__uint_as_float(vb[e].x), __uint_as_float(vb[e].y), pb[0]);
-      split_pair<NP>(__uint_as_float(vb[e].z), __uint_as_float(vb[e].w), pb[1]);
-#pragma unroll
-      for (int pl = 0; pl < NP; ++pl) *(lds_u32x2*)(imgB + wb0 + 2048 * e + 8192 * pl) = u32x2{pb[0][pl], pb[1][pl]};
+    for (int pl = 0; pl < NP; ++pl) {
+      *(lds_u32x4*)(imgB + wb0 + 8192 * pl) = vb[pl][0];
+      *(lds_u32x4*)(imgB + wb0 + 4096 + 8192 * pl) = vb[pl][1];
     }
-    // loads return in order: the small operands of block kb + 1 are issued BEFORE the logits of block kb + 2, so that the next step
-    // can wait for them (and for the logits of kb + 1, issued a step ago) with the newest four loads still in flight
-    // ... and UNCONDITIONALLY (the last blocks are fetched again, in bounds, and dropped): behind a branch the compiler's wait counts
-    // must hold for the path that issued nothing, i.e. they drain every load in flight at the top of each step
     __builtin_amdgcn_sched_barrier(0);
     fetch_small(kb + 1 < nkb ? kb + 1 : nkb - 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -970,7 +923,6 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
     step(kb, zv0);
     step(kb + 1, zv1);
   }
-  if constexpr (kDwAsmLoads) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the tail's redundant loads: landed before their registers are reused
   split_epilogue(acc, dW, 128, nullptr, 0, 1, t0, 0, wm, wn, i, h, nullptr, 0);
   if (db) {
     // column sums: register r of lane (i, h) is column 32 wave + (r & 3) + 8 (r >> 2) + 4 h summed over this lane's rows; add the 32 lanes of a half
@@ -985,12 +937,12 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
 }
 
 // dH (U x 128) += dz W over the columns [blockIdx.y * kchunk, + kchunk) (kchunk % 64 == 0), rows blockIdx.x * 128 .. + 127: wave w stages
-// rows 32 w .. + 31 (A image [r][t]: k contiguous), W's rows t are staged as in the planes kernel (k-major).  Float atomics into dH.
+// rows 32 w .. + 31 (A image [r][t]: k contiguous).  Float atomics into dH.  u0 = the chunk's first row inside the prepared planes.
 template <int NP>
 __global__ void __launch_bounds__(256, 2)
 hpd_dh_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowstat, const float* __restrict__ dot,
-                    const float* __restrict__ mw, const float* __restrict__ G, int L, const float* __restrict__ W,
-                    float* __restrict__ dH, int64_t U, int64_t T, int64_t kchunk) {
+                    const unsigned short* __restrict__ mwp, const unsigned short* __restrict__ Gtp, const unsigned short* __restrict__ Wp,
+                    int64_t rows_total, float* __restrict__ dH, int64_t U, int64_t T, int64_t kchunk) {
   __shared__ __attribute__((aligned(16))) unsigned char img[2 * NP * 8192];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
@@ -1002,43 +954,35 @@ hpd_dh_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
   const float rc_m = rowstat[2 * r], rc_rs = 1.0f / rowstat[2 * r + 1], rc_d = dot[r];
   Split3 Ms;
   {
-    float mx[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) mx[j] = (8 * h + j < L) ? mw[r * L + 8 * h + j] : 0.f;
-    Ms = split8(mx);
+    const unsigned short* m0 = mwp + r * 16 + 8 * h;
+    Ms.hi = *reinterpret_cast<const u32x4*>(m0);
+    Ms.mid = *reinterpret_cast<const u32x4*>(m0 + rows_total * 16);
+    Ms.lo = *reinterpret_cast<const u32x4*>(m0 + 2 * rows_total * 16);
   }
   const unsigned zo = 4u * ((unsigned)(32 * wave + i) * (unsigned)T + 4u * h);            // + 32 j bytes; window: 128 rows x T
-  unsigned ob[4];
+  const unsigned bo = 2u * ((unsigned)(tid >> 4) * 128u + 8u * (tid & 15));
+  const unsigned go = 2u * ((unsigned)i * 16u + 8u * h);
+  u32x4 zv0[4], zv1[4], vb[NP][2];                            // (two K-blocks of logits in flight: see hpd_dw_fused_kernel)
+  Split3 Gs;
+  auto fetch_z = [&](int kb, u32x4 (&zv)[4]) {
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z + r0 * T + kbeg + (int64_t)kb * 32), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int li = tid + e * 256;
-    ob[e] = 4u * ((unsigned)(li >> 5) * 128u + (li & 31) * 4);
-  }
-  u32x4 zv0[4], zv1[4], vb[4];                                // (two K-blocks of logits in flight: see hpd_dw_fused_kernel)
-  float gx[8];
-  const int Ls = L > 0 ? L : 1;
-  const int lsel = (8 * h < Ls) ? 8 * h : 0;
-  int64_t go[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) go[j] = (int64_t)((lsel + j < Ls) ? lsel + j : Ls - 1) * T + i;      // (masked at use: see hpd_dw_fused_kernel)
-  auto fetch_z = [&](int kb, u32x4 (&zv)[4]) {              // 4 loads
-    const __amdgpu_buffer_rsrc_t rz = settled<kDhAsmLoads>(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z + r0 * T + kbeg + (int64_t)kb * 32), 0, 0x7fffffff, 0x00020000));
-    zv[0] = fused_load_b128<kDhAsmLoads, 0>(zo, rz); zv[1] = fused_load_b128<kDhAsmLoads, 32>(zo, rz);
-    zv[2] = fused_load_b128<kDhAsmLoads, 64>(zo, rz); zv[3] = fused_load_b128<kDhAsmLoads, 96>(zo, rz);
+    for (int j = 0; j < 4; ++j) zv[j] = __builtin_amdgcn_raw_buffer_load_b128(rz, zo, 32 * j, 0);
   };
-  auto fetch_small = [&](int kb) {                          // 4 + 8 loads
+  auto fetch_small = [&](int kb) {
     const int64_t tb = kbeg + (int64_t)kb * 32;
-    const __amdgpu_buffer_rsrc_t rw = settled<kDhAsmLoads>(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + tb * 128), 0, 0x7fffffff, 0x00020000));
 #pragma unroll
-    for (int e = 0; e < 4; ++e) vb[e] = fused_load_b128<kDhAsmLoads, 0>(ob[e], rw);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) gx[j] = fused_load_f32<kDhAsmLoads>(G + tb + go[j]);
-  };
-  auto landed = [&](u32x4 (&zv)[4]) {                         // (see hpd_dw_fused_kernel)
-    if constexpr (!kDhAsmLoads) return;
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    asm volatile("" : "+v"(zv[0]), "+v"(zv[1]), "+v"(zv[2]), "+v"(zv[3]), "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]),
-                      "+v"(gx[0]), "+v"(gx[1]), "+v"(gx[2]), "+v"(gx[3]), "+v"(gx[4]), "+v"(gx[5]), "+v"(gx[6]), "+v"(gx[7]));
+    for (int pl = 0; pl < NP; ++pl) {
+      const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Wp + (pl * T + tb) * 128), 0, 0x7fffffff, 0x00020000);
+      vb[pl][0] = __builtin_amdgcn_raw_buffer_load_b128(rw, bo, 0, 0);
+      vb[pl][1] = __builtin_amdgcn_raw_buffer_load_b128(rw, bo, 4096, 0);
+    }
+    const __amdgpu_buffer_rsrc_t rg0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Gtp + tb * 16), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Gtp + (T + tb) * 16), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Gtp + (2 * T + tb) * 16), 0, 0x7fffffff, 0x00020000);
+    Gs.hi = __builtin_amdgcn_raw_buffer_load_b128(rg0, go, 0, 0);
+    Gs.mid = __builtin_amdgcn_raw_buffer_load_b128(rg1, go, 0, 0);
+    Gs.lo = __builtin_amdgcn_raw_buffer_load_b128(rg2, go, 0, 0);
   };
   fetch_z(0, zv0);
   fetch_small(0);
@@ -1054,20 +998,16 @@ hpd_dh_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
   unsigned wa[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) wa[j] = 64u * (32 * wave + i) + 16u * ((unsigned)j ^ swz) + 8u * h;
-  const unsigned wb0 = plane_write_offset<true>(tid);
+  const unsigned wb0 = plane_tile_write_offset<true>(tid);
   const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
   const unsigned ra0 = 64u * (wm * 64 + i) + 16u * ((unsigned)h ^ swz);
   const unsigned ra1 = 64u * (wm * 64 + i) + 16u * ((unsigned)(2 + h) ^ swz);
   const unsigned rb0 = 256u * (8 * h + q4) + 64u * ((2 * wn) ^ q4) + 32u * g1 + 8u * p4;
   const unsigned rb1 = 256u * (8 * h + q4) + 64u * ((2 * wn + 1) ^ q4) + 32u * g1 + 8u * p4;
   auto step = [&](int kb, u32x4 (&zv)[4]) {
-    landed(zv);
     {
       unsigned pk[4][2][NP];
-      float gm[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) gm[j] = (8 * h + j < L) ? gx[j] : 0.f;
-      const f32x16 g = fused_g_block(split8(gm), Ms);
+      const f32x16 g = fused_g_block(Gs, Ms);
       fused_dz_block<NP>(zv, g, rc_m, rc_rs, rc_d, pk, nullptr);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -1075,17 +1015,10 @@ hpd_dh_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
         for (int pl = 0; pl < NP; ++pl) *(lds_u32x2*)(imgA + wa[j] + 8192 * pl) = u32x2{pk[j][0][pl], pk[j][1][pl]};
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      unsigned pb[2][NP];
-      split_pair<NP>(__uint_as_float(vb[e].x), __uint_as_float(vb[e].y), pb[0]);
-      split_pair<NP>(__uint_as_float(vb[e].z), __uint_as_float(vb[e].w), pb[1]);
-#pragma unroll
-      for (int pl = 0; pl < NP; ++pl) *(lds_u32x2*)(imgB + wb0 + 2048 * e + 8192 * pl) = u32x2{pb[0][pl], pb[1][pl]};
+    for (int pl = 0; pl < NP; ++pl) {
+      *(lds_u32x4*)(imgB + wb0 + 8192 * pl) = vb[pl][0];
+      *(lds_u32x4*)(imgB + wb0 + 4096 + 8192 * pl) = vb[pl][1];
     }
-    // loads return in order: the small operands of block kb + 1 are issued BEFORE the logits of block kb + 2, so that the next step
-    // can wait for them (and for the logits of kb + 1, issued a step ago) with the newest four loads still in flight
-    // ... and UNCONDITIONALLY (the last blocks are fetched again, in bounds, and dropped): behind a branch the compiler's wait counts
-    // must hold for the path that issued nothing, i.e. they drain every load in flight at the top of each step
     __builtin_amdgcn_sched_barrier(0);
     fetch_small(kb + 1 < nkb ? kb + 1 : nkb - 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -1107,8 +1040,34 @@ hpd_dh_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
     step(kb, zv0);
     step(kb + 1, zv1);
   }
-  if constexpr (kDhAsmLoads) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   split_epilogue(acc, dH, 128, nullptr, 0, 1, r0, 0, wm, wn, i, h, nullptr, 0);
+}
+
+// gngf_hpd_bwd_prepare: X (rows, 128) fp32 -> NP planes (NP, rows, 128), and V (rows, Lv) -> three planes (3, rows, 16) zero-padded
+// (V = mw as it is; V = G^T through the strides: element (row, l) at V[row * vs_row + l * vs_l])
+template <int NP>
+__global__ void __launch_bounds__(256)
+hpd_prepare_kernel(const float* __restrict__ X, unsigned short* __restrict__ Xp, const float* __restrict__ V, int Lv, int64_t vs_row,
+                   int64_t vs_l, unsigned short* __restrict__ Vp, int64_t rows) {
+  const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (e < rows * 128) {
+    const float4 a = *reinterpret_cast<const float4*>(X + e), b = *reinterpret_cast<const float4*>(X + e + 4);
+    unsigned o[4][NP];
+    split_pair<NP>(a.x, a.y, o[0]); split_pair<NP>(a.z, a.w, o[1]); split_pair<NP>(b.x, b.y, o[2]); split_pair<NP>(b.z, b.w, o[3]);
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x4*>(Xp + pl * rows * 128 + e) = u32x4{o[0][pl], o[1][pl], o[2][pl], o[3][pl]};
+  }
+  if (e < rows * 16) {                                         // the first rows * 2 threads also write eight levels of one row of V's planes
+    const int64_t row = e >> 4;
+    const int l0 = (int)(e & 15);
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (l0 + j < Lv) ? V[row * vs_row + (l0 + j) * vs_l] : 0.f;
+    const Split3 s3 = split8(x);
+    *reinterpret_cast<u32x4*>(Vp + e) = s3.hi;
+    *reinterpret_cast<u32x4*>(Vp + rows * 16 + e) = s3.mid;
+    *reinterpret_cast<u32x4*>(Vp + 2 * rows * 16 + e) = s3.lo;
+  }
 }
 
 // the K top-K slots of a row add a = p_k dq_k to dz[r, topk_idx]: dW[slot,:] += a h[r,:], dH[r,:] += a W[slot,:], db[slot] += a.
@@ -1310,32 +1269,60 @@ extern "C" int gngf_hpd_bwd_fused_applies(int64_t U, int64_t T, int L, int K, in
   return (U > 0 && U % 128 == 0 && T % 128 == 0 && T < (1 << 22) && hidden == 128 && L >= 0 && L <= 16 && K >= 0 && K <= GNGF_MAX_TOPK) ? 1 : 0;
 }
 
+// The small operands of gngf_hpd_bwd_fused, split once per backward pass into bf16 planes (planes = 2 or 3 for h and W; always the
+// exact three for the operands of the small product g = mw G):
+//   h (rows, 128) -> hp (planes, rows, 128),  mw (rows, L) -> mwp (3, rows, 16) zero-padded      (rows = all vertices of the step)
+//   W (T, 128)    -> Wp (planes, T, 128),     G (L, T)     -> Gtp (3, T, 16) transposed, zero-padded
+// Either half may be skipped (h == NULL / W == NULL).  L = 0: mw / G may be NULL, their planes are zero-filled.
+extern "C" int gngf_hpd_bwd_prepare(const float* h, const float* mw, int64_t rows, void* hp, void* mwp, const float* W, const float* G,
+                                    int64_t T, void* Wp, void* Gtp, int L, int hidden, int planes, void* stream) {
+  GNGF_CHECK_ARG(rows >= 0 && T >= 0 && hidden == 128 && L >= 0 && L <= 16 && (planes == 2 || planes == 3));
+  hipStream_t s = as_stream(stream);
+  if (h && rows > 0) {
+    GNGF_CHECK_ARG(hp && mwp && (L == 0 || mw));
+    const dim3 g((unsigned)ceil_div(rows * 128 / 8, 256));
+    if (planes == 2) hpd_prepare_kernel<2><<<g, dim3(256), 0, s>>>(h, static_cast<unsigned short*>(hp), mw, L, L, 1, static_cast<unsigned short*>(mwp), rows);
+    else hpd_prepare_kernel<3><<<g, dim3(256), 0, s>>>(h, static_cast<unsigned short*>(hp), mw, L, L, 1, static_cast<unsigned short*>(mwp), rows);
+  }
+  if (W && T > 0) {
+    GNGF_CHECK_ARG(Wp && Gtp && (L == 0 || G));
+    const dim3 g((unsigned)ceil_div(T * 128 / 8, 256));
+    if (planes == 2) hpd_prepare_kernel<2><<<g, dim3(256), 0, s>>>(W, static_cast<unsigned short*>(Wp), G, L, 1, T, static_cast<unsigned short*>(Gtp), T);
+    else hpd_prepare_kernel<3><<<g, dim3(256), 0, s>>>(W, static_cast<unsigned short*>(Wp), G, L, 1, T, static_cast<unsigned short*>(Gtp), T);
+  }
+  GNGF_RETURN_LAUNCH();
+}
+
 // Backward of the HashProbDistribution's last layer from the logits of one chunk (see hpd_dw_fused_kernel):
 //   dW (T,128) += dz^T h,  db (T) += colsum dz,  dH (U,128) += dz W      with dz = p (mw G - dot) + [top-K slots] p_k dq_k
-// logits (U,T), rowstat (U,2) = (max, sum exp), dot (U) from gngf_hpd_bwd_dot, dq / topk_p / topk_idx (U,K) or K = 0, mw (U,L),
-// G (L,T) or L = 0, h (U,128), W (T,128).  planes: 3 = exact three-way split, 2 = two planes (three products).
+// logits (U,T), rowstat (U,2) = (max, sum exp), dot (U) from gngf_hpd_bwd_dot, dq / topk_p / topk_idx (U,K) or K = 0;
+// hp / mwp = the planes of gngf_hpd_bwd_prepare AT THE CHUNK'S FIRST ROW (pointer + u0 * 128 resp. + u0 * 16 elements; rows_total = the
+// rows they were prepared with: the plane stride), Wp / Gtp as prepared; h (U,128) and W (T,128) in fp32 for the K top-K terms (K = 0: unused).
+// planes: as prepared.  + 16 / + 32 / + 48 on `planes` run the dW / the dH / the top-K part alone (diagnostic).
 extern "C" int gngf_hpd_bwd_fused(const float* logits, const float* rowstat, const float* dot, const float* dq, const float* topk_p,
-                                  const int32_t* topk_idx, const float* mw, const float* G, int L, const float* h, const float* W,
-                                  float* dW, float* db, float* dH, int64_t U, int64_t T, int K, int hidden, int planes, void* stream) {
-  const int only = planes >> 4;                             // diagnostic: + 16 = dW / db only, + 32 = dH only, + 48 = the top-K terms only
+                                  const int32_t* topk_idx, const void* hp, const void* mwp, int64_t rows_total, const void* Wp,
+                                  const void* Gtp, const float* h, const float* W, float* dW, float* db, float* dH, int64_t U,
+                                  int64_t T, int K, int hidden, int planes, void* stream) {
+  const int only = planes >> 4;
   planes &= 15;
-  GNGF_CHECK_ARG(gngf_hpd_bwd_fused_applies(U, T, L, K, hidden) && (planes == 2 || planes == 3));
-  GNGF_CHECK_ARG(logits && rowstat && dot && h && W && dW && dH && (L == 0 || (mw && G)) && (K == 0 || (dq && topk_p && topk_idx)));
+  GNGF_CHECK_ARG(gngf_hpd_bwd_fused_applies(U, T, 0, K, hidden) && (planes == 2 || planes == 3) && rows_total >= U);
+  GNGF_CHECK_ARG(logits && rowstat && dot && hp && mwp && Wp && Gtp && dW && dH && (K == 0 || (dq && topk_p && topk_idx && h && W)));
   hipStream_t s = as_stream(stream);
-  if (L == 0) { mw = rowstat; G = logits; }                  // read (clamped index 0) and masked: never used
+  const unsigned short *hp_ = static_cast<const unsigned short*>(hp), *mwp_ = static_cast<const unsigned short*>(mwp);
+  const unsigned short *Wp_ = static_cast<const unsigned short*>(Wp), *Gtp_ = static_cast<const unsigned short*>(Gtp);
   const dim3 gw((unsigned)(T / 128));
-  // dh: enough column slices for ~1024 workgroups, each a multiple of 32 columns
+  // dh: enough column slices for ~1024 workgroups, each an even number of 32-column K-blocks
   const int64_t rtiles = U / 128;
   int64_t slices = ceil_div(1024, rtiles);
-  int64_t kchunk = ceil_div(ceil_div(T, slices), 64) * 64;      // (an even number of 32-column K-blocks per slice)
+  int64_t kchunk = ceil_div(ceil_div(T, slices), 64) * 64;
   slices = ceil_div(T, kchunk);
   const dim3 gh((unsigned)rtiles, (unsigned)slices);
   if (planes == 2) {
-    if (only == 0 || only == 1) hpd_dw_fused_kernel<2><<<gw, dim3(256), 0, s>>>(logits, rowstat, dot, mw, G, L, h, dW, db, U, T);
-    if (only == 0 || only == 2) hpd_dh_fused_kernel<2><<<gh, dim3(256), 0, s>>>(logits, rowstat, dot, mw, G, L, W, dH, U, T, kchunk);
+    if (only == 0 || only == 1) hpd_dw_fused_kernel<2><<<gw, dim3(256), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, hp_, rows_total, dW, db, U, T);
+    if (only == 0 || only == 2) hpd_dh_fused_kernel<2><<<gh, dim3(256), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, Wp_, rows_total, dH, U, T, kchunk);
   } else {
-    if (only == 0 || only == 1) hpd_dw_fused_kernel<3><<<gw, dim3(256), 0, s>>>(logits, rowstat, dot, mw, G, L, h, dW, db, U, T);
-    if (only == 0 || only == 2) hpd_dh_fused_kernel<3><<<gh, dim3(256), 0, s>>>(logits, rowstat, dot, mw, G, L, W, dH, U, T, kchunk);
+    if (only == 0 || only == 1) hpd_dw_fused_kernel<3><<<gw, dim3(256), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, hp_, rows_total, dW, db, U, T);
+    if (only == 0 || only == 2) hpd_dh_fused_kernel<3><<<gh, dim3(256), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, Wp_, rows_total, dH, U, T, kchunk);
   }
   if (K > 0 && (only == 0 || only == 3))
     hpd_topk_side_kernel<<<dim3((unsigned)(U * K)), dim3(128), 0, s>>>(topk_p, dq, topk_idx, h, W, dW, db, dH, K);

@@ -494,6 +494,27 @@ class HpdAux:
 # TUNING.hpd_epilogue_stats (default True)
 
 
+class _HpdBwdPlanes:
+    """the small operands of gngf_hpd_bwd_fused split once per backward pass into bf16 planes (csrc/linear.hip: gngf_hpd_bwd_prepare)"""
+
+    def __init__(self, h_all, mw, W, G, L, planes):
+        NV, Hd = h_all.shape
+        T = W.shape[0]
+        dev = W.device
+        self.NV, self.Hd, self.planes, self.L = NV, Hd, planes, L
+        self.hp = torch.empty((planes, NV, Hd), dtype=torch.int16, device=dev)
+        self.mwp = torch.empty((3, NV, 16), dtype=torch.int16, device=dev)
+        self.Wp = torch.empty((planes, T, Hd), dtype=torch.int16, device=dev)
+        self.Gtp = torch.empty((3, T, 16), dtype=torch.int16, device=dev)
+        call("gngf_hpd_bwd_prepare", ptr(h_all, _f32), ptr(mw if L else None), NV, ptr(self.hp), ptr(self.mwp), ptr(W, _f32),
+             ptr(G if L else None), T, ptr(self.Wp), ptr(self.Gtp), L, Hd, planes, stream_ptr())
+
+    def fused(self, dz, rowstat, dots, g_tv, tv, ti, h, W, dW, db, dH, u0, n, T, K):
+        call("gngf_hpd_bwd_fused", ptr(dz), ptr(rowstat), ptr(dots), ptr(g_tv if K else None), ptr(tv if K else None),
+             ptr(ti if K else None), _lib._P(self.hp.data_ptr() + 2 * u0 * self.Hd), _lib._P(self.mwp.data_ptr() + 2 * u0 * 16), self.NV,
+             ptr(self.Wp), ptr(self.Gtp), ptr(h), ptr(W), ptr(dW), ptr(db), ptr(dH), n, T, K, self.Hd, self.planes, stream_ptr())
+
+
 class _split_gemm:
     """scope in which large aligned GEMMs of this process use the split-bf16 kernel (when HPD_GEMM_SPLIT_BF16)"""
 
@@ -695,6 +716,7 @@ class HpdVertexFunction(torch.autograd.Function):
                                                   dz_bufs, hs_all, dH)
             HpdVertexFunction._hidden_backward(hs_all, dH, params, grads, n_layers)
             return (None, None, None, None, None, None, None, *grads)
+        prep_serial = None
         for u0 in range(0, NV, rows):
             n = min(rows, NV - u0)
             hs = [h[u0:u0 + n] for h in hs_all]
@@ -712,14 +734,14 @@ class HpdVertexFunction(torch.autograd.Function):
                 Lq, Kq = (L if g_pbar is not None else 0), (K if g_tv is not None else 0)
                 if (TUNING.hpd_bwd_fused and TUNING.hpd_gemm_split_bf16
                         and query("gngf_hpd_bwd_fused_applies", n, T, Lq, Kq, W_last.shape[1]) == 1):
+                    if prep_serial is None:
+                        prep_serial = _HpdBwdPlanes(hs_all[-1], mw, W_last, g_pbar, Lq, 2 if TUNING.hpd_bwd_two_planes else 3)
                     dotv = scratch[:n]
                     call("gngf_hpd_bwd_dot", ptr(dz), ptr(rowstat[u0:u0 + n]), ptr(g_tv[u0:u0 + n] if Kq else None),
                          ptr(tv[u0:u0 + n] if Kq else None), ptr(mw[u0:u0 + n] if Lq else None), ptr(g_pbar if Lq else None), Lq,
                          ptr(dotv), n, T, Kq, stream_ptr())
-                    call("gngf_hpd_bwd_fused", ptr(dz), ptr(rowstat[u0:u0 + n]), ptr(dotv), ptr(g_tv[u0:u0 + n] if Kq else None),
-                         ptr(tv[u0:u0 + n] if Kq else None), ptr(ti[u0:u0 + n] if Kq else None), ptr(mw[u0:u0 + n] if Lq else None),
-                         ptr(g_pbar if Lq else None), Lq, ptr(hs[-1]), ptr(W_last), ptr(grads[-2]), ptr(grads[-1]), ptr(dH[u0:u0 + n]),
-                         n, T, Kq, W_last.shape[1], 2 if TUNING.hpd_bwd_two_planes else 3, stream_ptr())
+                    prep_serial.fused(dz, rowstat[u0:u0 + n], dotv, g_tv[u0:u0 + n] if Kq else None, tv[u0:u0 + n] if Kq else None,
+                                      ti[u0:u0 + n] if Kq else None, hs[-1], W_last, grads[-2], grads[-1], dH[u0:u0 + n], u0, n, T, Kq)
                     continue
                 call("gngf_softmax_bwd_lowrank", ptr(dz), ptr(rowstat[u0:u0 + n]),
                      ptr(g_tv[u0:u0 + n] if g_tv is not None else None), ptr(ti[u0:u0 + n]),
@@ -775,6 +797,7 @@ class HpdVertexFunction(torch.autograd.Function):
         def fused(n):
             return (TUNING.hpd_bwd_fused and TUNING.hpd_gemm_split_bf16
                     and query("gngf_hpd_bwd_fused_applies", n, T, Lq, Kq, W_last.shape[1]) == 1)
+        prep = (_HpdBwdPlanes(hs_all[-1], mw, W_last, g_pbar, Lq, planes) if fused(min(rows, NV)) else None)
 
         def stage_b(dz, n, u0):
             if fused(n):          # one read of the logits: the row dots only
@@ -791,10 +814,8 @@ class HpdVertexFunction(torch.autograd.Function):
         def stage_c(dz, hs, done_b, n, u0):
             main.wait_event(done_b)
             if fused(n):          # dz formed in the loaders of both GEMMs, which read the logits (dz IS the logits here)
-                call("gngf_hpd_bwd_fused", ptr(dz), ptr(rowstat[u0:u0 + n]), ptr(dots[u0:u0 + n]), ptr(g_tv[u0:u0 + n] if Kq else None),
-                     ptr(tv[u0:u0 + n] if Kq else None), ptr(ti[u0:u0 + n] if Kq else None), ptr(mw[u0:u0 + n] if Lq else None),
-                     ptr(g_pbar if Lq else None), Lq, ptr(hs[-1]), ptr(W_last), ptr(grads[-2]), ptr(grads[-1]), ptr(dH[u0:u0 + n]),
-                     n, T, Kq, W_last.shape[1], planes, stream_ptr())
+                prep.fused(dz, rowstat[u0:u0 + n], dots[u0:u0 + n], g_tv[u0:u0 + n] if Kq else None, tv[u0:u0 + n] if Kq else None,
+                           ti[u0:u0 + n] if Kq else None, hs[-1], W_last, grads[-2], grads[-1], dH[u0:u0 + n], u0, n, T, Kq)
                 return
             with _split_gemm(accumulating=True):
                 linear_bwd_weight(dz, None, hs[-1], grads[-2], None, ACT_NONE)

@@ -356,16 +356,25 @@ int gngf_softmax_bwd_lowrank(float* logits_dz, const float* rowstat, const float
  *   dW (T,hidden) += dz^T h,  db (T) += column sums of dz (NULL: skipped),  dH (U,hidden) += dz W        (all three accumulate)
  * — what gngf_softmax_bwd_lowrank + gngf_linear_bwd_weight + gngf_gemm_acc compute (the autograd backward of models.py:84-85,
  * 105-116 under the batch-mean loss utils.py:138,159), with two passes over the (U,T) matrix instead of five.
- * h (U,hidden) = the last hidden layer, W (T,hidden) = the last layer's weight.  planes: 3 = every fp32 operand split exactly into
- * three bf16 terms (six products, fp32 accumulation), 2 = two terms, three products (|error| <= 3 * 2^-18 |a b| per product).
+ * The small operands are split ONCE per backward pass into bf16 planes by gngf_hpd_bwd_prepare:
+ *   h (rows,hidden) = the last hidden layer of ALL vertices -> hp (planes, rows, hidden);  mw (rows,L) -> mwp (3, rows, 16), zero-padded
+ *   W (T,hidden) = the last layer's weight -> Wp (planes, T, hidden);                      G (L,T) -> Gtp (3, T, 16), transposed
+ * (either half may be skipped: h == NULL / W == NULL; L = 0: mw / G may be NULL).  planes: 3 = every fp32 value split exactly into
+ * three bf16 terms (six products, fp32 accumulation), 2 = two terms, three products (|error| <= 3 * 2^-18 |a b| per product); the
+ * operands of the small product mw G always keep the exact three.  gngf_hpd_bwd_fused takes hp / mwp AT THE CHUNK'S FIRST ROW
+ * (pointer + u0 * hidden resp. + u0 * 16 elements) and rows_total = the rows they were prepared with (the plane stride); h (U,hidden)
+ * and W in fp32 serve the K top-K terms only (K = 0: unused).
  * Shapes: gngf_hpd_bwd_fused_applies(U, T, L, K, hidden) != 0 (U % 128 == 0, T % 128 == 0, T < 2^22, hidden == 128, L <= 16);
  * anything else is rejected (hipErrorInvalidValue) — the caller then takes the three separate entry points. */
 int gngf_hpd_bwd_dot(const float* logits, const float* rowstat, const float* dq, const float* topk_p, const float* mw,
                      const float* G, int L, float* dot, int64_t U, int64_t T, int K, void* stream);
 int gngf_hpd_bwd_fused_applies(int64_t U, int64_t T, int L, int K, int hidden);
+int gngf_hpd_bwd_prepare(const float* h, const float* mw, int64_t rows, void* hp, void* mwp, const float* W, const float* G, int64_t T,
+                         void* Wp, void* Gtp, int L, int hidden, int planes, void* stream);
 int gngf_hpd_bwd_fused(const float* logits, const float* rowstat, const float* dot, const float* dq, const float* topk_p,
-                       const int32_t* topk_idx, const float* mw, const float* G, int L, const float* h, const float* W,
-                       float* dW, float* db, float* dH, int64_t U, int64_t T, int K, int hidden, int planes, void* stream);
+                       const int32_t* topk_idx, const void* hp, const void* mwp, int64_t rows_total, const void* Wp, const void* Gtp,
+                       const float* h, const float* W, float* dW, float* db, float* dH, int64_t U, int64_t T, int K, int hidden,
+                       int planes, void* stream);
 /* topk_p (optional; (U,K)): the top-K probabilities gngf_logits_topk_pbar / gngf_softmax_topk returned for these logits — the
  * backward then takes p at the top-K slots from them instead of reading the logits again at random. */
 

@@ -955,8 +955,17 @@ def test_softmax_backward_formed_in_the_gemm_loaders(ops, U, T, L, K, planes):
     dW, db, dH = torch.zeros((T, Hd), device=DEV), torch.zeros((T,), device=DEV), torch.zeros((U, Hd), device=DEV)
     assert query("gngf_hpd_bwd_fused_applies", U, T, L, K, Hd) == 1
     call("gngf_hpd_bwd_dot", ptr(z), ptr(rowstat), ptr(dq), ptr(pk), ptr(mw), ptr(G), L, ptr(dotv), U, T, K, stream_ptr())
-    call("gngf_hpd_bwd_fused", ptr(z), ptr(rowstat), ptr(dotv), ptr(dq), ptr(pk), ptr(ti32), ptr(mw), ptr(G), L, ptr(h), ptr(W),
-         ptr(dW), ptr(db), ptr(dH), U, T, K, Hd, planes, stream_ptr())
+    # the small operands split once: prepared for a LARGER row set (the step's vertices), this chunk starting at row u0 of it
+    u0, rows_total = 128, U + 256
+    h_all = torch.cat([torch.full((u0, Hd), 7.0, device=DEV), h, torch.full((rows_total - U - u0, Hd), -3.0, device=DEV)])
+    mw_all = torch.cat([torch.ones((u0, max(L, 1)), device=DEV), mw if L else torch.zeros((U, 1), device=DEV),
+                        torch.ones((rows_total - U - u0, max(L, 1)), device=DEV)]) if L else None
+    prep = ops._HpdBwdPlanes(h_all, mw_all, W, G, L, planes)
+    if L:
+        back = prep.mwp.view(torch.bfloat16).float().double().sum(dim=0)[u0:u0 + U, :L]
+        assert torch.equal(back.float(), mw) and float(prep.mwp[:, :, L:].abs().max() if L < 16 else 0) == 0
+        assert torch.equal(prep.Gtp.view(torch.bfloat16).float().double().sum(dim=0)[:, :L].float(), G.T.contiguous())
+    prep.fused(z, rowstat, dotv, dq, pk, ti32, h, W, dW, db, dH, u0, U, T, K)
     # the three entry points it replaces
     dz1 = z.clone()
     scratch = torch.empty((U * (1 + max(K, 1)),), device=DEV)
@@ -978,5 +987,4 @@ def test_softmax_backward_formed_in_the_gemm_loaders(ops, U, T, L, K, planes):
     # shapes the fused form does not take are rejected, never computed wrongly
     assert query("gngf_hpd_bwd_fused_applies", U + 3, T, L, K, Hd) == 0 and query("gngf_hpd_bwd_fused_applies", U, T, 17, K, Hd) == 0
     with pytest.raises(RuntimeError):
-        call("gngf_hpd_bwd_fused", ptr(z), ptr(rowstat), ptr(dotv), ptr(dq), ptr(pk), ptr(ti32), ptr(mw), ptr(G), L, ptr(h), ptr(W),
-             ptr(dW), ptr(db), ptr(dH), U, T, K, 64, planes, stream_ptr())
+        prep.fused(z, rowstat, dotv, dq, pk, ti32, h, W, dW, db, dH, u0, U + 3, T, K)

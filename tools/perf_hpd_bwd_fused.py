@@ -33,9 +33,9 @@ scratch = torch.empty((U * (1 + K),), device=dev)
 dz = torch.empty_like(z)
 def f_dot():
     call("gngf_hpd_bwd_dot", ptr(z), ptr(rowstat), ptr(dq), ptr(pk), ptr(mw), ptr(G), L, ptr(dot), U, T, K, stream_ptr())
+preps = {2: ops._HpdBwdPlanes(h, mw, W, G, L, 2), 3: ops._HpdBwdPlanes(h, mw, W, G, L, 3)}
 def f_fused(planes):
-    call("gngf_hpd_bwd_fused", ptr(z), ptr(rowstat), ptr(dot), ptr(dq), ptr(pk), ptr(ti32), ptr(mw), ptr(G), L, ptr(h), ptr(W),
-         ptr(dW), ptr(db), ptr(dH), U, T, K, H, planes, stream_ptr())
+    preps[planes].fused(z, rowstat, dot, dq, pk, ti32, h, W, dW, db, dH, 0, U, T, K)
 def f_lowrank():
     call("gngf_softmax_bwd_lowrank", ptr(dz), ptr(rowstat), ptr(dq), ptr(ti32), ptr(mw), ptr(G), L, ptr(db), ptr(scratch), ptr(pk),
          U, T, K, stream_ptr())
@@ -47,10 +47,11 @@ def f_gemms(mode):
 for rep in range(2):
     dz.copy_(z)
     t_dot = timeit(f_dot)
+    t_prep = timeit(lambda: ops._HpdBwdPlanes(h, mw, W, G, L, 2), reps=3)
     t_f2, t_f3 = timeit(lambda: f_fused(2)), timeit(lambda: f_fused(3))
     t_lr = timeit(f_lowrank, reps=3)           # (in place: after the first call it runs on its own output — same traffic)
     t_g2, t_g1 = timeit(lambda: f_gemms(2)), timeit(lambda: f_gemms(1))
-    print(f"dot {t_dot:.2f} ms | fused dW+dh: two planes {t_f2:.2f}, three {t_f3:.2f} | separate: softmax backward (dot+apply) {t_lr:.2f}, "
+    print(f"prepare (once per backward pass; here for one chunk's rows) {t_prep:.2f} ms | dot {t_dot:.2f} ms | fused dW+dh: two planes {t_f2:.2f}, three {t_f3:.2f} | separate: softmax backward (dot+apply) {t_lr:.2f}, "
           f"dW+dh two planes {t_g2:.2f}, three {t_g1:.2f}  ->  per chunk {t_dot + t_f2:.2f} / {t_dot + t_f3:.2f} vs {t_lr + t_g2:.2f} / {t_lr + t_g1:.2f} ms")
 # accuracy at full size against float64 on a sample
 dW.zero_(); db.zero_(); dH.zero_(); f_dot(); f_fused(2); torch.cuda.synchronize()
