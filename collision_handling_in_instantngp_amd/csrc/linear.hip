@@ -861,9 +861,12 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
     rc_ms = *reinterpret_cast<const u32x2*>(rowstat + 2 * (r0 + i));
     rc_d = dot[r0 + i];
   };
-  fetch_z(0, zv0);
+  fetch_z(0, zv0);                                            // (in the loop's own order: the wait counts at the loop header are sized for
+  __builtin_amdgcn_sched_barrier(0);                          //  the worse of its two predecessors)
   fetch_small(0);
+  __builtin_amdgcn_sched_barrier(0);
   fetch_z(nkb > 1 ? 1 : 0, zv1);
+  __builtin_amdgcn_sched_barrier(0);
   f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -984,9 +987,12 @@ hpd_dh_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
     Gs.mid = __builtin_amdgcn_raw_buffer_load_b128(rg1, go, 0, 0);
     Gs.lo = __builtin_amdgcn_raw_buffer_load_b128(rg2, go, 0, 0);
   };
-  fetch_z(0, zv0);
+  fetch_z(0, zv0);                                            // (in the loop's own order: the wait counts at the loop header are sized for
+  __builtin_amdgcn_sched_barrier(0);                          //  the worse of its two predecessors)
   fetch_small(0);
+  __builtin_amdgcn_sched_barrier(0);
   fetch_z(nkb > 1 ? 1 : 0, zv1);
+  __builtin_amdgcn_sched_barrier(0);
   f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
