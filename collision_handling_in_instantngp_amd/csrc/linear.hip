@@ -418,42 +418,57 @@ __device__ __forceinline__ void split_epilogue(f32x16 (&acc)[2][2], float* __res
     // models.py:85,105-116): for every row of the tile and each 64-column half (this wave's columns) the maximum and
     // sum exp(z - max) — 8 bytes per 256 bytes of logits — so that the row maxima / normalisers and the top-K (which lies inside
     // the K half-tiles with the largest maxima) come out of a merge over these partials instead of a second pass over the logits
-    // (hpd.hip: rowstats_topk_kernel).  Reduction over the 32 lanes that share a row: four DPP steps inside each 16-lane row
-    // (quad_perm, half mirror, mirror: every lane of the row ends up with the row's result) and row_bcast15 into rows 1 / 3;
-    // lanes 16 (h = 0) and 48 (h = 1) store.  A NaN logit makes the half's sum NaN (the maximum ignores it, as fmaxf does).
+    // (hpd.hip: rowstats_topk_kernel).  Reduction over the 32 lanes that share a row, for the 16 row-registers of a lane at once: the
+    // first step TRANSPOSES — v_permlane16_swap exchanges the upper 16 lanes of register r with the lower 16 of register r + 8, so one
+    // max / add folds two registers into one whose lower 16 lanes carry row-register r and whose upper 16 carry r + 8 — and four DPP
+    // steps inside each 16-lane row finish 8 registers instead of 16 (quad_perm, half mirror, mirror: every lane of the row ends up with
+    // the result); the same swap of a register with itself hands both maxima back to all 32 lanes for the exponentials.  Lanes 0 / 16 /
+    // 32 / 48 store.  A NaN logit makes the half's sum NaN (the maximum ignores it, as fmaxf does).
+#define GNGF_DPP_F(x, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), ctrl, 0xF, 0xF, false))
+#define GNGF_DPP_ADD(x, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xF, 0xF, false))
     constexpr float kLog2e = 1.4426950408889634f;
     const int64_t part = (n0 >> 6) + wn;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < 2; ++tm) {
+      float w[8], mall[16], sx[16];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float va = fmaxf(acc[tm][0][r], acc[tm][1][r]), vb = fmaxf(acc[tm][0][r + 8], acc[tm][1][r + 8]);
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+        float m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        m = fmaxf(m, GNGF_DPP_F(m, 0xB1));
+        m = fmaxf(m, GNGF_DPP_F(m, 0x4E));
+        m = fmaxf(m, GNGF_DPP_F(m, 0x141));
+        m = fmaxf(m, GNGF_DPP_F(m, 0x140));
+        w[r] = m;                                                // rows 0 / 2 of the wave: row-register r; rows 1 / 3: row-register r + 8
+        const auto bc = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+        mall[r] = __uint_as_float(bc[0]);
+        mall[r + 8] = __uint_as_float(bc[1]);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float a = acc[tm][0][r], b = acc[tm][1][r];
-        float m = fmaxf(a, b);
-        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0xB1, 0xF, 0xF, false)));
-        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x4E, 0xF, 0xF, false)));
-        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x141, 0xF, 0xF, false)));
-        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x140, 0xF, 0xF, false)));
-        // rows 1 and 3 take lane 15 of rows 0 and 2; rows 0 and 2 keep their own value (it is not used)
-        const float mo = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x142, 0xA, 0xF, false));
-        m = fmaxf(m, mo);
-        // every lane needs the maximum of ALL 32 lanes for its exponentials: lane 16 holds it for h = 0, lane 48 for h = 1
-        const float m_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 16));
-        const float m_hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 48));
-        const float mall = h ? m_hi : m_lo;
-        float sx = (mall == -INFINITY) ? 0.f
-                                       : __builtin_amdgcn_exp2f((a - mall) * kLog2e) + __builtin_amdgcn_exp2f((b - mall) * kLog2e);
-        if (a != a || b != b) sx = __int_as_float(0x7fc00000);
-        sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0xB1, 0xF, 0xF, false));
-        sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x4E, 0xF, 0xF, false));
-        sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x141, 0xF, 0xF, false));
-        sx += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x140, 0xF, 0xF, false));
-        const float so2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), 0x142, 0xA, 0xF, true));
-        sx += so2;                                               // (rows 0 / 2 receive 0: bound_ctrl; their sums are not used)
-        if (i == 16) {
-          const int64_t row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          rowparts[row * nparts + part] = make_float2(mall, sx);
+        float e = (mall[r] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((a - mall[r]) * kLog2e) + __builtin_amdgcn_exp2f((b - mall[r]) * kLog2e);
+        if (a != a || b != b) e = __int_as_float(0x7fc00000);
+        sx[r] = e;
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(sx[r]), __float_as_uint(sx[r + 8]), false, false);
+        float t = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        t += GNGF_DPP_ADD(t, 0xB1);
+        t += GNGF_DPP_ADD(t, 0x4E);
+        t += GNGF_DPP_ADD(t, 0x141);
+        t += GNGF_DPP_ADD(t, 0x140);
+        if ((i & 15) == 0) {
+          const int reg = r + 8 * (i >> 4);
+          const int64_t row = m0 + wm * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          rowparts[row * nparts + part] = make_float2(w[r], t);
         }
       }
+    }
+#undef GNGF_DPP_F
+#undef GNGF_DPP_ADD
   }
 }
 
