@@ -492,6 +492,11 @@ class HpdAux:
 # (U, T) logit matrix less (learning mode is HBM-bound as a whole).  Needs the split-bf16 GEMM and whole 128 x 128 tiles; other
 # chunks (the ragged last one) take the separate statistics pass as before.
 # TUNING.hpd_epilogue_stats (default True)
+# Round 5: TUNING.hpd_gemm_kernel = 1 — the split GEMMs split a value once on its way into LDS (bf16 planes; 17 = the round-4 kernel);
+# TUNING.hpd_bwd_two_planes — dW and dh, which accumulate over >= 4096 terms, on two planes / three products (3 * 2^-18 |a b| per
+# product; the logits keep the exact split); TUNING.hpd_bwd_fused — the backward forms the d-logits inside the dW / dh GEMMs' loaders
+# from the logits (gngf_hpd_bwd_dot + gngf_hpd_bwd_prepare + gngf_hpd_bwd_fused) for every chunk of whole 128-row tiles; the ragged
+# last chunk of a step, L > 16 or a hidden width other than 128 take the three separate entry points.
 
 
 class _HpdBwdPlanes:

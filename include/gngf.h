@@ -236,10 +236,14 @@ int gngf_vertex_grid_bwd_sorted(const void* tables, int feat_dtype, const int32_
                                 int Ls, int F, int64_t T, int K, int vstride, int64_t NV, void* stream);
 
 /* Large aligned GEMMs (full 128 x 128 tiles, contraction a multiple of 32) of the dense-layer entry points run on the
- * split-bf16 kernel while this is on: every fp32 operand is split exactly into three bf16 terms and six of the nine cross
+ * split-bf16 kernels while this is non-zero: every fp32 operand is split exactly into three bf16 terms and six of the nine cross
  * products are accumulated in fp32 on the bf16 matrix pipe (error <= ~2e-7 sum |a_k b_k|, at or below the rounding of an
- * fp32 fma chain; 2-2.7x the fp32-MFMA rate).  Process-wide; returns the previous setting.  Default off (exact fp32 MFMA). */
-int gngf_set_gemm_split_bf16(int on);
+ * fp32 fma chain; 2-2.7x the fp32-MFMA rate).  Process-wide; returns the previous setting.  Default 0 (exact fp32 MFMA).
+ *   1  (any other non-zero value too): operands split once on the way into LDS, bf16 planes (round 5)
+ *   2  as 1, and GEMMs that ACCUMULATE into their output (gngf_linear_bwd_weight, gngf_gemm_acc) use two planes and three
+ *      products: |error| <= 3 * 2^-18 |a b| per product (the HashProbDistribution's dW / dh, contractions of >= 4096 terms)
+ *   17 the round-4 kernel: every wave splits the fragments it reads (kept for A/B; same numbers as 1) */
+int gngf_set_gemm_split_bf16(int mode);
 /* The same switch for the fused decoder (gngf_decoder_fwd / gngf_decoder_bwd) at in_dim 32 or 64: exact three-way bf16
  * split of every operand, six cross products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  While on, the hidden-layer
  * buffer is neither written by the forward nor read by the backward (the backward recomputes the two layers).  Process-wide;
