@@ -954,18 +954,27 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
   }
 }
 
-// dH (U x 128) += dz W over the columns [blockIdx.y * kchunk, + kchunk) (kchunk % 64 == 0), rows blockIdx.x * 128 .. + 127: wave w stages
+// dH (U x 128) += dz W over the columns [slice * kchunk, + kchunk) (kchunk % 64 == 0), rows 128 * row tile .. + 127: wave w stages
 // rows 32 w .. + 31 (A image [r][t]: k contiguous).  Float atomics into dH.  u0 = the chunk's first row inside the prepared planes.
 template <int NP>
 __global__ void __launch_bounds__(256, 2)
 hpd_dh_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowstat, const float* __restrict__ dot,
                     const unsigned short* __restrict__ mwp, const unsigned short* __restrict__ Gtp, const unsigned short* __restrict__ Wp,
-                    int64_t rows_total, float* __restrict__ dH, int64_t U, int64_t T, int64_t kchunk) {
+                    int64_t rows_total, float* __restrict__ dH, int64_t U, int64_t T, int64_t kchunk, int rtiles, int slices) {
   __shared__ __attribute__((aligned(16))) unsigned char img[2 * NP * 8192];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
-  const int64_t r0 = (int64_t)blockIdx.x * 128;
-  const int64_t kbeg = (int64_t)blockIdx.y * kchunk;
+  // Workgroups are dealt round-robin to the 8 XCDs (one L2 each).  All row tiles of a column slice read the same rows of W: they are
+  // given to ONE XCD (slice s -> XCD s % 8), so that W's planes come from HBM once per chunk and not once per XCD (268 MB against 2.1 GB
+  // beside the 8.6 GB of logits).  The logits are read by one workgroup each wherever it runs.
+  int rt = (int)(blockIdx.x % rtiles), sl = (int)(blockIdx.x / rtiles);
+  if ((slices & 7) == 0) {
+    const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+    sl = (j / rtiles) * 8 + xcd;
+    rt = j % rtiles;
+  }
+  const int64_t r0 = (int64_t)rt * 128;
+  const int64_t kbeg = (int64_t)sl * kchunk;
   const int64_t kend = (kbeg + kchunk < T) ? kbeg + kchunk : T;
   const int nkb = (int)((kend - kbeg) / 32);
   const int64_t r = r0 + 32 * wave + i;                                                  // this lane's row, for the whole kernel
@@ -1337,13 +1346,13 @@ extern "C" int gngf_hpd_bwd_fused(const float* logits, const float* rowstat, con
   int64_t slices = ceil_div(1024, rtiles);
   int64_t kchunk = ceil_div(ceil_div(T, slices), 64) * 64;
   slices = ceil_div(T, kchunk);
-  const dim3 gh((unsigned)rtiles, (unsigned)slices);
+  const dim3 gh((unsigned)(rtiles * slices));
   if (planes == 2) {
     if (only == 0 || only == 1) hpd_dw_fused_kernel<2><<<gw, dim3(256), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, hp_, rows_total, dW, db, U, T);
-    if (only == 0 || only == 2) hpd_dh_fused_kernel<2><<<gh, dim3(256), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, Wp_, rows_total, dH, U, T, kchunk);
+    if (only == 0 || only == 2) hpd_dh_fused_kernel<2><<<gh, dim3(256), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, Wp_, rows_total, dH, U, T, kchunk, (int)rtiles, (int)slices);
   } else {
     if (only == 0 || only == 1) hpd_dw_fused_kernel<3><<<gw, dim3(256), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, hp_, rows_total, dW, db, U, T);
-    if (only == 0 || only == 2) hpd_dh_fused_kernel<3><<<gh, dim3(256), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, Wp_, rows_total, dH, U, T, kchunk);
+    if (only == 0 || only == 2) hpd_dh_fused_kernel<3><<<gh, dim3(256), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, Wp_, rows_total, dH, U, T, kchunk, (int)rtiles, (int)slices);
   }
   if (K > 0 && (only == 0 || only == 3))
     hpd_topk_side_kernel<<<dim3((unsigned)(U * K)), dim3(128), 0, s>>>(topk_p, dq, topk_idx, h, W, dW, db, dH, K);
