@@ -8,7 +8,6 @@
 // +1 padded stride (bank = (17*row + k) % 32: conflict-free ds_read_b32 for the one-float A/B operands).
 #include "gngf_common.h"
 #include <utility>
-#include <cstdlib>
 
 namespace gngf {
 
@@ -822,6 +821,23 @@ template <> __device__ __forceinline__ unsigned plane_tile_write_offset<true>(in
   return 256u * k + 64u * ((unsigned)(c16 >> 2) ^ (k & 3)) + 16u * (c16 & 3);
 }
 
+// A wave's 32 rows x 32 columns of logits are LOADED the way the streaming passes load them — whole 128-byte lines, eight rows per
+// instruction (lane -> row 8 e + (lane >> 3), 16-byte chunk lane & 7) — and turned into the layout the loader computes in (lane (i, h)
+// -> row i, chunks 2 j + h) through 4 KB of LDS private to the wave (no barrier: a wave's LDS operations execute in order): 128-byte
+// rows, chunk c of row r at c ^ ((r >> 1) & 7) — conflict-free for the row-wise stores and for the 16-byte reads of 16 lanes.
+// Loading in the computing layout directly (each lane 16 bytes of its own row: 32 rows x 32 bytes per instruction) held both kernels
+// at 2.4-2.9 TB/s of logits whatever the prefetch depth, the waits or the split of the work over waves.
+__device__ __forceinline__ void wave_block_transpose(lds_byte* scr, int lane, const u32x4 (&in)[4], u32x4 (&out)[4]) {
+  const int rsub = lane >> 3, c = lane & 7, i = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int row = 8 * e + rsub;
+    *(lds_u32x4*)(scr + 128 * row + 16 * (c ^ ((row >> 1) & 7))) = in[e];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[j] = *(const lds_u32x4*)(scr + 128 * i + 16 * ((2 * j + h) ^ ((i >> 1) & 7)));
+}
+
 // dW (T x 128) += dz^T h, db (T) += column sums of dz.  A workgroup owns 128 columns t for ALL U rows (U % 64 == 0): wave w stages the
 // 32 columns t0 + 32 w .. + 31 of every 32-row block (A image k-major: [r][t], 8-byte units permuted: read_frag_km8).
 template <int NP>
@@ -829,7 +845,7 @@ __global__ void __launch_bounds__(256, 2)
 hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowstat, const float* __restrict__ dot,
                     const unsigned short* __restrict__ mwp, const unsigned short* __restrict__ Gtp, const unsigned short* __restrict__ hp,
                     int64_t rows_total, float* __restrict__ dW, float* __restrict__ db, int64_t U, int64_t T) {
-  __shared__ __attribute__((aligned(16))) unsigned char img[2 * NP * 8192];
+  __shared__ __attribute__((aligned(16))) unsigned char img[2 * NP * 8192 + 4 * 4096];   // planes of A, planes of B, four private 4 KB blocks
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
   int64_t tile = blockIdx.x;
@@ -845,7 +861,8 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
     Gs.mid = *reinterpret_cast<const u32x4*>(g0 + T * 16);
     Gs.lo = *reinterpret_cast<const u32x4*>(g0 + 2 * T * 16);
   }
-  const unsigned zo = 4u * ((unsigned)i * (unsigned)T + 32u * wave + 4u * h);             // + 32 j bytes; window: 32 rows x T
+  const unsigned zo = 4u * ((unsigned)(lane >> 3) * (unsigned)T + 32u * wave) + 16u * (lane & 7);   // + e * 8 rows; window: 32 rows x T
+  const unsigned z8 = 32u * (unsigned)T;                                                  // eight rows, in bytes
   const unsigned bo = 2u * ((unsigned)(tid >> 4) * 128u + 8u * (tid & 15));               // + 4096 in the second pass; window: 32 rows x 128
   const unsigned mo = 2u * ((unsigned)i * 16u + 8u * h);                                  // window: 32 rows x 16
   // two K-blocks of logits in flight per workgroup (register ring zv0 / zv1, the loop unrolled by two); the small operands (L2 hits)
@@ -858,7 +875,7 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
   auto fetch_z = [&](int kb, u32x4 (&zv)[4]) {
     const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z + (int64_t)kb * 32 * T + t0), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) zv[j] = __builtin_amdgcn_raw_buffer_load_b128(rz, zo, 32 * j, 0);
+    for (int e = 0; e < 4; ++e) zv[e] = __builtin_amdgcn_raw_buffer_load_b128(rz, zo, e * z8, 0);
   };
   auto fetch_small = [&](int kb) {
     const int64_t r0 = (int64_t)kb * 32;
@@ -906,11 +923,14 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
       ra[tt][r2] = 256u * (8 * h + q4) + 64u * ((unsigned)(2 * wm + tt) ^ q4) + 8u * ((unsigned)(4 * g1 + p4) ^ (unsigned)((4 * h + (q4 >> 1)) ^ (2 * r2)));
   const unsigned rb0 = 256u * (8 * h + q4) + 64u * ((2 * wn) ^ q4) + 32u * g1 + 8u * p4;
   const unsigned rb1 = 256u * (8 * h + q4) + 64u * ((2 * wn + 1) ^ q4) + 32u * g1 + 8u * p4;
+  lds_byte* const scr = imgB + NP * 8192 + 4096 * wave;
   auto step = [&](int kb, u32x4 (&zv)[4]) {
     {
       unsigned pk[4][2][NP];
+      u32x4 zt[4];
+      wave_block_transpose(scr, lane, zv, zt);
       const f32x16 g = fused_g_block(Gs, Ms);
-      fused_dz_block<NP>(zv, g, __uint_as_float(rc_ms.x), 1.0f / __uint_as_float(rc_ms.y), rc_d, pk, &dacc);
+      fused_dz_block<NP>(zt, g, __uint_as_float(rc_ms.x), 1.0f / __uint_as_float(rc_ms.y), rc_d, pk, &dacc);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -962,7 +982,7 @@ __global__ void __launch_bounds__(256, 2)
 hpd_dh_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowstat, const float* __restrict__ dot,
                     const unsigned short* __restrict__ mwp, const unsigned short* __restrict__ Gtp, const unsigned short* __restrict__ Wp,
                     int64_t rows_total, float* __restrict__ dH, int64_t U, int64_t T, int64_t kchunk, int rtiles, int slices) {
-  __shared__ __attribute__((aligned(16))) unsigned char img[2 * NP * 8192];
+  __shared__ __attribute__((aligned(16))) unsigned char img[2 * NP * 8192 + 4 * 4096];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
   // Workgroups are dealt round-robin to the 8 XCDs (one L2 each).  All row tiles of a column slice read the same rows of W: they are
@@ -987,7 +1007,8 @@ hpd_dh_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
     Ms.mid = *reinterpret_cast<const u32x4*>(m0 + rows_total * 16);
     Ms.lo = *reinterpret_cast<const u32x4*>(m0 + 2 * rows_total * 16);
   }
-  const unsigned zo = 4u * ((unsigned)(32 * wave + i) * (unsigned)T + 4u * h);            // + 32 j bytes; window: 128 rows x T
+  const unsigned zo = 4u * ((unsigned)(32 * wave + (lane >> 3)) * (unsigned)T) + 16u * (lane & 7);   // + e * 8 rows; window: 128 rows x T
+  const unsigned z8 = 32u * (unsigned)T;
   const unsigned bo = 2u * ((unsigned)(tid >> 4) * 128u + 8u * (tid & 15));
   const unsigned go = 2u * ((unsigned)i * 16u + 8u * h);
   u32x4 zv0[4], zv1[4], vb[NP][2];                            // (two K-blocks of logits in flight: see hpd_dw_fused_kernel)
@@ -995,7 +1016,7 @@ hpd_dh_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
   auto fetch_z = [&](int kb, u32x4 (&zv)[4]) {
     const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z + r0 * T + kbeg + (int64_t)kb * 32), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) zv[j] = __builtin_amdgcn_raw_buffer_load_b128(rz, zo, 32 * j, 0);
+    for (int e = 0; e < 4; ++e) zv[e] = __builtin_amdgcn_raw_buffer_load_b128(rz, zo, e * z8, 0);
   };
   auto fetch_small = [&](int kb) {
     const int64_t tb = kbeg + (int64_t)kb * 32;
@@ -1035,11 +1056,14 @@ hpd_dh_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
   const unsigned ra1 = 64u * (wm * 64 + i) + 16u * ((unsigned)(2 + h) ^ swz);
   const unsigned rb0 = 256u * (8 * h + q4) + 64u * ((2 * wn) ^ q4) + 32u * g1 + 8u * p4;
   const unsigned rb1 = 256u * (8 * h + q4) + 64u * ((2 * wn + 1) ^ q4) + 32u * g1 + 8u * p4;
+  lds_byte* const scr = imgB + NP * 8192 + 4096 * wave;
   auto step = [&](int kb, u32x4 (&zv)[4]) {
     {
       unsigned pk[4][2][NP];
+      u32x4 zt[4];
+      wave_block_transpose(scr, lane, zv, zt);
       const f32x16 g = fused_g_block(Gs, Ms);
-      fused_dz_block<NP>(zv, g, rc_m, rc_rs, rc_d, pk, nullptr);
+      fused_dz_block<NP>(zt, g, rc_m, rc_rs, rc_d, pk, nullptr);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1072,150 +1096,6 @@ hpd_dh_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
     step(kb + 1, zv1);
   }
   split_epilogue(acc, dH, 128, nullptr, 0, 1, r0, 0, wm, wn, i, h, nullptr, 0);
-}
-
-// ------------------------------------------------------------------------------- the same two kernels, wave-specialised
-// In the kernels above a wave does everything of a K-block one after the other (g, dz, split, LDS stores, barrier, fragment reads, 24
-// MFMAs, barrier) and two workgroups per CU cannot hide one wave's chain behind the other's.  Here a workgroup is EIGHT waves: waves
-// 0-3 stage (the loader above, unchanged: dz planes and the B tile into LDS buffer kb & 1), waves 4-7 multiply (fragment reads and
-// the 24 MFMAs of block kb - 1 out of the other buffer); one barrier per K-block.  The accumulators live in the multiplying waves
-// only, the logits ring, the small operands and the column sums in the staging waves only.
-template <int NP>
-__global__ void __launch_bounds__(512, 2)
-hpd_dw_fused_ws_kernel(const float* __restrict__ Z, const float* __restrict__ rowstat, const float* __restrict__ dot,
-                       const unsigned short* __restrict__ mwp, const unsigned short* __restrict__ Gtp, const unsigned short* __restrict__ hp,
-                       int64_t rows_total, float* __restrict__ dW, float* __restrict__ db, int64_t U, int64_t T) {
-  __shared__ __attribute__((aligned(16))) unsigned char img[2 * 2 * NP * 8192];        // two buffers of (A planes, B planes)
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;                    // (inside the role's four waves)
-  const bool stager = threadIdx.x < 256;
-  const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
-  int64_t tile = blockIdx.x;
-  const int64_t ntiles = T / 128;
-  if ((ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
-  const int64_t t0 = tile * 128;
-  const int nkb = (int)(U / 32);
-  lds_byte* const base = (lds_byte*)img;
-  constexpr int kBuf = 2 * NP * 8192;
-  if (stager) {
-    Split3 Gs;
-    {
-      const unsigned short* g0 = Gtp + (t0 + 32 * wave + i) * 16 + 8 * h;
-      Gs.hi = *reinterpret_cast<const u32x4*>(g0);
-      Gs.mid = *reinterpret_cast<const u32x4*>(g0 + T * 16);
-      Gs.lo = *reinterpret_cast<const u32x4*>(g0 + 2 * T * 16);
-    }
-    const unsigned zo = 4u * ((unsigned)i * (unsigned)T + 32u * wave + 4u * h);
-    const unsigned bo = 2u * ((unsigned)(tid >> 4) * 128u + 8u * (tid & 15));
-    const unsigned mo = 2u * ((unsigned)i * 16u + 8u * h);
-    u32x4 zv0[4], vb[NP][2];                                  // (ONE block of logits ahead: 128 registers = four waves per SIMD)
-    Split3 Ms;
-    u32x2 rc_ms;
-    float rc_d;
-    auto fetch_z = [&](int kb, u32x4 (&zv)[4]) {
-      const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z + (int64_t)kb * 32 * T + t0), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) zv[j] = __builtin_amdgcn_raw_buffer_load_b128(rz, zo, 32 * j, 0);
-    };
-    auto fetch_small = [&](int kb) {
-      const int64_t r0 = (int64_t)kb * 32;
-#pragma unroll
-      for (int pl = 0; pl < NP; ++pl) {
-        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(hp + (pl * rows_total + r0) * 128), 0, 0x7fffffff, 0x00020000);
-        vb[pl][0] = __builtin_amdgcn_raw_buffer_load_b128(rh, bo, 0, 0);
-        vb[pl][1] = __builtin_amdgcn_raw_buffer_load_b128(rh, bo, 4096, 0);
-      }
-      const __amdgpu_buffer_rsrc_t rm0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(mwp + r0 * 16), 0, 0x7fffffff, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rm1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(mwp + (rows_total + r0) * 16), 0, 0x7fffffff, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rm2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(mwp + (2 * rows_total + r0) * 16), 0, 0x7fffffff, 0x00020000);
-      Ms.hi = __builtin_amdgcn_raw_buffer_load_b128(rm0, mo, 0, 0);
-      Ms.mid = __builtin_amdgcn_raw_buffer_load_b128(rm1, mo, 0, 0);
-      Ms.lo = __builtin_amdgcn_raw_buffer_load_b128(rm2, mo, 0, 0);
-      rc_ms = *reinterpret_cast<const u32x2*>(rowstat + 2 * (r0 + i));
-      rc_d = dot[r0 + i];
-    };
-    fetch_z(0, zv0);
-    __builtin_amdgcn_sched_barrier(0);
-    fetch_small(0);
-    __builtin_amdgcn_sched_barrier(0);
-    float dacc[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
-    unsigned wa[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wa[j] = 256u * i + 64u * ((unsigned)wave ^ (i & 3)) + 8u * ((unsigned)(2 * j + h) ^ ((i >> 1) & 7));
-    const unsigned wb0 = plane_tile_write_offset<true>(tid);
-    auto stage = [&](int kb, u32x4 (&zv)[4]) {
-      lds_byte* const imgA = base + (kb & 1) * kBuf;
-      lds_byte* const imgB = imgA + NP * 8192;
-      {
-        unsigned pk[4][2][NP];
-        const f32x16 g = fused_g_block(Gs, Ms);
-        fused_dz_block<NP>(zv, g, __uint_as_float(rc_ms.x), 1.0f / __uint_as_float(rc_ms.y), rc_d, pk, &dacc);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int pl = 0; pl < NP; ++pl) *(lds_u32x2*)(imgA + wa[j] + 8192 * pl) = u32x2{pk[j][0][pl], pk[j][1][pl]};
-      }
-#pragma unroll
-      for (int pl = 0; pl < NP; ++pl) {
-        *(lds_u32x4*)(imgB + wb0 + 8192 * pl) = vb[pl][0];
-        *(lds_u32x4*)(imgB + wb0 + 4096 + 8192 * pl) = vb[pl][1];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      fetch_small(kb + 1 < nkb ? kb + 1 : nkb - 1);
-      __builtin_amdgcn_sched_barrier(0);
-      fetch_z(kb + 1 < nkb ? kb + 1 : nkb - 1, zv);
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();                                           // (1)
-    };
-    for (int kb = 0; kb < nkb; ++kb) stage(kb, zv0);
-    __syncthreads();                                             // (2): the multiplying waves' last block
-    if (db) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = dacc[r];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (i == 0) atomicAdd(db + t0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h, v);
-      }
-    }
-  } else {
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) acc[a][b] = 0;
-    const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
-    unsigned ra[2][2];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int r2 = 0; r2 < 2; ++r2)
-        ra[tt][r2] = 256u * (8 * h + q4) + 64u * ((unsigned)(2 * wm + tt) ^ q4) + 8u * ((unsigned)(4 * g1 + p4) ^ (unsigned)((4 * h + (q4 >> 1)) ^ (2 * r2)));
-    const unsigned rb0 = 256u * (8 * h + q4) + 64u * ((2 * wn) ^ q4) + 32u * g1 + 8u * p4;
-    const unsigned rb1 = 256u * (8 * h + q4) + 64u * ((2 * wn + 1) ^ q4) + 32u * g1 + 8u * p4;
-    auto mma = [&](int kb) {
-      const lds_byte* imgA = base + (kb & 1) * kBuf;
-      const lds_byte* imgB = imgA + NP * 8192;
-      unrolled<2>([&](auto S_) {
-        constexpr int ks = S_.value;
-        const Frag<NP> fa0 = read_frag_km8<NP, ks, 0>(imgA, ra), fa1 = read_frag_km8<NP, ks, 1>(imgA, ra);
-        const Frag<NP> fb0 = read_frag<true, NP, ks, 0>(imgB, rb0, rb1), fb1 = read_frag<true, NP, ks, 1>(imgB, rb0, rb1);
-        acc[0][0] = split_products<NP>(fa0, fb0, acc[0][0]);
-        acc[0][1] = split_products<NP>(fa0, fb1, acc[0][1]);
-        acc[1][0] = split_products<NP>(fa1, fb0, acc[1][0]);
-        acc[1][1] = split_products<NP>(fa1, fb1, acc[1][1]);
-      });
-    };
-    __syncthreads();                                             // (1) of block 0: nothing to multiply yet
-    for (int kb = 1; kb < nkb; ++kb) {
-      mma(kb - 1);
-      __syncthreads();                                           // (1) of block kb
-    }
-    mma(nkb - 1);
-    __syncthreads();                                             // (2)
-    split_epilogue(acc, dW, 128, nullptr, 0, 1, t0, 0, wm, wn, i, h, nullptr, 0);
-  }
 }
 
 // gngf_hpd_bwd_prepare: X (rows, 128) fp32 -> NP planes (NP, rows, 128), and V (rows, Lv) -> three planes (3, rows, 16) zero-padded
@@ -1492,16 +1372,11 @@ extern "C" int gngf_hpd_bwd_fused(const float* logits, const float* rowstat, con
   int64_t kchunk = ceil_div(ceil_div(T, slices), 64) * 64;
   slices = ceil_div(T, kchunk);
   const dim3 gh((unsigned)(rtiles * slices));
-  static const int ws = [] { const char* e = getenv("GNGF_HPD_BWD_WS"); return e ? atoi(e) : 0; }();     // (experiment: wave-specialised kernels)
-  if (ws && (only == 0 || only == 1)) {
-    if (planes == 2) hpd_dw_fused_ws_kernel<2><<<gw, dim3(512), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, hp_, rows_total, dW, db, U, T);
-    else hpd_dw_fused_ws_kernel<3><<<gw, dim3(512), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, hp_, rows_total, dW, db, U, T);
-  }
   if (planes == 2) {
-    if (!ws && (only == 0 || only == 1)) hpd_dw_fused_kernel<2><<<gw, dim3(256), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, hp_, rows_total, dW, db, U, T);
+    if (only == 0 || only == 1) hpd_dw_fused_kernel<2><<<gw, dim3(256), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, hp_, rows_total, dW, db, U, T);
     if (only == 0 || only == 2) hpd_dh_fused_kernel<2><<<gh, dim3(256), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, Wp_, rows_total, dH, U, T, kchunk, (int)rtiles, (int)slices);
   } else {
-    if (!ws && (only == 0 || only == 1)) hpd_dw_fused_kernel<3><<<gw, dim3(256), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, hp_, rows_total, dW, db, U, T);
+    if (only == 0 || only == 1) hpd_dw_fused_kernel<3><<<gw, dim3(256), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, hp_, rows_total, dW, db, U, T);
     if (only == 0 || only == 2) hpd_dh_fused_kernel<3><<<gh, dim3(256), 0, s>>>(logits, rowstat, dot, mwp_, Gtp_, Wp_, rows_total, dH, U, T, kchunk, (int)rtiles, (int)slices);
   }
   if (K > 0 && (only == 0 || only == 3))
