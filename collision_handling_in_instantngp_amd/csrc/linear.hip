@@ -861,7 +861,10 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
     Gs.mid = *reinterpret_cast<const u32x4*>(g0 + T * 16);
     Gs.lo = *reinterpret_cast<const u32x4*>(g0 + 2 * T * 16);
   }
-  const unsigned zo = 4u * ((unsigned)(lane >> 3) * (unsigned)T + 32u * wave) + 16u * (lane & 7);   // + e * 8 rows; window: 32 rows x T
+  // the workgroup's 32 rows x 512 bytes of a K-block are loaded by all four waves together, 512 contiguous bytes per row (thread ->
+  // row 8 e + (tid >> 5), 16-byte chunk tid & 31), parked in a shared 16 KB tile between the two barriers of the step before, and
+  // read back by each wave in its computing layout (row i, chunks 8 wave + 2 j + h); chunk c of row r at c ^ (r & 15): conflict-free
+  const unsigned zo = 4u * ((unsigned)(tid >> 5) * (unsigned)T) + 16u * (tid & 31);        // + e * 8 rows; window: 32 rows x T
   const unsigned z8 = 32u * (unsigned)T;                                                  // eight rows, in bytes
   const unsigned bo = 2u * ((unsigned)(tid >> 4) * 128u + 8u * (tid & 15));               // + 4096 in the second pass; window: 32 rows x 128
   const unsigned mo = 2u * ((unsigned)i * 16u + 8u * h);                                  // window: 32 rows x 16
@@ -923,12 +926,22 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
       ra[tt][r2] = 256u * (8 * h + q4) + 64u * ((unsigned)(2 * wm + tt) ^ q4) + 8u * ((unsigned)(4 * g1 + p4) ^ (unsigned)((4 * h + (q4 >> 1)) ^ (2 * r2)));
   const unsigned rb0 = 256u * (8 * h + q4) + 64u * ((2 * wn) ^ q4) + 32u * g1 + 8u * p4;
   const unsigned rb1 = 256u * (8 * h + q4) + 64u * ((2 * wn + 1) ^ q4) + 32u * g1 + 8u * p4;
-  lds_byte* const scr = imgB + NP * 8192 + 4096 * wave;
-  auto step = [&](int kb, u32x4 (&zv)[4]) {
+  lds_byte* const raw = imgB + NP * 8192;                                               // 32 rows x 512 bytes
+  auto park = [&](const u32x4 (&zv)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = 8 * e + (tid >> 5);
+      *(lds_u32x4*)(raw + 512 * row + 16 * ((tid & 31) ^ (row & 15))) = zv[e];
+    }
+  };
+  park(zv0);                                                  // block 0 (its loads are waited for here: once)
+  __syncthreads();
+  auto step = [&](int kb, u32x4 (&zv)[4]) {                   // zv: block kb + 1 in flight (block kb is in the shared tile)
     {
       unsigned pk[4][2][NP];
       u32x4 zt[4];
-      wave_block_transpose(scr, lane, zv, zt);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) zt[j] = *(const lds_u32x4*)(raw + 512 * i + 16 * ((8 * wave + 2 * j + h) ^ (i & 15)));
       const f32x16 g = fused_g_block(Gs, Ms);
       fused_dz_block<NP>(zt, g, __uint_as_float(rc_ms.x), 1.0f / __uint_as_float(rc_ms.y), rc_d, pk, &dacc);
 #pragma unroll
@@ -944,9 +957,11 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
     __builtin_amdgcn_sched_barrier(0);
     fetch_small(kb + 1 < nkb ? kb + 1 : nkb - 1);
     __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    park(zv);                                                 // every wave has read block kb out of the tile: block kb + 1 goes in
+    __builtin_amdgcn_sched_barrier(0);
     fetch_z(kb + 2 < nkb ? kb + 2 : nkb - 1, zv);
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
     unrolled<2>([&](auto S_) {
       constexpr int ks = S_.value;
       const Frag<NP> fa0 = read_frag_km8<NP, ks, 0>(imgA, ra), fa1 = read_frag_km8<NP, ks, 1>(imgA, ra);
@@ -959,8 +974,8 @@ hpd_dw_fused_kernel(const float* __restrict__ Z, const float* __restrict__ rowst
     __syncthreads();
   };
   for (int kb = 0; kb < nkb; kb += 2) {                       // (nkb = U / 32 is even: U % 128 == 0)
-    step(kb, zv0);
-    step(kb + 1, zv1);
+    step(kb, zv1);                                            // zv1 holds block kb + 1; refilled with block kb + 2
+    step(kb + 1, zv1);                                        // ... which this step parks; refilled with block kb + 3
   }
   split_epilogue(acc, dW, 128, nullptr, 0, 1, t0, 0, wm, wn, i, h, nullptr, 0);
   if (db) {
