@@ -367,7 +367,8 @@ int gngf_softmax_bwd_lowrank(float* logits_dz, const float* rowstat, const float
  * three bf16 terms (six products, fp32 accumulation), 2 = two terms, three products (|error| <= 3 * 2^-18 |a b| per product); the
  * operands of the small product mw G always keep the exact three.  gngf_hpd_bwd_fused takes hp / mwp AT THE CHUNK'S FIRST ROW
  * (pointer + u0 * hidden resp. + u0 * 16 elements) and rows_total = the rows they were prepared with (the plane stride); h (U,hidden)
- * and W in fp32 serve the K top-K terms only (K = 0: unused).
+ * and W in fp32 serve the K top-K terms only (K = 0: unused).  Diagnostic: planes + 16 / + 32 / + 48 run the dW + db part / the dH
+ * part / the top-K terms alone.
  * Shapes: gngf_hpd_bwd_fused_applies(U, T, L, K, hidden) != 0 (U % 128 == 0, T % 128 == 0, T < 2^22, hidden == 128, L <= 16);
  * anything else is rejected (hipErrorInvalidValue) — the caller then takes the three separate entry points. */
 int gngf_hpd_bwd_dot(const float* logits, const float* rowstat, const float* dq, const float* topk_p, const float* mw,
