@@ -399,20 +399,29 @@ __device__ __forceinline__ void split_epilogue(f32x16 (&acc)[2][2], float* __res
                                                float2* __restrict__ rowparts, int nparts) {
   const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(C + m0 * ldc + n0, 0, 0x7fffffff, 0x00020000);
   const unsigned oc = 4u * ((unsigned)(wm * 64 + 4 * h) * (unsigned)ldc + wn * 64 + i);
+  // the mode (accumulate / plain store / activation) is decided ONCE, outside the 64 stores: tested per value it cost the logits
+  // kernel ~900 of its 1600 vector instructions per wave and tile (compares, selects and the never-taken activation code in between)
+  const int mode = atomic_out ? 0 : (act == 0 ? 1 : 2);
+  auto stores = [&](auto MODE) {
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const float bv = (bias && blockIdx.y == 0) ? bias[n0 + wn * 64 + tn * 32 + i] : 0.f;
+    for (int tn = 0; tn < 2; ++tn) {
+      const float bv = (bias && blockIdx.y == 0) ? bias[n0 + wn * 64 + tn * 32 + i] : 0.f;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+      for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned so = 4u * ((unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)ldc + tn * 32);
-        const float v = acc[tm][tn][r] + bv;
-        if (atomic_out) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rsc, oc, so, 0);
-        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(act_fwd(v, act)), rsc, oc, so, 0);
-        if (rowparts) acc[tm][tn][r] = v;                        // (the statistics below are taken on the stored values)
-      }
-  }
+        for (int r = 0; r < 16; ++r) {
+          const unsigned so = 4u * ((unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)ldc + tn * 32);
+          const float v = acc[tm][tn][r] + bv;
+          if constexpr (MODE.value == 0) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rsc, oc, so, 0);
+          else if constexpr (MODE.value == 1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsc, oc, so, 0);
+          else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(act_fwd(v, act)), rsc, oc, so, 0);
+          acc[tm][tn][r] = v;                                    // (the statistics below are taken on the stored values)
+        }
+    }
+  };
+  if (mode == 0) stores(std::integral_constant<int, 0>{});
+  else if (mode == 1) stores(std::integral_constant<int, 1>{});
+  else stores(std::integral_constant<int, 2>{});
   if (rowparts) {
     // ROW STATISTICS OF THE TILE IN THE EPILOGUE (the logits product of the chunked HashProbDistribution, reference
     // models.py:85,105-116): for every row of the tile and each 64-column half (this wave's columns) the maximum and
