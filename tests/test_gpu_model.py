@@ -777,3 +777,45 @@ def test_three_models_interleaved_do_not_share_state(golden):
                 close(got[n_], alone[k][n_].cpu().numpy(), 0, 1e-5 * scale, f"interleaved == alone ({kind}: {n_})")
     finally:
         models.should_use_hash_function = False
+
+
+def test_learning_step_gradients_do_not_depend_on_how_the_hpd_backward_is_run(golden):
+    """Round 5: at a shape whose chunks are whole 128-row tiles (T = 2^14, last hidden width 128, 128-row chunks: many chunks + a ragged
+    last one) one learning step gives the same gradients with the d-logits formed inside the dW / dh GEMMs (gngf_hpd_bwd_dot +
+    gngf_hpd_bwd_prepare + gngf_hpd_bwd_fused) as with the three separate entry points, chunks pipelined over two streams or one after
+    the other, two planes or three — the paths `ops.HpdVertexFunction.backward` chooses between (reference: autograd through
+    models.py:84-85,105-123 and utils.py:138,159)."""
+    from collision_handling_in_instantngp_amd import ops, models as M, train
+    X, Y, h, w = strawberry(golden)
+    M.should_use_hash_function = False
+    kw = dict(input_dim=2, hash_table_size=2 ** 14, num_levels=8, n_min=16, n_max=128, MLP_hidden_layers_widths=[64, 64],
+              HPD_hidden_layers_widths=[32, 64, 128], HPD_out_features=2 ** 14, feature_dim=2, topk_k=4)
+    torch.manual_seed(11)
+    net = M.GeneralNeuralGaugeFields(**kw).to(DEV)
+    net.dense_probs = False
+    T = 2 ** 14
+    loss_fn = train.Loss(delta=1, gamma=-2, epsilon=1)
+    xb, yb = X[:30000], Y[:30000]
+    old = (M.HPD_CHUNK_BYTES, ops.HPD_BWD_FUSED, ops.HPD_PIPELINE, ops.HPD_BWD_TWO_PLANES)
+    outs = {}
+    try:
+        M.HPD_CHUNK_BYTES = 128 * 4 * T
+        for fused, pipe, two in ((0, 1, 1), (1, 1, 1), (1, 0, 1), (1, 1, 0), (0, 0, 1)):
+            ops.HPD_BWD_FUSED, ops.HPD_PIPELINE, ops.HPD_BWD_TWO_PLANES = bool(fused), bool(pipe), bool(two)
+            net.zero_grad()
+            rgb, probs, idx, _ = net(xb, 1 / 3)
+            empty = torch.tensor([], device=DEV)
+            mse, kls, coll = loss_fn(rgb, yb, probs.shape[-1], probs, empty, empty)
+            train.assemble_loss(mse, kls, coll, 1, 1, 1e-3).backward()
+            torch.cuda.synchronize()
+            outs[(fused, pipe, two)] = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+            st = net.hpd_stats
+            assert st["chunks"] >= 3 and st["rows_total"] % 128 != 0, st        # several whole chunks and a ragged one
+    finally:
+        M.HPD_CHUNK_BYTES, ops.HPD_BWD_FUSED, ops.HPD_PIPELINE, ops.HPD_BWD_TWO_PLANES = old
+    ref = outs[(0, 1, 1)]
+    assert any(k.startswith("HPD") for k in ref)
+    for key, other in outs.items():
+        for k in ref:
+            scale = float(ref[k].abs().max()) + 1e-30
+            close(other[k], ref[k].cpu().numpy(), 1e-4, 2e-5 * scale, f"{key} {k}")
